@@ -1,0 +1,65 @@
+/*
+ * vksift_ext.h — additive extensions to the vksift_* API for the MI355X build.
+ *
+ * Nothing here exists in the reference; none of it changes the layout or behaviour of the reference
+ * API (include/vulkansift/vulkansift.h). The extensions expose what a 288 GB / 8 TB/s device makes
+ * worthwhile: batched detection (the reference handles one image at a time per instance,
+ * vulkansift.c:326-327), device-resident inputs/outputs for multi-GPU pipelines, and stage timings
+ * taken with HIP events on the instance's own stream.
+ */
+#ifndef VKSIFT_EXT_H
+#define VKSIFT_EXT_H
+
+#include "vulkansift/vulkansift.h"
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+  /* Like vksift_createInstance, but reserves `batch_capacity` pyramids so that up to that many
+   * same-sized images can be processed by one vksift_ext_detectFeaturesBatch call.
+   * config->sift_buffer_count must be >= batch_capacity. */
+  VKSIFT_EXPORT vksift_Result vksift_ext_createInstanceBatched(vksift_Instance *instance_ptr, const vksift_Config *config, uint32_t batch_capacity);
+
+  /* Detect on `count` images of identical resolution; image i fills SIFT buffer first_gpu_buffer_id+i.
+   * Same asynchronous contract and error behaviour as vksift_detectFeatures. */
+  VKSIFT_EXPORT void vksift_ext_detectFeaturesBatch(vksift_Instance instance, const uint8_t *const *images, uint32_t count, uint32_t image_width,
+                                                    uint32_t image_height, uint32_t first_gpu_buffer_id);
+  /* Same, images already in device memory (contiguous, image i at d_images + i*width*height). */
+  VKSIFT_EXPORT void vksift_ext_detectFeaturesBatchDevice(vksift_Instance instance, const uint8_t *d_images, uint32_t count, uint32_t image_width,
+                                                          uint32_t image_height, uint32_t first_gpu_buffer_id);
+
+  /* Stage timings (milliseconds, HIP events on the instance stream) of the last detect call.
+   * Enabled with vksift_ext_setProfiling(instance, true); disabled by default. Blocking. */
+  typedef struct
+  {
+    float upload_ms;      /* host->device image copy */
+    float pyramid_ms;     /* input blit + all blur/DoG + down-sample launches */
+    float extrema_ms;     /* detect + scan + emit */
+    float orientation_ms;
+    float descriptor_ms;
+    float total_ms;
+    uint32_t nb_blur_launches;
+    uint64_t pyramid_algorithmic_bytes; /* SURVEY.md §8(d) definition, whole batch */
+  } vksift_ext_DetectTimings;
+  VKSIFT_EXPORT void vksift_ext_setProfiling(vksift_Instance instance, bool enabled);
+  VKSIFT_EXPORT void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *out);
+  /* Time (ms) of the last matching pipeline (gather + 2-NN kernel), HIP events; needs profiling on. */
+  VKSIFT_EXPORT float vksift_ext_getMatchTime(vksift_Instance instance);
+
+  /* Copy the descriptors of a SIFT buffer, in download order, as dense 128-byte rows into caller
+   * provided DEVICE memory (>= vksift_getFeaturesNumber()*128 bytes, 16-byte aligned). Blocking.
+   * Returns the number of rows written. Used to feed the RCCL all-gather of the sharded matcher. */
+  VKSIFT_EXPORT uint32_t vksift_ext_exportDescriptorsDevice(vksift_Instance instance, uint32_t gpu_buffer_id, uint8_t *d_descriptors);
+
+  /* Deterministic synthetic test image: 128 + sum of Gaussian blobs + uniform noise,
+   * splitmix64-seeded, clamped to [0,255]. nb_blobs == 0 picks the density used by the benchmarks. */
+  VKSIFT_EXPORT void vksift_ext_genSyntheticImage(uint64_t seed, uint32_t width, uint32_t height, uint32_t nb_blobs, uint8_t *out);
+  /* Deterministic SIFT-like descriptor rows: min(255, trunc(512*|g|/||g||)), g ~ N(0,1)^128. */
+  VKSIFT_EXPORT void vksift_ext_genSyntheticDescriptors(uint64_t seed, uint32_t rows, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKSIFT_EXT_H */

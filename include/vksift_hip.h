@@ -1,0 +1,149 @@
+/*
+ * vksift_hip.h — the thin C-ABI between the C host (vulkansift_amd/csrc/host/) and the hand-written
+ * HIP kernels for gfx950 (vulkansift_amd/csrc/hip/). Plain pointers, sizes and an opaque stream
+ * handle only: no HIP, torch or C++ types appear in any signature, so the same entry points can be
+ * bound from C, ctypes or any FFI.
+ *
+ * Each launch shim replaces one recorded Vulkan command of the reference's detection / matching
+ * command buffers (reference file:line given per function; paths relative to src/vulkansift/).
+ * All shims are asynchronous on `stream` and return 0 on success or a non-zero hipError_t value.
+ *
+ * Data layout in HBM:
+ *   plane      : fp32, row-major, row pitch `pitch` floats (multiple of 64 floats = 256 B)
+ *   octave     : (S+3) Gaussian planes then (S+2) DoG planes, plane stride = pitch*h floats
+ *   batch      : image b of a batched detect lives `img_stride` floats after image b-1
+ *   SIFT buffer: per octave section of 164-byte vksift_Feature records; counters live in a
+ *                separate u32 array (found[o], un-clamped like nb_elem in the reference)
+ */
+#ifndef VKSIFT_HIP_H
+#define VKSIFT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+#define VKSIFT_HIP_MAX_TAPS 20 /* VKSIFT_DETECTOR_MAX_GAUSSIAN_KERNEL_SIZE, sift_detector.h:9 */
+#define VKSIFT_HIP_MAX_ORI 18  /* a 36-bin circular histogram has at most 18 strict local maxima */
+
+  typedef void *vksift_hip_stream;
+  typedef void *vksift_hip_event;
+
+  /* ------------------------------------------------------------------ runtime (replaces the vkenv directory) */
+  int vksift_hip_init(void);                          /* vulkan_device.c:17 vkenv_createInstance */
+  int vksift_hip_device_count(void);                  /* vulkan_device.c: vkenv_getPhysicalDevicesProperties */
+  int vksift_hip_device_name(int idx, char *out256);
+  int vksift_hip_set_device(int idx);
+  size_t vksift_hip_device_free_mem(void);
+  void *vksift_hip_malloc(size_t bytes);              /* NULL on failure */
+  void vksift_hip_free(void *p);
+  void *vksift_hip_host_malloc(size_t bytes);         /* pinned; replaces HOST_VISIBLE staging buffers */
+  void vksift_hip_host_free(void *p);
+  vksift_hip_stream vksift_hip_stream_create(void);
+  void vksift_hip_stream_destroy(vksift_hip_stream s);
+  int vksift_hip_stream_sync(vksift_hip_stream s);    /* vkWaitForFences */
+  int vksift_hip_stream_busy(vksift_hip_stream s);    /* vkGetFenceStatus: 1 busy, 0 idle, <0 error */
+  vksift_hip_event vksift_hip_event_create(void);
+  void vksift_hip_event_destroy(vksift_hip_event e);
+  int vksift_hip_event_record(vksift_hip_event e, vksift_hip_stream s);
+  int vksift_hip_event_sync(vksift_hip_event e);
+  int vksift_hip_event_busy(vksift_hip_event e);
+  float vksift_hip_event_elapsed_ms(vksift_hip_event a, vksift_hip_event b);
+  int vksift_hip_stream_wait_event(vksift_hip_stream s, vksift_hip_event e);
+  int vksift_hip_memcpy_h2d(void *dst, const void *src, size_t n, vksift_hip_stream s);
+  int vksift_hip_memcpy_d2h(void *dst, const void *src, size_t n, vksift_hip_stream s);
+  int vksift_hip_memcpy_d2d(void *dst, const void *src, size_t n, vksift_hip_stream s);
+  int vksift_hip_memcpy2d_d2h(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t height, vksift_hip_stream s);
+  int vksift_hip_memset(void *dst, int value, size_t n, vksift_hip_stream s);
+  const char *vksift_hip_error_string(int err);
+  void vksift_hip_range_push(const char *name);       /* roctx marker == VK_EXT_debug_marker region */
+  void vksift_hip_range_pop(void);
+
+  /* ------------------------------------------------------------------ pyramid */
+  /* A batch of same-sized planes. */
+  typedef struct
+  {
+    float *base;         /* plane of image 0 */
+    uint32_t w, h;       /* valid extent */
+    uint32_t pitch;      /* floats per row */
+    uint64_t img_stride; /* floats between consecutive images of the batch */
+  } vksift_hip_Plane;
+
+  /* vkCmdCopyBufferToImage + vkCmdBlitImage(LINEAR) of sift_detector.c:881,909-916:
+   * u8 row-major images (src_stride bytes between images) -> fp32 plane, value/255, bilinear 2x (or
+   * 1:1 copy when the sizes match), clamp-to-edge. */
+  int vksift_hip_input_blit(const uint8_t *src, uint32_t sw, uint32_t sh, uint64_t src_img_stride, vksift_hip_Plane dst, uint32_t batch,
+                            vksift_hip_stream s);
+
+  /* One Gaussian scale step = the H and V GaussianBlur*.comp dispatches of sift_detector.c:927-1001
+   * fused through LDS, plus (dog.base != NULL) the DifferenceOfGaussian.comp layer dst - src
+   * (sift_detector.c:1039-1079). taps[0..ntaps) are one-sided direct weights, centre first; the
+   * borders use mirrored-repeat addressing. src and dst must not alias. */
+  int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const float *taps, uint32_t ntaps, uint32_t batch,
+                      vksift_hip_stream s);
+
+  /* vkCmdBlitImage(NEAREST) of sift_detector.c:1003-1034: dst(x,y) = src(floor((x+.5)*sw/dw), ...). */
+  int vksift_hip_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, uint32_t batch, vksift_hip_stream s);
+
+  /* ------------------------------------------------------------------ keypoints */
+  typedef struct
+  {
+    float *dog;          /* DoG layer 0 of image 0 of this octave */
+    float *gauss;        /* Gaussian layer 0 of image 0 */
+    uint32_t w, h, pitch;
+    uint64_t plane_stride; /* floats between layers */
+    uint64_t img_stride;   /* floats between images */
+    uint32_t S;            /* scales per octave */
+    int32_t octave_idx;    /* octave index minus 1 when up-sampling (sift_detector.c:1134) */
+    float seed_sigma;
+    float dog_threshold;   /* intensity_threshold / S (sift_detector.c:1136) */
+    float edge_limit;      /* (edge+1)^2/edge (ExtractKeypoints.comp:203) */
+    /* SIFT buffer section of this octave for image 0; image b uses + b*feat_img_stride bytes */
+    uint8_t *feats;        /* vksift_Feature records */
+    uint64_t feat_img_stride; /* bytes */
+    uint32_t cap;          /* section capacity (max_nb_feat) */
+    uint32_t *found;       /* per image: counter of this octave, image b at found[b*found_img_stride] */
+    uint32_t found_img_stride;
+    /* scratch, per image: */
+    uint64_t *seg_mask;    /* S*h*nseg words, nseg = ceil(w/64) */
+    uint32_t *seg_off;     /* same count */
+    uint64_t seg_img_stride; /* elements between images (both arrays) */
+    float *ori_ang;        /* cap*VKSIFT_HIP_MAX_ORI floats */
+    uint32_t *ori_cnt;     /* cap */
+    uint64_t ori_img_stride; /* in keypoints */
+    uint32_t max_ori;      /* max_nb_orientation_per_keypoint (0 = unlimited) */
+    uint32_t use_vlfeat;
+    const float *desc_fp_tab; /* fixed-point multipliers indexed by R/2 (ComputeDescriptors.comp:116-124) */
+    uint32_t desc_fp_tab_len;
+  } vksift_hip_OctaveJob;
+
+  /* ExtractKeypoints.comp (sift_detector.c:1106-1189) as a deterministic 3-step compaction:
+   * detect+refine -> per-64-pixel-segment ballot masks; exclusive scan; emit in raster order.
+   * found[] receives the un-clamped keypoint count. */
+  int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s);
+  /* ComputeOrientation.comp (sift_detector.c:1191-1241): main orientation written in place, extra
+   * orientations appended in (keypoint, bin) order; found[] updated. */
+  int vksift_hip_orientations(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s);
+  /* ComputeDescriptors.comp (sift_detector.c:1243-1259). */
+  int vksift_hip_descriptors(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s);
+
+  /* ------------------------------------------------------------------ matcher */
+  /* Get2NearestNeighbors.comp (sift_matcher.c:246-279). feats_* are packed vksift_Feature arrays
+   * (stride 164 B). desc_a/desc_b are scratch for the dense 128-byte descriptor rows (na*128,
+   * max(nb,2)*128 bytes). matches: na records of 20 B. */
+  int vksift_hip_match_2nn(const uint8_t *feats_a, uint32_t na, const uint8_t *feats_b, uint32_t nb, uint8_t *desc_a, uint8_t *desc_b, uint8_t *matches,
+                           vksift_hip_stream s);
+  /* Same on dense descriptor matrices already in HBM (rows of 128 B, 16-byte aligned); row indices
+   * written to idx_a are a_index_base + row. Used by the query-sharded multi-GPU matcher. */
+  int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint8_t *matches,
+                                vksift_hip_stream s);
+  /* AoS -> dense descriptor rows */
+  int vksift_hip_gather_descriptors(const uint8_t *feats, uint32_t n, uint8_t *desc, vksift_hip_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKSIFT_HIP_H */

@@ -1,0 +1,95 @@
+"""GPU parity: the HIP path (through the vksift_* C-ABI) against the CPU oracle.
+
+The oracle runs in its "det" math mode (shared detmath.h) for bit-exact checks, and in libm mode for
+the tolerance checks that bound how far any IEEE-ish exp/atan implementation may move the result.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfgs(vk, oracle, **kw):
+    okw = {}
+    vkw = {}
+    for k, v in kw.items():
+        if k in ("use_input_upsampling", "use_hardware_interpolated_blur"):
+            okw[k] = int(v)
+            vkw[k] = bool(v)
+        elif k == "descriptor_format":
+            okw["use_vlfeat_format"] = int(v)
+            vkw[k] = int(v)
+        else:
+            okw[k] = v
+            vkw[k] = v
+    return vk.default_config(**vkw), oracle.default_config(math_mode=1, **okw)
+
+
+@pytest.mark.parametrize("w,h,kw", [
+    (320, 240, {}),
+    (200, 150, {"use_input_upsampling": False}),
+    (257, 131, {"use_hardware_interpolated_blur": False}),
+])
+def test_pyramid_bit_exact(vk, oracle, w, h, kw):
+    vcfg, ocfg = _cfgs(vk, oracle, **kw)
+    img = vk.gen_synthetic_image(7, w, h)
+    with vk.Instance(vcfg) as inst:
+        inst.detectFeatures(img, 0)
+        pyr = oracle.Pyramid(ocfg, img)
+        assert inst.getScaleSpaceNbOctaves() == pyr.nb_octaves
+        S = vcfg.nb_scales_per_octave
+        for o in range(pyr.nb_octaves):
+            assert inst.getScaleSpaceOctaveResolution(o) == pyr.resolution(o)
+            for s in range(S + 3):
+                g = inst.downloadScaleSpaceImage(o, s)
+                ref = pyr.gauss(o, s)
+                assert np.array_equal(g.view(np.uint32), ref.view(np.uint32)), (o, s, np.abs(g - ref).max())
+            for s in range(S + 2):
+                d = inst.downloadDoGImage(o, s)
+                ref = pyr.dog(o, s)
+                assert np.array_equal(d.view(np.uint32), ref.view(np.uint32)), (o, s, np.abs(d - ref).max())
+
+
+@pytest.mark.parametrize("w,h,kw", [
+    (320, 240, {}),
+    (200, 150, {"use_input_upsampling": False}),
+    (320, 240, {"descriptor_format": 1, "max_nb_orientation_per_keypoint": 0}),
+])
+def test_features_bit_exact(vk, oracle, w, h, kw):
+    vcfg, ocfg = _cfgs(vk, oracle, **kw)
+    img = vk.gen_synthetic_image(11, w, h)
+    with vk.Instance(vcfg) as inst:
+        inst.detectFeatures(img, 0)
+        feats = inst.downloadFeatures(0)
+    ref, counts = oracle.detect(ocfg, img)
+    assert len(feats) == len(ref) and len(ref) > 50
+    for name in ("scale_idx", "octave_idx"):
+        assert np.array_equal(feats[name], ref[name]), name
+    for name in ("x", "y", "scale_x", "scale_y", "sigma", "orientation", "intensity"):
+        assert np.array_equal(feats[name].view(np.uint32), ref[name].view(np.uint32)), name
+    assert np.array_equal(feats["descriptor"], ref["descriptor"])
+
+
+def test_match_bit_exact(vk, oracle):
+    a = vk.gen_synthetic_descriptors(1, 1000)
+    b = vk.gen_synthetic_descriptors(2, 777)
+    b[5] = b[3]            # duplicate rows: equal distances, earlier index must win
+    b[1] = b[0]            # tie between b[0] and b[1]: index 1 becomes best (quirk Q7)
+    a[10] = b[0]
+    fa = np.zeros(len(a), vk.FEATURE_DTYPE)
+    fb = np.zeros(len(b), vk.FEATURE_DTYPE)
+    fa["descriptor"] = a
+    fb["descriptor"] = b
+    cfg = vk.default_config()
+    with vk.Instance(cfg) as inst:
+        inst.uploadFeatures(fa, 0)
+        inst.uploadFeatures(fb, 1)
+        inst.matchFeatures(0, 1)
+        assert inst.getMatchesNumber() == len(a)
+        m = inst.downloadMatches()
+    ref = oracle.match_2nn(a, b)
+    for name in ("idx_a", "idx_b1", "idx_b2"):
+        assert np.array_equal(m[name], ref[name]), name
+    assert np.array_equal(m["dist_a_b1"].view(np.uint32), ref["dist_a_b1"].view(np.uint32))
+    assert np.array_equal(m["dist_a_b2"].view(np.uint32), ref["dist_a_b2"].view(np.uint32))
+    assert m["idx_b1"][10] == 1 and m["idx_b2"][10] == 0

@@ -1,0 +1,88 @@
+"""Build libvulkansift.so in-tree: gcc for the C host, hipcc (gfx950) for the kernels.
+
+    python -m vulkansift_amd.build [--force]
+
+The shared library lands in vulkansift_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).
+hipcc cross-compiles gfx950 without a GPU, so this also serves as the "does it build" check.
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+OUT_DIR = os.path.join(PKG, "lib")
+OBJ_DIR = os.path.join(OUT_DIR, "obj")
+LIB_PATH = os.path.join(OUT_DIR, "libvulkansift.so")
+
+HOST_SRCS = ["host/vksift_api.c", "host/vksift_hostmath.c", "host/vksift_log.c", "host/vksift_synth.c"]
+HIP_SRCS = ["hip/runtime.hip", "hip/pyramid.hip", "hip/extrema.hip", "hip/features.hip", "hip/match.hip"]
+
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+INCLUDES = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "host"), "-I" + CSRC]
+
+# -ffp-contract=off: fused multiply-adds are spelled fmaf() in the sources; nothing else may be
+# contracted, so the kernels stay bit-identical to the CPU oracle (see csrc/detmath.h).
+CFLAGS = ["-O2", "-std=gnu11", "-fPIC", "-fexceptions", "-ffp-contract=off", "-fno-fast-math", "-mavx2", "-mfma", "-Wall", "-Wextra",
+          "-Wno-unused-parameter"]
+HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+            "-fno-gpu-rdc"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _all_headers():
+    hs = []
+    for d in (os.path.join(ROOT, "include"), CSRC):
+        for base, _, files in os.walk(d):
+            hs += [os.path.join(base, f) for f in files if f.endswith(".h")]
+    return hs
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError("build step failed: " + os.path.basename(cmd[-1]))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = _all_headers()
+    objs = []
+    for src in HOST_SRCS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            if verbose:
+                print("[cc ]", src)
+            _run(["gcc"] + CFLAGS + INCLUDES + ["-DVKSIFT_BUILD", "-c", s, "-o", o])
+    for src in HIP_SRCS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            if verbose:
+                print("[hip]", src)
+            _run([HIPCC] + HIPFLAGS + INCLUDES + ["-c", s, "-o", o])
+    if force or _newer(LIB_PATH, objs):
+        if verbose:
+            print("[ld ]", os.path.relpath(LIB_PATH, ROOT))
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs +
+             ["-L" + os.path.join(ROCM, "lib"), "-lroctx64", "-lm", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, verbose=True)
+    print(p)

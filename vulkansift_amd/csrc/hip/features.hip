@@ -1,0 +1,419 @@
+// features.hip — keypoint orientation assignment and 4x4x8 descriptor extraction (gfx950, wave64).
+//
+// Replaces ComputeOrientation.comp (dispatch sift_detector.c:1191-1241) and ComputeDescriptors.comp
+// (sift_detector.c:1243-1259). The reference launches them with vkCmdDispatchIndirect, one small
+// workgroup per keypoint; HIP has no indirect dispatch, so both kernels are persistent grid-stride
+// loops that read the keypoint count from HBM. One 64-lane wave owns one keypoint; histograms are
+// accumulated with integer LDS atomics (ds_add_u32) on the reference's fixed-point scale, so the
+// result does not depend on the order in which lanes arrive (bit-reproducible run to run).
+//
+// Extra orientations are appended through a prefix scan (k_orientation_finalize) instead of the
+// reference's global atomicAdd (ComputeOrientation.comp:170-183): order = (keypoint, histogram bin).
+//
+// All per-pixel arithmetic mirrors oracle/sift_oracle.c (orc_orientations / orc_descriptor) in its
+// "det" math mode operation for operation; exp/atan2/sin/cos come from detmath.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../detmath.h"
+#include "vksift_hip.h"
+
+namespace
+{
+
+#define PI_F 3.14159265358979323846f
+
+struct GaussView
+{
+  const float *base; // Gaussian layer 0 of this image/octave
+  int w, h, pitch;
+  size_t plane;
+};
+
+// imageLoad with robust out-of-bounds behaviour (returns 0) — quirk Q2 relies on it.
+__device__ __forceinline__ float ldg(const GaussView &g, const float *layer, int x, int y)
+{
+  if ((unsigned)x >= (unsigned)g.w || (unsigned)y >= (unsigned)g.h)
+    return 0.f;
+  return layer[(size_t)y * g.pitch + x];
+}
+
+struct FeatArgs
+{
+  const float *gauss;
+  int w, h, pitch;
+  uint64_t plane_stride, img_stride;
+  uint8_t *feats;
+  uint64_t feat_img_stride;
+  uint32_t cap;
+  uint32_t *found;
+  uint32_t found_img_stride;
+  float *ori_ang;
+  uint32_t *ori_cnt;
+  uint64_t ori_img_stride;
+  uint32_t max_keep; // orientations kept per keypoint (1..18)
+  uint32_t use_vlfeat;
+  const float *desc_fp_tab;
+  uint32_t desc_fp_tab_len;
+};
+
+// -------------------------------------------------------------------------------------------------
+// Orientation histogram (ComputeOrientation.comp:52-186). grid = (blocks, batch); 4 keypoints/block.
+// -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
+{
+  __shared__ uint32_t s_hist[4][36];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const uint32_t found = a.found[(size_t)b * a.found_img_stride];
+  const uint32_t n0 = found < a.cap ? found : a.cap;
+  GaussView g{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride};
+  uint8_t *feats = a.feats + (size_t)b * a.feat_img_stride;
+
+  for (uint32_t base = blockIdx.x * 4; base < n0; base += gridDim.x * 4)
+  {
+    const uint32_t k = base + wave;
+    const bool active = k < n0;
+    if (lane < 36)
+      s_hist[wave][lane] = 0;
+    __syncthreads();
+    float fp = 0.f;
+    if (active)
+    {
+      const float *rec = (const float *)(feats + (size_t)k * 164);
+      const float scale_x = rec[2], scale_y = rec[3];
+      const uint32_t scale_idx = ((const uint32_t *)rec)[4];
+      const int octave_idx = ((const int *)rec)[5];
+      const float sigma = rec[6];
+      const float *layer = g.base + (size_t)scale_idx * g.plane;
+
+      float scale_factor = dm_pow2i(octave_idx);
+      float lambda = 1.5f * (sigma / scale_factor);
+      int r = (int)floorf(3 * lambda);
+      float es = -1.f / (2.f * lambda * lambda);
+
+      // fixed-point scale: M = (sum_i e^{es i^2})^2 * sqrt(2)  (separable form of :75-79, same order as the oracle's det mode)
+      float gsum = 1.f;
+      for (int cb = 0; cb <= r; cb += 64)
+      {
+        int i = cb + lane;
+        float e = (i >= 1 && i <= r) ? dm_expf(es * (float)(i * i)) : 0.f;
+        int lim = r - cb < 63 ? r - cb : 63;
+        for (int j = 0; j <= lim; j++)
+        {
+          float ej = __shfl(e, j, 64);
+          if (cb + j >= 1)
+            gsum += 2.f * ej;
+        }
+      }
+      float M = (gsum * gsum) * sqrtf(2.f);
+      fp = (float)(1u << (uint32_t)(30 - dm_ceil_log2f(M)));
+
+      float rsx = roundf(scale_x), rsy = roundf(scale_y);
+      int box = 2 * r + 1;
+      int npix = box * box;
+      for (int pix = lane; pix < npix; pix += 64)
+      {
+        int dy = (pix / box) - r, dx = (pix % box) - r;
+        int gx = (int)rsx + dx, gy = (int)rsy + dy;
+        float sdx = (rsx + (float)dx) - scale_x;
+        float sdy = (rsy + (float)dy) - scale_y;
+        float d2 = (sdx * sdx) + (sdy * sdy);
+        if ((gx < 1 || gx >= (g.w - 1) || gy < 1 || gy >= (g.h - 1)) && (d2 > (float)(r * r)))
+          continue; // quirk Q2 ('&&')
+        float gradX = 0.5f * (ldg(g, layer, gx + 1, gy) - ldg(g, layer, gx - 1, gy));
+        float gradY = 0.5f * (ldg(g, layer, gx, gy + 1) - ldg(g, layer, gx, gy - 1));
+        float mag = dm_expf(d2 * es) * sqrtf((gradX * gradX) + (gradY * gradY));
+        float ori = dm_atan2f(gradY, gradX);
+        if (ori < 0)
+          ori += 2.f * PI_F;
+        else if (ori > (2.f * PI_F))
+          ori -= 2.f * PI_F;
+        int bin = (int)((ori * 36.f / (2.f * PI_F)));
+        if (bin < 0)
+          bin += 36;
+        else if (bin >= 36)
+          bin -= 36;
+        atomicAdd(&s_hist[wave][bin], (uint32_t)(mag * fp));
+      }
+    }
+    __syncthreads();
+    if (active)
+    {
+      // 3 x 2 box-filter passes in registers (lane i holds bin i), :130-147
+      const int li = lane < 36 ? lane : 0;
+      uint32_t hv = s_hist[wave][li];
+      const int lm = (li + 35) % 36, lp = (li + 1) % 36;
+#pragma unroll
+      for (int it = 0; it < 6; it++)
+      {
+        uint32_t hm = __shfl(hv, lm, 64), hp = __shfl(hv, lp, 64);
+        hv = (uint32_t)((float)(hm + hv + hp) / 3.f);
+      }
+      uint32_t hm = __shfl(hv, lm, 64), hp = __shfl(hv, lp, 64);
+      uint32_t mx = lane < 36 ? hv : 0u;
+#pragma unroll
+      for (int dlt = 32; dlt >= 1; dlt >>= 1)
+      {
+        uint32_t t = __shfl_xor(mx, dlt, 64);
+        mx = t > mx ? t : mx;
+      }
+      bool peak = lane < 36 && ((float)hv >= (0.8f * (float)mx)) && (hv > hm) && (hv > hp);
+      unsigned long long pm = __ballot(peak);
+      uint32_t npk = (uint32_t)__popcll(pm);
+      if (peak)
+      {
+        uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+        if (rank < a.max_keep)
+        {
+          uint32_t num = hm - hp;                 // quirk Q3: uint32 wrap-around
+          uint32_t den = hm - (2u * hv) + hp;
+          float idx = (float)lane + 0.5f * ((float)num / (float)den);
+          float ang = (idx + 0.5f) * (2.f * PI_F) / 36.f;
+          a.ori_ang[((size_t)b * a.ori_img_stride + k) * VKSIFT_HIP_MAX_ORI + rank] = ang;
+        }
+      }
+      if (lane == 0)
+        a.ori_cnt[(size_t)b * a.ori_img_stride + k] = npk < a.max_keep ? npk : a.max_keep;
+    }
+    __syncthreads();
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Write main orientations in place and append the extra-orientation copies in (keypoint, bin) order
+// (ComputeOrientation.comp:170-183, made deterministic). One 1024-thread block per image.
+// -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_orientation_finalize(FeatArgs a)
+{
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t found = a.found[(size_t)b * a.found_img_stride];
+  const uint32_t n0 = found < a.cap ? found : a.cap;
+  uint8_t *feats = a.feats + (size_t)b * a.feat_img_stride;
+  const uint32_t *cnt = a.ori_cnt + (size_t)b * a.ori_img_stride;
+  const float *ang = a.ori_ang + (size_t)b * a.ori_img_stride * VKSIFT_HIP_MAX_ORI;
+  if (threadIdx.x == 0)
+    carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n0; base += 1024)
+  {
+    uint32_t k = base + threadIdx.x;
+    uint32_t c = k < n0 ? cnt[k] : 0u;
+    uint32_t v = c > 1 ? c - 1 : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1)
+    {
+      uint32_t t = __shfl_up(incl, dlt, 64);
+      if (lane >= dlt)
+        incl += t;
+    }
+    if (lane == 63)
+      wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    for (int wv = 0; wv < wave; wv++)
+      wave_base += wave_tot[wv];
+    uint32_t carry = carry_s;
+    uint32_t excl = carry + wave_base + incl - v;
+    if (k < n0 && c >= 1)
+    {
+      uint32_t *rec = (uint32_t *)(feats + (size_t)k * 164);
+      rec[7] = __float_as_uint(ang[(size_t)k * VKSIFT_HIP_MAX_ORI]);
+      for (uint32_t j = 1; j < c; j++)
+      {
+        uint32_t idx = found + excl + (j - 1);
+        if (idx < a.cap)
+        {
+          uint32_t *dst = (uint32_t *)(feats + (size_t)idx * 164);
+#pragma unroll
+          for (int q = 0; q < 9; q++)
+            dst[q] = rec[q];
+          dst[7] = __float_as_uint(ang[(size_t)k * VKSIFT_HIP_MAX_ORI + j]);
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023)
+      carry_s = carry + wave_base + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    a.found[(size_t)b * a.found_img_stride] = found + carry_s;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Descriptor (ComputeDescriptors.comp:84-274). grid = (blocks, batch); 4 keypoints per block.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int smod8(int v) { return v & 7; } // floored modulo for a power of two (quirk Q5, OpSMod)
+
+__global__ void __launch_bounds__(256) k_descriptor(FeatArgs a)
+{
+  __shared__ uint32_t s_work[4][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const uint32_t found = a.found[(size_t)b * a.found_img_stride];
+  const uint32_t n1 = found < a.cap ? found : a.cap;
+  GaussView g{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride};
+  uint8_t *feats = a.feats + (size_t)b * a.feat_img_stride;
+
+  for (uint32_t base = blockIdx.x * 4; base < n1; base += gridDim.x * 4)
+  {
+    const uint32_t k = base + wave;
+    const bool active = k < n1;
+    s_work[wave][lane] = 0;
+    s_work[wave][lane + 64] = 0;
+    __syncthreads();
+    if (active)
+    {
+      const float *rec = (const float *)(feats + (size_t)k * 164);
+      const float scale_x = rec[2], scale_y = rec[3];
+      const uint32_t scale_idx = ((const uint32_t *)rec)[4];
+      const int octave_idx = ((const int *)rec)[5];
+      const float sigma = rec[6], kori = rec[7];
+      const float *layer = g.base + (size_t)scale_idx * g.plane;
+
+      float scale_factor = dm_pow2i(octave_idx);
+      float lambda = 3.0f * (sigma / scale_factor);
+      float radius = sqrtf(2.f) * lambda * 5.f * 0.5f;
+      int R = (int)floorf(radius + 0.5f);
+      float sn, cs;
+      dm_sincosf(kori, &sn, &cs);
+      float kcos = cs / lambda, ksin = sn / lambda;
+      const float es = -1.f / (2.f * 2 * 2);
+      uint32_t ti = (uint32_t)(R / 2);
+      float fp = a.desc_fp_tab[ti < a.desc_fp_tab_len ? ti : a.desc_fp_tab_len - 1];
+
+      float rsx = roundf(scale_x), rsy = roundf(scale_y);
+      int box = 2 * R + 1;
+      int npix = box * box;
+      for (int pix = lane; pix < npix; pix += 64)
+      {
+        int dy = (pix / box) - R, dx = (pix % box) - R;
+        int ix = (int)rsx + dx, iy = (int)rsy + dy;
+        float sdx = (rsx + (float)dx) - scale_x;
+        float sdy = (rsy + (float)dy) - scale_y;
+        if (ix < 1 || ix >= (g.w - 1) || iy < 1 || iy >= (g.h - 1))
+          continue;
+        float ox = kcos * sdx + ksin * sdy;
+        float oy = kcos * sdy - ksin * sdx;
+        float gradX = 0.5f * (layer[(size_t)iy * g.pitch + ix + 1] - layer[(size_t)iy * g.pitch + ix - 1]);
+        float gradY = 0.5f * (layer[(size_t)(iy + 1) * g.pitch + ix] - layer[(size_t)(iy - 1) * g.pitch + ix]);
+        float ori = dm_atan2f(gradY, gradX);
+        if (ori < 0)
+          ori += 2.f * PI_F;
+        else if (ori > (2.f * PI_F))
+          ori -= 2.f * PI_F;
+        ori = ori - kori;
+        if (ori < 0)
+          ori += 2.f * PI_F;
+        else if (ori > (2.f * PI_F))
+          ori -= 2.f * PI_F;
+        float mag = dm_expf(es * ((ox * ox) + (oy * oy))) * sqrtf((gradX * gradX) + (gradY * gradY));
+
+        float fhx = ox + 2.f, fhy = oy + 2.f;
+        float fbin = a.use_vlfeat ? (ori * 8.f / (2.f * PI_F)) : (-ori * 8.f / (2.f * PI_F));
+        int hx = (int)floorf(fhx - 0.5f), hy = (int)floorf(fhy - 0.5f), hb = (int)floorf(fbin);
+        float rhx = fhx - ((float)hx + 0.5f), rhy = fhy - ((float)hy + 0.5f), rb = fbin - (float)hb;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++)
+              if ((i + hx) >= 0 && (i + hx) < 4 && (j + hy) >= 0 && (j + hy) < 4)
+              {
+                int idx = (j + hy) * 32 + (i + hx) * 8 + smod8(kk + hb);
+                float val = fabsf(1.f - (float)i - rhx) * fabsf(1.f - (float)j - rhy) * fabsf(1.f - (float)kk - rb) * mag;
+                atomicAdd(&s_work[wave][idx], (uint32_t)(val * fp));
+              }
+      }
+    }
+    __syncthreads();
+    if (active)
+    {
+      // normalise -> clamp at 0.2*norm -> renormalise -> x512 -> u8 (:200-265)
+      uint32_t w0 = s_work[wave][lane], w1 = s_work[wave][lane + 64];
+      uint32_t acc = w0 * w0 + w1 * w1;
+#pragma unroll
+      for (int dlt = 32; dlt >= 1; dlt >>= 1)
+        acc += __shfl_xor(acc, dlt, 64);
+      float norm = sqrtf((float)acc);
+      uint32_t lim = (uint32_t)(norm * 0.2f);
+      w0 = w0 < lim ? w0 : lim;
+      w1 = w1 < lim ? w1 : lim;
+      acc = w0 * w0 + w1 * w1;
+#pragma unroll
+      for (int dlt = 32; dlt >= 1; dlt >>= 1)
+        acc += __shfl_xor(acc, dlt, 64);
+      norm = sqrtf((float)acc);
+      float scale = 512.f / norm;
+      float v0 = (float)w0 * scale, v1 = (float)w1 * scale;
+      uint32_t b0 = (v0 != v0) ? 0u : (v0 < 0.f ? 0u : (v0 > 255.f ? 255u : (uint32_t)v0));
+      uint32_t b1 = (v1 != v1) ? 0u : (v1 < 0.f ? 0u : (v1 > 255.f ? 255u : (uint32_t)v1));
+      // pack 4 consecutive bytes per dword: lanes 4q..4q+3 hold bytes of dword q (first half) / q+16 (second half)
+      uint32_t sh = (uint32_t)(lane & 3) * 8u;
+      uint32_t p0 = b0 << sh, p1 = b1 << sh;
+      p0 |= __shfl_xor(p0, 1, 64);
+      p0 |= __shfl_xor(p0, 2, 64);
+      p1 |= __shfl_xor(p1, 1, 64);
+      p1 |= __shfl_xor(p1, 2, 64);
+      if ((lane & 3) == 0)
+      {
+        uint32_t *desc = (uint32_t *)(feats + (size_t)k * 164 + 36);
+        desc[lane >> 2] = p0;
+        desc[16 + (lane >> 2)] = p1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+FeatArgs make_args(const vksift_hip_OctaveJob *job)
+{
+  FeatArgs a;
+  a.gauss = job->gauss;
+  a.w = (int)job->w, a.h = (int)job->h, a.pitch = (int)job->pitch;
+  a.plane_stride = job->plane_stride, a.img_stride = job->img_stride;
+  a.feats = job->feats, a.feat_img_stride = job->feat_img_stride, a.cap = job->cap;
+  a.found = job->found, a.found_img_stride = job->found_img_stride;
+  a.ori_ang = job->ori_ang, a.ori_cnt = job->ori_cnt, a.ori_img_stride = job->ori_img_stride;
+  uint32_t mk = job->max_ori == 0 ? VKSIFT_HIP_MAX_ORI : job->max_ori;
+  a.max_keep = mk > VKSIFT_HIP_MAX_ORI ? VKSIFT_HIP_MAX_ORI : mk;
+  a.use_vlfeat = job->use_vlfeat;
+  a.desc_fp_tab = job->desc_fp_tab, a.desc_fp_tab_len = job->desc_fp_tab_len;
+  return a;
+}
+
+} // namespace
+
+extern "C"
+{
+  int vksift_hip_orientations(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s)
+  {
+    FeatArgs a = make_args(job);
+    uint32_t blocks = (job->cap + 3) / 4;
+    if (blocks > 1024)
+      blocks = 1024;
+    if (blocks == 0)
+      blocks = 1;
+    hipLaunchKernelGGL(k_orientation, dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
+    hipLaunchKernelGGL(k_orientation_finalize, dim3(batch), dim3(1024), 0, (hipStream_t)s, a);
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_descriptors(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s)
+  {
+    FeatArgs a = make_args(job);
+    uint32_t blocks = (job->cap + 3) / 4;
+    if (blocks > 2048)
+      blocks = 2048;
+    if (blocks == 0)
+      blocks = 1;
+    hipLaunchKernelGGL(k_descriptor, dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
+    return (int)hipGetLastError();
+  }
+}

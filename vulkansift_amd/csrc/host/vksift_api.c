@@ -1,0 +1,1108 @@
+/*
+ * vksift_api.c — the vksift_* C API over the HIP kernel layer (include/vksift_hip.h).
+ *
+ * Mirrors the behaviour of the reference façade src/vulkansift/vulkansift.c (validation, error
+ * callback contract, blocking/asynchronous split) and the bookkeeping part of
+ * src/vulkansift/sift_memory.c (octave geometry, SIFT-buffer sections, packed/sectioned state,
+ * count read-back), with Vulkan objects replaced by plain HBM allocations:
+ *
+ *   pyramid   one allocation; per image: for each octave (S+3) Gaussian planes then (S+2) DoG planes,
+ *             fp32, row pitch padded to 64 floats (256 B)
+ *   buffers   sift_buffer_count x max_nb_sift_per_buffer records of 164 B; after a detection a buffer
+ *             is "sectioned" (one section per octave, capacities from sift_memory.c:40-87), after an
+ *             upload it is one packed section
+ *   counters  found[buffer][octave] u32 in HBM + a pinned host mirror filled by an async copy at
+ *             the end of every detection (replaces the HOST_VISIBLE count staging buffers)
+ *   streams   one HIP stream per instance = the reference's single general queue; two events play
+ *             the role of end_of_detection_fence / end_of_matching_fence
+ *
+ * Built as C with -fexceptions: user error callbacks may throw through these frames
+ * (vulkansift_types.h:148-152 of the reference).
+ */
+#include "vksift_ext.h"
+#include "vksift_hip.h"
+#include "vksift_hostmath.h"
+#include "vksift_log.h"
+#include "vulkansift/vulkansift.h"
+
+#include <assert.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static const char LOG_TAG[] = "VulkanSift";
+
+#define FEAT_BYTES 164u
+#define MATCH_BYTES 20u
+#define PITCH_ALIGN 64u
+#define DESC_FP_TAB_MAX 1024u
+
+typedef struct
+{
+  bool is_packed;       /* true: one section [0, nb_stored) (after upload / after matching) */
+  uint32_t nb_stored;   /* valid when is_packed */
+  uint32_t nb_sections; /* octaves of the detection that last filled the buffer */
+  uint32_t sec_off[VKSIFT_MAX_OCTAVES]; /* in features */
+  uint32_t sec_cap[VKSIFT_MAX_OCTAVES];
+  uint32_t in_w, in_h;  /* resolution of that detection */
+} BufferInfo;
+
+typedef struct
+{
+  uint32_t n_oct;
+  uint32_t w[VKSIFT_MAX_OCTAVES], h[VKSIFT_MAX_OCTAVES], pitch[VKSIFT_MAX_OCTAVES];
+  uint64_t plane_stride[VKSIFT_MAX_OCTAVES]; /* floats */
+  uint64_t gauss_off[VKSIFT_MAX_OCTAVES];    /* floats from the image's pyramid base */
+  uint64_t dog_off[VKSIFT_MAX_OCTAVES];
+  uint64_t img_floats; /* floats used by one image */
+} PyrLayout;
+
+struct vksift_Instance_T
+{
+  vksift_Config cfg;
+  void (*error_cb)(vksift_Result);
+  int device;
+  uint32_t S;
+  uint32_t max_image_size; /* rounded up to a square, sift_memory.c:644-647 */
+  uint32_t max_octaves;
+  uint32_t batch_cap;
+
+  /* blur taps */
+  float taps[(VKSIFT_MAX_SCALES + 3) * VKSIFT_MAX_TAPS];
+  uint32_t ntaps[VKSIFT_MAX_SCALES + 3];
+
+  /* current scale-space */
+  uint32_t cur_w, cur_h, cur_batch;
+  PyrLayout lay;
+
+  /* device memory */
+  float *d_pyr;
+  uint64_t pyr_img_stride; /* floats reserved per image */
+  uint8_t *d_input, *h_input;
+  uint8_t *d_feats;
+  uint64_t buf_stride; /* bytes */
+  uint32_t *d_found, *h_found;
+  uint64_t *d_seg_mask;
+  uint32_t *d_seg_off;
+  uint64_t seg_cap; /* elements reserved per image */
+  float *d_ori_ang;
+  uint32_t *d_ori_cnt;
+  uint64_t ori_cap; /* keypoints reserved per image */
+  float *d_desc_fp;
+  uint32_t desc_fp_len;
+  uint8_t *d_desc_a, *d_desc_b, *d_matches, *h_matches;
+  BufferInfo *bufs;
+
+  vksift_hip_stream stream;
+  vksift_hip_event ev_detect, ev_match;
+  bool detect_pending, match_pending;
+  uint32_t detect_first_buf, detect_count;
+  uint32_t match_a, match_b;
+  uint32_t curr_nb_matches;
+
+  /* profiling */
+  bool profiling;
+  vksift_hip_event ev_t[8];
+  vksift_hip_event ev_m[2];
+  bool timings_valid, match_timing_valid;
+  uint32_t last_blur_launches;
+  uint64_t last_alg_bytes;
+  bool device_input_last;
+};
+
+static bool g_loaded = false;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* defaults + validation (vulkansift.c:31-66, 550-661)                                              */
+/* ------------------------------------------------------------------------------------------------ */
+static void default_error_callback(vksift_Result err)
+{
+  if (err == VKSIFT_INVALID_INPUT_ERROR)
+    logDebug(LOG_TAG, "Aborting after invalid input error...");
+  else if (err == VKSIFT_VULKAN_ERROR)
+    logDebug(LOG_TAG, "Aborting after GPU runtime error...");
+  abort();
+}
+
+vksift_Config vksift_getDefaultConfig()
+{
+  vksift_Config c;
+  memset(&c, 0, sizeof(c));
+  c.input_image_max_size = 1920u * 1080u;
+  c.sift_buffer_count = 2u;
+  c.max_nb_sift_per_buffer = 100000u;
+  c.use_input_upsampling = true;
+  c.nb_octaves = 0;
+  c.nb_scales_per_octave = 3u;
+  c.input_image_blur_level = 0.5f;
+  c.seed_scale_sigma = 1.6f;
+  c.intensity_threshold = 0.04f;
+  c.edge_threshold = 10.f;
+  c.max_nb_orientation_per_keypoint = 4; /* the code default of the reference (its header comment says 0) */
+  c.descriptor_format = VKSIFT_DESCRIPTOR_FORMAT_UBC;
+  c.gpu_device_index = -1;
+  c.use_hardware_interpolated_blur = true;
+  c.pyramid_precision_mode = VKSIFT_PYRAMID_PRECISION_FLOAT32;
+  c.on_error_callback_function = default_error_callback;
+  c.use_gpu_debug_functions = false;
+  c.gpu_debug_external_window_info.context = NULL;
+  c.gpu_debug_external_window_info.window = NULL;
+  return c;
+}
+
+static bool cfg_check(bool cond, const char *msg)
+{
+  if (!cond)
+    logError(LOG_TAG, "%s", msg);
+  return cond;
+}
+
+static bool config_is_valid(const vksift_Config *c)
+{
+  bool ok = true;
+  ok &= cfg_check(c->input_image_max_size >= 1024, "Invalid configuration: input image size must be greater than or equal to 1024");
+  ok &= cfg_check(c->sift_buffer_count > 0, "Invalid configuration: number of SIFT buffers must be greater than zero");
+  ok &= cfg_check(c->max_nb_sift_per_buffer > 0, "Invalid configuration: number of SIFT features per buffers must be greater than zero");
+  ok &= cfg_check(c->nb_scales_per_octave > 0, "Invalid configuration: number of scales per octave must be greater than zero");
+  ok &= cfg_check(c->nb_scales_per_octave <= VKSIFT_MAX_SCALES, "Invalid configuration: number of scales per octave is limited to 13 in this build");
+  ok &= cfg_check(c->input_image_blur_level >= 0.f, "Invalid configuration: input image blur level cannot be negative");
+  ok &= cfg_check(c->seed_scale_sigma >= 0, "Invalid configuration: seed scale blur level cannot be negative");
+  ok &= cfg_check(((c->use_input_upsampling ? 2.f : 1.f) * c->input_image_blur_level) <= c->seed_scale_sigma,
+                  "Invalid configuration: the input image blur level (2x if upscaling activated) must be less than the seed scale blur level");
+  ok &= cfg_check(c->intensity_threshold >= 0.f, "Invalid configuration: the DoG intensity threshold cannot be negative");
+  ok &= cfg_check(c->edge_threshold >= 0.f, "Invalid configuration: the DoG edge threshold cannot be negative");
+  ok &= cfg_check(c->on_error_callback_function != NULL, "Invalid configuration: the error callback function must not be NULL");
+  switch (c->pyramid_precision_mode)
+  {
+  case VKSIFT_PYRAMID_PRECISION_FLOAT16:
+  case VKSIFT_PYRAMID_PRECISION_FLOAT32:
+    break;
+  default:
+    logError(LOG_TAG, "Invalid configuration: invalid scale-space pyramid format precision specified)");
+    ok = false;
+  }
+  return ok;
+}
+
+/* Note: the reference tests `idx > count` (vulkansift.c:588), letting idx == count through to an
+ * out-of-bounds access; its header and error-handling demo document `idx >= count` as invalid, which
+ * is what this build enforces. */
+static bool buffer_idx_valid(vksift_Instance inst, uint32_t idx)
+{
+  if (idx >= inst->cfg.sift_buffer_count)
+  {
+    logError(LOG_TAG, "Provided target buffer index is (%d) but the number of reserved buffers is (%d).", idx, inst->cfg.sift_buffer_count);
+    return false;
+  }
+  return true;
+}
+
+static bool resolution_valid(vksift_Instance inst, uint32_t w, uint32_t h)
+{
+  uint64_t size = (uint64_t)w * h;
+  if (size > inst->max_image_size)
+  {
+    logError(LOG_TAG, "Provided input image size (%d*%d=%llu) is greater than the configured maximum image size (%d).", w, h, (unsigned long long)size,
+             inst->max_image_size);
+    return false;
+  }
+  if (size < 1024u)
+  {
+    logError(LOG_TAG, "Invalid input image size (%d*%d=%llu). Input image size must be greater than or equal to 1024", w, h, (unsigned long long)size);
+    return false;
+  }
+  return true;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* runtime life-cycle                                                                               */
+/* ------------------------------------------------------------------------------------------------ */
+vksift_Result vksift_loadVulkan()
+{
+  if (g_loaded)
+  {
+    logError(LOG_TAG, "vksift_loadVulkan() failure: the GPU runtime is already loaded.");
+    return VKSIFT_VULKAN_ERROR;
+  }
+  int e = vksift_hip_init();
+  if (e != 0)
+  {
+    logError(LOG_TAG, "vksift_loadVulkan() failure when setting up the HIP runtime: %s", vksift_hip_error_string(e));
+    return VKSIFT_VULKAN_ERROR;
+  }
+  g_loaded = true;
+  logInfo(LOG_TAG, "vksift_loadVulkan() success");
+  return VKSIFT_SUCCESS;
+}
+
+void vksift_unloadVulkan() { g_loaded = false; }
+
+void vksift_getAvailableGPUs(uint32_t *gpu_count, VKSIFT_GPU_NAME *gpu_names)
+{
+  uint32_t n = (uint32_t)vksift_hip_device_count();
+  if (gpu_names == NULL)
+  {
+    *gpu_count = n;
+    return;
+  }
+  if (*gpu_count > n)
+    *gpu_count = n;
+  for (uint32_t i = 0; i < *gpu_count; i++)
+    vksift_hip_device_name((int)i, gpu_names[i]);
+}
+
+void vksift_setLogLevel(vksift_LogLevel level)
+{
+  switch (level)
+  {
+  case VKSIFT_NO_LOG:
+    vksift_log_set_level(VKSIFT_LOGLVL_NONE);
+    break;
+  case VKSIFT_LOG_ERROR:
+    vksift_log_set_level(VKSIFT_LOGLVL_ERROR);
+    break;
+  case VKSIFT_LOG_WARNING:
+    vksift_log_set_level(VKSIFT_LOGLVL_WARNING);
+    break;
+  case VKSIFT_LOG_INFO:
+    vksift_log_set_level(VKSIFT_LOGLVL_INFO);
+    break;
+  case VKSIFT_LOG_DEBUG:
+    vksift_log_set_level(VKSIFT_LOGLVL_DEBUG);
+    break;
+  default:
+    logError(LOG_TAG, "vksift_LogLevel in vksift_setLogLevel() is not handled");
+    break;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* layout helpers                                                                                   */
+/* ------------------------------------------------------------------------------------------------ */
+static uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+static void compute_layout(vksift_Instance inst, uint32_t w, uint32_t h, PyrLayout *L)
+{
+  memset(L, 0, sizeof(*L));
+  L->n_oct = vksift_hm_octaves_for(&inst->cfg, inst->max_octaves, w, h, L->w, L->h);
+  uint64_t off = 0;
+  for (uint32_t o = 0; o < L->n_oct; o++)
+  {
+    L->pitch[o] = round_up(L->w[o], PITCH_ALIGN);
+    L->plane_stride[o] = (uint64_t)L->pitch[o] * L->h[o];
+    L->gauss_off[o] = off;
+    off += L->plane_stride[o] * (inst->S + 3);
+    L->dog_off[o] = off;
+    off += L->plane_stride[o] * (inst->S + 2);
+  }
+  L->img_floats = off;
+}
+
+static uint64_t seg_count(const PyrLayout *L, uint32_t S)
+{
+  uint64_t mx = 0;
+  for (uint32_t o = 0; o < L->n_oct; o++)
+  {
+    uint64_t n = (uint64_t)S * L->h[o] * ((L->w[o] + 63) / 64);
+    if (n > mx)
+      mx = n;
+  }
+  return mx;
+}
+
+static void set_buffer_sections(vksift_Instance inst, uint32_t buf, uint32_t n_oct, uint32_t w, uint32_t h)
+{
+  BufferInfo *b = &inst->bufs[buf];
+  memset(b->sec_off, 0, sizeof(b->sec_off));
+  memset(b->sec_cap, 0, sizeof(b->sec_cap));
+  b->is_packed = false;
+  b->nb_stored = 0;
+  b->nb_sections = n_oct;
+  b->in_w = w;
+  b->in_h = h;
+  vksift_hm_section_caps(inst->cfg.max_nb_sift_per_buffer, n_oct, b->sec_cap);
+  uint32_t off = 0;
+  for (uint32_t o = 0; o < n_oct; o++)
+  {
+    b->sec_off[o] = off;
+    off += b->sec_cap[o];
+  }
+}
+
+#define HIP_CHECK(expr, what)                                                      \
+  do                                                                               \
+  {                                                                                \
+    int _e = (expr);                                                               \
+    if (_e != 0)                                                                   \
+    {                                                                              \
+      logError(LOG_TAG, "%s failed: %s", what, vksift_hip_error_string(_e));       \
+      goto gpu_error;                                                              \
+    }                                                                              \
+  } while (0)
+
+/* ------------------------------------------------------------------------------------------------ */
+/* instance                                                                                         */
+/* ------------------------------------------------------------------------------------------------ */
+static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift_Config *config, uint32_t batch_cap)
+{
+  assert(instance_ptr != NULL);
+  assert(*instance_ptr == NULL);
+  assert(config != NULL);
+
+  if (!g_loaded)
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: GPU runtime not available. vksift_loadVulkan() must be called before using this function.");
+    return VKSIFT_VULKAN_ERROR;
+  }
+  if (!config_is_valid(config))
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: Invalid configuration detected.");
+    return VKSIFT_INVALID_INPUT_ERROR;
+  }
+  if (batch_cap == 0 || batch_cap > config->sift_buffer_count)
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: batch capacity (%u) must be in [1, sift_buffer_count=%u].", batch_cap, config->sift_buffer_count);
+    return VKSIFT_INVALID_INPUT_ERROR;
+  }
+
+  vksift_Instance inst = (vksift_Instance)calloc(1, sizeof(struct vksift_Instance_T));
+  if (!inst)
+    return VKSIFT_VULKAN_ERROR;
+  *instance_ptr = inst;
+  inst->cfg = *config;
+  inst->error_cb = config->on_error_callback_function;
+  inst->S = config->nb_scales_per_octave;
+  inst->batch_cap = batch_cap;
+
+  int ndev = vksift_hip_device_count();
+  int dev = config->gpu_device_index;
+  if (dev < 0)
+    dev = 0; /* all MI355X of a node are identical: "best" = first (reference scores by type/VRAM, vulkan_device.c:394-494) */
+  if (dev >= ndev)
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: gpu_device_index %d but only %d device(s) available", dev, ndev);
+    vksift_destroyInstance(instance_ptr);
+    return VKSIFT_VULKAN_ERROR;
+  }
+  inst->device = dev;
+  if (vksift_hip_set_device(dev) != 0)
+  {
+    vksift_destroyInstance(instance_ptr);
+    return VKSIFT_VULKAN_ERROR;
+  }
+  if (config->pyramid_precision_mode == VKSIFT_PYRAMID_PRECISION_FLOAT16)
+    logWarning(LOG_TAG, "VKSIFT_PYRAMID_PRECISION_FLOAT16 requested: this build keeps the scale-space in fp32 (superset precision).");
+  if (config->use_gpu_debug_functions)
+    logWarning(LOG_TAG, "use_gpu_debug_functions requested: there is no frame presenter in the HIP build; use rocprofv3 / roctx ranges instead.");
+
+  inst->max_octaves = vksift_hm_max_octaves(config, &inst->max_image_size);
+  vksift_hm_blur_taps(config, inst->taps, inst->ntaps);
+
+  /* ---- reserve device memory for the configured maxima (sift_memory.c:133-360 equivalent) ---- */
+  uint32_t side = (uint32_t)ceilf(sqrtf((float)config->input_image_max_size));
+  PyrLayout L;
+  compute_layout(inst, side, side, &L);
+  /* Non-square images of the same area need a little more because of the row-pitch padding: keep slack. */
+  inst->pyr_img_stride = L.img_floats + L.img_floats / 4 + 4096;
+  inst->seg_cap = seg_count(&L, inst->S) * 2 + 1024;
+  uint32_t caps[VKSIFT_MAX_OCTAVES] = {0};
+  vksift_hm_section_caps(config->max_nb_sift_per_buffer, 1, caps);
+  inst->ori_cap = config->max_nb_sift_per_buffer; /* a single-octave detection gives the largest section */
+  inst->buf_stride = ((uint64_t)config->max_nb_sift_per_buffer * FEAT_BYTES + 255u) & ~(uint64_t)255u;
+
+  float fp_tab[DESC_FP_TAB_MAX];
+  inst->desc_fp_len = vksift_hm_desc_fp_table(config, fp_tab, DESC_FP_TAB_MAX);
+
+  bool ok = true;
+#define ALLOC_D(ptr, bytes) ok = ok && ((ptr = vksift_hip_malloc(bytes)) != NULL)
+#define ALLOC_H(ptr, bytes) ok = ok && ((ptr = vksift_hip_host_malloc(bytes)) != NULL)
+  ALLOC_D(inst->d_pyr, sizeof(float) * inst->pyr_img_stride * batch_cap);
+  ALLOC_D(inst->d_input, (size_t)inst->max_image_size * batch_cap);
+  ALLOC_H(inst->h_input, (size_t)inst->max_image_size * batch_cap);
+  ALLOC_D(inst->d_feats, inst->buf_stride * config->sift_buffer_count);
+  ALLOC_D(inst->d_found, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
+  ALLOC_H(inst->h_found, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
+  ALLOC_D(inst->d_seg_mask, sizeof(uint64_t) * inst->seg_cap * batch_cap);
+  ALLOC_D(inst->d_seg_off, sizeof(uint32_t) * inst->seg_cap * batch_cap);
+  ALLOC_D(inst->d_ori_ang, sizeof(float) * VKSIFT_HIP_MAX_ORI * inst->ori_cap * batch_cap);
+  ALLOC_D(inst->d_ori_cnt, sizeof(uint32_t) * inst->ori_cap * batch_cap);
+  ALLOC_D(inst->d_desc_fp, sizeof(float) * DESC_FP_TAB_MAX);
+  ALLOC_D(inst->d_desc_a, (size_t)config->max_nb_sift_per_buffer * 128u + 256u);
+  ALLOC_D(inst->d_desc_b, (size_t)config->max_nb_sift_per_buffer * 128u + 256u);
+  ALLOC_D(inst->d_matches, (size_t)config->max_nb_sift_per_buffer * MATCH_BYTES);
+  ALLOC_H(inst->h_matches, (size_t)config->max_nb_sift_per_buffer * MATCH_BYTES);
+  inst->bufs = (BufferInfo *)calloc(config->sift_buffer_count, sizeof(BufferInfo));
+  ok = ok && inst->bufs != NULL;
+  inst->stream = vksift_hip_stream_create();
+  inst->ev_detect = vksift_hip_event_create();
+  inst->ev_match = vksift_hip_event_create();
+  for (int i = 0; i < 8; i++)
+    inst->ev_t[i] = vksift_hip_event_create();
+  inst->ev_m[0] = vksift_hip_event_create();
+  inst->ev_m[1] = vksift_hip_event_create();
+  ok = ok && inst->stream && inst->ev_detect && inst->ev_match;
+  if (!ok)
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: Failed to setup the required memory objects");
+    vksift_destroyInstance(instance_ptr);
+    return VKSIFT_VULKAN_ERROR;
+  }
+  memset(inst->h_found, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
+  if (vksift_hip_memset(inst->d_found, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count, inst->stream) != 0 ||
+      vksift_hip_memcpy_h2d(inst->d_desc_fp, fp_tab, sizeof(float) * inst->desc_fp_len, inst->stream) != 0 || vksift_hip_stream_sync(inst->stream) != 0)
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: device initialisation failed");
+    vksift_destroyInstance(instance_ptr);
+    return VKSIFT_VULKAN_ERROR;
+  }
+
+  /* default scale-space = the square of maximal area, like the reference (sift_memory.c:644-662) */
+  inst->cur_w = side;
+  inst->cur_h = side;
+  inst->cur_batch = 1;
+  inst->lay = L;
+  for (uint32_t b = 0; b < config->sift_buffer_count; b++)
+    set_buffer_sections(inst, b, L.n_oct, side, side);
+
+  logInfo(LOG_TAG, "vksift_createInstance() success");
+  return VKSIFT_SUCCESS;
+}
+
+vksift_Result vksift_createInstance(vksift_Instance *instance_ptr, const vksift_Config *config) { return create_instance(instance_ptr, config, 1); }
+
+vksift_Result vksift_ext_createInstanceBatched(vksift_Instance *instance_ptr, const vksift_Config *config, uint32_t batch_capacity)
+{
+  return create_instance(instance_ptr, config, batch_capacity);
+}
+
+void vksift_destroyInstance(vksift_Instance *instance_ptr)
+{
+  assert(instance_ptr != NULL);
+  assert(*instance_ptr != NULL);
+  vksift_Instance inst = *instance_ptr;
+  vksift_hip_set_device(inst->device);
+  if (inst->stream)
+    vksift_hip_stream_sync(inst->stream);
+  vksift_hip_free(inst->d_pyr);
+  vksift_hip_free(inst->d_input);
+  vksift_hip_host_free(inst->h_input);
+  vksift_hip_free(inst->d_feats);
+  vksift_hip_free(inst->d_found);
+  vksift_hip_host_free(inst->h_found);
+  vksift_hip_free(inst->d_seg_mask);
+  vksift_hip_free(inst->d_seg_off);
+  vksift_hip_free(inst->d_ori_ang);
+  vksift_hip_free(inst->d_ori_cnt);
+  vksift_hip_free(inst->d_desc_fp);
+  vksift_hip_free(inst->d_desc_a);
+  vksift_hip_free(inst->d_desc_b);
+  vksift_hip_free(inst->d_matches);
+  vksift_hip_host_free(inst->h_matches);
+  free(inst->bufs);
+  vksift_hip_event_destroy(inst->ev_detect);
+  vksift_hip_event_destroy(inst->ev_match);
+  for (int i = 0; i < 8; i++)
+    vksift_hip_event_destroy(inst->ev_t[i]);
+  vksift_hip_event_destroy(inst->ev_m[0]);
+  vksift_hip_event_destroy(inst->ev_m[1]);
+  vksift_hip_stream_destroy(inst->stream);
+  free(inst);
+  *instance_ptr = NULL;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* synchronisation helpers (fences of the reference)                                                */
+/* ------------------------------------------------------------------------------------------------ */
+static bool detect_running(vksift_Instance inst)
+{
+  if (!inst->detect_pending)
+    return false;
+  if (vksift_hip_event_busy(inst->ev_detect) == 1)
+    return true;
+  inst->detect_pending = false;
+  return false;
+}
+static bool match_running(vksift_Instance inst)
+{
+  if (!inst->match_pending)
+    return false;
+  if (vksift_hip_event_busy(inst->ev_match) == 1)
+    return true;
+  inst->match_pending = false;
+  return false;
+}
+static int wait_all(vksift_Instance inst)
+{
+  vksift_hip_set_device(inst->device);
+  int e = vksift_hip_stream_sync(inst->stream);
+  inst->detect_pending = false;
+  inst->match_pending = false;
+  return e;
+}
+
+bool vksift_isBufferAvailable(vksift_Instance instance, const uint32_t gpu_buffer_id)
+{
+  vksift_hip_set_device(instance->device);
+  if (detect_running(instance) && gpu_buffer_id >= instance->detect_first_buf && gpu_buffer_id < instance->detect_first_buf + instance->detect_count)
+    return false;
+  if (match_running(instance) && (gpu_buffer_id == instance->match_a || gpu_buffer_id == instance->match_b))
+    return false;
+  return true;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* detection (vulkansift.c:315-344 + sift_memory.c:891-955 + sift_detector.c:1313-1410,1462-1542)   */
+/* ------------------------------------------------------------------------------------------------ */
+static vksift_hip_Plane plane_at(vksift_Instance inst, uint32_t o, uint64_t base_off, uint32_t layer)
+{
+  vksift_hip_Plane p;
+  p.base = inst->d_pyr + base_off + (uint64_t)layer * inst->lay.plane_stride[o];
+  p.w = inst->lay.w[o];
+  p.h = inst->lay.h[o];
+  p.pitch = inst->lay.pitch[o];
+  p.img_stride = inst->pyr_img_stride;
+  return p;
+}
+
+static uint64_t algorithmic_pyramid_bytes(vksift_Instance inst, uint32_t w, uint32_t h)
+{
+  /* (S+3 Gaussian writes + S+2 blur reads + S+2 DoG writes) * 4 B per octave pixel,
+   * plus on octave 0: input read (1 B/px of input), up-sample plane write and seed-blur read (4 B each). */
+  const PyrLayout *L = &inst->lay;
+  uint64_t bytes = 0;
+  for (uint32_t o = 0; o < L->n_oct; o++)
+    bytes += (uint64_t)L->w[o] * L->h[o] * 4u * ((inst->S + 3) + (inst->S + 2) + (inst->S + 2));
+  bytes += (uint64_t)w * h + (uint64_t)L->w[0] * L->h[0] * 8u;
+  return bytes;
+}
+
+static void detect_impl(vksift_Instance inst, const uint8_t *const *images, const uint8_t *d_images, uint32_t count, uint32_t w, uint32_t h,
+                        uint32_t first_buf, const char *fn)
+{
+  bool valid = count >= 1 && count <= inst->batch_cap && buffer_idx_valid(inst, first_buf) && buffer_idx_valid(inst, first_buf + count - 1) &&
+               resolution_valid(inst, w, h);
+  if (valid)
+  {
+    uint32_t shortest = w < h ? w : h;
+    if (shortest < 16)
+    {
+      logError(LOG_TAG, "Input image %ux%u is too small to build a single octave.", w, h);
+      valid = false;
+    }
+  }
+  if (!valid)
+  {
+    logError(LOG_TAG, "%s error: invalid input.", fn);
+    inst->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+
+  /* a new pipeline first waits for the running ones (vulkansift.c:326-327) */
+  HIP_CHECK(wait_all(inst), "stream synchronisation");
+
+  if (inst->cur_w != w || inst->cur_h != h)
+  {
+    PyrLayout L;
+    compute_layout(inst, w, h, &L);
+    if (L.n_oct == 0 || L.img_floats > inst->pyr_img_stride || seg_count(&L, inst->S) > inst->seg_cap)
+    {
+      logError(LOG_TAG, "Failed to fit the scale-space of a %ux%u image in the memory reserved for input_image_max_size", w, h);
+      goto gpu_error;
+    }
+    inst->lay = L;
+    inst->cur_w = w;
+    inst->cur_h = h;
+  }
+  inst->cur_batch = count;
+  const PyrLayout *L = &inst->lay;
+  for (uint32_t i = 0; i < count; i++)
+    set_buffer_sections(inst, first_buf + i, L->n_oct, w, h);
+
+  vksift_hip_stream st = inst->stream;
+  const bool prof = inst->profiling;
+  const size_t img_bytes = (size_t)w * h;
+  if (prof)
+    vksift_hip_event_record(inst->ev_t[0], st);
+
+  /* stage the images; the caller may reuse its memory as soon as we return (sift_memory.c:943) */
+  const uint8_t *d_src = d_images;
+  if (images)
+  {
+    for (uint32_t i = 0; i < count; i++)
+      memcpy(inst->h_input + i * img_bytes, images[i], img_bytes);
+    HIP_CHECK(vksift_hip_memcpy_h2d(inst->d_input, inst->h_input, img_bytes * count, st), "image upload");
+    d_src = inst->d_input;
+  }
+  inst->device_input_last = images == NULL;
+  if (prof)
+    vksift_hip_event_record(inst->ev_t[1], st);
+
+  /* recClearBufferDataCmds (sift_detector.c:1081-1104) */
+  HIP_CHECK(vksift_hip_memset(inst->d_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * count, st),
+            "counter reset");
+
+  /* ---- scale-space construction + DoG ---- */
+  vksift_hip_range_push("Scale space construction");
+  uint32_t nblur = 0;
+  const vksift_hip_Plane no_dog = {NULL, 0, 0, 0, 0};
+  for (uint32_t o = 0; o < L->n_oct; o++)
+  {
+    if (o == 0)
+    {
+      /* blit into the (still unused) layer-1 slot, then seed-blur it into layer 0 */
+      vksift_hip_Plane tmp = plane_at(inst, 0, L->gauss_off[0], 1);
+      HIP_CHECK(vksift_hip_input_blit(d_src, w, h, img_bytes, tmp, count, st), "input blit");
+      HIP_CHECK(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), no_dog, &inst->taps[0], inst->ntaps[0], count, st), "seed blur");
+      nblur++;
+    }
+    for (uint32_t s = 1; s < inst->S + 3; s++)
+    {
+      HIP_CHECK(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), plane_at(inst, o, L->gauss_off[o], s), plane_at(inst, o, L->dog_off[o], s - 1),
+                                &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, st),
+                "blur");
+      nblur++;
+    }
+    if (o + 1 < L->n_oct)
+      HIP_CHECK(vksift_hip_downsample(plane_at(inst, o, L->gauss_off[o], inst->S), plane_at(inst, o + 1, L->gauss_off[o + 1], 0), count, st), "downsample");
+  }
+  vksift_hip_range_pop();
+  inst->last_blur_launches = nblur;
+  inst->last_alg_bytes = algorithmic_pyramid_bytes(inst, w, h) * count;
+  if (prof)
+    vksift_hip_event_record(inst->ev_t[2], st);
+
+  /* ---- keypoints ---- */
+  vksift_hip_OctaveJob jobs[VKSIFT_MAX_OCTAVES];
+  const BufferInfo *b0 = &inst->bufs[first_buf];
+  for (uint32_t o = 0; o < L->n_oct; o++)
+  {
+    vksift_hip_OctaveJob *j = &jobs[o];
+    memset(j, 0, sizeof(*j));
+    j->dog = inst->d_pyr + L->dog_off[o];
+    j->gauss = inst->d_pyr + L->gauss_off[o];
+    j->w = L->w[o], j->h = L->h[o], j->pitch = L->pitch[o];
+    j->plane_stride = L->plane_stride[o];
+    j->img_stride = inst->pyr_img_stride;
+    j->S = inst->S;
+    j->octave_idx = (int32_t)o - (inst->cfg.use_input_upsampling ? 1 : 0);
+    j->seed_sigma = inst->cfg.seed_scale_sigma;
+    j->dog_threshold = inst->cfg.intensity_threshold / (float)inst->S;
+    j->edge_limit = ((inst->cfg.edge_threshold + 1.f) * (inst->cfg.edge_threshold + 1.f)) / inst->cfg.edge_threshold;
+    j->feats = inst->d_feats + (uint64_t)first_buf * inst->buf_stride + (uint64_t)b0->sec_off[o] * FEAT_BYTES;
+    j->feat_img_stride = inst->buf_stride;
+    j->cap = b0->sec_cap[o];
+    j->found = inst->d_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES + o;
+    j->found_img_stride = VKSIFT_MAX_OCTAVES;
+    j->seg_mask = inst->d_seg_mask;
+    j->seg_off = inst->d_seg_off;
+    j->seg_img_stride = inst->seg_cap;
+    j->ori_ang = inst->d_ori_ang;
+    j->ori_cnt = inst->d_ori_cnt;
+    j->ori_img_stride = inst->ori_cap;
+    j->max_ori = inst->cfg.max_nb_orientation_per_keypoint;
+    j->use_vlfeat = inst->cfg.descriptor_format == VKSIFT_DESCRIPTOR_FORMAT_VLFEAT ? 1u : 0u;
+    j->desc_fp_tab = inst->d_desc_fp;
+    j->desc_fp_tab_len = inst->desc_fp_len;
+  }
+  vksift_hip_range_push("ExtractKeypoints");
+  for (uint32_t o = 0; o < L->n_oct; o++)
+    HIP_CHECK(vksift_hip_extract_keypoints(&jobs[o], count, st), "keypoint extraction");
+  vksift_hip_range_pop();
+  if (prof)
+    vksift_hip_event_record(inst->ev_t[3], st);
+  vksift_hip_range_push("ComputeOrientation");
+  for (uint32_t o = 0; o < L->n_oct; o++)
+    HIP_CHECK(vksift_hip_orientations(&jobs[o], count, st), "orientation");
+  vksift_hip_range_pop();
+  if (prof)
+    vksift_hip_event_record(inst->ev_t[4], st);
+  vksift_hip_range_push("ComputeDescriptors");
+  for (uint32_t o = 0; o < L->n_oct; o++)
+    HIP_CHECK(vksift_hip_descriptors(&jobs[o], count, st), "descriptor");
+  vksift_hip_range_pop();
+  if (prof)
+    vksift_hip_event_record(inst->ev_t[5], st);
+
+  /* recCopySIFTCountCmds (sift_detector.c:1261-1291) */
+  HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES, inst->d_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES,
+                                  sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * count, st),
+            "count read-back");
+  if (prof)
+  {
+    vksift_hip_event_record(inst->ev_t[6], st);
+    inst->timings_valid = true;
+  }
+  HIP_CHECK(vksift_hip_event_record(inst->ev_detect, st), "event record");
+  inst->detect_pending = true;
+  inst->detect_first_buf = first_buf;
+  inst->detect_count = count;
+  return;
+
+gpu_error:
+  logError(LOG_TAG, "%s error: Failed to start the detection pipeline.", fn);
+  inst->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+void vksift_detectFeatures(vksift_Instance instance, const uint8_t *image_data, const uint32_t image_width, const uint32_t image_height,
+                           const uint32_t gpu_buffer_id)
+{
+  const uint8_t *imgs[1] = {image_data};
+  vksift_hip_set_device(instance->device);
+  detect_impl(instance, imgs, NULL, 1, image_width, image_height, gpu_buffer_id, "vksift_detectFeatures()");
+}
+
+void vksift_ext_detectFeaturesBatch(vksift_Instance instance, const uint8_t *const *images, uint32_t count, uint32_t image_width, uint32_t image_height,
+                                    uint32_t first_gpu_buffer_id)
+{
+  vksift_hip_set_device(instance->device);
+  detect_impl(instance, images, NULL, count, image_width, image_height, first_gpu_buffer_id, "vksift_ext_detectFeaturesBatch()");
+}
+
+void vksift_ext_detectFeaturesBatchDevice(vksift_Instance instance, const uint8_t *d_images, uint32_t count, uint32_t image_width, uint32_t image_height,
+                                          uint32_t first_gpu_buffer_id)
+{
+  vksift_hip_set_device(instance->device);
+  if (d_images == NULL)
+  {
+    logError(LOG_TAG, "vksift_ext_detectFeaturesBatchDevice() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  detect_impl(instance, NULL, d_images, count, image_width, image_height, first_gpu_buffer_id, "vksift_ext_detectFeaturesBatchDevice()");
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* feature count / download / upload (sift_memory.c:1060-1272)                                      */
+/* ------------------------------------------------------------------------------------------------ */
+static void wait_for_buffer(vksift_Instance inst, uint32_t buf)
+{
+  if (!vksift_isBufferAvailable(inst, buf))
+    wait_all(inst);
+}
+
+/* per-section stored counts, clamped to the section capacity (sift_memory.c:1080-1095) */
+static uint32_t buffer_counts(vksift_Instance inst, uint32_t buf, uint32_t *cnt, bool log_lost)
+{
+  const BufferInfo *b = &inst->bufs[buf];
+  if (b->is_packed && b->nb_sections == 0)
+    return b->nb_stored;
+  uint32_t sum = 0, lost = 0;
+  const uint32_t *found = inst->h_found + (size_t)buf * VKSIFT_MAX_OCTAVES;
+  for (uint32_t o = 0; o < b->nb_sections; o++)
+  {
+    uint32_t n = found[o];
+    if (n > b->sec_cap[o])
+    {
+      lost += n - b->sec_cap[o];
+      n = b->sec_cap[o];
+    }
+    if (cnt)
+      cnt[o] = n;
+    sum += n;
+  }
+  if (lost > 0 && log_lost)
+    logError(LOG_TAG,
+             "%d feature(s) lost because the SIFT buffer was full, consider increasing "
+             "the maximum number of SIFT features per buffer in the configuration.",
+             lost);
+  return sum;
+}
+
+uint32_t vksift_getFeaturesNumber(vksift_Instance instance, const uint32_t gpu_buffer_id)
+{
+  if (!buffer_idx_valid(instance, gpu_buffer_id))
+  {
+    logError(LOG_TAG, "vksift_getFeaturesNumber() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return 0;
+  }
+  wait_for_buffer(instance, gpu_buffer_id);
+  return buffer_counts(instance, gpu_buffer_id, NULL, true);
+}
+
+void vksift_downloadFeatures(vksift_Instance instance, vksift_Feature *feats_ptr, uint32_t gpu_buffer_id)
+{
+  if (!buffer_idx_valid(instance, gpu_buffer_id))
+  {
+    logError(LOG_TAG, "vksift_downloadFeatures() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  vksift_Instance inst = instance;
+  wait_for_buffer(inst, gpu_buffer_id);
+  const BufferInfo *b = &inst->bufs[gpu_buffer_id];
+  const uint8_t *base = inst->d_feats + (uint64_t)gpu_buffer_id * inst->buf_stride;
+  if (b->nb_sections == 0)
+  {
+    HIP_CHECK(vksift_hip_memcpy_d2h(feats_ptr, base, (size_t)b->nb_stored * FEAT_BYTES, inst->stream), "feature download");
+  }
+  else
+  {
+    uint32_t cnt[VKSIFT_MAX_OCTAVES] = {0};
+    buffer_counts(inst, gpu_buffer_id, cnt, false);
+    uint32_t out = 0;
+    for (uint32_t o = 0; o < b->nb_sections; o++)
+    {
+      HIP_CHECK(vksift_hip_memcpy_d2h((uint8_t *)feats_ptr + (size_t)out * FEAT_BYTES, base + (size_t)b->sec_off[o] * FEAT_BYTES, (size_t)cnt[o] * FEAT_BYTES,
+                                      inst->stream),
+                "feature download");
+      out += cnt[o];
+    }
+  }
+  HIP_CHECK(vksift_hip_stream_sync(inst->stream), "feature download");
+  return;
+gpu_error:
+  logError(LOG_TAG, "vksift_downloadFeatures() error when downloading detection results.");
+  instance->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+void vksift_uploadFeatures(vksift_Instance instance, const vksift_Feature *feats_ptr, const uint32_t nb_feats, const uint32_t gpu_buffer_id)
+{
+  if (!buffer_idx_valid(instance, gpu_buffer_id) || nb_feats > instance->cfg.max_nb_sift_per_buffer)
+  {
+    if (nb_feats > instance->cfg.max_nb_sift_per_buffer)
+      logError(LOG_TAG, "Provided features count (%d) is greater than the configured maximum number of features per GPU buffer size (%d).", nb_feats,
+               instance->cfg.max_nb_sift_per_buffer);
+    logError(LOG_TAG, "vksift_uploadFeatures() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  vksift_Instance inst = instance;
+  wait_for_buffer(inst, gpu_buffer_id);
+  BufferInfo *b = &inst->bufs[gpu_buffer_id];
+  HIP_CHECK(vksift_hip_memcpy_h2d(inst->d_feats + (uint64_t)gpu_buffer_id * inst->buf_stride, feats_ptr, (size_t)nb_feats * FEAT_BYTES, inst->stream),
+            "feature upload");
+  HIP_CHECK(vksift_hip_stream_sync(inst->stream), "feature upload");
+  /* the buffer becomes one packed section (sift_memory.c:1262-1266) */
+  b->is_packed = true;
+  b->nb_stored = nb_feats;
+  b->nb_sections = 0;
+  return;
+gpu_error:
+  logError(LOG_TAG, "vksift_uploadFeatures() error when uploading SIFT features to GPU memory.");
+  instance->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* matching (vulkansift.c:417-462, sift_memory.c:957-1058, sift_matcher.c:408-486)                  */
+/* ------------------------------------------------------------------------------------------------ */
+/* Dense descriptor rows of a buffer in download order. The reference physically packs the octave
+ * sections first (pack_BufferMemory); gathering section by section gives the same row order without
+ * the overlapping in-buffer copies. */
+static int gather_buffer_descriptors(vksift_Instance inst, uint32_t buf, uint8_t *d_dst, uint32_t *n_out)
+{
+  const BufferInfo *b = &inst->bufs[buf];
+  const uint8_t *base = inst->d_feats + (uint64_t)buf * inst->buf_stride;
+  uint32_t out = 0;
+  if (b->nb_sections == 0)
+  {
+    int e = vksift_hip_gather_descriptors(base, b->nb_stored, d_dst, inst->stream);
+    if (e)
+      return e;
+    out = b->nb_stored;
+  }
+  else
+  {
+    uint32_t cnt[VKSIFT_MAX_OCTAVES] = {0};
+    buffer_counts(inst, buf, cnt, false);
+    for (uint32_t o = 0; o < b->nb_sections; o++)
+    {
+      int e = vksift_hip_gather_descriptors(base + (size_t)b->sec_off[o] * FEAT_BYTES, cnt[o], d_dst + (size_t)out * 128u, inst->stream);
+      if (e)
+        return e;
+      out += cnt[o];
+    }
+  }
+  *n_out = out;
+  return 0;
+}
+
+void vksift_matchFeatures(vksift_Instance instance, uint32_t gpu_buffer_id_A, uint32_t gpu_buffer_id_B)
+{
+  if (!buffer_idx_valid(instance, gpu_buffer_id_A) || !buffer_idx_valid(instance, gpu_buffer_id_B))
+  {
+    logError(LOG_TAG, "vksift_matchFeatures() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  vksift_Instance inst = instance;
+  vksift_hip_set_device(inst->device);
+  HIP_CHECK(wait_all(inst), "stream synchronisation");
+
+  uint32_t na = 0, nb = 0;
+  if (inst->profiling)
+    vksift_hip_event_record(inst->ev_m[0], inst->stream);
+  vksift_hip_range_push("Matching");
+  HIP_CHECK(gather_buffer_descriptors(inst, gpu_buffer_id_A, inst->d_desc_a, &na), "descriptor gather");
+  HIP_CHECK(gather_buffer_descriptors(inst, gpu_buffer_id_B, inst->d_desc_b, &nb), "descriptor gather");
+  /* after packing the reference marks both buffers packed with their stored count (sift_memory.c:1039-1041) */
+  inst->bufs[gpu_buffer_id_A].is_packed = true;
+  inst->bufs[gpu_buffer_id_A].nb_stored = na;
+  inst->bufs[gpu_buffer_id_B].is_packed = true;
+  inst->bufs[gpu_buffer_id_B].nb_stored = nb;
+  inst->curr_nb_matches = na;
+  if (na > 0)
+  {
+    if (nb < 2)
+    {
+      /* Get2NearestNeighbors.comp:66-67 reads b[0] and b[1] unconditionally (stale memory in the reference);
+       * here the missing rows are defined as all-zero descriptors. */
+      HIP_CHECK(vksift_hip_memset(inst->d_desc_b + (size_t)nb * 128u, 0, (size_t)(2 - nb) * 128u, inst->stream), "descriptor padding");
+      logWarning(LOG_TAG, "vksift_matchFeatures(): buffer B holds %u feature(s); missing neighbours are matched against zero descriptors.", nb);
+    }
+    HIP_CHECK(vksift_hip_match_2nn_desc(inst->d_desc_a, na, 0u, inst->d_desc_b, nb < 2 ? 2u : nb, inst->d_matches, inst->stream), "2-NN matching");
+    HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_matches, inst->d_matches, (size_t)na * MATCH_BYTES, inst->stream), "match read-back");
+  }
+  vksift_hip_range_pop();
+  if (inst->profiling)
+  {
+    vksift_hip_event_record(inst->ev_m[1], inst->stream);
+    inst->match_timing_valid = true;
+  }
+  HIP_CHECK(vksift_hip_event_record(inst->ev_match, inst->stream), "event record");
+  inst->match_pending = true;
+  inst->match_a = gpu_buffer_id_A;
+  inst->match_b = gpu_buffer_id_B;
+  return;
+gpu_error:
+  logError(LOG_TAG, "vksift_matchFeatures() error: Failed to start the matching pipeline.");
+  instance->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+uint32_t vksift_getMatchesNumber(vksift_Instance instance) { return instance->curr_nb_matches; }
+
+void vksift_downloadMatches(vksift_Instance instance, vksift_Match_2NN *matches)
+{
+  vksift_Instance inst = instance;
+  vksift_hip_set_device(inst->device);
+  if (inst->match_pending)
+  {
+    HIP_CHECK(vksift_hip_event_sync(inst->ev_match), "match wait");
+    inst->match_pending = false;
+  }
+  memcpy(matches, inst->h_matches, (size_t)inst->curr_nb_matches * MATCH_BYTES);
+  return;
+gpu_error:
+  logError(LOG_TAG, "vksift_downloadMatches() error when downloading SIFT matches from GPU memory.");
+  instance->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* scale-space inspection (vulkansift.c:464-518, sift_memory.c:1303-1383)                           */
+/* ------------------------------------------------------------------------------------------------ */
+uint8_t vksift_getScaleSpaceNbOctaves(vksift_Instance instance) { return (uint8_t)instance->lay.n_oct; }
+
+void vksift_getScaleSpaceOctaveResolution(vksift_Instance instance, const uint8_t octave, uint32_t *octave_images_width, uint32_t *octave_images_height)
+{
+  if (octave >= instance->lay.n_oct)
+  {
+    logError(LOG_TAG, "vksift_getScaleSpaceOctaveResolution() error: invalid input. Requested octave idx is %d but the current number of octave is %d",
+             octave, instance->lay.n_oct);
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  *octave_images_width = instance->lay.w[octave];
+  *octave_images_height = instance->lay.h[octave];
+}
+
+static void download_plane(vksift_Instance inst, uint8_t octave, uint8_t scale, bool is_dog, float *dst, const char *fn)
+{
+  uint32_t nscales = inst->S + (is_dog ? 2 : 3);
+  if (octave >= inst->lay.n_oct || scale >= nscales)
+  {
+    if (octave >= inst->lay.n_oct)
+      logError(LOG_TAG, "Requested octave idx is %d but the current number of octaves is %d", octave, inst->lay.n_oct);
+    else
+      logError(LOG_TAG, "Requested scale idx is %d but the number of %s scales is %d", scale, is_dog ? "DoG" : "blurred", nscales);
+    logError(LOG_TAG, "%s error: invalid input.", fn);
+    inst->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  vksift_hip_set_device(inst->device);
+  /* images cannot be read while a detection runs (vulkansift.c:490-491) */
+  HIP_CHECK(wait_all(inst), "stream synchronisation");
+  const PyrLayout *L = &inst->lay;
+  const float *src = inst->d_pyr + (is_dog ? L->dog_off[octave] : L->gauss_off[octave]) + (uint64_t)scale * L->plane_stride[octave];
+  HIP_CHECK(vksift_hip_memcpy2d_d2h(dst, sizeof(float) * L->w[octave], src, sizeof(float) * L->pitch[octave], sizeof(float) * L->w[octave], L->h[octave],
+                                    inst->stream),
+            "plane download");
+  HIP_CHECK(vksift_hip_stream_sync(inst->stream), "plane download");
+  return;
+gpu_error:
+  logError(LOG_TAG, "%s error when downloading pyramid image from GPU memory.", fn);
+  inst->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+void vksift_downloadScaleSpaceImage(vksift_Instance instance, const uint8_t octave, const uint8_t scale, float *blurred_image)
+{
+  download_plane(instance, octave, scale, false, blurred_image, "vksift_downloadScaleSpaceImage()");
+}
+
+void vksift_downloadDoGImage(vksift_Instance instance, const uint8_t octave, const uint8_t scale, float *dog_image)
+{
+  download_plane(instance, octave, scale, true, dog_image, "vksift_downloadDoGImage()");
+}
+
+void vksift_presentDebugFrame(vksift_Instance instance)
+{
+  (void)instance;
+  logWarning(LOG_TAG, "vksift_presentDebugFrame() was called but instance has no external window configured.");
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* extensions                                                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+void vksift_ext_setProfiling(vksift_Instance instance, bool enabled)
+{
+  instance->profiling = enabled;
+  instance->timings_valid = false;
+  instance->match_timing_valid = false;
+}
+
+void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *out)
+{
+  memset(out, 0, sizeof(*out));
+  if (!instance->profiling || !instance->timings_valid)
+    return;
+  vksift_hip_set_device(instance->device);
+  wait_all(instance);
+  vksift_hip_event *e = instance->ev_t;
+  out->upload_ms = vksift_hip_event_elapsed_ms(e[0], e[1]);
+  out->pyramid_ms = vksift_hip_event_elapsed_ms(e[1], e[2]);
+  out->extrema_ms = vksift_hip_event_elapsed_ms(e[2], e[3]);
+  out->orientation_ms = vksift_hip_event_elapsed_ms(e[3], e[4]);
+  out->descriptor_ms = vksift_hip_event_elapsed_ms(e[4], e[5]);
+  out->total_ms = vksift_hip_event_elapsed_ms(e[0], e[6]);
+  out->nb_blur_launches = instance->last_blur_launches;
+  out->pyramid_algorithmic_bytes = instance->last_alg_bytes;
+}
+
+float vksift_ext_getMatchTime(vksift_Instance instance)
+{
+  if (!instance->profiling || !instance->match_timing_valid)
+    return -1.f;
+  vksift_hip_set_device(instance->device);
+  wait_all(instance);
+  return vksift_hip_event_elapsed_ms(instance->ev_m[0], instance->ev_m[1]);
+}
+
+uint32_t vksift_ext_exportDescriptorsDevice(vksift_Instance instance, uint32_t gpu_buffer_id, uint8_t *d_descriptors)
+{
+  if (!buffer_idx_valid(instance, gpu_buffer_id) || d_descriptors == NULL)
+  {
+    logError(LOG_TAG, "vksift_ext_exportDescriptorsDevice() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return 0;
+  }
+  vksift_Instance inst = instance;
+  vksift_hip_set_device(inst->device);
+  uint32_t n = 0;
+  HIP_CHECK(wait_all(inst), "stream synchronisation");
+  HIP_CHECK(gather_buffer_descriptors(inst, gpu_buffer_id, d_descriptors, &n), "descriptor gather");
+  HIP_CHECK(vksift_hip_stream_sync(inst->stream), "descriptor gather");
+  return n;
+gpu_error:
+  logError(LOG_TAG, "vksift_ext_exportDescriptorsDevice() error when exporting descriptors.");
+  instance->error_cb(VKSIFT_VULKAN_ERROR);
+  return 0;
+}
