@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the vksift detect/match hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): SIFT detect+match frames/s on 640x480 frames with ~2k keypoints.
+One "step" = one pass of the hot path over one batch of `--batch` synthetic 640x480 frames that are
+already resident in HBM: batched detection (default vksift_Config: 2x up-sampling, automatic octave
+count = 5, 3 scales/octave) followed by the 2-NN self-match of every frame (matchFeatures(i, i), the
+call sequence of BASELINE config 2). Every step recomputes everything; nothing is cached between steps.
+
+Multi-GPU: one process per GPU; each rank owns its own batch (weak scaling, detection is per image and
+needs no collective); the timed region is bracketed by a barrier + device synchronize and the maximum
+over ranks is reported. PyTorch is used for torch.distributed (RCCL) and device buffers only.
+
+Extra objects on the JSON line:
+  roofline     pyramid+DoG pass (k_blur_tile launches): algorithmic bytes per launch /
+               average launch duration measured with HIP events on the library's own stream
+  cpu_baseline the CPU oracle (a scalar C port of the same algorithm) timed on a bounded sample, rank 0, N=1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="frames per step and per GPU")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--no-match", action="store_true", help="detect only (BASELINE config 3 style runs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the workload given to the CPU oracle")
+    return ap.parse_args()
+
+
+def cpu_baseline(frames, do_match):
+    """Time the oracle (scalar C port, 1 thread) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+
+    cfg = O.default_config(math_mode=0)
+    t0 = time.perf_counter()
+    nfeat = 0
+    for img in frames:
+        feats, _ = O.detect(cfg, img)
+        nfeat += len(feats)
+        if do_match and len(feats) >= 2:
+            O.match_2nn(feats, feats)
+    dt = time.perf_counter() - t0
+    return {
+        "value": len(frames) / dt,
+        "unit": "frames/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{len(frames)} of the benchmark's {frames[0].shape[1]}x{frames[0].shape[0]} frames, detect"
+                  + ("+self-match" if do_match else "") + f", {nfeat // max(len(frames), 1)} features/frame, {dt:.1f} s wall, "
+                  + f"host has {os.cpu_count()} logical cores",
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from vulkansift_amd import api
+
+    api.lib().vksift_setLogLevel(api.VKSIFT_LOG_ERROR)
+    W, H, B = args.width, args.height, args.batch
+    do_match = not args.no_match
+
+    # synthetic frames (seeded per global frame index), uploaded once: inputs are HBM-resident when timing starts
+    frames = [api.gen_synthetic_image(0x5EED0000 + rank * B + i, W, H) for i in range(B)]
+    d_frames = torch.from_numpy(np.stack(frames)).to(dev)
+    torch.cuda.synchronize()
+
+    cfg = api.default_config(sift_buffer_count=B, gpu_device_index=dev.index, input_image_max_size=max(W * H, 1024))
+    inst = api.Instance(cfg, batch_capacity=B)
+
+    def step():
+        inst.detectFeaturesBatchDevice(d_frames.data_ptr(), B, W, H, 0)
+        if do_match:
+            for i in range(B):
+                inst.matchFeatures(i, i)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    nfeat = [inst.getFeaturesNumber(i) for i in range(B)]
+
+    inst.setProfiling(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    acc = inst.getAccumulatedDetectTimings()
+    match_ms = inst.getMatchTime() if do_match else None
+    inst.close()
+
+    if rank == 0:
+        frames_total = B * world * args.steps
+        launches = max(acc["nb_blur_launches"], 1)
+        alg_per_launch = acc["pyramid_algorithmic_bytes"] / launches
+        avg_launch_s = (acc["pyramid_ms"] * 1e-3) / launches
+        achieved = alg_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        out = {
+            "metric": "SIFT detect+match frames/sec (640x480, ~2k kp)" if do_match else "SIFT detect frames/sec",
+            "value": frames_total / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE config 2: {W}x{H} uint8 frames, detect" + (" + 2-NN self-match" if do_match else "")
+                            + ", default vksift_Config (2x up-sampling, auto octaves, 3 scales/octave), inputs resident in HBM",
+                "frames_per_step_per_gpu": B,
+                "octaves": 5 if (W, H) == (640, 480) else None,
+                "mean_features_per_frame": float(np.mean(nfeat)),
+                "parallelism": f"batch split x{world}, no collectives",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_blur_tile (pyramid + DoG pass)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_per_launch,
+                "avg_launch_us": avg_launch_s * 1e6,
+                "launches_per_step": launches / max(acc["nb_calls"], 1),
+            },
+            "stage_ms_per_step": {k: acc[k] / max(acc["nb_calls"], 1) for k in
+                                  ("upload_ms", "pyramid_ms", "extrema_ms", "orientation_ms", "descriptor_ms", "total_ms")},
+            "last_match_ms": match_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames[: max(1, min(args.cpu_frames, B))], do_match)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,9 @@ extern "C"
   } vksift_ext_DetectTimings;
   VKSIFT_EXPORT void vksift_ext_setProfiling(vksift_Instance instance, bool enabled);
   VKSIFT_EXPORT void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *out);
+  /* Sums over all detect calls since profiling was enabled (or since the last reset); nb_blur_launches and
+   * pyramid_algorithmic_bytes are summed too. Blocking. */
+  VKSIFT_EXPORT void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *sum, uint32_t *nb_calls, bool reset);
   /* Time (ms) of the last matching pipeline (gather + 2-NN kernel), HIP events; needs profiling on. */
   VKSIFT_EXPORT float vksift_ext_getMatchTime(vksift_Instance instance);
 

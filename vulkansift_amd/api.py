@@ -114,6 +114,7 @@ def lib():
     L.vksift_ext_detectFeaturesBatchDevice.argtypes = [inst, C.c_void_p, u32, u32, u32, u32]
     L.vksift_ext_setProfiling.argtypes = [inst, C.c_bool]
     L.vksift_ext_getDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings)]
+    L.vksift_ext_getAccumulatedDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.POINTER(u32), C.c_bool]
     L.vksift_ext_getMatchTime.argtypes = [inst]
     L.vksift_ext_getMatchTime.restype = C.c_float
     L.vksift_ext_exportDescriptorsDevice.argtypes = [inst, u32, C.c_void_p]
@@ -327,6 +328,14 @@ class Instance:
         t = vksift_ext_DetectTimings()
         lib().vksift_ext_getDetectTimings(self._h, C.byref(t))
         return {f[0]: getattr(t, f[0]) for f in t._fields_}
+
+    def getAccumulatedDetectTimings(self, reset=False):
+        t = vksift_ext_DetectTimings()
+        n = C.c_uint32(0)
+        lib().vksift_ext_getAccumulatedDetectTimings(self._h, C.byref(t), C.byref(n), reset)
+        d = {f[0]: getattr(t, f[0]) for f in t._fields_}
+        d["nb_calls"] = n.value
+        return d
 
     def getMatchTime(self):
         return lib().vksift_ext_getMatchTime(self._h)

@@ -105,6 +105,10 @@ struct vksift_Instance_T
   vksift_hip_event ev_t[8];
   vksift_hip_event ev_m[2];
   bool timings_valid, match_timing_valid;
+  bool timings_accounted;
+  double acc_ms[6];
+  uint32_t acc_calls;
+  uint64_t acc_blur_launches, acc_alg_bytes;
   uint32_t last_blur_launches;
   uint64_t last_alg_bytes;
   bool device_input_last;
@@ -576,6 +580,24 @@ static uint64_t algorithmic_pyramid_bytes(vksift_Instance inst, uint32_t w, uint
   return bytes;
 }
 
+/* fold the (completed) event timings of the previous detect call into the running sums */
+static void account_timings(vksift_Instance inst)
+{
+  if (!inst->profiling || !inst->timings_valid || inst->timings_accounted)
+    return;
+  vksift_hip_event *e = inst->ev_t;
+  inst->acc_ms[0] += vksift_hip_event_elapsed_ms(e[0], e[1]);
+  inst->acc_ms[1] += vksift_hip_event_elapsed_ms(e[1], e[2]);
+  inst->acc_ms[2] += vksift_hip_event_elapsed_ms(e[2], e[3]);
+  inst->acc_ms[3] += vksift_hip_event_elapsed_ms(e[3], e[4]);
+  inst->acc_ms[4] += vksift_hip_event_elapsed_ms(e[4], e[5]);
+  inst->acc_ms[5] += vksift_hip_event_elapsed_ms(e[0], e[6]);
+  inst->acc_calls++;
+  inst->acc_blur_launches += inst->last_blur_launches;
+  inst->acc_alg_bytes += inst->last_alg_bytes;
+  inst->timings_accounted = true;
+}
+
 static void detect_impl(vksift_Instance inst, const uint8_t *const *images, const uint8_t *d_images, uint32_t count, uint32_t w, uint32_t h,
                         uint32_t first_buf, const char *fn)
 {
@@ -599,6 +621,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
 
   /* a new pipeline first waits for the running ones (vulkansift.c:326-327) */
   HIP_CHECK(wait_all(inst), "stream synchronisation");
+  account_timings(inst);
 
   if (inst->cur_w != w || inst->cur_h != h)
   {
@@ -731,6 +754,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   {
     vksift_hip_event_record(inst->ev_t[6], st);
     inst->timings_valid = true;
+    inst->timings_accounted = false;
   }
   HIP_CHECK(vksift_hip_event_record(inst->ev_detect, st), "event record");
   inst->detect_pending = true;
@@ -1057,6 +1081,38 @@ void vksift_ext_setProfiling(vksift_Instance instance, bool enabled)
   instance->profiling = enabled;
   instance->timings_valid = false;
   instance->match_timing_valid = false;
+  instance->timings_accounted = false;
+  memset(instance->acc_ms, 0, sizeof(instance->acc_ms));
+  instance->acc_calls = 0;
+  instance->acc_blur_launches = 0;
+  instance->acc_alg_bytes = 0;
+}
+
+void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *sum, uint32_t *nb_calls, bool reset)
+{
+  memset(sum, 0, sizeof(*sum));
+  *nb_calls = 0;
+  if (!instance->profiling)
+    return;
+  vksift_hip_set_device(instance->device);
+  wait_all(instance);
+  account_timings(instance);
+  sum->upload_ms = (float)instance->acc_ms[0];
+  sum->pyramid_ms = (float)instance->acc_ms[1];
+  sum->extrema_ms = (float)instance->acc_ms[2];
+  sum->orientation_ms = (float)instance->acc_ms[3];
+  sum->descriptor_ms = (float)instance->acc_ms[4];
+  sum->total_ms = (float)instance->acc_ms[5];
+  sum->nb_blur_launches = (uint32_t)instance->acc_blur_launches;
+  sum->pyramid_algorithmic_bytes = instance->acc_alg_bytes;
+  *nb_calls = instance->acc_calls;
+  if (reset)
+  {
+    memset(instance->acc_ms, 0, sizeof(instance->acc_ms));
+    instance->acc_calls = 0;
+    instance->acc_blur_launches = 0;
+    instance->acc_alg_bytes = 0;
+  }
 }
 
 void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *out)
