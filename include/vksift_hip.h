@@ -131,17 +131,16 @@ extern "C"
   int vksift_hip_descriptors(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s);
 
   /* ------------------------------------------------------------------ matcher */
-  /* Get2NearestNeighbors.comp (sift_matcher.c:246-279). feats_* are packed vksift_Feature arrays
-   * (stride 164 B). desc_a/desc_b are scratch for the dense 128-byte descriptor rows (na*128,
-   * max(nb,2)*128 bytes). matches: na records of 20 B. */
-  int vksift_hip_match_2nn(const uint8_t *feats_a, uint32_t na, const uint8_t *feats_b, uint32_t nb, uint8_t *desc_a, uint8_t *desc_b, uint8_t *matches,
-                           vksift_hip_stream s);
-  /* Same on dense descriptor matrices already in HBM (rows of 128 B, 16-byte aligned); row indices
-   * written to idx_a are a_index_base + row. Used by the query-sharded multi-GPU matcher. */
-  int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint8_t *matches,
-                                vksift_hip_stream s);
-  /* AoS -> dense descriptor rows */
+  /* vksift_Feature records (stride 164 B) -> dense 128-byte descriptor rows (16-byte aligned). Replaces the
+   * section packing of sift_memory.c:957-1047 as the matcher's input preparation. */
   int vksift_hip_gather_descriptors(const uint8_t *feats, uint32_t n, uint8_t *desc, vksift_hip_stream s);
+  /* Get2NearestNeighbors.comp (sift_matcher.c:246-279) on dense descriptor matrices in HBM, as an exact int8
+   * MFMA contraction with a fused top-2 epilogue. desc_a: na rows, desc_b: nb >= 2 rows (callers pad, quirk Q6).
+   * norm_scratch: na + nb u32 of scratch. matches: na records of 20 B {idx_a = a_index_base + row, idx_b1,
+   * idx_b2, dist1, dist2}; B rows are scanned in index order, so sharding A rows over GPUs (a_index_base =
+   * shard offset) gives bit-identical results to a single call. */
+  int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
+                                uint8_t *matches, vksift_hip_stream s);
 
 #ifdef __cplusplus
 }

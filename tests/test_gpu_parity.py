@@ -93,3 +93,61 @@ def test_match_bit_exact(vk, oracle):
     assert np.array_equal(m["dist_a_b1"].view(np.uint32), ref["dist_a_b1"].view(np.uint32))
     assert np.array_equal(m["dist_a_b2"].view(np.uint32), ref["dist_a_b2"].view(np.uint32))
     assert m["idx_b1"][10] == 1 and m["idx_b2"][10] == 0
+
+
+def _match_via_api(vk, a, b, max_nb=None):
+    fa = np.zeros(len(a), vk.FEATURE_DTYPE)
+    fb = np.zeros(len(b), vk.FEATURE_DTYPE)
+    fa["descriptor"] = a
+    fb["descriptor"] = b
+    cfg = vk.default_config(max_nb_sift_per_buffer=max(len(a), len(b), 1000))
+    with vk.Instance(cfg) as inst:
+        inst.uploadFeatures(fa, 0)
+        inst.uploadFeatures(fb, 1)
+        inst.matchFeatures(0, 1)
+        return inst.downloadMatches()
+
+
+def _assert_matches_equal(m, ref):
+    for name in ("idx_a", "idx_b1", "idx_b2"):
+        assert np.array_equal(m[name], ref[name]), (name, np.flatnonzero(m[name] != ref[name])[:10])
+    for name in ("dist_a_b1", "dist_a_b2"):
+        assert np.array_equal(m[name].view(np.uint32), ref[name].view(np.uint32)), name
+
+
+@pytest.mark.parametrize("na,nb,seed", [(64, 2, 5), (1, 3, 6), (300, 17, 7), (2049, 1000, 8), (17000, 1501, 9)])
+def test_match_shapes(vk, oracle, na, nb, seed):
+    """ragged sizes (not multiples of the 16/64 tiles), both kernel instantiations (na > 16384 -> 64 rows/wave)"""
+    a = vk.gen_synthetic_descriptors(seed, na)
+    b = vk.gen_synthetic_descriptors(seed + 100, nb)
+    _assert_matches_equal(_match_via_api(vk, a, b), oracle.match_2nn(a, b))
+
+
+def test_match_heavy_ties(vk, oracle):
+    """few distinct byte values -> many exactly equal distances: the earlier index must win everywhere"""
+    rng = np.random.default_rng(3)
+    a = (rng.integers(0, 2, (700, 128)) * 255).astype(np.uint8)
+    b = (rng.integers(0, 2, (900, 128)) * 255).astype(np.uint8)
+    b[::7] = b[0]          # many duplicates, including b[0] == b[7] == ...
+    b[1] = b[0]            # quirk Q7 for every row of A
+    a[::5] = b[0]
+    _assert_matches_equal(_match_via_api(vk, a, b), oracle.match_2nn(a, b))
+
+
+def test_match_float_collisions(vk, oracle):
+    """full-range random bytes: d2 up to 2^23 where different integers share one float sqrt (quirk Q8)"""
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 256, (512, 128), dtype=np.uint8)
+    b = rng.integers(0, 256, (4096, 128), dtype=np.uint8)
+    a[:64] = np.where(rng.random((64, 128)) < 0.5, 0, 255).astype(np.uint8)
+    b[:512] = np.where(rng.random((512, 128)) < 0.5, 0, 255).astype(np.uint8)
+    _assert_matches_equal(_match_via_api(vk, a, b), oracle.match_2nn(a, b))
+
+
+def test_match_fewer_than_two_b_rows(vk, oracle):
+    """nb < 2: this build defines the rows the shader would read as stale memory as zero descriptors"""
+    a = vk.gen_synthetic_descriptors(21, 40)
+    b = vk.gen_synthetic_descriptors(22, 1)
+    m = _match_via_api(vk, a, b)
+    ref = oracle.match_2nn(a, np.vstack([b, np.zeros((1, 128), np.uint8)]))
+    _assert_matches_equal(m, ref)

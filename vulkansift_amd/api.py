@@ -122,7 +122,7 @@ def lib():
     L.vksift_ext_genSyntheticImage.argtypes = [C.c_uint64, u32, u32, u32, C.c_void_p]
     L.vksift_ext_genSyntheticDescriptors.argtypes = [C.c_uint64, u32, C.c_void_p]
     # kernel-layer C-ABI (include/vksift_hip.h) entry points used directly by bench.py / tests
-    L.vksift_hip_match_2nn_desc.argtypes = [C.c_void_p, u32, u32, C.c_void_p, u32, C.c_void_p, C.c_void_p]
+    L.vksift_hip_match_2nn_desc.argtypes = [C.c_void_p, u32, u32, C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.vksift_hip_match_2nn_desc.restype = C.c_int
     L.vksift_hip_gather_descriptors.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p]
     L.vksift_hip_gather_descriptors.restype = C.c_int

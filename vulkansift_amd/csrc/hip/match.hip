@@ -1,18 +1,26 @@
-// match.hip — brute-force 2-nearest-neighbour descriptor matcher (gfx950).
+// match.hip — brute-force 2-nearest-neighbour descriptor matcher on the gfx950 matrix cores.
 //
 // Replaces Get2NearestNeighbors.comp (dispatch sift_matcher.c:246-279): for every row of A the two
-// closest rows of B under the L2 distance of the 128 uint8 descriptor bytes.
+// closest rows of B under the L2 distance of the 128 uint8 descriptor bytes, scanned in index order
+// with strict '<' (ties keep the earlier index) after an unconditional initialisation from b[0], b[1].
 //
-// Exactness: squared distances are computed in integers, d2 = |a|^2 + |b|^2 - 2 a.b with
-// v_dot4_u32_u8 (all terms < 2^24, exact). The reference compares sqrt(float(d2)) values with
-// strict '<' while scanning B in index order; integer d2 order equals float sqrt order except when
-// two different d2 round to the same float, so the float comparison is evaluated (with a correctly
-// rounded sqrtf) only when the integer test says "closer than the current second best" — rare,
-// O(log nb) times per row — which reproduces the reference's choice bit for bit (quirk Q8), as well
-// as the unconditional b[0]/b[1] initialisation (Q6) and its tie rule (Q7).
+// Formulation (exact integers): with a' = a - 128, b' = b - 128 as int8 (byte XOR 0x80),
+//     d2(a,b) = sum (a-b)^2 = |a'|^2 + |b'|^2 - 2 a'.b'        (every term < 2^22, int32 exact)
+// and a'.b' for a 16x16 block of (A rows x B rows) is two v_mfma_i32_16x16x64_i8 (K = 128).
+// The N_A x N_B distance matrix never leaves registers: each lane folds its 4 outputs per MFMA into a
+// running top-2 per A row (fused epilogue), lanes are merged once at the end.
 //
-// Layout: descriptors are first gathered from the 164-byte feature records into dense 128-byte rows
-// (16-byte aligned) so that A rows load as 8 x dwordx4 and B tiles stream through LDS.
+// Bit-exactness with the reference's float comparison (quirk Q8): the shader compares
+// sqrt(float(d2)) values, and two different d2 can round to the same float. A lane sees its B columns
+// in increasing index order, so the integer test d2 < (current second best d2) is a safe pre-filter
+// (sqrt is monotone) and the float comparison is evaluated only on that rare path; cross-lane merges
+// compare (sqrtf(d2), index) lexicographically. Quirk Q7 (d(b0) == d(b1) makes index 1 the best) is an
+// index-priority swap of columns 0 and 1 for that A row. Quirk Q6 (b[0], b[1] read unconditionally):
+// callers pad B to two rows.
+//
+// MFMA operand layout used (16x16x64 i8): lane l supplies 16 consecutive K bytes (l>>4)*16.. of A row
+// (l&15) / B row (l&15); since A and B use the same K slicing any K permutation cancels in the dot
+// product. Accumulator: lane l holds column (l&15), rows (l>>4)*4 + r, r = 0..3.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -21,7 +29,11 @@
 namespace
 {
 
-constexpr int B_TILE = 128; // B rows per LDS tile (16 KiB)
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int BT = 64;          // B rows staged in LDS per iteration
+constexpr int B_STRIDE = 144;   // bytes per staged row (128 + 16 pad: ds_read_b128 of 16 rows hits 16 distinct bank quads)
+constexpr uint32_t QMAX = 0xFFFFFFFFu;
 
 __global__ void __launch_bounds__(256) k_gather_desc(const uint8_t *__restrict__ feats, uint32_t n, uint32_t *__restrict__ desc)
 {
@@ -32,139 +44,220 @@ __global__ void __launch_bounds__(256) k_gather_desc(const uint8_t *__restrict__
   desc[i] = *(const uint32_t *)(feats + (size_t)row * 164 + 36 + 4 * j);
 }
 
-__global__ void __launch_bounds__(256) k_zero_rows(uint32_t *desc, uint32_t first_row, uint32_t nrows)
+// |d - 128|^2 per row: sum d^2 - 256 sum d + 128*128^2
+__global__ void __launch_bounds__(256) k_shifted_norms(const uint32_t *__restrict__ desc, uint32_t n, uint32_t *__restrict__ norms)
 {
-  uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < nrows * 32u)
-    desc[(size_t)first_row * 32 + i] = 0u;
+  uint32_t row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= n)
+    return;
+  const uint4 *p = (const uint4 *)(desc + (size_t)row * 32);
+  uint32_t s2 = 0, s1 = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+  {
+    uint4 v = p[j];
+    s2 = __builtin_amdgcn_udot4(v.x, v.x, s2, false);
+    s2 = __builtin_amdgcn_udot4(v.y, v.y, s2, false);
+    s2 = __builtin_amdgcn_udot4(v.z, v.z, s2, false);
+    s2 = __builtin_amdgcn_udot4(v.w, v.w, s2, false);
+    s1 = __builtin_amdgcn_udot4(v.x, 0x01010101u, s1, false);
+    s1 = __builtin_amdgcn_udot4(v.y, 0x01010101u, s1, false);
+    s1 = __builtin_amdgcn_udot4(v.z, 0x01010101u, s1, false);
+    s1 = __builtin_amdgcn_udot4(v.w, 0x01010101u, s1, false);
+  }
+  norms[row] = s2 - 256u * s1 + 128u * 128u * 128u;
 }
 
-struct Best2
+struct Top2
 {
-  float d1, d2f;  // float distances of best / second
-  uint32_t i1, i2;
-  uint32_t q1, q2; // their integer squared distances
+  uint32_t q1, k1, q2, k2; // squared distances and index keys of best / second
 };
 
-__device__ __forceinline__ void consider(Best2 &r, uint32_t q, uint32_t idx)
+// (sqrtf(q), key) lexicographic order — the order the reference's scan realises
+__device__ __forceinline__ bool lex_less(uint32_t qa, uint32_t ka, uint32_t qb, uint32_t kb)
 {
-  if (q < r.q2)
+  if (qa == qb)
+    return ka < kb;
+  float da = sqrtf((float)qa), db = sqrtf((float)qb);
+  return da < db || (da == db && ka < kb);
+}
+
+// in-lane insertion; keys arrive in increasing order so a tie never displaces a holder
+__device__ __forceinline__ void insert_seq(Top2 &t, uint32_t q, uint32_t key)
+{
+  float d = sqrtf((float)q);
+  if (d < sqrtf((float)t.q1))
   {
-    float d = sqrtf((float)q);
-    if (d < r.d1)
-    {
-      r.d2f = r.d1, r.i2 = r.i1, r.q2 = r.q1;
-      r.d1 = d, r.i1 = idx, r.q1 = q;
-    }
-    else if (d < r.d2f)
-    {
-      r.d2f = d, r.i2 = idx, r.q2 = q;
-    }
+    t.q2 = t.q1, t.k2 = t.k1;
+    t.q1 = q, t.k1 = key;
+  }
+  else if (d < sqrtf((float)t.q2))
+  {
+    t.q2 = q, t.k2 = key;
   }
 }
 
-// One thread per A row; B streamed through LDS in tiles, every lane reads the same B row (LDS
-// broadcast). nb_eff = max(nb, 2): rows beyond nb are zero-filled by the host wrapper (Q6).
-__global__ void __launch_bounds__(256) k_match_2nn(const uint32_t *__restrict__ desc_a, uint32_t na, uint32_t a_index_base,
-                                                   const uint32_t *__restrict__ desc_b, uint32_t nb, uint32_t *__restrict__ matches)
+__device__ __forceinline__ Top2 merge2(const Top2 &a, const Top2 &b)
 {
-  __shared__ uint4 s_b[B_TILE * 8];
-  __shared__ uint32_t s_nb2[B_TILE];
-  const uint32_t row = blockIdx.x * 256 + threadIdx.x;
-  const bool active = row < na;
-
-  uint32_t a[32];
+  Top2 r;
+  if (lex_less(a.q1, a.k1, b.q1, b.k1))
   {
-    const uint4 *pa = (const uint4 *)(desc_a + (size_t)(active ? row : 0) * 32);
+    r.q1 = a.q1, r.k1 = a.k1;
+    if (lex_less(a.q2, a.k2, b.q1, b.k1))
+      r.q2 = a.q2, r.k2 = a.k2;
+    else
+      r.q2 = b.q1, r.k2 = b.k1;
+  }
+  else
+  {
+    r.q1 = b.q1, r.k1 = b.k1;
+    if (lex_less(b.q2, b.k2, a.q1, a.k1))
+      r.q2 = b.q2, r.k2 = b.k2;
+    else
+      r.q2 = a.q1, r.k2 = a.k1;
+  }
+  return r;
+}
+
+// AT = 16-row A tiles per wave. Block = 4 waves = 64*AT A rows; B streams through LDS.
+template <int AT>
+__global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
+                                                    uint32_t a_index_base, const uint32_t *__restrict__ desc_b, const uint32_t *__restrict__ norm_b,
+                                                    uint32_t nb, uint32_t *__restrict__ matches)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t s_b[BT * B_STRIDE];
+  __shared__ uint32_t s_nb[BT];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, grp = lane >> 4;
+  const uint32_t row_base = (blockIdx.x * 4 + wave) * (16 * AT);
+
+  // A fragments (XOR 0x80 -> int8) and norms of the rows this lane accumulates
+  v4i afrag[AT][2];
+  uint32_t an[AT][4];
 #pragma unroll
-    for (int j = 0; j < 8; j++)
+  for (int t = 0; t < AT; t++)
+  {
+    uint32_t r = row_base + t * 16 + col;
+    if (r >= na)
+      r = na - 1;
+    const uint4 *p = (const uint4 *)(desc_a + (size_t)r * 32);
+    uint4 v0 = p[grp], v1 = p[4 + grp];
+    afrag[t][0] = v4i{(int)(v0.x ^ 0x80808080u), (int)(v0.y ^ 0x80808080u), (int)(v0.z ^ 0x80808080u), (int)(v0.w ^ 0x80808080u)};
+    afrag[t][1] = v4i{(int)(v1.x ^ 0x80808080u), (int)(v1.y ^ 0x80808080u), (int)(v1.z ^ 0x80808080u), (int)(v1.w ^ 0x80808080u)};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
     {
-      uint4 v = pa[j];
-      a[4 * j + 0] = v.x, a[4 * j + 1] = v.y, a[4 * j + 2] = v.z, a[4 * j + 3] = v.w;
+      uint32_t rr = row_base + t * 16 + grp * 4 + j;
+      an[t][j] = norm_a[rr < na ? rr : na - 1];
     }
   }
-  uint32_t na2 = 0;
+
+  Top2 st[AT][4];
 #pragma unroll
-  for (int j = 0; j < 32; j++)
-    na2 = __builtin_amdgcn_udot4(a[j], a[j], na2, false);
+  for (int t = 0; t < AT; t++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      st[t][j] = Top2{QMAX, QMAX, QMAX, QMAX};
+  uint32_t swap_bits = 0; // bit (t*4+j): d(b0) == d(b1) for that A row (quirk Q7)
 
-  Best2 r;
-  r.d1 = r.d2f = 0.f;
-  r.i1 = r.i2 = 0;
-  r.q1 = r.q2 = 0;
-
-  for (uint32_t t0 = 0; t0 < nb; t0 += B_TILE)
+  for (uint32_t t0 = 0; t0 < nb; t0 += BT)
   {
-    const uint32_t rows = nb - t0 < (uint32_t)B_TILE ? nb - t0 : (uint32_t)B_TILE;
     __syncthreads();
-    // stage tile: rows*8 uint4, coalesced
-    for (uint32_t i = threadIdx.x; i < rows * 8; i += 256)
-      s_b[i] = ((const uint4 *)(desc_b + (size_t)t0 * 32))[i];
-    __syncthreads();
-    // row norms: 2 threads per row would conflict on banks; use one thread per (row) with a skewed walk
-    if (threadIdx.x < rows)
+    // stage BT rows (zero beyond nb), converting to int8
+    for (int i = threadIdx.x; i < BT * 8; i += 256)
     {
-      uint32_t acc = 0;
-#pragma unroll
-      for (int j = 0; j < 8; j++)
-      {
-        uint4 v = s_b[threadIdx.x * 8 + ((j + threadIdx.x) & 7)];
-        acc = __builtin_amdgcn_udot4(v.x, v.x, acc, false);
-        acc = __builtin_amdgcn_udot4(v.y, v.y, acc, false);
-        acc = __builtin_amdgcn_udot4(v.z, v.z, acc, false);
-        acc = __builtin_amdgcn_udot4(v.w, v.w, acc, false);
-      }
-      s_nb2[threadIdx.x] = acc;
+      int r = i >> 3, c = i & 7;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (t0 + r < nb)
+        v = ((const uint4 *)(desc_b + (size_t)(t0 + r) * 32))[c];
+      v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
+      *(uint4 *)(s_b + r * B_STRIDE + c * 16) = v;
     }
+    if (threadIdx.x < BT)
+      s_nb[threadIdx.x] = t0 + threadIdx.x < nb ? norm_b[t0 + threadIdx.x] : 0u;
     __syncthreads();
 
-    for (uint32_t bi = 0; bi < rows; bi++)
-    {
-      uint32_t dot = 0;
 #pragma unroll
-      for (int j = 0; j < 8; j++)
+    for (int sub = 0; sub < BT / 16; sub++)
+    {
+      const uint32_t bcol = t0 + sub * 16 + col; // B index this lane's outputs belong to
+      if (t0 + sub * 16 >= nb)
+        break;
+      const uint8_t *pb = s_b + (sub * 16 + col) * B_STRIDE + grp * 16;
+      const v4i b0 = *(const v4i *)pb;
+      const v4i b1 = *(const v4i *)(pb + 64);
+      const uint32_t bn = s_nb[sub * 16 + col];
+      const bool first = (t0 == 0 && sub == 0);
+#pragma unroll
+      for (int t = 0; t < AT; t++)
       {
-        uint4 v = s_b[bi * 8 + j];
-        dot = __builtin_amdgcn_udot4(a[4 * j + 0], v.x, dot, false);
-        dot = __builtin_amdgcn_udot4(a[4 * j + 1], v.y, dot, false);
-        dot = __builtin_amdgcn_udot4(a[4 * j + 2], v.z, dot, false);
-        dot = __builtin_amdgcn_udot4(a[4 * j + 3], v.w, dot, false);
-      }
-      const uint32_t q = na2 + s_nb2[bi] - 2u * dot;
-      const uint32_t gb = t0 + bi;
-      if (gb >= 2)
-        consider(r, q, gb);
-      else if (gb == 0)
-      {
-        r.q1 = q, r.d1 = sqrtf((float)q), r.i1 = 0; // provisional: holds b[0] until b[1] is seen
-      }
-      else
-      {
-        // Get2NearestNeighbors.comp:66-80
-        float d0 = r.d1, d1 = sqrtf((float)q);
-        uint32_t q0 = r.q1;
-        if (d0 < d1)
+        v4i acc = v4i{0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[t][0], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[t][1], b1, acc, 0, 0, 0);
+        uint32_t q[4];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
         {
-          r.d1 = d0, r.i1 = 0, r.q1 = q0;
-          r.d2f = d1, r.i2 = 1, r.q2 = q;
+          q[j] = bcol < nb ? an[t][j] + bn - 2u * (uint32_t)acc[j] : QMAX;
+          any = any || (q[j] < st[t][j].q2);
         }
-        else
+        if (first)
         {
-          r.d1 = d1, r.i1 = 1, r.q1 = q;
-          r.d2f = d0, r.i2 = 0, r.q2 = q0;
+          // quirk Q7: exchange d2(b0) / d2(b1) between the col-0 and col-1 lanes of each row group
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+          {
+            uint32_t other = __shfl_xor(q[j], 1, 64);
+            bool sw = col < 2 && sqrtf((float)q[j]) == sqrtf((float)other);
+            if (sw)
+              swap_bits |= 1u << (t * 4 + j);
+            uint32_t key = (col < 2 && sw) ? (uint32_t)(col ^ 1) : bcol;
+            if (q[j] != QMAX)
+              insert_seq(st[t][j], q[j], key);
+          }
+        }
+        else if (any)
+        {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (q[j] < st[t][j].q2)
+              insert_seq(st[t][j], q[j], bcol);
         }
       }
     }
   }
-  if (active)
-  {
-    uint32_t *m = matches + (size_t)row * 5;
-    m[0] = a_index_base + row;
-    m[1] = r.i1;
-    m[2] = r.i2;
-    m[3] = __float_as_uint(r.d1);
-    m[4] = __float_as_uint(r.d2f);
-  }
+
+  // merge the 16 lanes that share A rows (butterfly over the column bits), then lane col==0 writes
+#pragma unroll
+  for (int t = 0; t < AT; t++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      Top2 s = st[t][j];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1)
+      {
+        Top2 o;
+        o.q1 = __shfl_xor(s.q1, m, 64), o.k1 = __shfl_xor(s.k1, m, 64);
+        o.q2 = __shfl_xor(s.q2, m, 64), o.k2 = __shfl_xor(s.k2, m, 64);
+        s = merge2(s, o);
+      }
+      uint32_t r = row_base + t * 16 + grp * 4 + j;
+      if (col == 0 && r < na)
+      {
+        bool sw = (swap_bits >> (t * 4 + j)) & 1u;
+        uint32_t i1 = (sw && s.k1 < 2) ? (s.k1 ^ 1u) : s.k1;
+        uint32_t i2 = (sw && s.k2 < 2) ? (s.k2 ^ 1u) : s.k2;
+        uint32_t *m = matches + (size_t)r * 5;
+        m[0] = a_index_base + r;
+        m[1] = i1;
+        m[2] = i2;
+        m[3] = __float_as_uint(sqrtf((float)s.q1));
+        m[4] = __float_as_uint(sqrtf((float)s.q2));
+      }
+    }
 }
 
 } // namespace
@@ -180,38 +273,29 @@ extern "C"
     return (int)hipGetLastError();
   }
 
-  int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint8_t *matches,
-                                vksift_hip_stream s)
+  int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
+                                uint8_t *matches, vksift_hip_stream s)
   {
     if (na == 0)
       return 0;
     if (nb < 2)
       return (int)hipErrorInvalidValue; /* callers pad B to two rows (quirk Q6) */
-    uint32_t blocks = (na + 255u) / 256u;
-    hipLaunchKernelGGL(k_match_2nn, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, na, a_index_base, (const uint32_t *)desc_b, nb,
-                       (uint32_t *)matches);
-    return (int)hipGetLastError();
-  }
-
-  int vksift_hip_match_2nn(const uint8_t *feats_a, uint32_t na, const uint8_t *feats_b, uint32_t nb, uint8_t *desc_a, uint8_t *desc_b, uint8_t *matches,
-                           vksift_hip_stream s)
-  {
-    if (na == 0)
-      return 0;
-    int e = vksift_hip_gather_descriptors(feats_a, na, desc_a, s);
-    if (e)
-      return e;
-    e = vksift_hip_gather_descriptors(feats_b, nb, desc_b, s);
-    if (e)
-      return e;
-    uint32_t nb_eff = nb;
-    if (nb < 2)
+    uint32_t *norm_a = norm_scratch, *norm_b = norm_scratch + na;
+    hipLaunchKernelGGL(k_shifted_norms, dim3((na + 255u) / 256u), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, na, norm_a);
+    hipLaunchKernelGGL(k_shifted_norms, dim3((nb + 255u) / 256u), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_b, nb, norm_b);
+    /* Small problems: 16 A rows per wave to fill more CUs; large ones: 64 rows per wave for B-tile reuse. */
+    if (na <= 16384u)
     {
-      /* The shader reads b[0] and b[1] unconditionally (stale memory when nb < 2, quirk Q6); this build
-       * defines the missing rows as all-zero descriptors. */
-      hipLaunchKernelGGL(k_zero_rows, dim3(1), dim3(256), 0, (hipStream_t)s, (uint32_t *)desc_b, nb, 2u - nb);
-      nb_eff = 2;
+      uint32_t blocks = (na + 63u) / 64u;
+      hipLaunchKernelGGL(k_match_mfma<1>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, norm_a, na, a_index_base,
+                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches);
     }
-    return vksift_hip_match_2nn_desc(desc_a, na, 0u, desc_b, nb_eff, matches, s);
+    else
+    {
+      uint32_t blocks = (na + 255u) / 256u;
+      hipLaunchKernelGGL(k_match_mfma<4>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, norm_a, na, a_index_base,
+                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches);
+    }
+    return (int)hipGetLastError();
   }
 }

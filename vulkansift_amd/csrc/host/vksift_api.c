@@ -91,6 +91,7 @@ struct vksift_Instance_T
   float *d_desc_fp;
   uint32_t desc_fp_len;
   uint8_t *d_desc_a, *d_desc_b, *d_matches, *h_matches;
+  uint32_t *d_norms;
   BufferInfo *bufs;
 
   vksift_hip_stream stream;
@@ -434,6 +435,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   ALLOC_D(inst->d_desc_a, (size_t)config->max_nb_sift_per_buffer * 128u + 256u);
   ALLOC_D(inst->d_desc_b, (size_t)config->max_nb_sift_per_buffer * 128u + 256u);
   ALLOC_D(inst->d_matches, (size_t)config->max_nb_sift_per_buffer * MATCH_BYTES);
+  ALLOC_D(inst->d_norms, sizeof(uint32_t) * (2u * (size_t)config->max_nb_sift_per_buffer + 64u));
   ALLOC_H(inst->h_matches, (size_t)config->max_nb_sift_per_buffer * MATCH_BYTES);
   inst->bufs = (BufferInfo *)calloc(config->sift_buffer_count, sizeof(BufferInfo));
   ok = ok && inst->bufs != NULL;
@@ -501,6 +503,7 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_free(inst->d_desc_a);
   vksift_hip_free(inst->d_desc_b);
   vksift_hip_free(inst->d_matches);
+  vksift_hip_free(inst->d_norms);
   vksift_hip_host_free(inst->h_matches);
   free(inst->bufs);
   vksift_hip_event_destroy(inst->ev_detect);
@@ -974,7 +977,8 @@ void vksift_matchFeatures(vksift_Instance instance, uint32_t gpu_buffer_id_A, ui
       HIP_CHECK(vksift_hip_memset(inst->d_desc_b + (size_t)nb * 128u, 0, (size_t)(2 - nb) * 128u, inst->stream), "descriptor padding");
       logWarning(LOG_TAG, "vksift_matchFeatures(): buffer B holds %u feature(s); missing neighbours are matched against zero descriptors.", nb);
     }
-    HIP_CHECK(vksift_hip_match_2nn_desc(inst->d_desc_a, na, 0u, inst->d_desc_b, nb < 2 ? 2u : nb, inst->d_matches, inst->stream), "2-NN matching");
+    HIP_CHECK(vksift_hip_match_2nn_desc(inst->d_desc_a, na, 0u, inst->d_desc_b, nb < 2 ? 2u : nb, inst->d_norms, inst->d_matches, inst->stream),
+              "2-NN matching");
     HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_matches, inst->d_matches, (size_t)na * MATCH_BYTES, inst->stream), "match read-back");
   }
   vksift_hip_range_pop();
