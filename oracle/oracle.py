@@ -96,6 +96,13 @@ def lib():
         L.orc_descriptor.argtypes = [cfgp, C.c_void_p, C.c_uint32, C.c_void_p, u32p]
         L.orc_match_2nn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_match_2nn_desc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        for fn in ("orc_dm_expf", "orc_dm_exp2f", "orc_dm_sinf", "orc_dm_cosf"):
+            getattr(L, fn).argtypes = [C.c_float]
+            getattr(L, fn).restype = C.c_float
+        L.orc_dm_atan2f.argtypes = [C.c_float, C.c_float]
+        L.orc_dm_atan2f.restype = C.c_float
+        L.orc_dm_ceil_log2f.argtypes = [C.c_float]
+        L.orc_dm_ceil_log2f.restype = C.c_int
         _lib = L
     return _lib
 

@@ -822,3 +822,23 @@ void orc_match_2nn(const orc_Feature *a, uint32_t na, const orc_Feature *b, uint
   match_rows(a->descriptor, sizeof(orc_Feature), na, b->descriptor, sizeof(orc_Feature), nb, out);
 }
 void orc_match_2nn_desc(const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb, orc_Match *out) { match_rows(a, 128, na, b, 128, nb, out); }
+
+/* ------------------------------------------------------------------------------------------- */
+/* detmath.h entry points exported for tests/test_detmath.py                                   */
+/* ------------------------------------------------------------------------------------------- */
+float orc_dm_expf(float x) { return dm_expf(x); }
+float orc_dm_exp2f(float x) { return dm_exp2f(x); }
+float orc_dm_atan2f(float y, float x) { return dm_atan2f(y, x); }
+float orc_dm_sinf(float t)
+{
+  float s, c;
+  dm_sincosf(t, &s, &c);
+  return s;
+}
+float orc_dm_cosf(float t)
+{
+  float s, c;
+  dm_sincosf(t, &s, &c);
+  return c;
+}
+int orc_dm_ceil_log2f(float m) { return dm_ceil_log2f(m); }

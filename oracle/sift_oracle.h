@@ -105,6 +105,14 @@ extern "C"
   /* same on bare 128-byte descriptor rows */
   void orc_match_2nn_desc(const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb, orc_Match *out);
 
+  /* detmath.h functions, exported for unit tests */
+  float orc_dm_expf(float x);
+  float orc_dm_exp2f(float x);
+  float orc_dm_atan2f(float y, float x);
+  float orc_dm_sinf(float t);
+  float orc_dm_cosf(float t);
+  int orc_dm_ceil_log2f(float m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,66 @@
+"""Accuracy of the deterministic elementary functions (csrc/detmath.h) against float64 libm.
+They are shared by the HIP kernels and the oracle's det mode, so they are pinned independently here."""
+import numpy as np
+
+
+def _ulp(got, ref64):
+    ref32 = ref64.astype(np.float32)
+    u = np.spacing(np.maximum(np.abs(ref32), np.float32(1e-30))).astype(np.float64)
+    return np.abs(got.astype(np.float64) - ref64) / u
+
+
+def _vec(fn, *args):
+    return np.array([fn(*[float(a) for a in t]) for t in zip(*args)], dtype=np.float32)
+
+
+def test_exp(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-20, 0, 20000), rng.uniform(-87, 10, 5000), [0.0, -0.0, -1e-8, -87.2]]).astype(np.float32)
+    got = _vec(L.orc_dm_expf, x)
+    assert _ulp(got, np.exp(x.astype(np.float64))).max() <= 2.0
+    assert L.orc_dm_expf(-100.0) == 0.0 and L.orc_dm_expf(0.0) == 1.0
+
+
+def test_exp2(oracle):
+    L = oracle.lib()
+    x = np.random.default_rng(1).uniform(-3, 6, 20000).astype(np.float32)
+    got = _vec(L.orc_dm_exp2f, x)
+    assert _ulp(got, np.exp2(x.astype(np.float64))).max() <= 1.5
+    for n in range(-5, 6):
+        assert L.orc_dm_exp2f(float(n)) == 2.0 ** n
+
+
+def test_atan2(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(2)
+    y = rng.normal(0, 1, 30000).astype(np.float32)
+    x = rng.normal(0, 1, 30000).astype(np.float32)
+    got = _vec(L.orc_dm_atan2f, y, x)
+    ref = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+    assert np.abs(got - ref).max() < 4e-7
+    assert L.orc_dm_atan2f(0.0, 0.0) == 0.0
+    assert abs(L.orc_dm_atan2f(1.0, 0.0) - np.pi / 2) < 2e-7 and abs(L.orc_dm_atan2f(0.0, -1.0) - np.pi) < 3e-7
+    assert abs(L.orc_dm_atan2f(-1.0, -1.0) + 3 * np.pi / 4) < 3e-7
+
+
+def test_sincos(oracle):
+    L = oracle.lib()
+    t = np.random.default_rng(3).uniform(-0.5, 7.0, 30000).astype(np.float32)
+    s = _vec(L.orc_dm_sinf, t)
+    c = _vec(L.orc_dm_cosf, t)
+    assert np.abs(s - np.sin(t.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(c - np.cos(t.astype(np.float64))).max() < 2.5e-7
+    assert L.orc_dm_sinf(0.0) == 0.0 and L.orc_dm_cosf(0.0) == 1.0
+
+
+def test_ceil_log2_exact(oracle):
+    L = oracle.lib()
+    for e in range(-20, 30):
+        p = np.float32(2.0 ** e)
+        assert L.orc_dm_ceil_log2f(float(p)) == e
+        assert L.orc_dm_ceil_log2f(float(np.nextafter(p, np.float32(np.inf)))) == e + 1
+        assert L.orc_dm_ceil_log2f(float(np.nextafter(p, np.float32(0)))) == e
+    x = np.random.default_rng(4).uniform(1e-3, 1e6, 5000).astype(np.float32)
+    got = np.array([L.orc_dm_ceil_log2f(float(v)) for v in x])
+    assert np.array_equal(got, np.ceil(np.log2(x.astype(np.float64))).astype(int))

@@ -1,0 +1,227 @@
+"""GPU tests of the API call sequences the reference's example programs exercise, the
+golden fixtures, and the batched / capacity edge cases. Everything goes through the C-ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _eq_feats(a, b):
+    assert len(a) == len(b)
+    for name in a.dtype.names:
+        x, y = a[name], b[name]
+        if x.dtype.kind == "f":
+            x, y = x.view(np.uint32), y.view(np.uint32)
+        assert np.array_equal(x, y), name
+
+
+def test_golden_features_and_matches(vk):
+    img = np.load(os.path.join(G, "img_160x120.npy"))
+    meta = json.load(open(os.path.join(G, "meta.json")))
+    with vk.Instance(vk.default_config()) as inst:
+        inst.detectFeatures(img, 0)
+        assert inst.getFeaturesNumber(0) == meta["det"]["n"]
+        _eq_feats(inst.downloadFeatures(0), np.load(os.path.join(G, "feats_160x120_default_det.npy")))
+    cfg = vk.default_config(use_input_upsampling=False, descriptor_format=vk.VKSIFT_DESCRIPTOR_FORMAT_VLFEAT, max_nb_orientation_per_keypoint=0,
+                            use_hardware_interpolated_blur=False)
+    with vk.Instance(cfg) as inst:
+        inst.detectFeatures(img, 1)
+        _eq_feats(inst.downloadFeatures(1), np.load(os.path.join(G, "feats_160x120_noups_vlfeat_det.npy")))
+        a = np.zeros(256, vk.FEATURE_DTYPE)
+        b = np.zeros(300, vk.FEATURE_DTYPE)
+        a["descriptor"] = np.load(os.path.join(G, "desc_a.npy"))
+        b["descriptor"] = np.load(os.path.join(G, "desc_b.npy"))
+        inst.uploadFeatures(a, 0)
+        inst.uploadFeatures(b, 1)
+        inst.matchFeatures(0, 1)
+        m = inst.downloadMatches()
+        ref = np.load(os.path.join(G, "matches_a_b.npy"))
+        for name in ref.dtype.names:
+            x, y = m[name], ref[name]
+            if x.dtype.kind == "f":
+                x, y = x.view(np.uint32), y.view(np.uint32)
+            assert np.array_equal(x, y), name
+
+
+def test_detect_match_sequence_like_test_sift_match(vk, oracle):
+    """test_sift_match.cpp:67-85: detect(0), detect(1), match(0,1), download, match(1,0), download, download features"""
+    img1 = vk.gen_synthetic_image(101, 320, 240)
+    img2 = np.roll(img1, (3, 5), axis=(0, 1))
+    with vk.Instance(vk.default_config()) as inst:
+        inst.detectFeatures(img1, 0)
+        inst.detectFeatures(img2, 1)
+        inst.matchFeatures(0, 1)
+        n01 = inst.getMatchesNumber()
+        m01 = inst.downloadMatches()
+        inst.matchFeatures(1, 0)
+        m10 = inst.downloadMatches()
+        f0, f1 = inst.downloadFeatures(0), inst.downloadFeatures(1)
+    assert n01 == len(f0) == len(m01) and len(m10) == len(f1)
+    r01, r10 = oracle.match_2nn(f0, f1), oracle.match_2nn(f1, f0)
+    assert np.array_equal(m01["idx_b1"], r01["idx_b1"]) and np.array_equal(m01["idx_b2"], r01["idx_b2"])
+    assert np.array_equal(m10["idx_b1"], r10["idx_b1"]) and np.array_equal(m10["idx_b2"], r10["idx_b2"])
+    # the shifted copy must be recognisable: cross-check + Lowe ratio as in test_sift_match.cpp:90-107
+    good = [(m["idx_a"], m["idx_b1"]) for m in m01 if m["dist_a_b1"] < 0.75 * m["dist_a_b2"] and m10[m["idx_b1"]]["idx_b1"] == m["idx_a"]]
+    assert len(good) > 0.3 * len(f0)
+    dx = np.array([f1[j]["x"] - f0[i]["x"] for i, j in good])
+    dy = np.array([f1[j]["y"] - f0[i]["y"] for i, j in good])
+    assert abs(np.median(dx) - 5) < 0.5 and abs(np.median(dy) - 3) < 0.5
+
+
+def test_download_upload_roundtrip_like_test_sift_gpu_debug(vk):
+    """test_sift_gpu_debug.cpp:92-124: detect -> download -> upload -> match"""
+    img = vk.gen_synthetic_image(102, 256, 256)
+    with vk.Instance(vk.default_config()) as inst:
+        inst.detectFeatures(img, 0)
+        f = inst.downloadFeatures(0)
+        inst.uploadFeatures(f, 1)
+        assert inst.getFeaturesNumber(1) == len(f)
+        _eq_feats(inst.downloadFeatures(1), f)
+        inst.matchFeatures(0, 1)
+        m = inst.downloadMatches()
+        assert inst.getFeaturesNumber(0) == len(f)  # buffer 0 is now "packed", same count
+        _eq_feats(inst.downloadFeatures(0), f)
+    uniq = np.unique(f["descriptor"], axis=0, return_index=True)[1]
+    assert np.all(m["dist_a_b1"] == 0)
+    assert np.array_equal(m["idx_b1"][uniq], m["idx_a"][uniq])
+
+
+def test_error_callback_contract_like_test_sift_error_handling(vk):
+    """test_sift_error_handling.cpp:52-60: invalid buffer index -> callback(VKSIFT_INVALID_INPUT_ERROR), instance stays usable"""
+    cfg = vk.default_config(sift_buffer_count=3)
+    img = vk.gen_synthetic_image(103, 128, 128)
+    with vk.Instance(cfg) as inst:
+        for idx in range(0, 6):
+            if idx < 3:
+                assert inst.getFeaturesNumber(idx) == 0
+            else:
+                with pytest.raises(vk.VksiftError) as e:
+                    inst.getFeaturesNumber(idx)
+                assert e.value.code == vk.VKSIFT_INVALID_INPUT_ERROR
+        with pytest.raises(vk.VksiftError):
+            inst.detectFeatures(img, 7)
+        with pytest.raises(vk.VksiftError):
+            inst.detectFeatures(np.zeros((16, 16), np.uint8), 0)          # < 1024 pixels
+        with pytest.raises(vk.VksiftError):
+            inst.detectFeatures(np.zeros((2000, 2000), np.uint8), 0)      # > input_image_max_size
+        with pytest.raises(vk.VksiftError):
+            inst.matchFeatures(0, 3)
+        with pytest.raises(vk.VksiftError):
+            inst.downloadScaleSpaceImage(0, 6)
+        with pytest.raises(vk.VksiftError):
+            inst.downloadDoGImage(9, 0)
+        inst.detectFeatures(img, 2)                                        # still usable
+        assert inst.getFeaturesNumber(2) > 0
+        inst.presentDebugFrame()                                           # warning + no-op
+
+
+def test_invalid_config_rejected(vk):
+    import ctypes as C
+    for kw in ({"input_image_max_size": 100}, {"sift_buffer_count": 0}, {"max_nb_sift_per_buffer": 0}, {"nb_scales_per_octave": 0},
+               {"seed_scale_sigma": 0.5}, {"intensity_threshold": -1.0}, {"pyramid_precision_mode": 7}):
+        cfg = vk.default_config(**kw)
+        h = C.c_void_p(None)
+        vk.load()
+        assert vk.lib().vksift_createInstance(C.byref(h), C.byref(cfg)) == vk.VKSIFT_INVALID_INPUT_ERROR and not h
+
+
+def test_async_contract_and_buffer_availability(vk):
+    img = vk.gen_synthetic_image(104, 640, 480)
+    with vk.Instance(vk.default_config()) as inst:
+        assert inst.isBufferAvailable(0) and inst.isBufferAvailable(1)
+        inst.detectFeatures(img, 0)
+        assert inst.isBufferAvailable(1)          # not the target of the running pipeline
+        n = inst.getFeaturesNumber(0)             # blocks
+        assert inst.isBufferAvailable(0) and n > 100
+        inst.detectFeatures(img, 1)
+        inst.matchFeatures(0, 1)
+        inst.downloadMatches()
+        assert inst.isBufferAvailable(0) and inst.isBufferAvailable(1)
+
+
+def test_resolution_change_and_scale_space_queries(vk, oracle):
+    """test_sift_show_pyr.cpp:45-76 + a resolution switch between detections"""
+    with vk.Instance(vk.default_config()) as inst:
+        for (w, h) in ((320, 200), (131, 257), (320, 200)):
+            img = vk.gen_synthetic_image(105, w, h)
+            inst.detectFeatures(img, 0)
+            pyr = oracle.Pyramid(oracle.default_config(math_mode=1), img)
+            assert inst.getScaleSpaceNbOctaves() == pyr.nb_octaves
+            o = pyr.nb_octaves - 1
+            assert inst.getScaleSpaceOctaveResolution(o) == pyr.resolution(o)
+            assert np.array_equal(inst.downloadScaleSpaceImage(o, 5), pyr.gauss(o, 5))
+            assert np.array_equal(inst.downloadDoGImage(o, 4), pyr.dog(o, 4))
+            ref, _ = pyr.detect()
+            _eq_feats(inst.downloadFeatures(0), ref)
+
+
+def test_batch_detect_equals_single(vk):
+    imgs = [vk.gen_synthetic_image(200 + i, 300, 220) for i in range(5)]
+    cfg = vk.default_config(sift_buffer_count=6)
+    with vk.Instance(cfg, batch_capacity=5) as inst:
+        inst.detectFeaturesBatch(imgs, 1)
+        batch = [inst.downloadFeatures(1 + i) for i in range(5)]
+        singles = []
+        for i, im in enumerate(imgs):
+            inst.detectFeatures(im, 0)
+            singles.append(inst.downloadFeatures(0))
+    for b, s in zip(batch, singles):
+        assert len(s) > 50
+        _eq_feats(b, s)
+
+
+def test_section_overflow_counts_and_clamps(vk, oracle):
+    """max_nb_sift_per_buffer too small: counters keep counting, stores are dropped (ExtractKeypoints.comp:208-212)"""
+    img = vk.gen_synthetic_image(106, 320, 240)
+    vcfg = vk.default_config(max_nb_sift_per_buffer=100)
+    ocfg = oracle.default_config(math_mode=1, max_nb_sift_per_buffer=100)
+    vk.lib().vksift_setLogLevel(vk.VKSIFT_NO_LOG)
+    try:
+        with vk.Instance(vcfg) as inst:
+            inst.detectFeatures(img, 0)
+            got = inst.downloadFeatures(0)
+    finally:
+        vk.lib().vksift_setLogLevel(vk.VKSIFT_LOG_INFO)
+    ref, counts = oracle.detect(ocfg, img)
+    assert sum(counts) > 100 and len(ref) <= 100
+    _eq_feats(got, ref)
+
+
+def test_nb_octaves_config_and_more_scales(vk, oracle):
+    img = vk.gen_synthetic_image(107, 256, 192)
+    for kw in ({"nb_octaves": 2}, {"nb_scales_per_octave": 4}, {"seed_scale_sigma": 2.0}):
+        vcfg = vk.default_config(**kw)
+        ocfg = oracle.default_config(math_mode=1, **kw)
+        with vk.Instance(vcfg) as inst:
+            inst.detectFeatures(img, 0)
+            got = inst.downloadFeatures(0)
+        ref, _ = oracle.detect(ocfg, img)
+        assert len(ref) > 10
+        _eq_feats(got, ref)
+
+
+def test_libm_oracle_within_tolerance(vk, oracle):
+    """HIP path vs the oracle with independent libm math: the stated float tolerance of the parity claim."""
+    img = vk.gen_synthetic_image(108, 640, 480)
+    with vk.Instance(vk.default_config()) as inst:
+        inst.detectFeatures(img, 0)
+        got = inst.downloadFeatures(0)
+    ref, _ = oracle.detect(oracle.default_config(math_mode=0), img)
+    assert abs(len(got) - len(ref)) <= max(2, len(ref) // 200)
+    # set-based comparison: match keypoints by (octave, scale_idx, rounded position, orientation bin)
+    def key(f):
+        return (int(f["octave_idx"]), int(f["scale_idx"]), int(round(float(f["scale_x"]))), int(round(float(f["scale_y"]))),
+                int(round(float(f["orientation"]) * 36 / (2 * np.pi) * 2)))
+    rmap = {key(f): f for f in ref}
+    hit = [(g, rmap[key(g)]) for g in got if key(g) in rmap]
+    assert len(hit) >= 0.995 * len(ref)
+    dx = np.array([abs(g["x"] - r["x"]) + abs(g["y"] - r["y"]) for g, r in hit])
+    ds = np.array([abs(g["sigma"] / r["sigma"] - 1) for g, r in hit])
+    do = np.array([abs(g["orientation"] - r["orientation"]) for g, r in hit])
+    assert dx.max() < 1e-4 and ds.max() < 1e-5 and do.max() < 1e-4
+    rms = np.array([np.sqrt(((g["descriptor"].astype(float) - r["descriptor"].astype(float)) ** 2).mean()) / 512.0 for g, r in hit])
+    assert np.median(rms) < 1e-4 and np.percentile(rms, 99) < 1e-3

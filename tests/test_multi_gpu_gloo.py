@@ -1,0 +1,88 @@
+"""world_size-2 run of the multi-GPU layer on CPU (gloo): batch splitting needs no collective, the
+query-sharded matcher needs exactly one all-gather of B and gives the single-process result bit for bit.
+The HIP matcher is replaced by the oracle here (compute stand-in); the collective logic is the real one."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_match_fn(desc_a, a_index_base, desc_b):
+    from oracle import oracle as O
+
+    m = O.match_2nn(desc_a.numpy(), desc_b.numpy())
+    m["idx_a"] += a_index_base
+    return torch.from_numpy(m.view(np.uint8).reshape(-1, 20).copy().view(np.int32).reshape(-1, 5))
+
+
+def _worker(rank, world, port, na, nb, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vulkansift_amd import api, multigpu
+
+    a = api.gen_synthetic_descriptors(31, na)
+    b = api.gen_synthetic_descriptors(32, nb)
+    b[1] = b[0]
+    a0, a1 = multigpu.shard_range(na, world, rank)
+    b0, b1 = multigpu.shard_range(nb, world, rank)
+    rec = multigpu.sharded_match(torch.from_numpy(a[a0:a1]), a0, torch.from_numpy(b[b0:b1]), match_fn=_oracle_match_fn)
+    # detection-side splitting: no collective, just a partition
+    imgs = list(range(13))
+    mine = multigpu.split_batch(imgs, world, rank)
+    q.put((rank, a0, rec.numpy(), mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("na,nb", [(101, 77), (8, 3)])
+def test_sharded_match_equals_single_process(oracle, vk, na, nb):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, na, nb, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from vulkansift_amd import multigpu
+
+    got = np.concatenate([multigpu.records_to_struct(r[2]) for r in res])
+    a = vk.gen_synthetic_descriptors(31, na)
+    b = vk.gen_synthetic_descriptors(32, nb)
+    b[1] = b[0]
+    ref = oracle.match_2nn(a, b)
+    for name in ref.dtype.names:
+        assert np.array_equal(got[name], ref[name]), name
+    assert sorted(sum([r[3] for r in res], [])) == list(range(13))
+
+
+def test_shard_range_partitions():
+    from vulkansift_amd import multigpu
+
+    for n in (0, 1, 7, 64, 50000):
+        for world in (1, 2, 3, 8):
+            parts = [multigpu.shard_range(n, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [e - s for s, e in parts]
+            assert max(sizes) - min(sizes) <= 1

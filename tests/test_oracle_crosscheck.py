@@ -1,0 +1,104 @@
+"""The C oracle against the independent numpy restatement (tests/np_restatement.py)."""
+import numpy as np
+import pytest
+
+import np_restatement as R
+
+
+def _img(seed, w, h):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.full((h, w), 120.0)
+    for _ in range(40):
+        cx, cy, s, a = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(1.5, 8), rng.uniform(-90, 90)
+        img += a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+    img += rng.uniform(-6, 6, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("interp", [1, 0])
+@pytest.mark.parametrize("ups", [1, 0])
+def test_octave0_planes(oracle, interp, ups):
+    img = _img(1, 96, 64)
+    cfg = oracle.default_config(use_hardware_interpolated_blur=interp, use_input_upsampling=ups, math_mode=0)
+    pyr = oracle.Pyramid(cfg, img)
+    g, d = R.build_octave0(img, interpolated=bool(interp), ups=bool(ups))
+    assert pyr.resolution(0) == (g[0].shape[1], g[0].shape[0])
+    for s in range(6):
+        assert np.abs(pyr.gauss(0, s) - g[s]).max() < 2e-6, s
+    for s in range(5):
+        assert np.abs(pyr.dog(0, s) - d[s]).max() < 3e-6, s
+
+
+def test_downsample_takes_odd_texels(oracle):
+    img = _img(2, 100, 70)  # odd octave sizes further down: 200x140 -> 100x70 -> 50x35 -> 25x17
+    cfg = oracle.default_config(math_mode=0)
+    pyr = oracle.Pyramid(cfg, img)
+    S = 3
+    for o in range(1, pyr.nb_octaves):
+        w, h = pyr.resolution(o)
+        src = pyr.gauss(o - 1, S)
+        assert np.array_equal(pyr.gauss(o, 0), R.downsample_nearest(src, w, h))
+
+
+def test_upsample_closed_form(oracle):
+    img = _img(3, 40, 30)
+    cfg = oracle.default_config(math_mode=0)
+    # a zero-width seed blur is not configurable, so compare through a direct call of the numpy blur on the
+    # closed-form up-sampled image (already covered by test_octave0_planes); here: mirrored border sanity
+    up = R.upsample2x(img)
+    assert up.shape == (60, 80)
+    assert np.isclose(up[0, 0], img[0, 0] / 255.0) and np.isclose(up[-1, -1], img[-1, -1] / 255.0)
+    assert np.isclose(up[0, 2], (0.25 * img[0, 0] + 0.75 * img[0, 1]) / 255.0)
+
+
+def test_matcher(oracle):
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (60, 128), dtype=np.uint8)
+    b = rng.integers(0, 256, (90, 128), dtype=np.uint8)
+    b[1] = b[0]
+    b[10] = b[4]
+    a[3] = b[0]
+    a[7] = b[10]
+    ref = R.match_2nn(a, b)
+    got = oracle.match_2nn(a, b)
+    for r, g in zip(ref, got):
+        assert (g["idx_a"], g["idx_b1"], g["idx_b2"]) == r[:3]
+        assert g["dist_a_b1"] == r[3] and g["dist_a_b2"] == r[4]
+    assert got[3]["idx_b1"] == 1 and got[3]["idx_b2"] == 0  # quirk Q7
+    assert got[7]["idx_b1"] == 4 and got[7]["idx_b2"] == 10  # equal distance: earlier index first
+
+
+def test_extrema_are_strict_26_neighbour_extrema(oracle):
+    """every emitted keypoint started from a texel that passes the 0.8*thr pre-filter and the strict 3x3x3 test"""
+    img = _img(6, 128, 96)
+    cfg = oracle.default_config(math_mode=0)
+    pyr = oracle.Pyramid(cfg, img)
+    thr = np.float32(0.04) / np.float32(3)
+    total = 0
+    for o in range(pyr.nb_octaves):
+        dog = np.stack([pyr.dog(o, s) for s in range(5)])
+        kps, n = pyr.extract_keypoints(o)
+        total += n
+        c = dog[1:4, 1:-1, 1:-1]
+        nb_max = np.full(c.shape, -np.inf, np.float32)
+        nb_min = np.full(c.shape, np.inf, np.float32)
+        for ds in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    if ds == dy == dx == 0:
+                        continue
+                    v = dog[1 + ds:4 + ds, 1 + dy:dog.shape[1] - 1 + dy, 1 + dx:dog.shape[2] - 1 + dx]
+                    nb_max = np.maximum(nb_max, v)
+                    nb_min = np.minimum(nb_min, v)
+        cand = (np.abs(c) > np.float32(0.8) * thr) & ((c > nb_max) | (c < nb_min))
+        assert n <= cand.sum()
+        # refined positions stay within 5 refinement moves + 1.5 px of some candidate texel
+        ys, xs = np.nonzero(cand.any(axis=0))
+        for kp in kps:
+            dist = np.min(np.hypot(xs + 1 - kp["scale_x"], ys + 1 - kp["scale_y"]))
+            assert dist < 6.0
+        w, h = pyr.resolution(o)
+        assert np.all((kps["scale_x"] >= 0) & (kps["scale_x"] < w) & (kps["scale_y"] >= 0) & (kps["scale_y"] < h))
+        assert np.all(np.abs(kps["intensity"]) > thr)
+    assert total > 5

@@ -73,18 +73,37 @@ struct Top2
   uint32_t q1, k1, q2, k2; // squared distances and index keys of best / second
 };
 
+// Below 2^22 the map q -> sqrtf(float(q)) is injective (gap 1/(2 sqrt q) > ulp), so integer order == float
+// order and the correctly rounded sqrtf (a ~20-instruction sequence) is only needed above it.
+constexpr uint32_t Q_EXACT = 1u << 22;
+
 // (sqrtf(q), key) lexicographic order — the order the reference's scan realises
 __device__ __forceinline__ bool lex_less(uint32_t qa, uint32_t ka, uint32_t qb, uint32_t kb)
 {
   if (qa == qb)
     return ka < kb;
+  if ((qa | qb) < Q_EXACT)
+    return qa < qb;
   float da = sqrtf((float)qa), db = sqrtf((float)qb);
   return da < db || (da == db && ka < kb);
 }
 
-// in-lane insertion; keys arrive in increasing order so a tie never displaces a holder
+// in-lane insertion; keys arrive in increasing order so a tie never displaces a holder.
+// Precondition (pre-filter): q < t.q2 as integers.
 __device__ __forceinline__ void insert_seq(Top2 &t, uint32_t q, uint32_t key)
 {
+  if (t.q2 < Q_EXACT)
+  {
+    // q < q2 < 2^22 and q1 <= q2: pure integer comparison is exact
+    if (q < t.q1)
+    {
+      t.q2 = t.q1, t.k2 = t.k1;
+      t.q1 = q, t.k1 = key;
+    }
+    else
+      t.q2 = q, t.k2 = key;
+    return;
+  }
   float d = sqrtf((float)q);
   if (d < sqrtf((float)t.q1))
   {
