@@ -142,6 +142,17 @@ extern "C"
   int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
                                 uint8_t *matches, vksift_hip_stream s);
 
+  /* Asynchronous matching pipeline used by vksift_matchFeatures (no host round trip for the feature counts):
+   * gather_sections walks up to 16 buffer sections whose stored counts are min(found_dev[o], sec_cap[o]) (or
+   * fixed_counts[o] when found_dev is NULL), writes the dense descriptor rows in download order, their shifted
+   * norms and the row total (*n_out_dev); rows up to pad_rows_to are zero-filled (quirk Q6). max_rows bounds the
+   * launch. match_2nn_async then reads {N_A, N_B} from n_dev[0..1]. */
+  int vksift_hip_gather_sections(const uint8_t *feats, uint32_t nsec, const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *fixed_counts,
+                                 const uint32_t *found_dev, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint32_t *norms, uint32_t *n_out_dev,
+                                 vksift_hip_stream s);
+  int vksift_hip_match_2nn_async(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t max_na, const uint8_t *desc_b, const uint32_t *norm_b,
+                                 const uint32_t *n_dev, uint8_t *matches, vksift_hip_stream s);
+
 #ifdef __cplusplus
 }
 #endif

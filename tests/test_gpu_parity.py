@@ -151,3 +151,10 @@ def test_match_fewer_than_two_b_rows(vk, oracle):
     m = _match_via_api(vk, a, b)
     ref = oracle.match_2nn(a, np.vstack([b, np.zeros((1, 128), np.uint8)]))
     _assert_matches_equal(m, ref)
+
+
+def test_match_largest_regime(vk, oracle):
+    """na > 32768 selects the 64-rows-per-wave kernel"""
+    a = vk.gen_synthetic_descriptors(41, 33001)
+    b = vk.gen_synthetic_descriptors(42, 130)
+    _assert_matches_equal(_match_via_api(vk, a, b), oracle.match_2nn(a, b))

@@ -250,93 +250,155 @@ __global__ void __launch_bounds__(1024) k_orientation_finalize(FeatArgs a)
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int smod8(int v) { return v & 7; } // floored modulo for a power of two (quirk Q5, OpSMod)
 
+// Per-pixel descriptor contribution (ComputeDescriptors.comp:139-197) for window offset (cdx, cdy).
+struct DescCtx
+{
+  const float *layer;
+  int pitch;
+  float scale_x, scale_y, rsx, rsy, kcos, ksin, kori, fp;
+  uint32_t use_vlfeat;
+};
+
+__device__ __forceinline__ void desc_accumulate(const DescCtx &c, int cdx, int cdy, uint32_t *s_work)
+{
+  const float es = -1.f / (2.f * 2 * 2);
+  const int ix = (int)c.rsx + cdx, iy = (int)c.rsy + cdy;
+  float sdx = (c.rsx + (float)cdx) - c.scale_x;
+  float sdy = (c.rsy + (float)cdy) - c.scale_y;
+  float ox = c.kcos * sdx + c.ksin * sdy;
+  float oy = c.kcos * sdy - c.ksin * sdx;
+  float gradX = 0.5f * (c.layer[(size_t)iy * c.pitch + ix + 1] - c.layer[(size_t)iy * c.pitch + ix - 1]);
+  float gradY = 0.5f * (c.layer[(size_t)(iy + 1) * c.pitch + ix] - c.layer[(size_t)(iy - 1) * c.pitch + ix]);
+  float ori = dm_atan2f(gradY, gradX);
+  if (ori < 0)
+    ori += 2.f * PI_F;
+  else if (ori > (2.f * PI_F))
+    ori -= 2.f * PI_F;
+  ori = ori - c.kori;
+  if (ori < 0)
+    ori += 2.f * PI_F;
+  else if (ori > (2.f * PI_F))
+    ori -= 2.f * PI_F;
+  float mag = dm_expf(es * ((ox * ox) + (oy * oy))) * sqrtf((gradX * gradX) + (gradY * gradY));
+
+  float fhx = ox + 2.f, fhy = oy + 2.f;
+  float fbin = c.use_vlfeat ? (ori * 8.f / (2.f * PI_F)) : (-ori * 8.f / (2.f * PI_F));
+  int hx = (int)floorf(fhx - 0.5f), hy = (int)floorf(fhy - 0.5f), hb = (int)floorf(fbin);
+  float rhx = fhx - ((float)hx + 0.5f), rhy = fhy - ((float)hy + 0.5f), rb = fbin - (float)hb;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++)
+        if ((i + hx) >= 0 && (i + hx) < 4 && (j + hy) >= 0 && (j + hy) < 4)
+        {
+          int idx = (j + hy) * 32 + (i + hx) * 8 + smod8(kk + hb);
+          float val = fabsf(1.f - (float)i - rhx) * fabsf(1.f - (float)j - rhy) * fabsf(1.f - (float)kk - rb) * mag;
+          atomicAdd(&s_work[idx], (uint32_t)(val * c.fp));
+        }
+}
+
+// One 256-thread workgroup per keypoint (the window of a coarse-scale keypoint has up to ~7.5k pixels; a single wave
+// would make it the critical path of the whole launch). Each wave first filters its 64 pixels with the cheap tests
+// — inside the image interior, and inside the 4x4 histogram grid after rotation — and compacts the survivors into a
+// per-wave LDS queue; the expensive part (gradient, atan2, exp, 8 fixed-point atomics) then always runs on full
+// 64-lane batches. About half of the window falls outside the rotated grid: the reference evaluates atan/exp for
+// those pixels and then drops the contribution (ComputeDescriptors.comp:189); skipping them changes no bit.
 __global__ void __launch_bounds__(256) k_descriptor(FeatArgs a)
 {
-  __shared__ uint32_t s_work[4][128];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ uint32_t s_work[128];
+  __shared__ uint32_t s_q[4][128];
+  const int tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const uint32_t found = a.found[(size_t)b * a.found_img_stride];
   const uint32_t n1 = found < a.cap ? found : a.cap;
   GaussView g{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride};
   uint8_t *feats = a.feats + (size_t)b * a.feat_img_stride;
+  uint32_t *q = s_q[wave];
 
-  for (uint32_t base = blockIdx.x * 4; base < n1; base += gridDim.x * 4)
+  for (uint32_t k = blockIdx.x; k < n1; k += gridDim.x)
   {
-    const uint32_t k = base + wave;
-    const bool active = k < n1;
-    s_work[wave][lane] = 0;
-    s_work[wave][lane + 64] = 0;
     __syncthreads();
-    if (active)
+    if (tid < 128)
+      s_work[tid] = 0;
+    __syncthreads();
+
+    const float *rec = (const float *)(feats + (size_t)k * 164);
+    const uint32_t scale_idx = ((const uint32_t *)rec)[4];
+    const int octave_idx = ((const int *)rec)[5];
+    const float sigma = rec[6];
+    DescCtx c;
+    c.scale_x = rec[2], c.scale_y = rec[3], c.kori = rec[7];
+    c.layer = g.base + (size_t)scale_idx * g.plane;
+    c.pitch = g.pitch;
+    c.use_vlfeat = a.use_vlfeat;
+    float scale_factor = dm_pow2i(octave_idx);
+    float lambda = 3.0f * (sigma / scale_factor);
+    float radius = sqrtf(2.f) * lambda * 5.f * 0.5f;
+    int R = (int)floorf(radius + 0.5f);
+    float sn, cs;
+    dm_sincosf(c.kori, &sn, &cs);
+    c.kcos = cs / lambda, c.ksin = sn / lambda;
+    uint32_t ti = (uint32_t)(R / 2);
+    c.fp = a.desc_fp_tab[ti < a.desc_fp_tab_len ? ti : a.desc_fp_tab_len - 1];
+    c.rsx = roundf(c.scale_x), c.rsy = roundf(c.scale_y);
+
+    const int box = 2 * R + 1;
+    const int npix = box * box;
+    // walk the window without per-pixel integer division: (dx, dy) advance by 256 pixels per iteration
+    int dy = tid / box - R, dx = tid % box - R;
+    const int step_y = 256 / box, step_x = 256 % box;
+    uint32_t qn = 0; // queue fill of this wave (wave-uniform)
+    for (int pix0 = 0; pix0 < npix; pix0 += 256)
     {
-      const float *rec = (const float *)(feats + (size_t)k * 164);
-      const float scale_x = rec[2], scale_y = rec[3];
-      const uint32_t scale_idx = ((const uint32_t *)rec)[4];
-      const int octave_idx = ((const int *)rec)[5];
-      const float sigma = rec[6], kori = rec[7];
-      const float *layer = g.base + (size_t)scale_idx * g.plane;
-
-      float scale_factor = dm_pow2i(octave_idx);
-      float lambda = 3.0f * (sigma / scale_factor);
-      float radius = sqrtf(2.f) * lambda * 5.f * 0.5f;
-      int R = (int)floorf(radius + 0.5f);
-      float sn, cs;
-      dm_sincosf(kori, &sn, &cs);
-      float kcos = cs / lambda, ksin = sn / lambda;
-      const float es = -1.f / (2.f * 2 * 2);
-      uint32_t ti = (uint32_t)(R / 2);
-      float fp = a.desc_fp_tab[ti < a.desc_fp_tab_len ? ti : a.desc_fp_tab_len - 1];
-
-      float rsx = roundf(scale_x), rsy = roundf(scale_y);
-      int box = 2 * R + 1;
-      int npix = box * box;
-      for (int pix = lane; pix < npix; pix += 64)
+      const int cdx = dx, cdy = dy;
+      dx += step_x;
+      dy += step_y;
+      if (dx > R)
       {
-        int dy = (pix / box) - R, dx = (pix % box) - R;
-        int ix = (int)rsx + dx, iy = (int)rsy + dy;
-        float sdx = (rsx + (float)dx) - scale_x;
-        float sdy = (rsy + (float)dy) - scale_y;
-        if (ix < 1 || ix >= (g.w - 1) || iy < 1 || iy >= (g.h - 1))
-          continue;
-        float ox = kcos * sdx + ksin * sdy;
-        float oy = kcos * sdy - ksin * sdx;
-        float gradX = 0.5f * (layer[(size_t)iy * g.pitch + ix + 1] - layer[(size_t)iy * g.pitch + ix - 1]);
-        float gradY = 0.5f * (layer[(size_t)(iy + 1) * g.pitch + ix] - layer[(size_t)(iy - 1) * g.pitch + ix]);
-        float ori = dm_atan2f(gradY, gradX);
-        if (ori < 0)
-          ori += 2.f * PI_F;
-        else if (ori > (2.f * PI_F))
-          ori -= 2.f * PI_F;
-        ori = ori - kori;
-        if (ori < 0)
-          ori += 2.f * PI_F;
-        else if (ori > (2.f * PI_F))
-          ori -= 2.f * PI_F;
-        float mag = dm_expf(es * ((ox * ox) + (oy * oy))) * sqrtf((gradX * gradX) + (gradY * gradY));
-
-        float fhx = ox + 2.f, fhy = oy + 2.f;
-        float fbin = a.use_vlfeat ? (ori * 8.f / (2.f * PI_F)) : (-ori * 8.f / (2.f * PI_F));
-        int hx = (int)floorf(fhx - 0.5f), hy = (int)floorf(fhy - 0.5f), hb = (int)floorf(fbin);
-        float rhx = fhx - ((float)hx + 0.5f), rhy = fhy - ((float)hy + 0.5f), rb = fbin - (float)hb;
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int kk = 0; kk < 2; kk++)
-              if ((i + hx) >= 0 && (i + hx) < 4 && (j + hy) >= 0 && (j + hy) < 4)
-              {
-                int idx = (j + hy) * 32 + (i + hx) * 8 + smod8(kk + hb);
-                float val = fabsf(1.f - (float)i - rhx) * fabsf(1.f - (float)j - rhy) * fabsf(1.f - (float)kk - rb) * mag;
-                atomicAdd(&s_work[wave][idx], (uint32_t)(val * fp));
-              }
+        dx -= box;
+        dy += 1;
+      }
+      bool ok = pix0 + tid < npix;
+      const int ix = (int)c.rsx + cdx, iy = (int)c.rsy + cdy;
+      ok = ok && !(ix < 1 || ix >= (g.w - 1) || iy < 1 || iy >= (g.h - 1));
+      if (ok)
+      {
+        float sdx = (c.rsx + (float)cdx) - c.scale_x;
+        float sdy = (c.rsy + (float)cdy) - c.scale_y;
+        float ox = c.kcos * sdx + c.ksin * sdy;
+        float oy = c.kcos * sdy - c.ksin * sdx;
+        int hx = (int)floorf((ox + 2.f) - 0.5f), hy = (int)floorf((oy + 2.f) - 0.5f);
+        ok = !(hx < -1 || hx > 3 || hy < -1 || hy > 3);
+      }
+      const unsigned long long m = __ballot(ok);
+      if (ok)
+        q[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(cdx & 0xffff)) | ((uint32_t)cdy << 16);
+      qn += (uint32_t)__popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      if (qn >= 64)
+      {
+        const uint32_t e = q[lane];
+        desc_accumulate(c, (int)(short)(e & 0xffff), (int)e >> 16, s_work);
+        const uint32_t rest = q[64 + lane];
+        __builtin_amdgcn_wave_barrier();
+        qn -= 64;
+        if ((uint32_t)lane < qn)
+          q[lane] = rest;
+        __builtin_amdgcn_wave_barrier();
       }
     }
+    if ((uint32_t)lane < qn)
+    {
+      const uint32_t e = q[lane];
+      desc_accumulate(c, (int)(short)(e & 0xffff), (int)e >> 16, s_work);
+    }
     __syncthreads();
-    if (active)
+    if (wave == 0)
     {
       // normalise -> clamp at 0.2*norm -> renormalise -> x512 -> u8 (:200-265)
-      uint32_t w0 = s_work[wave][lane], w1 = s_work[wave][lane + 64];
+      uint32_t w0 = s_work[lane], w1 = s_work[lane + 64];
       uint32_t acc = w0 * w0 + w1 * w1;
 #pragma unroll
       for (int dlt = 32; dlt >= 1; dlt >>= 1)
@@ -368,7 +430,6 @@ __global__ void __launch_bounds__(256) k_descriptor(FeatArgs a)
         desc[16 + (lane >> 2)] = p1;
       }
     }
-    __syncthreads();
   }
 }
 
@@ -408,7 +469,7 @@ extern "C"
   int vksift_hip_descriptors(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s)
   {
     FeatArgs a = make_args(job);
-    uint32_t blocks = (job->cap + 3) / 4;
+    uint32_t blocks = job->cap;
     if (blocks > 2048)
       blocks = 2048;
     if (blocks == 0)

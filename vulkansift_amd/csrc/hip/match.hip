@@ -68,6 +68,57 @@ __global__ void __launch_bounds__(256) k_shifted_norms(const uint32_t *__restric
   norms[row] = s2 - 256u * s1 + 128u * 128u * 128u;
 }
 
+// Gather the descriptors of a (sectioned or packed) SIFT buffer into dense rows in download order AND compute
+// their shifted norms, with the per-section feature counts read on the device (no host round trip):
+// row -> section by scanning the <= 16 section counts; one half-wave (32 lanes) per row, one dword per lane.
+struct SectionTable
+{
+  uint32_t nsec;
+  uint32_t off[16];   // first feature of each section inside the buffer
+  uint32_t cap[16];   // capacity (stored = min(found, cap))
+  uint32_t fixed[16]; // used instead of found[] when found == nullptr (uploaded / packed buffers)
+};
+
+__global__ void __launch_bounds__(256) k_gather_sections(const uint8_t *__restrict__ feats, SectionTable tab, const uint32_t *__restrict__ found,
+                                                         uint32_t *__restrict__ desc, uint32_t *__restrict__ norms, uint32_t *__restrict__ n_out,
+                                                         uint32_t pad_rows_to)
+{
+  const uint32_t row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const uint32_t j = threadIdx.x & 31u;
+  // section lookup (uniform per half-wave)
+  uint32_t base = 0, src_row = 0xFFFFFFFFu, total = 0;
+#pragma unroll 1
+  for (uint32_t o = 0; o < tab.nsec; o++)
+  {
+    uint32_t n = found ? found[o] : tab.fixed[o];
+    n = n < tab.cap[o] ? n : tab.cap[o];
+    if (row >= base && row < base + n)
+      src_row = tab.off[o] + (row - base);
+    base += n;
+  }
+  total = base;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    *n_out = total;
+  uint32_t v;
+  if (src_row != 0xFFFFFFFFu)
+    v = *(const uint32_t *)(feats + (size_t)src_row * 164 + 36 + 4 * j);
+  else if (row < pad_rows_to)
+    v = 0u; // quirk Q6 padding rows: all-zero descriptors
+  else
+    return;
+  desc[(size_t)row * 32 + j] = v;
+  uint32_t s2 = __builtin_amdgcn_udot4(v, v, 0u, false);
+  uint32_t s1 = __builtin_amdgcn_udot4(v, 0x01010101u, 0u, false);
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1)
+  {
+    s2 += __shfl_xor(s2, d, 64);
+    s1 += __shfl_xor(s1, d, 64);
+  }
+  if (j == 0)
+    norms[row] = s2 - 256u * s1 + 128u * 128u * 128u;
+}
+
 struct Top2
 {
   uint32_t q1, k1, q2, k2; // squared distances and index keys of best / second
@@ -142,8 +193,18 @@ __device__ __forceinline__ Top2 merge2(const Top2 &a, const Top2 &b)
 template <int AT>
 __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
                                                     uint32_t a_index_base, const uint32_t *__restrict__ desc_b, const uint32_t *__restrict__ norm_b,
-                                                    uint32_t nb, uint32_t *__restrict__ matches)
+                                                    uint32_t nb, uint32_t *__restrict__ matches, const uint32_t *__restrict__ n_dev,
+                                                    uint32_t na_lo, uint32_t na_hi)
 {
+  if (n_dev)
+  {
+    // asynchronous path: the row counts were produced on the device by k_gather_sections; this instantiation only
+    // serves na in (na_lo, na_hi] (the host launches one kernel per regime, the others exit here)
+    na = n_dev[0];
+    nb = n_dev[1] < 2u ? 2u : n_dev[1];
+    if (na <= na_lo || na > na_hi || blockIdx.x * (64u * AT) >= na)
+      return;
+  }
   __shared__ __attribute__((aligned(16))) uint8_t s_b[BT * B_STRIDE];
   __shared__ uint32_t s_nb[BT];
 
@@ -180,22 +241,43 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
       st[t][j] = Top2{QMAX, QMAX, QMAX, QMAX};
   uint32_t swap_bits = 0; // bit (t*4+j): d(b0) == d(b1) for that A row (quirk Q7)
 
+  // B tiles are prefetched one tile ahead into registers (2 x 16 B per thread) so that the global-load latency of
+  // tile t+1 hides behind the MFMA + epilogue work of tile t.
+  constexpr int NLD = BT * 8 / 256;
+  uint4 pfb[NLD];
+  uint32_t pfn = 0;
+  auto fetch_tile = [&](uint32_t t0) {
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
+    {
+      int i = threadIdx.x + q * 256;
+      int r = i >> 3, c = i & 7;
+      pfb[q] = make_uint4(0, 0, 0, 0);
+      if (t0 + r < nb)
+        pfb[q] = ((const uint4 *)(desc_b + (size_t)(t0 + r) * 32))[c];
+    }
+    pfn = (threadIdx.x < BT && t0 + threadIdx.x < nb) ? norm_b[t0 + threadIdx.x] : 0u;
+  };
+  fetch_tile(0);
+
   for (uint32_t t0 = 0; t0 < nb; t0 += BT)
   {
     __syncthreads();
-    // stage BT rows (zero beyond nb), converting to int8
-    for (int i = threadIdx.x; i < BT * 8; i += 256)
+    // stage the prefetched BT rows (zero beyond nb), converting to int8
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
     {
+      int i = threadIdx.x + q * 256;
       int r = i >> 3, c = i & 7;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (t0 + r < nb)
-        v = ((const uint4 *)(desc_b + (size_t)(t0 + r) * 32))[c];
+      uint4 v = pfb[q];
       v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
       *(uint4 *)(s_b + r * B_STRIDE + c * 16) = v;
     }
     if (threadIdx.x < BT)
-      s_nb[threadIdx.x] = t0 + threadIdx.x < nb ? norm_b[t0 + threadIdx.x] : 0u;
+      s_nb[threadIdx.x] = pfn;
     __syncthreads();
+    if (t0 + BT < nb)
+      fetch_tile(t0 + BT);
 
 #pragma unroll
     for (int sub = 0; sub < BT / 16; sub++)
@@ -279,6 +361,186 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
     }
 }
 
+// Small-problem variant: one workgroup = 16 A rows; its 4 waves each take one 16-row slice of every staged 64-row B
+// tile (wave w sees B indices t0 + 16w + col, increasing over tiles, so the in-lane pre-filter stays valid), and the
+// four partial top-2 lists are merged through LDS with the same (sqrt(d2), index) order. 4x more waves than the
+// row-per-wave kernel for a few thousand features, 4x shorter dependent chain per wave.
+__global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
+                                                          uint32_t a_index_base, const uint32_t *__restrict__ desc_b,
+                                                          const uint32_t *__restrict__ norm_b, uint32_t nb, uint32_t *__restrict__ matches,
+                                                          const uint32_t *__restrict__ n_dev, uint32_t na_lo, uint32_t na_hi)
+{
+  if (n_dev)
+  {
+    na = n_dev[0];
+    nb = n_dev[1] < 2u ? 2u : n_dev[1];
+    if (na <= na_lo || na > na_hi)
+      return;
+  }
+  if (blockIdx.x * 16u >= na)
+    return;
+  __shared__ __attribute__((aligned(16))) uint8_t s_b[2][BT * B_STRIDE];
+  __shared__ uint32_t s_nb[2][BT];
+  __shared__ uint32_t s_part[4][16][4];
+  __shared__ uint32_t s_swap;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, grp = lane >> 4;
+  const uint32_t row_base = blockIdx.x * 16u;
+
+  v4i afrag[2];
+  uint32_t an[4];
+  {
+    uint32_t r = row_base + col;
+    if (r >= na)
+      r = na - 1;
+    const uint4 *p = (const uint4 *)(desc_a + (size_t)r * 32);
+    uint4 v0 = p[grp], v1 = p[4 + grp];
+    afrag[0] = v4i{(int)(v0.x ^ 0x80808080u), (int)(v0.y ^ 0x80808080u), (int)(v0.z ^ 0x80808080u), (int)(v0.w ^ 0x80808080u)};
+    afrag[1] = v4i{(int)(v1.x ^ 0x80808080u), (int)(v1.y ^ 0x80808080u), (int)(v1.z ^ 0x80808080u), (int)(v1.w ^ 0x80808080u)};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      uint32_t rr = row_base + grp * 4 + j;
+      an[j] = norm_a[rr < na ? rr : na - 1];
+    }
+  }
+  Top2 st[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    st[j] = Top2{QMAX, QMAX, QMAX, QMAX};
+  uint32_t swap_bits = 0;
+
+  constexpr int NLD = BT * 8 / 256;
+  uint4 pfb[NLD];
+  uint32_t pfn = 0;
+  auto fetch_tile = [&](uint32_t t0) {
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
+    {
+      int i = threadIdx.x + q * 256;
+      int r = i >> 3, c = i & 7;
+      pfb[q] = make_uint4(0, 0, 0, 0);
+      if (t0 + r < nb)
+        pfb[q] = ((const uint4 *)(desc_b + (size_t)(t0 + r) * 32))[c];
+    }
+    pfn = (threadIdx.x < BT && t0 + threadIdx.x < nb) ? norm_b[t0 + threadIdx.x] : 0u;
+  };
+  fetch_tile(0);
+
+  int buf = 0;
+  for (uint32_t t0 = 0; t0 < nb; t0 += BT, buf ^= 1)
+  {
+    // double-buffered staging: one barrier per tile
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
+    {
+      int i = threadIdx.x + q * 256;
+      int r = i >> 3, c = i & 7;
+      uint4 v = pfb[q];
+      v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
+      *(uint4 *)(s_b[buf] + r * B_STRIDE + c * 16) = v;
+    }
+    if (threadIdx.x < BT)
+      s_nb[buf][threadIdx.x] = pfn;
+    __syncthreads();
+    if (t0 + BT < nb)
+      fetch_tile(t0 + BT);
+
+    const uint32_t sub0 = t0 + 16u * wave;
+    if (sub0 < nb)
+    {
+      const uint32_t bcol = sub0 + col;
+      const uint8_t *pb = s_b[buf] + (16 * wave + col) * B_STRIDE + grp * 16;
+      const v4i b0 = *(const v4i *)pb;
+      const v4i b1 = *(const v4i *)(pb + 64);
+      const uint32_t bn = s_nb[buf][16 * wave + col];
+      v4i acc = v4i{0, 0, 0, 0};
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[0], b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[1], b1, acc, 0, 0, 0);
+      uint32_t q[4];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        q[j] = bcol < nb ? an[j] + bn - 2u * (uint32_t)acc[j] : QMAX;
+        any = any || (q[j] < st[j].q2);
+      }
+      if (sub0 == 0)
+      {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+          uint32_t other = __shfl_xor(q[j], 1, 64);
+          bool sw = col < 2 && sqrtf((float)q[j]) == sqrtf((float)other);
+          if (sw)
+            swap_bits |= 1u << j;
+          uint32_t key = (col < 2 && sw) ? (uint32_t)(col ^ 1) : bcol;
+          if (q[j] != QMAX)
+            insert_seq(st[j], q[j], key);
+        }
+      }
+      else if (any)
+      {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (q[j] < st[j].q2)
+            insert_seq(st[j], q[j], bcol);
+      }
+    }
+  }
+
+  // merge across the 16 lanes of a row group, then across the 4 waves
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    Top2 s = st[j];
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1)
+    {
+      Top2 o;
+      o.q1 = __shfl_xor(s.q1, m, 64), o.k1 = __shfl_xor(s.k1, m, 64);
+      o.q2 = __shfl_xor(s.q2, m, 64), o.k2 = __shfl_xor(s.k2, m, 64);
+      s = merge2(s, o);
+    }
+    if (col == 0)
+    {
+      s_part[wave][grp * 4 + j][0] = s.q1, s_part[wave][grp * 4 + j][1] = s.k1;
+      s_part[wave][grp * 4 + j][2] = s.q2, s_part[wave][grp * 4 + j][3] = s.k2;
+    }
+  }
+  if (threadIdx.x == 0)
+    s_swap = 0;
+  __syncthreads();
+  if (wave == 0 && col == 0)
+    atomicOr(&s_swap, swap_bits << (grp * 4));
+  __syncthreads();
+  if (threadIdx.x < 16)
+  {
+    const int rr = threadIdx.x;
+    Top2 s{s_part[0][rr][0], s_part[0][rr][1], s_part[0][rr][2], s_part[0][rr][3]};
+#pragma unroll
+    for (int w = 1; w < 4; w++)
+    {
+      Top2 o{s_part[w][rr][0], s_part[w][rr][1], s_part[w][rr][2], s_part[w][rr][3]};
+      s = merge2(s, o);
+    }
+    const uint32_t r = row_base + rr;
+    if (r < na)
+    {
+      bool sw = (s_swap >> rr) & 1u;
+      uint32_t i1 = (sw && s.k1 < 2) ? (s.k1 ^ 1u) : s.k1;
+      uint32_t i2 = (sw && s.k2 < 2) ? (s.k2 ^ 1u) : s.k2;
+      uint32_t *m = matches + (size_t)r * 5;
+      m[0] = a_index_base + r;
+      m[1] = i1;
+      m[2] = i2;
+      m[3] = __float_as_uint(sqrtf((float)s.q1));
+      m[4] = __float_as_uint(sqrtf((float)s.q2));
+    }
+  }
+}
+
 } // namespace
 
 extern "C"
@@ -303,18 +565,73 @@ extern "C"
     hipLaunchKernelGGL(k_shifted_norms, dim3((na + 255u) / 256u), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, na, norm_a);
     hipLaunchKernelGGL(k_shifted_norms, dim3((nb + 255u) / 256u), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_b, nb, norm_b);
     /* Small problems: 16 A rows per wave to fill more CUs; large ones: 64 rows per wave for B-tile reuse. */
-    if (na <= 16384u)
+    if (na <= 8192u)
+    {
+      hipLaunchKernelGGL(k_match_mfma_split, dim3((na + 15u) / 16u), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, norm_a, na, a_index_base,
+                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
+    }
+    else if (na <= 32768u)
     {
       uint32_t blocks = (na + 63u) / 64u;
       hipLaunchKernelGGL(k_match_mfma<1>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, norm_a, na, a_index_base,
-                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches);
+                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
     }
     else
     {
       uint32_t blocks = (na + 255u) / 256u;
       hipLaunchKernelGGL(k_match_mfma<4>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, norm_a, na, a_index_base,
-                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches);
+                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
     }
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_gather_sections(const uint8_t *feats, uint32_t nsec, const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *fixed_counts,
+                                 const uint32_t *found_dev, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint32_t *norms, uint32_t *n_out_dev,
+                                 vksift_hip_stream s)
+  {
+    if (nsec > 16)
+      return (int)hipErrorInvalidValue;
+    SectionTable t;
+    t.nsec = nsec;
+    for (uint32_t o = 0; o < 16; o++)
+    {
+      t.off[o] = o < nsec ? sec_off[o] : 0u;
+      t.cap[o] = o < nsec ? sec_cap[o] : 0u;
+      t.fixed[o] = (o < nsec && fixed_counts) ? fixed_counts[o] : 0u;
+    }
+    if (max_rows < pad_rows_to)
+      max_rows = pad_rows_to;
+    uint32_t blocks = (max_rows + 7u) / 8u;
+    if (blocks == 0)
+      blocks = 1;
+    hipLaunchKernelGGL(k_gather_sections, dim3(blocks), dim3(256), 0, (hipStream_t)s, feats, t, found_dev, (uint32_t *)desc, norms, n_out_dev, pad_rows_to);
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_match_2nn_async(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t max_na, const uint8_t *desc_b, const uint32_t *norm_b,
+                                 const uint32_t *n_dev, uint8_t *matches, vksift_hip_stream s)
+  {
+    if (max_na == 0)
+      return 0;
+    /* The row count is only known on the device: launch for the capacity (surplus workgroups exit at once), one
+     * kernel per size regime, each of which returns immediately unless N_A falls in its range:
+     *   N_A <= 8192        B-split kernel, 16 A rows per workgroup (keeps a few thousand rows busy on every CU)
+     *   8192 < N_A <= 32768 16 A rows per wave
+     *   N_A > 32768         64 A rows per wave (B tile reuse) */
+    const uint32_t S1 = 8192u, S2 = 32768u;
+    hipStream_t hs = (hipStream_t)s;
+    const uint32_t n1 = max_na < S1 ? max_na : S1;
+    hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u, (const uint32_t *)desc_b,
+                       norm_b, 0u, (uint32_t *)matches, n_dev, 0u, S1);
+    if (max_na > S1)
+    {
+      const uint32_t n2 = max_na < S2 ? max_na : S2;
+      hipLaunchKernelGGL(k_match_mfma<1>, dim3((n2 + 63u) / 64u), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u, (const uint32_t *)desc_b,
+                         norm_b, 0u, (uint32_t *)matches, n_dev, S1, S2);
+    }
+    if (max_na > S2)
+      hipLaunchKernelGGL(k_match_mfma<4>, dim3((max_na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u,
+                         (const uint32_t *)desc_b, norm_b, 0u, (uint32_t *)matches, n_dev, S2, 0xFFFFFFFFu);
     return (int)hipGetLastError();
   }
 }

@@ -11,11 +11,15 @@
 //   compiled with -ffp-contract=off so nothing else is fused.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vksift_hip.h"
 
 namespace
 {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct Taps
 {
@@ -141,6 +145,208 @@ __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src
 }
 
 // ---------------------------------------------------------------------------------------------
+// Streaming separable blur (+ DoG): the production kernel.
+//
+// One wave owns a 128-column strip of a row segment [y0, y1) and marches down the "virtual" row
+// sequence r = y0-R .. y1-1+R in groups of NR = 8 rows; virtual row r is fed by source row mirror(r),
+// so the mirrored-repeat border needs no special case anywhere below the loads.
+//   stage   : float4 loads of the next group's source rows (prefetched one group ahead, 16 B/lane,
+//             coalesced, halo RA = R rounded up to 4, mirrored in x at the image edges) -> LDS
+//   H pass  : every lane blurs its 2 pixels of each new row from LDS (ds_read_b64, stride-1 lanes:
+//             conflict free) straight into the register window
+//   V pass  : the register window holds the 2R+8 most recent H rows of the lane's own two columns;
+//             8 output rows are produced per group, then the window shifts by 8 (2R v_mov per pixel
+//             column against 8*4R arithmetic instructions)
+//   DoG     : G - source centre; the centres wait R rows in a small LDS ring written by their own lane
+// Everything is unrolled on the tap count (template): taps sit in SGPRs, inner loops are straight
+// v_add/v_fma chains with 16 independent accumulators per lane. Only the staging buffer is shared
+// between lanes -> one barrier per group. LDS per wave: 8*(128+2RA)*4 + (R+8)*128*4 B (15 KiB at R = 12).
+// HBM traffic per pixel: 4 B read (x (128+2RA)/128 horizontally, x (SEG+2R)/SEG vertically) + 4 B G +
+// 4 B DoG written.
+// ---------------------------------------------------------------------------------------------
+struct StreamArgs
+{
+  const float *src;
+  float *dst;
+  float *dog;
+  uint64_t src_img_stride, dst_img_stride, dog_img_stride;
+  int spitch, dpitch, gpitch;
+  int w, h;
+  int seg; // output rows per workgroup (multiple of 8)
+  Taps taps;
+};
+
+__device__ __forceinline__ int pmod(int v, int m) { return (v + m * 4096) % m; } // v > -4096*m
+
+template <int NT, bool DOG, int NW>
+__global__ void __launch_bounds__(64 * NW) k_blur_stream(StreamArgs a)
+{
+  constexpr int R = NT - 1;
+  constexpr int RA = (R + 3) & ~3;
+  constexpr int TW = 128 * NW, NR = 8; // NW waves side by side: 128*NW contiguous columns per workgroup
+  constexpr int SW = TW + 2 * RA;
+  constexpr int CTR_ROWS = R + NR;
+  constexpr int NV4 = SW / 4;          // float4 per staged row
+  constexpr int NTHR = 64 * NW;
+  constexpr int NLD = (NR * NV4 + NTHR - 1) / NTHR; // staging float4 per thread and group
+  constexpr int OFS = (RA - R) & 1; // parity fix so that the H-pass window starts on an even float
+  constexpr int NP = R + 1 + OFS;   // float2 pairs read per row in the H pass
+  constexpr int C0 = R + OFS;       // index of pixel 0's centre inside the window
+  constexpr int NWIN = 2 * R + NR;
+  __shared__ __attribute__((aligned(16))) float s_stage[NR * SW];
+  __shared__ __attribute__((aligned(16))) float s_ctr[DOG ? CTR_ROWS * TW : 4];
+
+  const int tid = threadIdx.x;
+  const int W = a.w, H = a.h;
+  const int x0 = blockIdx.x * TW;
+  const int y0 = blockIdx.y * a.seg;
+  const int y1 = min(y0 + a.seg, H);
+  const float *src = a.src + (size_t)blockIdx.z * a.src_img_stride;
+  float *dst = a.dst + (size_t)blockIdx.z * a.dst_img_stride;
+  float *dog = DOG ? a.dog + (size_t)blockIdx.z * a.dog_img_stride : nullptr;
+
+  // staging assignment: element e = tid + q*NTHR of the group's NR x NV4 float4 grid (row-major)
+  int st_row[NLD], st_c4[NLD];
+  bool st_on[NLD], st_vec[NLD];
+#pragma unroll
+  for (int q = 0; q < NLD; q++)
+  {
+    int e = tid + q * NTHR;
+    st_on[q] = e < NR * NV4;
+    st_row[q] = e / NV4;
+    st_c4[q] = e - st_row[q] * NV4;
+    int gx = x0 - RA + 4 * st_c4[q];
+    st_vec[q] = gx >= 0 && gx + 3 < W;
+  }
+
+  auto load_elem = [&](int rg, int q) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (st_on[q])
+    {
+      const float *row = src + (size_t)mirror_idx(rg + st_row[q], H) * a.spitch;
+      const int gx = x0 - RA + 4 * st_c4[q];
+      if (st_vec[q])
+        v = *(const float4 *)(row + gx);
+      else
+        v = make_float4(row[mirror_idx(gx, W)], row[mirror_idx(gx + 1, W)], row[mirror_idx(gx + 2, W)], row[mirror_idx(gx + 3, W)]);
+    }
+    return v;
+  };
+
+  const int lx = 2 * tid; // this lane's first column inside the strip
+  const int px = x0 + lx;
+  const float k0 = a.taps.k[0];
+
+  int rg = y0 - R; // first virtual row of the current group
+  float4 pf[NLD];
+#pragma unroll
+  for (int q = 0; q < NLD; q++)
+    pf[q] = load_elem(rg, q);
+
+  float2 wv[NWIN]; // H rows of virtual rows rg-2R .. rg+NR-1 (this lane's two columns)
+#pragma unroll
+  for (int k = 0; k < NWIN; k++)
+    wv[k] = make_float2(0.f, 0.f);
+
+  for (; rg - R < y1; rg += NR)
+  {
+    // ---- stage the prefetched group, then prefetch the next one
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
+      if (st_on[q])
+        *(v4f *)(s_stage + st_row[q] * SW + 4 * st_c4[q]) = v4f{pf[q].x, pf[q].y, pf[q].z, pf[q].w};
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
+      pf[q] = load_elem(rg + NR, q);
+    __syncthreads();
+
+    // ---- horizontal pass of the new rows, into the top of the register window
+#pragma unroll
+    for (int j = 0; j < NR; j++)
+    {
+      const v2f *p = (const v2f *)(s_stage + j * SW + (RA - R - OFS) + lx);
+      float v[2 * NP];
+#pragma unroll
+      for (int q = 0; q < NP; q++)
+      {
+        v2f t = p[q];
+        v[2 * q] = t.x, v[2 * q + 1] = t.y;
+      }
+      float acc0 = v[C0] * k0, acc1 = v[C0 + 1] * k0;
+#pragma unroll
+      for (int i = 1; i < NT; i++)
+      {
+        acc0 = fmaf(v[C0 + i] + v[C0 - i], a.taps.k[i], acc0);
+        acc1 = fmaf(v[C0 + 1 + i] + v[C0 + 1 - i], a.taps.k[i], acc1);
+      }
+      wv[2 * R + j] = make_float2(acc0, acc1);
+      if (DOG)
+        *(v2f *)(s_ctr + pmod(rg + j, CTR_ROWS) * TW + lx) = v2f{v[C0], v[C0 + 1]};
+    }
+
+    // ---- vertical pass: output rows yb .. yb+NR-1
+    const int yb = rg - R;
+    if (yb + NR > y0)
+    {
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+      {
+        const int y = yb + j;
+        if (y >= y0 && y < y1)
+        {
+          float acc0 = wv[R + j].x * k0, acc1 = wv[R + j].y * k0;
+#pragma unroll
+          for (int i = 1; i < NT; i++)
+          {
+            acc0 = fmaf(wv[R + j + i].x + wv[R + j - i].x, a.taps.k[i], acc0);
+            acc1 = fmaf(wv[R + j + i].y + wv[R + j - i].y, a.taps.k[i], acc1);
+          }
+          float *o = dst + (size_t)y * a.dpitch + px;
+          if (px + 1 < W)
+            *(float2 *)o = make_float2(acc0, acc1);
+          else if (px < W)
+            o[0] = acc0;
+          if (DOG)
+          {
+            const v2f c = *(const v2f *)(s_ctr + pmod(y, CTR_ROWS) * TW + lx);
+            float *g = dog + (size_t)y * a.gpitch + px;
+            if (px + 1 < W)
+              *(float2 *)g = make_float2(acc0 - c.x, acc1 - c.y);
+            else if (px < W)
+              g[0] = acc0 - c.x;
+          }
+        }
+      }
+    }
+    // ---- slide the window
+#pragma unroll
+    for (int k = 0; k < 2 * R; k++)
+      wv[k] = wv[k + NR];
+  }
+}
+
+template <int NT, int NW>
+void launch_stream_nw(const StreamArgs &a, bool with_dog, dim3 grid, hipStream_t s)
+{
+  if (with_dog)
+    hipLaunchKernelGGL((k_blur_stream<NT, true, NW>), grid, dim3(64 * NW), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_blur_stream<NT, false, NW>), grid, dim3(64 * NW), 0, s, a);
+}
+
+template <int NT>
+void launch_stream(const StreamArgs &a, bool with_dog, int nw, dim3 grid, hipStream_t s)
+{
+  if (nw == 4)
+    launch_stream_nw<NT, 4>(a, with_dog, grid, s);
+  else if (nw == 2)
+    launch_stream_nw<NT, 2>(a, with_dog, grid, s);
+  else
+    launch_stream_nw<NT, 1>(a, with_dog, grid, s);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Nearest-neighbour resample (2:1 -> odd source texels), one thread per destination pixel.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_downsample(const float *__restrict__ src, uint64_t src_img_stride, int sw, int sh, int spitch,
@@ -171,14 +377,9 @@ extern "C"
     return (int)hipGetLastError();
   }
 
-  int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const float *taps, uint32_t ntaps, uint32_t batch,
-                      vksift_hip_stream s)
+  static int blur_tile_launch(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const Taps &t, uint32_t ntaps, uint32_t batch,
+                              vksift_hip_stream s)
   {
-    if (ntaps < 1 || ntaps > VKSIFT_HIP_MAX_TAPS || src.base == dst.base)
-      return (int)hipErrorInvalidValue;
-    Taps t;
-    for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
-      t.k[i] = i < ntaps ? taps[i] : 0.f;
     int R = (int)ntaps - 1;
     int SH = TILE + 2 * R, SS = TILE + 2 * R + 1;
     size_t lds_bytes = sizeof(float) * ((size_t)SH * SS + (size_t)SH * TILE);
@@ -196,6 +397,70 @@ extern "C"
     dim3 grid((src.w + TILE - 1) / TILE, (src.h + TILE - 1) / TILE, batch);
     hipLaunchKernelGGL(k_blur_tile, grid, dim3(256), lds_bytes, (hipStream_t)s, src.base, src.img_stride, (int)src.pitch, dst.base, dst.img_stride,
                        (int)dst.pitch, dog.base, dog.img_stride, (int)dog.pitch, (int)src.w, (int)src.h, t, (int)ntaps);
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const float *taps, uint32_t ntaps, uint32_t batch,
+                      vksift_hip_stream s)
+  {
+    if (ntaps < 1 || ntaps > VKSIFT_HIP_MAX_TAPS || src.base == dst.base)
+      return (int)hipErrorInvalidValue;
+    Taps t;
+    for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
+      t.k[i] = i < ntaps ? taps[i] : 0.f;
+    static int force_tile = -1;
+    if (force_tile < 0)
+    {
+      const char *e = getenv("VKSIFT_BLUR_KERNEL"); /* "tile" selects the simple 2-D tile kernel (debug / A-B runs) */
+      force_tile = (e && e[0] == 't') ? 1 : 0;
+    }
+    if (ntaps < 2 || force_tile)
+      return blur_tile_launch(src, dst, dog, t, ntaps, batch, s);
+
+    StreamArgs a;
+    a.src = src.base, a.dst = dst.base, a.dog = dog.base;
+    a.src_img_stride = src.img_stride, a.dst_img_stride = dst.img_stride, a.dog_img_stride = dog.img_stride;
+    a.spitch = (int)src.pitch, a.dpitch = (int)dst.pitch, a.gpitch = (int)dog.pitch;
+    a.w = (int)src.w, a.h = (int)src.h;
+    a.taps = t;
+    /* Row segments: enough workgroups to give every CU ~5 waves, but segments long enough that the 2R-row
+     * warm-up stays a small fraction. */
+    static int force_nw = -1;
+    if (force_nw < 0)
+    {
+      const char *e = getenv("VKSIFT_BLUR_WAVES"); /* 1, 2 or 4 waves (128 columns each) per workgroup; default by width */
+      force_nw = e ? atoi(e) : 0;
+    }
+    int nw = 1; /* measured: 1 wave per workgroup (most resident waves per CU) beats 2 or 4 side by side */
+    if (force_nw == 1 || force_nw == 2 || force_nw == 4)
+      nw = force_nw;
+    const uint32_t tw = 128u * (uint32_t)nw;
+    const uint32_t strips = (src.w + tw - 1u) / tw;
+    uint32_t nseg = (1536u / (uint32_t)nw + strips * batch - 1u) / (strips * batch);
+    uint32_t max_seg = (src.h + 63u) / 64u;
+    if (nseg > max_seg)
+      nseg = max_seg;
+    if (nseg < 1)
+      nseg = 1;
+    uint32_t seg = ((src.h + nseg - 1u) / nseg + 7u) & ~7u;
+    nseg = (src.h + seg - 1u) / seg;
+    a.seg = (int)seg;
+    dim3 grid(strips, nseg, batch);
+    const bool with_dog = dog.base != NULL;
+    hipStream_t hs = (hipStream_t)s;
+    switch (ntaps)
+    {
+#define VKSIFT_CASE(N)                    \
+  case N:                                 \
+    launch_stream<N>(a, with_dog, nw, grid, hs); \
+    break;
+      VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9) VKSIFT_CASE(10)
+      VKSIFT_CASE(11) VKSIFT_CASE(12) VKSIFT_CASE(13) VKSIFT_CASE(14) VKSIFT_CASE(15) VKSIFT_CASE(16) VKSIFT_CASE(17) VKSIFT_CASE(18)
+      VKSIFT_CASE(19) VKSIFT_CASE(20)
+#undef VKSIFT_CASE
+    default:
+      return (int)hipErrorInvalidValue;
+    }
     return (int)hipGetLastError();
   }
 

@@ -45,6 +45,7 @@ typedef struct
   uint32_t sec_off[VKSIFT_MAX_OCTAVES]; /* in features */
   uint32_t sec_cap[VKSIFT_MAX_OCTAVES];
   uint32_t in_w, in_h;  /* resolution of that detection */
+  bool counts_valid;    /* the host mirror of the per-octave counters is up to date */
 } BufferInfo;
 
 typedef struct
@@ -92,6 +93,9 @@ struct vksift_Instance_T
   uint32_t desc_fp_len;
   uint8_t *d_desc_a, *d_desc_b, *d_matches, *h_matches;
   uint32_t *d_norms;
+  uint32_t *d_match_n, *h_match_n; /* {N_A, N_B} of the last matching pipeline */
+  vksift_hip_event ev_staging;      /* host image staging buffer consumed by the H2D copy */
+  bool staging_pending;
   BufferInfo *bufs;
 
   vksift_hip_stream stream;
@@ -325,6 +329,7 @@ static void set_buffer_sections(vksift_Instance inst, uint32_t buf, uint32_t n_o
   b->nb_sections = n_oct;
   b->in_w = w;
   b->in_h = h;
+  b->counts_valid = false;
   vksift_hm_section_caps(inst->cfg.max_nb_sift_per_buffer, n_oct, b->sec_cap);
   uint32_t off = 0;
   for (uint32_t o = 0; o < n_oct; o++)
@@ -436,12 +441,15 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   ALLOC_D(inst->d_desc_b, (size_t)config->max_nb_sift_per_buffer * 128u + 256u);
   ALLOC_D(inst->d_matches, (size_t)config->max_nb_sift_per_buffer * MATCH_BYTES);
   ALLOC_D(inst->d_norms, sizeof(uint32_t) * (2u * (size_t)config->max_nb_sift_per_buffer + 64u));
+  ALLOC_D(inst->d_match_n, sizeof(uint32_t) * 4);
+  ALLOC_H(inst->h_match_n, sizeof(uint32_t) * 4);
   ALLOC_H(inst->h_matches, (size_t)config->max_nb_sift_per_buffer * MATCH_BYTES);
   inst->bufs = (BufferInfo *)calloc(config->sift_buffer_count, sizeof(BufferInfo));
   ok = ok && inst->bufs != NULL;
   inst->stream = vksift_hip_stream_create();
   inst->ev_detect = vksift_hip_event_create();
   inst->ev_match = vksift_hip_event_create();
+  inst->ev_staging = vksift_hip_event_create();
   for (int i = 0; i < 8; i++)
     inst->ev_t[i] = vksift_hip_event_create();
   inst->ev_m[0] = vksift_hip_event_create();
@@ -454,6 +462,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     return VKSIFT_VULKAN_ERROR;
   }
   memset(inst->h_found, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
+  memset(inst->h_match_n, 0, sizeof(uint32_t) * 4);
   if (vksift_hip_memset(inst->d_found, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count, inst->stream) != 0 ||
       vksift_hip_memcpy_h2d(inst->d_desc_fp, fp_tab, sizeof(float) * inst->desc_fp_len, inst->stream) != 0 || vksift_hip_stream_sync(inst->stream) != 0)
   {
@@ -468,7 +477,10 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   inst->cur_batch = 1;
   inst->lay = L;
   for (uint32_t b = 0; b < config->sift_buffer_count; b++)
+  {
     set_buffer_sections(inst, b, L.n_oct, side, side);
+    inst->bufs[b].counts_valid = true;
+  }
 
   logInfo(LOG_TAG, "vksift_createInstance() success");
   return VKSIFT_SUCCESS;
@@ -504,10 +516,13 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_free(inst->d_desc_b);
   vksift_hip_free(inst->d_matches);
   vksift_hip_free(inst->d_norms);
+  vksift_hip_free(inst->d_match_n);
+  vksift_hip_host_free(inst->h_match_n);
   vksift_hip_host_free(inst->h_matches);
   free(inst->bufs);
   vksift_hip_event_destroy(inst->ev_detect);
   vksift_hip_event_destroy(inst->ev_match);
+  vksift_hip_event_destroy(inst->ev_staging);
   for (int i = 0; i < 8; i++)
     vksift_hip_event_destroy(inst->ev_t[i]);
   vksift_hip_event_destroy(inst->ev_m[0]);
@@ -520,13 +535,21 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
 /* ------------------------------------------------------------------------------------------------ */
 /* synchronisation helpers (fences of the reference)                                                */
 /* ------------------------------------------------------------------------------------------------ */
+/* The stream is in-order: once the most recent detection has completed, every earlier one has too, so all the
+ * host-side counter mirrors are valid. */
+static void mark_detect_done(vksift_Instance inst)
+{
+  inst->detect_pending = false;
+  for (uint32_t b = 0; b < inst->cfg.sift_buffer_count; b++)
+    inst->bufs[b].counts_valid = true;
+}
 static bool detect_running(vksift_Instance inst)
 {
   if (!inst->detect_pending)
     return false;
   if (vksift_hip_event_busy(inst->ev_detect) == 1)
     return true;
-  inst->detect_pending = false;
+  mark_detect_done(inst);
   return false;
 }
 static bool match_running(vksift_Instance inst)
@@ -542,7 +565,7 @@ static int wait_all(vksift_Instance inst)
 {
   vksift_hip_set_device(inst->device);
   int e = vksift_hip_stream_sync(inst->stream);
-  inst->detect_pending = false;
+  mark_detect_done(inst);
   inst->match_pending = false;
   return e;
 }
@@ -550,7 +573,9 @@ static int wait_all(vksift_Instance inst)
 bool vksift_isBufferAvailable(vksift_Instance instance, const uint32_t gpu_buffer_id)
 {
   vksift_hip_set_device(instance->device);
-  if (detect_running(instance) && gpu_buffer_id >= instance->detect_first_buf && gpu_buffer_id < instance->detect_first_buf + instance->detect_count)
+  if (gpu_buffer_id >= instance->cfg.sift_buffer_count)
+    return true;
+  if (detect_running(instance) && !instance->bufs[gpu_buffer_id].counts_valid)
     return false;
   if (match_running(instance) && (gpu_buffer_id == instance->match_a || gpu_buffer_id == instance->match_b))
     return false;
@@ -622,9 +647,20 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     return;
   }
 
-  /* a new pipeline first waits for the running ones (vulkansift.c:326-327) */
-  HIP_CHECK(wait_all(inst), "stream synchronisation");
-  account_timings(inst);
+  /* The reference makes a new pipeline wait on the host for the running ones (vulkansift.c:326-327) because its
+   * command buffers and staging memory are single-instanced. Here the instance's HIP stream is in-order, so GPU
+   * work is already serialised; the host only has to wait for the resources it is about to overwrite: the pinned
+   * image staging buffer, and (when profiling) the event set of the previous detection. */
+  if (inst->staging_pending && images)
+  {
+    HIP_CHECK(vksift_hip_event_sync(inst->ev_staging), "staging synchronisation");
+    inst->staging_pending = false;
+  }
+  if (inst->profiling && inst->timings_valid && !inst->timings_accounted)
+  {
+    HIP_CHECK(vksift_hip_event_sync(inst->ev_t[6]), "profiling synchronisation");
+    account_timings(inst);
+  }
 
   if (inst->cur_w != w || inst->cur_h != h)
   {
@@ -657,6 +693,8 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     for (uint32_t i = 0; i < count; i++)
       memcpy(inst->h_input + i * img_bytes, images[i], img_bytes);
     HIP_CHECK(vksift_hip_memcpy_h2d(inst->d_input, inst->h_input, img_bytes * count, st), "image upload");
+    HIP_CHECK(vksift_hip_event_record(inst->ev_staging, st), "event record");
+    inst->staging_pending = true;
     d_src = inst->d_input;
   }
   inst->device_input_last = images == NULL;
@@ -803,8 +841,17 @@ void vksift_ext_detectFeaturesBatchDevice(vksift_Instance instance, const uint8_
 /* ------------------------------------------------------------------------------------------------ */
 static void wait_for_buffer(vksift_Instance inst, uint32_t buf)
 {
-  if (!vksift_isBufferAvailable(inst, buf))
-    wait_all(inst);
+  vksift_hip_set_device(inst->device);
+  if (!inst->bufs[buf].counts_valid || (inst->detect_pending && buf >= inst->detect_first_buf && buf < inst->detect_first_buf + inst->detect_count))
+  {
+    vksift_hip_event_sync(inst->ev_detect);
+    mark_detect_done(inst);
+  }
+  if (inst->match_pending && (buf == inst->match_a || buf == inst->match_b))
+  {
+    vksift_hip_event_sync(inst->ev_match);
+    inst->match_pending = false;
+  }
 }
 
 /* per-section stored counts, clamped to the section capacity (sift_memory.c:1080-1095) */
@@ -904,6 +951,7 @@ void vksift_uploadFeatures(vksift_Instance instance, const vksift_Feature *feats
   b->is_packed = true;
   b->nb_stored = nb_feats;
   b->nb_sections = 0;
+  b->counts_valid = true;
   return;
 gpu_error:
   logError(LOG_TAG, "vksift_uploadFeatures() error when uploading SIFT features to GPU memory.");
@@ -913,35 +961,41 @@ gpu_error:
 /* ------------------------------------------------------------------------------------------------ */
 /* matching (vulkansift.c:417-462, sift_memory.c:957-1058, sift_matcher.c:408-486)                  */
 /* ------------------------------------------------------------------------------------------------ */
-/* Dense descriptor rows of a buffer in download order. The reference physically packs the octave
- * sections first (pack_BufferMemory); gathering section by section gives the same row order without
- * the overlapping in-buffer copies. */
-static int gather_buffer_descriptors(vksift_Instance inst, uint32_t buf, uint8_t *d_dst, uint32_t *n_out)
+/* Section table of a buffer for the device-side gather. The reference physically packs the octave sections
+ * (pack_BufferMemory, sift_memory.c:957-1047) after reading the counts on the host; here the gather kernel reads
+ * the counters in HBM and walks the sections in the same order, so nothing waits on the host. */
+static int gather_buffer(vksift_Instance inst, uint32_t buf, uint8_t *d_desc, uint32_t *d_norm, uint32_t *d_n_out, uint32_t pad_rows_to, uint32_t *max_rows_out)
 {
   const BufferInfo *b = &inst->bufs[buf];
   const uint8_t *base = inst->d_feats + (uint64_t)buf * inst->buf_stride;
-  uint32_t out = 0;
+  uint32_t zero_off = 0, cap1, fixed1, max_rows = 0;
+  int e;
   if (b->nb_sections == 0)
   {
-    int e = vksift_hip_gather_descriptors(base, b->nb_stored, d_dst, inst->stream);
-    if (e)
-      return e;
-    out = b->nb_stored;
+    cap1 = b->nb_stored;
+    fixed1 = b->nb_stored;
+    max_rows = b->nb_stored;
+    e = vksift_hip_gather_sections(base, 1, &zero_off, &cap1, &fixed1, NULL, max_rows, pad_rows_to, d_desc, d_norm, d_n_out, inst->stream);
   }
   else
   {
-    uint32_t cnt[VKSIFT_MAX_OCTAVES] = {0};
-    buffer_counts(inst, buf, cnt, false);
     for (uint32_t o = 0; o < b->nb_sections; o++)
+      max_rows += b->sec_cap[o];
+    /* counts already on the host? then bound the launch by the real total */
+    detect_running(inst); /* refreshes counts_valid if the last detection has finished */
+    if (b->counts_valid)
     {
-      int e = vksift_hip_gather_descriptors(base + (size_t)b->sec_off[o] * FEAT_BYTES, cnt[o], d_dst + (size_t)out * 128u, inst->stream);
-      if (e)
-        return e;
-      out += cnt[o];
+      uint32_t known = 0;
+      const uint32_t *found = inst->h_found + (size_t)buf * VKSIFT_MAX_OCTAVES;
+      for (uint32_t o = 0; o < b->nb_sections; o++)
+        known += found[o] < b->sec_cap[o] ? found[o] : b->sec_cap[o];
+      max_rows = known;
     }
+    e = vksift_hip_gather_sections(base, b->nb_sections, b->sec_off, b->sec_cap, NULL, inst->d_found + (size_t)buf * VKSIFT_MAX_OCTAVES, max_rows,
+                                   pad_rows_to, d_desc, d_norm, d_n_out, inst->stream);
   }
-  *n_out = out;
-  return 0;
+  *max_rows_out = max_rows;
+  return e;
 }
 
 void vksift_matchFeatures(vksift_Instance instance, uint32_t gpu_buffer_id_A, uint32_t gpu_buffer_id_B)
@@ -954,33 +1008,19 @@ void vksift_matchFeatures(vksift_Instance instance, uint32_t gpu_buffer_id_A, ui
   }
   vksift_Instance inst = instance;
   vksift_hip_set_device(inst->device);
-  HIP_CHECK(wait_all(inst), "stream synchronisation");
-
-  uint32_t na = 0, nb = 0;
+  const uint32_t cap = inst->cfg.max_nb_sift_per_buffer;
+  uint32_t max_na = 0, max_nb = 0;
   if (inst->profiling)
     vksift_hip_event_record(inst->ev_m[0], inst->stream);
   vksift_hip_range_push("Matching");
-  HIP_CHECK(gather_buffer_descriptors(inst, gpu_buffer_id_A, inst->d_desc_a, &na), "descriptor gather");
-  HIP_CHECK(gather_buffer_descriptors(inst, gpu_buffer_id_B, inst->d_desc_b, &nb), "descriptor gather");
-  /* after packing the reference marks both buffers packed with their stored count (sift_memory.c:1039-1041) */
-  inst->bufs[gpu_buffer_id_A].is_packed = true;
-  inst->bufs[gpu_buffer_id_A].nb_stored = na;
-  inst->bufs[gpu_buffer_id_B].is_packed = true;
-  inst->bufs[gpu_buffer_id_B].nb_stored = nb;
-  inst->curr_nb_matches = na;
-  if (na > 0)
-  {
-    if (nb < 2)
-    {
-      /* Get2NearestNeighbors.comp:66-67 reads b[0] and b[1] unconditionally (stale memory in the reference);
-       * here the missing rows are defined as all-zero descriptors. */
-      HIP_CHECK(vksift_hip_memset(inst->d_desc_b + (size_t)nb * 128u, 0, (size_t)(2 - nb) * 128u, inst->stream), "descriptor padding");
-      logWarning(LOG_TAG, "vksift_matchFeatures(): buffer B holds %u feature(s); missing neighbours are matched against zero descriptors.", nb);
-    }
-    HIP_CHECK(vksift_hip_match_2nn_desc(inst->d_desc_a, na, 0u, inst->d_desc_b, nb < 2 ? 2u : nb, inst->d_norms, inst->d_matches, inst->stream),
-              "2-NN matching");
-    HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_matches, inst->d_matches, (size_t)na * MATCH_BYTES, inst->stream), "match read-back");
-  }
+  HIP_CHECK(gather_buffer(inst, gpu_buffer_id_A, inst->d_desc_a, inst->d_norms, inst->d_match_n, 0u, &max_na), "descriptor gather");
+  /* Get2NearestNeighbors.comp:66-67 reads b[0] and b[1] unconditionally (stale memory in the reference when B holds
+   * fewer than two features); here the missing rows are defined as all-zero descriptors. */
+  HIP_CHECK(gather_buffer(inst, gpu_buffer_id_B, inst->d_desc_b, inst->d_norms + cap + 32u, inst->d_match_n + 1, 2u, &max_nb), "descriptor gather");
+  HIP_CHECK(vksift_hip_match_2nn_async(inst->d_desc_a, inst->d_norms, max_na, inst->d_desc_b, inst->d_norms + cap + 32u, inst->d_match_n, inst->d_matches,
+                                       inst->stream),
+            "2-NN matching");
+  HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n, inst->d_match_n, sizeof(uint32_t) * 2, inst->stream), "match count read-back");
   vksift_hip_range_pop();
   if (inst->profiling)
   {
@@ -997,18 +1037,34 @@ gpu_error:
   instance->error_cb(VKSIFT_VULKAN_ERROR);
 }
 
-uint32_t vksift_getMatchesNumber(vksift_Instance instance) { return instance->curr_nb_matches; }
+static void wait_match(vksift_Instance inst)
+{
+  vksift_hip_set_device(inst->device);
+  if (inst->match_pending)
+  {
+    vksift_hip_event_sync(inst->ev_match);
+    inst->match_pending = false;
+  }
+  inst->curr_nb_matches = inst->h_match_n[0];
+}
+
+/* The reference knows N_A on the host when vksift_matchFeatures returns (it blocks while packing); here the count is
+ * produced on the device, so this accessor waits for the matching pipeline if it is still running. */
+uint32_t vksift_getMatchesNumber(vksift_Instance instance)
+{
+  wait_match(instance);
+  return instance->curr_nb_matches;
+}
 
 void vksift_downloadMatches(vksift_Instance instance, vksift_Match_2NN *matches)
 {
   vksift_Instance inst = instance;
-  vksift_hip_set_device(inst->device);
-  if (inst->match_pending)
+  wait_match(inst);
+  if (inst->curr_nb_matches > 0)
   {
-    HIP_CHECK(vksift_hip_event_sync(inst->ev_match), "match wait");
-    inst->match_pending = false;
+    HIP_CHECK(vksift_hip_memcpy_d2h(matches, inst->d_matches, (size_t)inst->curr_nb_matches * MATCH_BYTES, inst->stream), "match read-back");
+    HIP_CHECK(vksift_hip_stream_sync(inst->stream), "match read-back");
   }
-  memcpy(matches, inst->h_matches, (size_t)inst->curr_nb_matches * MATCH_BYTES);
   return;
 gpu_error:
   logError(LOG_TAG, "vksift_downloadMatches() error when downloading SIFT matches from GPU memory.");
@@ -1156,10 +1212,12 @@ uint32_t vksift_ext_exportDescriptorsDevice(vksift_Instance instance, uint32_t g
   }
   vksift_Instance inst = instance;
   vksift_hip_set_device(inst->device);
-  uint32_t n = 0;
+  uint32_t n = 0, max_rows = 0;
   HIP_CHECK(wait_all(inst), "stream synchronisation");
-  HIP_CHECK(gather_buffer_descriptors(inst, gpu_buffer_id, d_descriptors, &n), "descriptor gather");
+  HIP_CHECK(gather_buffer(inst, gpu_buffer_id, d_descriptors, inst->d_norms, inst->d_match_n + 2, 0u, &max_rows), "descriptor gather");
+  HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n + 2, inst->d_match_n + 2, sizeof(uint32_t), inst->stream), "descriptor gather");
   HIP_CHECK(vksift_hip_stream_sync(inst->stream), "descriptor gather");
+  n = inst->h_match_n[2];
   return n;
 gpu_error:
   logError(LOG_TAG, "vksift_ext_exportDescriptorsDevice() error when exporting descriptors.");
