@@ -8,8 +8,8 @@
 Metric (BASELINE.json): SIFT detect+match frames/s on 640x480 frames with ~2k keypoints.
 One "step" = one pass of the hot path over one batch of `--batch` synthetic 640x480 frames that are
 already resident in HBM: batched detection (default vksift_Config: 2x up-sampling, automatic octave
-count = 5, 3 scales/octave) followed by the 2-NN self-match of every frame (matchFeatures(i, i), the
-call sequence of BASELINE config 2). Every step recomputes everything; nothing is cached between steps.
+count = 5, 3 scales/octave) followed by the 2-NN self-match of every frame (matchFeatures(i, i) of BASELINE
+config 2, issued through the batched extension vksift_ext_matchFeaturesBatch). Every step recomputes everything; nothing is cached between steps.
 
 Multi-GPU: one process per GPU; each rank owns its own batch (weak scaling, detection is per image and
 needs no collective); the timed region is bracketed by a barrier + device synchronize and the maximum
@@ -105,8 +105,9 @@ def main():
     def step():
         inst.detectFeaturesBatchDevice(d_frames.data_ptr(), B, W, H, 0)
         if do_match:
-            for i in range(B):
-                inst.matchFeatures(i, i)
+            for i0 in range(0, B, 64):      # 2-NN self-match of every frame, batched launches of <= 64 pairs
+                ids = list(range(i0, min(B, i0 + 64)))
+                inst.matchFeaturesBatch(ids, ids)
 
     for _ in range(args.warmup):
         step()

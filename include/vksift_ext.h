@@ -30,6 +30,14 @@ extern "C"
   VKSIFT_EXPORT void vksift_ext_detectFeaturesBatchDevice(vksift_Instance instance, const uint8_t *d_images, uint32_t count, uint32_t image_width,
                                                           uint32_t image_height, uint32_t first_gpu_buffer_id);
 
+  /* 2-NN matching of `count` buffer pairs (A[i], B[i]) in one launch sequence; count <= batch capacity.
+   * Same asynchronous contract and error behaviour as vksift_matchFeatures; pair 0 is also what
+   * vksift_getMatchesNumber / vksift_downloadMatches return. */
+  VKSIFT_EXPORT void vksift_ext_matchFeaturesBatch(vksift_Instance instance, uint32_t count, const uint32_t *gpu_buffer_ids_A,
+                                                   const uint32_t *gpu_buffer_ids_B);
+  VKSIFT_EXPORT uint32_t vksift_ext_getMatchesNumberBatch(vksift_Instance instance, uint32_t pair);
+  VKSIFT_EXPORT void vksift_ext_downloadMatchesBatch(vksift_Instance instance, uint32_t pair, vksift_Match_2NN *matches);
+
   /* Stage timings (milliseconds, HIP events on the instance stream) of the last detect call.
    * Enabled with vksift_ext_setProfiling(instance, true); disabled by default. Blocking. */
   typedef struct

@@ -111,6 +111,11 @@ extern "C"
     uint64_t *seg_mask;    /* S*h*nseg words, nseg = ceil(w/64) */
     uint32_t *seg_off;     /* same count */
     uint64_t seg_img_stride; /* elements between images (both arrays) */
+    uint32_t *cand_xy;     /* cand_cap packed candidate coordinates */
+    uint32_t *cand_flag;   /* cand_cap accept flags */
+    uint32_t *cand_n;      /* one counter per image (consecutive) */
+    uint64_t cand_img_stride; /* elements between images (cand_xy, cand_flag) */
+    uint32_t cand_cap;
     float *ori_ang;        /* cap*VKSIFT_HIP_MAX_ORI floats */
     uint32_t *ori_cnt;     /* cap */
     uint64_t ori_img_stride; /* in keypoints */
@@ -120,9 +125,9 @@ extern "C"
     uint32_t desc_fp_tab_len;
   } vksift_hip_OctaveJob;
 
-  /* ExtractKeypoints.comp (sift_detector.c:1106-1189) as a deterministic 3-step compaction:
-   * detect+refine -> per-64-pixel-segment ballot masks; exclusive scan; emit in raster order.
-   * found[] receives the un-clamped keypoint count. */
+  /* ExtractKeypoints.comp (sift_detector.c:1106-1189) as a deterministic, atomic-free pipeline: streaming
+   * 26-neighbour test -> per-64-pixel-segment candidate ballots -> exclusive scan -> compact candidate list ->
+   * dense refinement -> per-image scan + emit in raster order. found[] receives the un-clamped keypoint count. */
   int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s);
   /* ComputeOrientation.comp (sift_detector.c:1191-1241): main orientation written in place, extra
    * orientations appended in (keypoint, bin) order; found[] updated. */
@@ -142,16 +147,21 @@ extern "C"
   int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
                                 uint8_t *matches, vksift_hip_stream s);
 
-  /* Asynchronous matching pipeline used by vksift_matchFeatures (no host round trip for the feature counts):
-   * gather_sections walks up to 16 buffer sections whose stored counts are min(found_dev[o], sec_cap[o]) (or
-   * fixed_counts[o] when found_dev is NULL), writes the dense descriptor rows in download order, their shifted
-   * norms and the row total (*n_out_dev); rows up to pad_rows_to are zero-filled (quirk Q6). max_rows bounds the
-   * launch. match_2nn_async then reads {N_A, N_B} from n_dev[0..1]. */
-  int vksift_hip_gather_sections(const uint8_t *feats, uint32_t nsec, const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *fixed_counts,
-                                 const uint32_t *found_dev, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint32_t *norms, uint32_t *n_out_dev,
-                                 vksift_hip_stream s);
+  /* Asynchronous (and batched) matching pipeline used by vksift_matchFeatures / vksift_ext_matchFeaturesBatch — no
+   * host round trip for the feature counts. Slot i of a batch handles SIFT buffer buf_ids[i] (feats_base +
+   * buf_ids[i]*buf_stride, counters found_base + buf_ids[i]*found_buf_stride); all buffers of one call share the
+   * section table. gather_sections walks up to 16 sections whose stored counts are min(found[o], sec_cap[o]) (or
+   * fixed_counts[o] when found_base is NULL), writes the dense descriptor rows in download order, their shifted norms
+   * and the row total (n_out_dev[slot*n_slot_stride]); rows below pad_rows_to are zero-filled (quirk Q6). max_rows
+   * bounds the launch. match_2nn_async reads {N_A, N_B} of slot i from n_dev[i*n_slot_stride + 0..1].
+   * Slot strides are in bytes for desc/matches and in u32 elements for norms/n. */
+  int vksift_hip_gather_sections(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, uint32_t nslots, uint32_t nsec,
+                                 const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *fixed_counts, const uint32_t *found_base,
+                                 uint32_t found_buf_stride, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint64_t desc_slot_stride,
+                                 uint32_t *norms, uint64_t norm_slot_stride, uint32_t *n_out_dev, uint32_t n_slot_stride, vksift_hip_stream s);
   int vksift_hip_match_2nn_async(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t max_na, const uint8_t *desc_b, const uint32_t *norm_b,
-                                 const uint32_t *n_dev, uint8_t *matches, vksift_hip_stream s);
+                                 const uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t desc_slot_stride, uint64_t norm_slot_stride,
+                                 uint64_t match_slot_stride, uint32_t n_slot_stride, vksift_hip_stream s);
 
 #ifdef __cplusplus
 }

@@ -226,3 +226,34 @@ def test_libm_oracle_within_tolerance(vk, oracle):
     assert dx.max() < 1e-4 and ds.max() < 1e-5 and do.max() < 1e-4
     rms = np.array([np.sqrt(((g["descriptor"].astype(float) - r["descriptor"].astype(float)) ** 2).mean()) / 512.0 for g, r in hit])
     assert np.median(rms) < 1e-4 and np.percentile(rms, 99) < 1e-3
+
+
+def test_batched_match_equals_single_calls(vk, oracle):
+    """vksift_ext_matchFeaturesBatch: detection buffers (device-side counts, shared section layout) and a mixed
+    case with uploaded buffers of different sizes (falls back to pair-by-pair launches)."""
+    imgs = [vk.gen_synthetic_image(300 + i, 320, 240) for i in range(4)]
+    cfg = vk.default_config(sift_buffer_count=8)
+    with vk.Instance(cfg, batch_capacity=4) as inst:
+        inst.detectFeaturesBatch(imgs, 0)
+        inst.matchFeaturesBatch([0, 1, 2, 3], [1, 2, 3, 0])     # enqueued while the detection is still running
+        got = [inst.downloadMatchesBatch(i) for i in range(4)]
+        feats = [inst.downloadFeatures(i) for i in range(4)]
+        for i in range(4):
+            ref = oracle.match_2nn(feats[i], feats[(i + 1) % 4])
+            assert inst.getMatchesNumberBatch(i) == len(feats[i])
+            for name in ("idx_a", "idx_b1", "idx_b2"):
+                assert np.array_equal(got[i][name], ref[name]), (i, name)
+            assert np.array_equal(got[i]["dist_a_b1"].view(np.uint32), ref["dist_a_b1"].view(np.uint32))
+        # pair 0 is what the classic accessors see
+        assert inst.getMatchesNumber() == len(feats[0])
+        assert np.array_equal(inst.downloadMatches()["idx_b1"], got[0]["idx_b1"])
+        # non-uniform layouts: uploaded buffers of different sizes
+        inst.uploadFeatures(feats[0][:50], 4)
+        inst.uploadFeatures(feats[1][:77], 5)
+        inst.matchFeaturesBatch([4, 5, 0], [5, 4, 4])
+        for i, (a, b) in enumerate([(feats[0][:50], feats[1][:77]), (feats[1][:77], feats[0][:50]), (feats[0], feats[0][:50])]):
+            ref = oracle.match_2nn(a, b)
+            m = inst.downloadMatchesBatch(i)
+            assert np.array_equal(m["idx_b1"], ref["idx_b1"]) and np.array_equal(m["idx_b2"], ref["idx_b2"]), i
+        with pytest.raises(vk.VksiftError):
+            inst.matchFeaturesBatch([0] * 5, [1] * 5)             # more pairs than the batch capacity

@@ -112,6 +112,10 @@ def lib():
     L.vksift_ext_createInstanceBatched.restype = C.c_int
     L.vksift_ext_detectFeaturesBatch.argtypes = [inst, C.POINTER(C.c_void_p), u32, u32, u32, u32]
     L.vksift_ext_detectFeaturesBatchDevice.argtypes = [inst, C.c_void_p, u32, u32, u32, u32]
+    L.vksift_ext_matchFeaturesBatch.argtypes = [inst, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.vksift_ext_getMatchesNumberBatch.argtypes = [inst, u32]
+    L.vksift_ext_getMatchesNumberBatch.restype = u32
+    L.vksift_ext_downloadMatchesBatch.argtypes = [inst, u32, C.c_void_p]
     L.vksift_ext_setProfiling.argtypes = [inst, C.c_bool]
     L.vksift_ext_getDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings)]
     L.vksift_ext_getAccumulatedDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.POINTER(u32), C.c_bool]
@@ -260,6 +264,27 @@ class Instance:
     def matchFeatures(self, buf_a, buf_b):
         lib().vksift_matchFeatures(self._h, buf_a, buf_b)
         _check_pending()
+
+    def matchFeaturesBatch(self, bufs_a, bufs_b):
+        n = len(bufs_a)
+        assert n == len(bufs_b)
+        a = (C.c_uint32 * n)(*bufs_a)
+        b = (C.c_uint32 * n)(*bufs_b)
+        lib().vksift_ext_matchFeaturesBatch(self._h, n, a, b)
+        _check_pending()
+
+    def getMatchesNumberBatch(self, pair):
+        n = lib().vksift_ext_getMatchesNumberBatch(self._h, pair)
+        _check_pending()
+        return n
+
+    def downloadMatchesBatch(self, pair):
+        n = self.getMatchesNumberBatch(pair)
+        out = np.zeros(n, MATCH_DTYPE)
+        if n:
+            lib().vksift_ext_downloadMatchesBatch(self._h, pair, out.ctypes.data)
+            _check_pending()
+        return out
 
     # -- transfers
     def getFeaturesNumber(self, gpu_buffer_id):

@@ -2,12 +2,13 @@
 //
 // Replaces ExtractKeypoints.comp (dispatch: sift_detector.c:1106-1189). The reference appends
 // keypoints with a global atomicAdd (ExtractKeypoints.comp:208), which makes their order
-// non-deterministic. Here the append is a three-step, atomic-free compaction:
-//   k_extrema_detect : one wave per 64-pixel row segment; every lane tests + refines its texel,
-//                      the wave's acceptance ballot (one u64) is stored per segment
+// non-deterministic. Here the append is an atomic-free pipeline whose output order is raster (scale, y, x):
+//   k_extrema_stream : streaming 26-neighbour test; one u64 candidate ballot per 64-pixel row segment
 //   k_segment_scan   : exclusive prefix sum of popcount(mask) over segments in (scale, y, x) order
-//   k_extrema_emit   : lanes whose bit is set recompute their record and store it at
-//                      offset[segment] + (number of lower set bits)            -> raster order
+//   k_cand_list      : one thread per segment writes its candidates' packed (x, y, s) at offset + rank
+//   k_refine_flags   : one thread per CANDIDATE (dense waves: no lane idles while a neighbour refines) -> accept flag
+//   k_cand_finalize  : per image: scan of the accept flags, accepted candidates recompute their record and store it
+//                      at their rank (clamped to the section capacity); the un-clamped count goes to found[]
 // The arithmetic of refine_texel() is kept operation-for-operation identical to
 // oracle/sift_oracle.c:extract_one (fp32, no contraction) so results are bit-exact.
 #include <hip/hip_runtime.h>
@@ -162,53 +163,101 @@ struct ExtremaArgs
   uint32_t cap;
   uint32_t *found;
   uint32_t found_img_stride;
+  uint32_t *cand_xy;   // packed x | y << 14 | scale << 28, raster order
+  uint32_t *cand_flag; // 1 = accepted by the refinement
+  uint32_t *cand_n;    // per image: number of candidates (clamped to cand_cap)
+  uint64_t cand_img_stride;
+  uint32_t cand_cap;
 };
 
-template <bool EMIT>
-__global__ void __launch_bounds__(256) k_extrema(ExtremaArgs a)
+// Streaming detection pass: one wave owns a 64-column segment and marches down a band of
+// rows. For every DoG layer it keeps, for the last three rows, the horizontal 3-max / 3-min of its column
+// (neighbours come from lane shuffles, the two halo columns from one extra 2-lane load), so the 26-neighbour test of
+// a texel of scale s is  c > max over {layers s-1,s,s+1} x {rows y-1,y,y+1} of the 3-max  with the centre's own
+// entry replaced by max(left, right) — identical to 26 strict comparisons for finite values. Each DoG plane is read
+// exactly once (20 B per octave pixel at S = 3, coalesced) instead of 27 scattered loads per candidate. The
+// per-segment candidate ballots feed k_segment_scan / k_cand_list; refinement happens later on dense waves.
+template <int S>
+__global__ void __launch_bounds__(64) k_extrema_stream(ExtremaArgs a, int band)
 {
-  const int lane = threadIdx.x & 63;
+  constexpr int NL = S + 2;
+  const int lane = threadIdx.x;
   const int segx = blockIdx.x;
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int sz = blockIdx.z % a.S; // scale - 1
-  const int b = blockIdx.z / a.S;
-  if (y >= a.h)
-    return;
+  const int b = blockIdx.z;
+  const int y0 = blockIdx.y * band;
+  const int y1 = min(y0 + band, a.h);
+  const int x0 = segx * 64, x = x0 + lane;
   DogView d{a.dog + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
-  const size_t seg = ((size_t)sz * a.h + y) * a.nseg + segx + (size_t)b * a.seg_img_stride;
-  const int x = segx * 64 + lane;
-  KpRecord kp;
-  if (!EMIT)
+  const bool xin = x < a.w;
+  const int hx = lane == 0 ? x0 - 1 : x0 + 64;
+  const bool hok = (lane == 0 || lane == 63) && hx >= 0 && hx < a.w;
+  const float pre = a.dog_threshold * 0.8f;
+
+  float hmx[NL][3], hmn[NL][3]; // horizontal 3-max / 3-min of rows (y-1, y, y+1) per layer
+  float ctr[NL][2], lrx[NL][2], lrn[NL][2]; // centre value and max/min(left,right) of rows (y, y+1)
+#pragma unroll
+  for (int l = 0; l < NL; l++)
   {
-    bool ok = test_texel(d, x, y, sz + 1, a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
-    unsigned long long m = __ballot(ok);
-    if (lane == 0)
-      a.seg_mask[seg] = m;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      hmx[l][k] = hmn[l][k] = 0.f;
+    ctr[l][0] = ctr[l][1] = lrx[l][0] = lrx[l][1] = lrn[l][0] = lrn[l][1] = 0.f;
   }
-  else
+
+  for (int r = y0 - 1; r <= y1; r++)
   {
-    unsigned long long m = a.seg_mask[seg];
-    if (m == 0ull)
-      return;
-    if ((m >> lane) & 1ull)
+    // slide the window and load row r of every layer
+#pragma unroll
+    for (int l = 0; l < NL; l++)
     {
-      uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      uint32_t idx = a.seg_off[seg] + rank;
-      if (idx < a.cap)
+      hmx[l][0] = hmx[l][1], hmx[l][1] = hmx[l][2];
+      hmn[l][0] = hmn[l][1], hmn[l][1] = hmn[l][2];
+      ctr[l][0] = ctr[l][1], lrx[l][0] = lrx[l][1], lrn[l][0] = lrn[l][1];
+    }
+    if (r >= 0 && r < a.h)
+    {
+#pragma unroll
+      for (int l = 0; l < NL; l++)
       {
-        // recompute (bit-identical) instead of round-tripping candidate records through HBM
-        refine_texel(d, x, y, sz + 1, a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
-        uint32_t *rec = (uint32_t *)(a.feats + (size_t)b * a.feat_img_stride + (size_t)idx * 164);
-        rec[0] = __float_as_uint(kp.x);
-        rec[1] = __float_as_uint(kp.y);
-        rec[2] = __float_as_uint(kp.scale_x);
-        rec[3] = __float_as_uint(kp.scale_y);
-        rec[4] = kp.scale_idx;
-        rec[5] = (uint32_t)kp.octave_idx;
-        rec[6] = __float_as_uint(kp.sigma);
-        rec[7] = __float_as_uint(kp.orientation);
-        rec[8] = __float_as_uint(kp.intensity);
+        const float *row = d.base + (size_t)l * d.plane + (size_t)r * d.pitch;
+        float v = xin ? row[x] : 0.f;
+        float hv = hok ? row[hx] : 0.f;
+        float left = __shfl_up(v, 1, 64), right = __shfl_down(v, 1, 64);
+        if (lane == 0)
+          left = hv;
+        if (lane == 63)
+          right = hv;
+        float mx = fmaxf(left, right), mn = fminf(left, right);
+        ctr[l][1] = v, lrx[l][1] = mx, lrn[l][1] = mn;
+        hmx[l][2] = fmaxf(mx, v), hmn[l][2] = fminf(mn, v);
       }
+    }
+    const int y = r - 1;
+    if (y < y0 || y >= y1)
+      continue;
+    const bool interior = x >= 1 && x < a.w - 1 && y >= 1 && y < a.h - 1;
+#pragma unroll
+    for (int sz = 0; sz < S; sz++)
+    {
+      const int l = sz + 1;
+      const float c = ctr[l][0];
+      bool cand = interior && fabsf(c) > pre;
+      if (cand)
+      {
+        float nmx = lrx[l][0], nmn = lrn[l][0];
+        nmx = fmaxf(nmx, fmaxf(hmx[l][0], hmx[l][2]));
+        nmn = fminf(nmn, fminf(hmn[l][0], hmn[l][2]));
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+          nmx = fmaxf(nmx, fmaxf(hmx[l - 1][k], hmx[l + 1][k]));
+          nmn = fminf(nmn, fminf(hmn[l - 1][k], hmn[l + 1][k]));
+        }
+        cand = (c > nmx) || (c < nmn);
+      }
+      unsigned long long m = __ballot(cand);
+      if (lane == 0)
+        a.seg_mask[((size_t)sz * a.h + y) * a.nseg + segx + (size_t)b * a.seg_img_stride] = m;
     }
   }
 }
@@ -257,10 +306,117 @@ __global__ void __launch_bounds__(1024) k_segment_scan(const uint64_t *__restric
     found[(size_t)b * found_img_stride] = carry_s;
 }
 
+// One thread per 64-pixel segment: expand its candidate ballot into packed coordinates at offset + rank.
+__global__ void __launch_bounds__(256) k_cand_list(ExtremaArgs a, uint32_t nsegs)
+{
+  const uint32_t seg = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (seg >= nsegs)
+    return;
+  unsigned long long m = a.seg_mask[seg + (size_t)b * a.seg_img_stride];
+  if (m == 0ull)
+    return;
+  uint32_t pos = a.seg_off[seg + (size_t)b * a.seg_img_stride];
+  const uint32_t segx = seg % (uint32_t)a.nseg;
+  const uint32_t yy = (seg / (uint32_t)a.nseg) % (uint32_t)a.h;
+  const uint32_t sz = seg / ((uint32_t)a.nseg * (uint32_t)a.h);
+  uint32_t *out = a.cand_xy + (size_t)b * a.cand_img_stride;
+  while (m)
+  {
+    const int bit = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    if (pos < a.cand_cap)
+      out[pos] = (segx * 64u + (uint32_t)bit) | (yy << 14) | ((sz + 1u) << 28);
+    pos++;
+  }
+}
+
+// Dense refinement: thread i of image b refines candidate i. grid-stride, count read from HBM.
+__global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
+{
+  const int b = blockIdx.y;
+  uint32_t n = a.cand_n[b];
+  n = n < a.cand_cap ? n : a.cand_cap;
+  DogView d{a.dog + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
+  const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
+  uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+  {
+    const uint32_t c = xy[i];
+    KpRecord kp;
+    bool ok = refine_texel(d, (int)(c & 0x3fffu), (int)((c >> 14) & 0x3fffu), (int)(c >> 28), a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx,
+                           &kp);
+    flag[i] = ok ? 1u : 0u;
+  }
+}
+
+// Per image: exclusive scan of the accept flags (raster order is preserved), accepted candidates recompute their
+// record (bit-identical) and store it at their rank if it fits the section; found[] gets the un-clamped count.
+__global__ void __launch_bounds__(1024) k_cand_finalize(ExtremaArgs a)
+{
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t n = a.cand_n[b];
+  n = n < a.cand_cap ? n : a.cand_cap;
+  DogView d{a.dog + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
+  const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
+  const uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
+  if (threadIdx.x == 0)
+    carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 1024)
+  {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n ? flag[i] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1)
+    {
+      uint32_t t = __shfl_up(incl, dlt, 64);
+      if (lane >= dlt)
+        incl += t;
+    }
+    if (lane == 63)
+      wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    for (int wv = 0; wv < wave; wv++)
+      wave_base += wave_tot[wv];
+    const uint32_t carry = carry_s;
+    const uint32_t idx = carry + wave_base + incl - v;
+    if (v && idx < a.cap)
+    {
+      const uint32_t c = xy[i];
+      KpRecord kp;
+      refine_texel(d, (int)(c & 0x3fffu), (int)((c >> 14) & 0x3fffu), (int)(c >> 28), a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
+      uint32_t *rec = (uint32_t *)(a.feats + (size_t)b * a.feat_img_stride + (size_t)idx * 164);
+      rec[0] = __float_as_uint(kp.x);
+      rec[1] = __float_as_uint(kp.y);
+      rec[2] = __float_as_uint(kp.scale_x);
+      rec[3] = __float_as_uint(kp.scale_y);
+      rec[4] = kp.scale_idx;
+      rec[5] = (uint32_t)kp.octave_idx;
+      rec[6] = __float_as_uint(kp.sigma);
+      rec[7] = __float_as_uint(kp.orientation);
+      rec[8] = __float_as_uint(kp.intensity);
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023)
+      carry_s = carry + wave_base + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    a.found[(size_t)b * a.found_img_stride] = carry_s;
+}
+
 } // namespace
 
 extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s)
 {
+  if (job->w >= 16384u || job->h >= 16384u || job->S > 14u)
+    return (int)hipErrorInvalidValue; /* candidate coordinates are packed 14 + 14 + 4 bits */
   ExtremaArgs a;
   a.dog = job->dog;
   a.w = (int)job->w, a.h = (int)job->h, a.pitch = (int)job->pitch;
@@ -271,11 +427,34 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   a.nseg = (int)((job->w + 63) / 64);
   a.feats = job->feats, a.feat_img_stride = job->feat_img_stride, a.cap = job->cap;
   a.found = job->found, a.found_img_stride = job->found_img_stride;
-  dim3 grid(a.nseg, (job->h + 3) / 4, job->S * batch);
-  uint32_t nsegs = job->S * job->h * (uint32_t)a.nseg;
-  hipLaunchKernelGGL(k_extrema<false>, grid, dim3(256), 0, (hipStream_t)s, a);
-  hipLaunchKernelGGL(k_segment_scan, dim3(batch), dim3(1024), 0, (hipStream_t)s, (const uint64_t *)a.seg_mask, a.seg_off, a.seg_img_stride, nsegs, a.found,
-                     a.found_img_stride);
-  hipLaunchKernelGGL(k_extrema<true>, grid, dim3(256), 0, (hipStream_t)s, a);
+  a.cand_xy = job->cand_xy, a.cand_flag = job->cand_flag, a.cand_n = job->cand_n;
+  a.cand_img_stride = job->cand_img_stride, a.cand_cap = job->cand_cap;
+  hipStream_t hs = (hipStream_t)s;
+  const uint32_t nsegs = job->S * job->h * (uint32_t)a.nseg;
+
+  /* 1. candidate ballots */
+  const int band = 32;
+  dim3 sgrid(a.nseg, (job->h + band - 1) / band, batch);
+  switch (job->S)
+  {
+#define VKSIFT_CASE(N)                                                       \
+  case N:                                                                    \
+    hipLaunchKernelGGL(k_extrema_stream<N>, sgrid, dim3(64), 0, hs, a, band); \
+    break;
+    VKSIFT_CASE(1) VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9)
+    VKSIFT_CASE(10) VKSIFT_CASE(11) VKSIFT_CASE(12) VKSIFT_CASE(13)
+#undef VKSIFT_CASE
+  default:
+    return (int)hipErrorInvalidValue;
+  }
+  /* 2. offsets + candidate count */
+  hipLaunchKernelGGL(k_segment_scan, dim3(batch), dim3(1024), 0, hs, (const uint64_t *)a.seg_mask, a.seg_off, a.seg_img_stride, nsegs, a.cand_n, 1u);
+  /* 3. compact list, 4. dense refinement, 5. accepted -> records */
+  hipLaunchKernelGGL(k_cand_list, dim3((nsegs + 255u) / 256u, batch), dim3(256), 0, hs, a, nsegs);
+  uint32_t rblocks = (a.cand_cap + 255u) / 256u;
+  if (rblocks > 512u)
+    rblocks = 512u;
+  hipLaunchKernelGGL(k_refine_flags, dim3(rblocks, batch), dim3(256), 0, hs, a);
+  hipLaunchKernelGGL(k_cand_finalize, dim3(batch), dim3(1024), 0, hs, a);
   return (int)hipGetLastError();
 }

@@ -79,45 +79,80 @@ struct SectionTable
   uint32_t fixed[16]; // used instead of found[] when found == nullptr (uploaded / packed buffers)
 };
 
-__global__ void __launch_bounds__(256) k_gather_sections(const uint8_t *__restrict__ feats, SectionTable tab, const uint32_t *__restrict__ found,
-                                                         uint32_t *__restrict__ desc, uint32_t *__restrict__ norms, uint32_t *__restrict__ n_out,
-                                                         uint32_t pad_rows_to)
+struct SlotMap
 {
-  const uint32_t row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  uint32_t buf[64]; // SIFT buffer index handled by slot blockIdx.y
+};
+
+__global__ void __launch_bounds__(256) k_gather_sections(const uint8_t *__restrict__ feats_base, uint64_t buf_stride, SlotMap map, SectionTable tab,
+                                                         const uint32_t *__restrict__ found_base, uint32_t found_buf_stride, uint32_t *__restrict__ desc,
+                                                         uint64_t desc_slot_stride, uint32_t *__restrict__ norms, uint64_t norm_slot_stride,
+                                                         uint32_t *__restrict__ n_out, uint32_t n_slot_stride, uint32_t pad_rows_to)
+{
+  const uint32_t slot = blockIdx.y;
+  const uint32_t bufi = map.buf[slot];
+  const uint8_t *feats = feats_base + (size_t)bufi * buf_stride;
+  const uint32_t *found = found_base ? found_base + (size_t)bufi * found_buf_stride : nullptr;
+  desc += (size_t)slot * desc_slot_stride;
+  norms += (size_t)slot * norm_slot_stride;
+  n_out += (size_t)slot * n_slot_stride;
+
   const uint32_t j = threadIdx.x & 31u;
-  // section lookup (uniform per half-wave)
-  uint32_t base = 0, src_row = 0xFFFFFFFFu, total = 0;
-#pragma unroll 1
-  for (uint32_t o = 0; o < tab.nsec; o++)
+  // stored count of every section (uniform), then a grid-stride walk over the rows that exist
+  uint32_t cnt[16];
+  uint32_t total = 0;
+#pragma unroll
+  for (uint32_t o = 0; o < 16; o++)
   {
-    uint32_t n = found ? found[o] : tab.fixed[o];
-    n = n < tab.cap[o] ? n : tab.cap[o];
-    if (row >= base && row < base + n)
-      src_row = tab.off[o] + (row - base);
-    base += n;
+    uint32_t n = 0;
+    if (o < tab.nsec)
+    {
+      n = found ? found[o] : tab.fixed[o];
+      n = n < tab.cap[o] ? n : tab.cap[o];
+    }
+    cnt[o] = n;
+    total += n;
   }
-  total = base;
   if (blockIdx.x == 0 && threadIdx.x == 0)
     *n_out = total;
-  uint32_t v;
-  if (src_row != 0xFFFFFFFFu)
-    v = *(const uint32_t *)(feats + (size_t)src_row * 164 + 36 + 4 * j);
-  else if (row < pad_rows_to)
-    v = 0u; // quirk Q6 padding rows: all-zero descriptors
-  else
-    return;
-  desc[(size_t)row * 32 + j] = v;
-  uint32_t s2 = __builtin_amdgcn_udot4(v, v, 0u, false);
-  uint32_t s1 = __builtin_amdgcn_udot4(v, 0x01010101u, 0u, false);
-#pragma unroll
-  for (int d = 16; d >= 1; d >>= 1)
+  const uint32_t nrows = total > pad_rows_to ? total : pad_rows_to;
+  for (uint32_t row = blockIdx.x * 8 + (threadIdx.x >> 5); row < nrows; row += gridDim.x * 8)
   {
-    s2 += __shfl_xor(s2, d, 64);
-    s1 += __shfl_xor(s1, d, 64);
+    uint32_t v = 0u; // rows in [total, pad_rows_to): quirk Q6 padding, all-zero descriptors
+    if (row < total)
+    {
+      uint32_t base = 0, src_row = 0;
+#pragma unroll
+      for (uint32_t o = 0; o < 16; o++)
+      {
+        if (row >= base && row < base + cnt[o])
+          src_row = tab.off[o] + (row - base);
+        base += cnt[o];
+      }
+      v = *(const uint32_t *)(feats + (size_t)src_row * 164 + 36 + 4 * j);
+    }
+    desc[(size_t)row * 32 + j] = v;
+    uint32_t s2 = __builtin_amdgcn_udot4(v, v, 0u, false);
+    uint32_t s1 = __builtin_amdgcn_udot4(v, 0x01010101u, 0u, false);
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1)
+    {
+      s2 += __shfl_xor(s2, d, 64);
+      s1 += __shfl_xor(s1, d, 64);
+    }
+    if (j == 0)
+      norms[row] = s2 - 256u * s1 + 128u * 128u * 128u;
   }
-  if (j == 0)
-    norms[row] = s2 - 256u * s1 + 128u * 128u * 128u;
 }
+
+// Per-slot strides of a batched matching launch (blockIdx.y = slot); all zero for a single pair.
+struct SlotStrides
+{
+  uint64_t desc_a, desc_b; // dwords
+  uint64_t norm_a, norm_b; // u32
+  uint64_t matches;        // dwords
+  uint32_t n;              // u32 between the {N_A, N_B} pairs
+};
 
 struct Top2
 {
@@ -194,15 +229,19 @@ template <int AT>
 __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
                                                     uint32_t a_index_base, const uint32_t *__restrict__ desc_b, const uint32_t *__restrict__ norm_b,
                                                     uint32_t nb, uint32_t *__restrict__ matches, const uint32_t *__restrict__ n_dev,
-                                                    uint32_t na_lo, uint32_t na_hi)
+                                                    uint32_t na_lo, uint32_t na_hi, SlotStrides ss)
 {
+  desc_a += (size_t)blockIdx.y * ss.desc_a, desc_b += (size_t)blockIdx.y * ss.desc_b;
+  norm_a += (size_t)blockIdx.y * ss.norm_a, norm_b += (size_t)blockIdx.y * ss.norm_b;
+  matches += (size_t)blockIdx.y * ss.matches;
   if (n_dev)
   {
+    n_dev += (size_t)blockIdx.y * ss.n;
     // asynchronous path: the row counts were produced on the device by k_gather_sections; this instantiation only
     // serves na in (na_lo, na_hi] (the host launches one kernel per regime, the others exit here)
     na = n_dev[0];
     nb = n_dev[1] < 2u ? 2u : n_dev[1];
-    if (na <= na_lo || na > na_hi || blockIdx.x * (64u * AT) >= na)
+    if (na <= na_lo || na > na_hi)
       return;
   }
   __shared__ __attribute__((aligned(16))) uint8_t s_b[BT * B_STRIDE];
@@ -210,7 +249,10 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, grp = lane >> 4;
-  const uint32_t row_base = (blockIdx.x * 4 + wave) * (16 * AT);
+  // the grid may be smaller than the number of 64*AT-row blocks (bounded launch): loop over row blocks
+  for (uint32_t rb = blockIdx.x; rb * (64u * AT) < na; rb += gridDim.x)
+  {
+  const uint32_t row_base = (rb * 4 + wave) * (16 * AT);
 
   // A fragments (XOR 0x80 -> int8) and norms of the rows this lane accumulates
   v4i afrag[AT][2];
@@ -359,6 +401,7 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
         m[4] = __float_as_uint(sqrtf((float)s.q2));
       }
     }
+  } // row-block loop
 }
 
 // Small-problem variant: one workgroup = 16 A rows; its 4 waves each take one 16-row slice of every staged 64-row B
@@ -368,10 +411,14 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
 __global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
                                                           uint32_t a_index_base, const uint32_t *__restrict__ desc_b,
                                                           const uint32_t *__restrict__ norm_b, uint32_t nb, uint32_t *__restrict__ matches,
-                                                          const uint32_t *__restrict__ n_dev, uint32_t na_lo, uint32_t na_hi)
+                                                          const uint32_t *__restrict__ n_dev, uint32_t na_lo, uint32_t na_hi, SlotStrides ss)
 {
+  desc_a += (size_t)blockIdx.y * ss.desc_a, desc_b += (size_t)blockIdx.y * ss.desc_b;
+  norm_a += (size_t)blockIdx.y * ss.norm_a, norm_b += (size_t)blockIdx.y * ss.norm_b;
+  matches += (size_t)blockIdx.y * ss.matches;
   if (n_dev)
   {
+    n_dev += (size_t)blockIdx.y * ss.n;
     na = n_dev[0];
     nb = n_dev[1] < 2u ? 2u : n_dev[1];
     if (na <= na_lo || na > na_hi)
@@ -568,28 +615,29 @@ extern "C"
     if (na <= 8192u)
     {
       hipLaunchKernelGGL(k_match_mfma_split, dim3((na + 15u) / 16u), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, norm_a, na, a_index_base,
-                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
+                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, SlotStrides{0, 0, 0, 0, 0, 0});
     }
     else if (na <= 32768u)
     {
       uint32_t blocks = (na + 63u) / 64u;
       hipLaunchKernelGGL(k_match_mfma<1>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, norm_a, na, a_index_base,
-                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
+                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, SlotStrides{0, 0, 0, 0, 0, 0});
     }
     else
     {
       uint32_t blocks = (na + 255u) / 256u;
       hipLaunchKernelGGL(k_match_mfma<4>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, norm_a, na, a_index_base,
-                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
+                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, SlotStrides{0, 0, 0, 0, 0, 0});
     }
     return (int)hipGetLastError();
   }
 
-  int vksift_hip_gather_sections(const uint8_t *feats, uint32_t nsec, const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *fixed_counts,
-                                 const uint32_t *found_dev, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint32_t *norms, uint32_t *n_out_dev,
-                                 vksift_hip_stream s)
+  int vksift_hip_gather_sections(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, uint32_t nslots, uint32_t nsec,
+                                 const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *fixed_counts, const uint32_t *found_base,
+                                 uint32_t found_buf_stride, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint64_t desc_slot_stride,
+                                 uint32_t *norms, uint64_t norm_slot_stride, uint32_t *n_out_dev, uint32_t n_slot_stride, vksift_hip_stream s)
   {
-    if (nsec > 16)
+    if (nsec > 16 || nslots < 1 || nslots > 64)
       return (int)hipErrorInvalidValue;
     SectionTable t;
     t.nsec = nsec;
@@ -599,20 +647,34 @@ extern "C"
       t.cap[o] = o < nsec ? sec_cap[o] : 0u;
       t.fixed[o] = (o < nsec && fixed_counts) ? fixed_counts[o] : 0u;
     }
+    SlotMap m;
+    for (uint32_t i = 0; i < 64; i++)
+      m.buf[i] = i < nslots ? buf_ids[i] : 0u;
     if (max_rows < pad_rows_to)
       max_rows = pad_rows_to;
     uint32_t blocks = (max_rows + 7u) / 8u;
+    if (blocks > 256u)
+      blocks = 256u; /* grid-stride over the rows that actually exist (count read on the device) */
     if (blocks == 0)
       blocks = 1;
-    hipLaunchKernelGGL(k_gather_sections, dim3(blocks), dim3(256), 0, (hipStream_t)s, feats, t, found_dev, (uint32_t *)desc, norms, n_out_dev, pad_rows_to);
+    hipLaunchKernelGGL(k_gather_sections, dim3(blocks, nslots), dim3(256), 0, (hipStream_t)s, feats_base, buf_stride, m, t, found_base, found_buf_stride,
+                       (uint32_t *)desc, desc_slot_stride / 4, norms, norm_slot_stride, n_out_dev, n_slot_stride, pad_rows_to);
     return (int)hipGetLastError();
   }
 
   int vksift_hip_match_2nn_async(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t max_na, const uint8_t *desc_b, const uint32_t *norm_b,
-                                 const uint32_t *n_dev, uint8_t *matches, vksift_hip_stream s)
+                                 const uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t desc_slot_stride, uint64_t norm_slot_stride,
+                                 uint64_t match_slot_stride, uint32_t n_slot_stride, vksift_hip_stream s)
   {
     if (max_na == 0)
       return 0;
+    if (nslots < 1)
+      return (int)hipErrorInvalidValue;
+    SlotStrides ss;
+    ss.desc_a = ss.desc_b = desc_slot_stride / 4;
+    ss.norm_a = ss.norm_b = norm_slot_stride;
+    ss.matches = match_slot_stride / 4;
+    ss.n = n_slot_stride;
     /* The row count is only known on the device: launch for the capacity (surplus workgroups exit at once), one
      * kernel per size regime, each of which returns immediately unless N_A falls in its range:
      *   N_A <= 8192        B-split kernel, 16 A rows per workgroup (keeps a few thousand rows busy on every CU)
@@ -620,18 +682,20 @@ extern "C"
      *   N_A > 32768         64 A rows per wave (B tile reuse) */
     const uint32_t S1 = 8192u, S2 = 32768u;
     hipStream_t hs = (hipStream_t)s;
+    /* regimes 2/3 loop over their row blocks, so their grids stay small even when only the capacity is known */
+    auto bounded = [](uint32_t blocks, uint32_t slots) { uint32_t lim = slots >= 8 ? 64u : 1024u; return blocks < lim ? blocks : lim; };
     const uint32_t n1 = max_na < S1 ? max_na : S1;
-    hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u, (const uint32_t *)desc_b,
-                       norm_b, 0u, (uint32_t *)matches, n_dev, 0u, S1);
+    hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u, nslots), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u,
+                       (const uint32_t *)desc_b, norm_b, 0u, (uint32_t *)matches, n_dev, 0u, S1, ss);
     if (max_na > S1)
     {
       const uint32_t n2 = max_na < S2 ? max_na : S2;
-      hipLaunchKernelGGL(k_match_mfma<1>, dim3((n2 + 63u) / 64u), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u, (const uint32_t *)desc_b,
-                         norm_b, 0u, (uint32_t *)matches, n_dev, S1, S2);
+      hipLaunchKernelGGL(k_match_mfma<1>, dim3(bounded((n2 + 63u) / 64u, nslots), nslots), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u,
+                         (const uint32_t *)desc_b, norm_b, 0u, (uint32_t *)matches, n_dev, S1, S2, ss);
     }
     if (max_na > S2)
-      hipLaunchKernelGGL(k_match_mfma<4>, dim3((max_na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u,
-                         (const uint32_t *)desc_b, norm_b, 0u, (uint32_t *)matches, n_dev, S2, 0xFFFFFFFFu);
+      hipLaunchKernelGGL(k_match_mfma<4>, dim3(bounded((max_na + 255u) / 256u, nslots), nslots), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u,
+                         (const uint32_t *)desc_b, norm_b, 0u, (uint32_t *)matches, n_dev, S2, 0xFFFFFFFFu, ss);
     return (int)hipGetLastError();
   }
 }

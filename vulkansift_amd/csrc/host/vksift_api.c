@@ -86,6 +86,8 @@ struct vksift_Instance_T
   uint64_t *d_seg_mask;
   uint32_t *d_seg_off;
   uint64_t seg_cap; /* elements reserved per image */
+  uint32_t *d_cand_xy, *d_cand_flag, *d_cand_n;
+  uint64_t cand_cap; /* candidates reserved per image */
   float *d_ori_ang;
   uint32_t *d_ori_cnt;
   uint64_t ori_cap; /* keypoints reserved per image */
@@ -93,7 +95,10 @@ struct vksift_Instance_T
   uint32_t desc_fp_len;
   uint8_t *d_desc_a, *d_desc_b, *d_matches, *h_matches;
   uint32_t *d_norms;
-  uint32_t *d_match_n, *h_match_n; /* {N_A, N_B} of the last matching pipeline */
+  uint32_t *d_match_n, *h_match_n; /* per match slot: {N_A, N_B, spare, spare} of the last matching pipeline */
+  uint64_t desc_slot_stride, match_slot_stride; /* bytes */
+  uint64_t norm_slot_stride;                    /* u32 elements */
+  uint32_t match_slots_used;
   vksift_hip_event ev_staging;      /* host image staging buffer consumed by the H2D copy */
   bool staging_pending;
   BufferInfo *bufs;
@@ -415,6 +420,9 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   /* Non-square images of the same area need a little more because of the row-pitch padding: keep slack. */
   inst->pyr_img_stride = L.img_floats + L.img_floats / 4 + 4096;
   inst->seg_cap = seg_count(&L, inst->S) * 2 + 1024;
+  /* strict 3x3x3 extrema cannot be denser than 1/4 of the texels; 1/8 (after the contrast pre-filter) is reserved,
+   * excess candidates of a pathological image are dropped in raster order */
+  inst->cand_cap = (uint64_t)inst->S * L.w[0] * L.h[0] / 8u + 4096u;
   uint32_t caps[VKSIFT_MAX_OCTAVES] = {0};
   vksift_hm_section_caps(config->max_nb_sift_per_buffer, 1, caps);
   inst->ori_cap = config->max_nb_sift_per_buffer; /* a single-octave detection gives the largest section */
@@ -434,16 +442,23 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   ALLOC_H(inst->h_found, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
   ALLOC_D(inst->d_seg_mask, sizeof(uint64_t) * inst->seg_cap * batch_cap);
   ALLOC_D(inst->d_seg_off, sizeof(uint32_t) * inst->seg_cap * batch_cap);
+  ALLOC_D(inst->d_cand_xy, sizeof(uint32_t) * inst->cand_cap * batch_cap);
+  ALLOC_D(inst->d_cand_flag, sizeof(uint32_t) * inst->cand_cap * batch_cap);
+  ALLOC_D(inst->d_cand_n, sizeof(uint32_t) * batch_cap);
   ALLOC_D(inst->d_ori_ang, sizeof(float) * VKSIFT_HIP_MAX_ORI * inst->ori_cap * batch_cap);
   ALLOC_D(inst->d_ori_cnt, sizeof(uint32_t) * inst->ori_cap * batch_cap);
   ALLOC_D(inst->d_desc_fp, sizeof(float) * DESC_FP_TAB_MAX);
-  ALLOC_D(inst->d_desc_a, (size_t)config->max_nb_sift_per_buffer * 128u + 256u);
-  ALLOC_D(inst->d_desc_b, (size_t)config->max_nb_sift_per_buffer * 128u + 256u);
-  ALLOC_D(inst->d_matches, (size_t)config->max_nb_sift_per_buffer * MATCH_BYTES);
-  ALLOC_D(inst->d_norms, sizeof(uint32_t) * (2u * (size_t)config->max_nb_sift_per_buffer + 64u));
-  ALLOC_D(inst->d_match_n, sizeof(uint32_t) * 4);
-  ALLOC_H(inst->h_match_n, sizeof(uint32_t) * 4);
-  ALLOC_H(inst->h_matches, (size_t)config->max_nb_sift_per_buffer * MATCH_BYTES);
+  /* matching scratch: one slot per batch entry (slot 0 serves vksift_matchFeatures) */
+  inst->desc_slot_stride = (((uint64_t)config->max_nb_sift_per_buffer * 128u + 256u) + 255u) & ~(uint64_t)255u;
+  inst->match_slot_stride = (((uint64_t)config->max_nb_sift_per_buffer * MATCH_BYTES) + 255u) & ~(uint64_t)255u;
+  inst->norm_slot_stride = 2u * (uint64_t)config->max_nb_sift_per_buffer + 64u;
+  ALLOC_D(inst->d_desc_a, inst->desc_slot_stride * batch_cap);
+  ALLOC_D(inst->d_desc_b, inst->desc_slot_stride * batch_cap);
+  ALLOC_D(inst->d_matches, inst->match_slot_stride * batch_cap);
+  ALLOC_D(inst->d_norms, sizeof(uint32_t) * inst->norm_slot_stride * batch_cap);
+  ALLOC_D(inst->d_match_n, sizeof(uint32_t) * 4 * batch_cap);
+  ALLOC_H(inst->h_match_n, sizeof(uint32_t) * 4 * batch_cap);
+  inst->h_matches = NULL;
   inst->bufs = (BufferInfo *)calloc(config->sift_buffer_count, sizeof(BufferInfo));
   ok = ok && inst->bufs != NULL;
   inst->stream = vksift_hip_stream_create();
@@ -462,7 +477,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     return VKSIFT_VULKAN_ERROR;
   }
   memset(inst->h_found, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
-  memset(inst->h_match_n, 0, sizeof(uint32_t) * 4);
+  memset(inst->h_match_n, 0, sizeof(uint32_t) * 4 * batch_cap);
   if (vksift_hip_memset(inst->d_found, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count, inst->stream) != 0 ||
       vksift_hip_memcpy_h2d(inst->d_desc_fp, fp_tab, sizeof(float) * inst->desc_fp_len, inst->stream) != 0 || vksift_hip_stream_sync(inst->stream) != 0)
   {
@@ -509,6 +524,9 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_host_free(inst->h_found);
   vksift_hip_free(inst->d_seg_mask);
   vksift_hip_free(inst->d_seg_off);
+  vksift_hip_free(inst->d_cand_xy);
+  vksift_hip_free(inst->d_cand_flag);
+  vksift_hip_free(inst->d_cand_n);
   vksift_hip_free(inst->d_ori_ang);
   vksift_hip_free(inst->d_ori_cnt);
   vksift_hip_free(inst->d_desc_fp);
@@ -760,6 +778,11 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     j->seg_mask = inst->d_seg_mask;
     j->seg_off = inst->d_seg_off;
     j->seg_img_stride = inst->seg_cap;
+    j->cand_xy = inst->d_cand_xy;
+    j->cand_flag = inst->d_cand_flag;
+    j->cand_n = inst->d_cand_n;
+    j->cand_img_stride = inst->cand_cap;
+    j->cand_cap = (uint32_t)inst->cand_cap;
     j->ori_ang = inst->d_ori_ang;
     j->ori_cnt = inst->d_ori_cnt;
     j->ori_img_stride = inst->ori_cap;
@@ -961,66 +984,116 @@ gpu_error:
 /* ------------------------------------------------------------------------------------------------ */
 /* matching (vulkansift.c:417-462, sift_memory.c:957-1058, sift_matcher.c:408-486)                  */
 /* ------------------------------------------------------------------------------------------------ */
-/* Section table of a buffer for the device-side gather. The reference physically packs the octave sections
- * (pack_BufferMemory, sift_memory.c:957-1047) after reading the counts on the host; here the gather kernel reads
- * the counters in HBM and walks the sections in the same order, so nothing waits on the host. */
-static int gather_buffer(vksift_Instance inst, uint32_t buf, uint8_t *d_desc, uint32_t *d_norm, uint32_t *d_n_out, uint32_t pad_rows_to, uint32_t *max_rows_out)
+/* Same section layout (so one kernel launch can serve both buffers)? */
+static bool same_layout(const BufferInfo *x, const BufferInfo *y)
 {
-  const BufferInfo *b = &inst->bufs[buf];
-  const uint8_t *base = inst->d_feats + (uint64_t)buf * inst->buf_stride;
-  uint32_t zero_off = 0, cap1, fixed1, max_rows = 0;
+  if (x->nb_sections != y->nb_sections)
+    return false;
+  if (x->nb_sections == 0)
+    return x->nb_stored == y->nb_stored;
+  for (uint32_t o = 0; o < x->nb_sections; o++)
+    if (x->sec_off[o] != y->sec_off[o] || x->sec_cap[o] != y->sec_cap[o])
+      return false;
+  return true;
+}
+
+/* Device-side gather of `count` buffers (all with the layout of bufs[ids[0]]) into match slots first_slot.. .
+ * The reference physically packs the octave sections (pack_BufferMemory, sift_memory.c:957-1047) after reading the
+ * counts on the host; here the gather kernel reads the counters in HBM and walks the sections in the same order, so
+ * nothing waits on the host. Returns the launch bound on the row count through *max_rows_out. */
+static int gather_buffers(vksift_Instance inst, const uint32_t *ids, uint32_t count, uint32_t first_slot, bool side_b, uint8_t *d_desc_base,
+                          uint32_t n_index, uint32_t pad_rows_to, uint32_t *max_rows_out)
+{
+  const BufferInfo *b = &inst->bufs[ids[0]];
+  const uint32_t cap = inst->cfg.max_nb_sift_per_buffer;
+  uint8_t *d_desc = d_desc_base + (uint64_t)first_slot * inst->desc_slot_stride;
+  uint32_t *d_norm = inst->d_norms + (uint64_t)first_slot * inst->norm_slot_stride + (side_b ? cap + 32u : 0u);
+  uint32_t *d_n = inst->d_match_n + (size_t)first_slot * 4 + n_index;
+  uint32_t max_rows = 0;
   int e;
   if (b->nb_sections == 0)
   {
-    cap1 = b->nb_stored;
-    fixed1 = b->nb_stored;
+    uint32_t zero_off = 0, cap1 = b->nb_stored, fixed1 = b->nb_stored;
     max_rows = b->nb_stored;
-    e = vksift_hip_gather_sections(base, 1, &zero_off, &cap1, &fixed1, NULL, max_rows, pad_rows_to, d_desc, d_norm, d_n_out, inst->stream);
+    e = vksift_hip_gather_sections(inst->d_feats, inst->buf_stride, ids, count, 1, &zero_off, &cap1, &fixed1, NULL, 0, max_rows, pad_rows_to, d_desc,
+                                   inst->desc_slot_stride, d_norm, inst->norm_slot_stride, d_n, 4, inst->stream);
   }
   else
   {
-    for (uint32_t o = 0; o < b->nb_sections; o++)
-      max_rows += b->sec_cap[o];
-    /* counts already on the host? then bound the launch by the real total */
     detect_running(inst); /* refreshes counts_valid if the last detection has finished */
-    if (b->counts_valid)
+    bool all_known = true;
+    uint32_t known_max = 0, cap_sum = 0;
+    for (uint32_t o = 0; o < b->nb_sections; o++)
+      cap_sum += b->sec_cap[o];
+    for (uint32_t i = 0; i < count; i++)
     {
+      const BufferInfo *bi = &inst->bufs[ids[i]];
+      if (!bi->counts_valid)
+      {
+        all_known = false;
+        break;
+      }
       uint32_t known = 0;
-      const uint32_t *found = inst->h_found + (size_t)buf * VKSIFT_MAX_OCTAVES;
-      for (uint32_t o = 0; o < b->nb_sections; o++)
-        known += found[o] < b->sec_cap[o] ? found[o] : b->sec_cap[o];
-      max_rows = known;
+      const uint32_t *found = inst->h_found + (size_t)ids[i] * VKSIFT_MAX_OCTAVES;
+      for (uint32_t o = 0; o < bi->nb_sections; o++)
+        known += found[o] < bi->sec_cap[o] ? found[o] : bi->sec_cap[o];
+      if (known > known_max)
+        known_max = known;
     }
-    e = vksift_hip_gather_sections(base, b->nb_sections, b->sec_off, b->sec_cap, NULL, inst->d_found + (size_t)buf * VKSIFT_MAX_OCTAVES, max_rows,
-                                   pad_rows_to, d_desc, d_norm, d_n_out, inst->stream);
+    max_rows = all_known ? known_max : cap_sum; /* counts already on the host? then bound the launch by the real total */
+    e = vksift_hip_gather_sections(inst->d_feats, inst->buf_stride, ids, count, b->nb_sections, b->sec_off, b->sec_cap, NULL, inst->d_found,
+                                   VKSIFT_MAX_OCTAVES, max_rows, pad_rows_to, d_desc, inst->desc_slot_stride, d_norm, inst->norm_slot_stride, d_n, 4,
+                                   inst->stream);
   }
   *max_rows_out = max_rows;
   return e;
 }
 
-void vksift_matchFeatures(vksift_Instance instance, uint32_t gpu_buffer_id_A, uint32_t gpu_buffer_id_B)
+static int match_slots(vksift_Instance inst, const uint32_t *ids_a, const uint32_t *ids_b, uint32_t count, uint32_t first_slot)
 {
-  if (!buffer_idx_valid(instance, gpu_buffer_id_A) || !buffer_idx_valid(instance, gpu_buffer_id_B))
-  {
-    logError(LOG_TAG, "vksift_matchFeatures() error: invalid input.");
-    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
-    return;
-  }
-  vksift_Instance inst = instance;
-  vksift_hip_set_device(inst->device);
   const uint32_t cap = inst->cfg.max_nb_sift_per_buffer;
   uint32_t max_na = 0, max_nb = 0;
+  int e = gather_buffers(inst, ids_a, count, first_slot, false, inst->d_desc_a, 0, 0u, &max_na);
+  if (e)
+    return e;
+  /* Get2NearestNeighbors.comp:66-67 reads b[0] and b[1] unconditionally (stale memory in the reference when B holds
+   * fewer than two features); here the missing rows are defined as all-zero descriptors. */
+  e = gather_buffers(inst, ids_b, count, first_slot, true, inst->d_desc_b, 1, 2u, &max_nb);
+  if (e)
+    return e;
+  const uint32_t *norm_a = inst->d_norms + (uint64_t)first_slot * inst->norm_slot_stride;
+  return vksift_hip_match_2nn_async(inst->d_desc_a + (uint64_t)first_slot * inst->desc_slot_stride, norm_a, max_na,
+                                    inst->d_desc_b + (uint64_t)first_slot * inst->desc_slot_stride, norm_a + cap + 32u,
+                                    inst->d_match_n + (size_t)first_slot * 4, inst->d_matches + (uint64_t)first_slot * inst->match_slot_stride, count,
+                                    inst->desc_slot_stride, inst->norm_slot_stride, inst->match_slot_stride, 4, inst->stream);
+}
+
+static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32_t *ids_b, uint32_t count, const char *fn)
+{
+  bool valid = count >= 1 && count <= inst->batch_cap && count <= 64;
+  for (uint32_t i = 0; valid && i < count; i++)
+    valid = buffer_idx_valid(inst, ids_a[i]) && buffer_idx_valid(inst, ids_b[i]);
+  if (!valid)
+  {
+    logError(LOG_TAG, "%s error: invalid input.", fn);
+    inst->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  vksift_hip_set_device(inst->device);
   if (inst->profiling)
     vksift_hip_event_record(inst->ev_m[0], inst->stream);
   vksift_hip_range_push("Matching");
-  HIP_CHECK(gather_buffer(inst, gpu_buffer_id_A, inst->d_desc_a, inst->d_norms, inst->d_match_n, 0u, &max_na), "descriptor gather");
-  /* Get2NearestNeighbors.comp:66-67 reads b[0] and b[1] unconditionally (stale memory in the reference when B holds
-   * fewer than two features); here the missing rows are defined as all-zero descriptors. */
-  HIP_CHECK(gather_buffer(inst, gpu_buffer_id_B, inst->d_desc_b, inst->d_norms + cap + 32u, inst->d_match_n + 1, 2u, &max_nb), "descriptor gather");
-  HIP_CHECK(vksift_hip_match_2nn_async(inst->d_desc_a, inst->d_norms, max_na, inst->d_desc_b, inst->d_norms + cap + 32u, inst->d_match_n, inst->d_matches,
-                                       inst->stream),
-            "2-NN matching");
-  HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n, inst->d_match_n, sizeof(uint32_t) * 2, inst->stream), "match count read-back");
+  /* one batched launch sequence when every A buffer and every B buffer share a section layout (always the case
+   * after a batched detection), otherwise pair by pair */
+  bool uniform = true;
+  for (uint32_t i = 1; i < count && uniform; i++)
+    uniform = same_layout(&inst->bufs[ids_a[0]], &inst->bufs[ids_a[i]]) && same_layout(&inst->bufs[ids_b[0]], &inst->bufs[ids_b[i]]);
+  if (uniform)
+    HIP_CHECK(match_slots(inst, ids_a, ids_b, count, 0), "2-NN matching");
+  else
+    for (uint32_t i = 0; i < count; i++)
+      HIP_CHECK(match_slots(inst, ids_a + i, ids_b + i, 1, i), "2-NN matching");
+  HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n, inst->d_match_n, sizeof(uint32_t) * 4 * count, inst->stream), "match count read-back");
   vksift_hip_range_pop();
   if (inst->profiling)
   {
@@ -1029,12 +1102,23 @@ void vksift_matchFeatures(vksift_Instance instance, uint32_t gpu_buffer_id_A, ui
   }
   HIP_CHECK(vksift_hip_event_record(inst->ev_match, inst->stream), "event record");
   inst->match_pending = true;
-  inst->match_a = gpu_buffer_id_A;
-  inst->match_b = gpu_buffer_id_B;
+  inst->match_slots_used = count;
+  inst->match_a = ids_a[0];
+  inst->match_b = ids_b[0];
   return;
 gpu_error:
-  logError(LOG_TAG, "vksift_matchFeatures() error: Failed to start the matching pipeline.");
-  instance->error_cb(VKSIFT_VULKAN_ERROR);
+  logError(LOG_TAG, "%s error: Failed to start the matching pipeline.", fn);
+  inst->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+void vksift_matchFeatures(vksift_Instance instance, uint32_t gpu_buffer_id_A, uint32_t gpu_buffer_id_B)
+{
+  match_impl(instance, &gpu_buffer_id_A, &gpu_buffer_id_B, 1, "vksift_matchFeatures()");
+}
+
+void vksift_ext_matchFeaturesBatch(vksift_Instance instance, uint32_t count, const uint32_t *gpu_buffer_ids_A, const uint32_t *gpu_buffer_ids_B)
+{
+  match_impl(instance, gpu_buffer_ids_A, gpu_buffer_ids_B, count, "vksift_ext_matchFeaturesBatch()");
 }
 
 static void wait_match(vksift_Instance inst)
@@ -1056,19 +1140,45 @@ uint32_t vksift_getMatchesNumber(vksift_Instance instance)
   return instance->curr_nb_matches;
 }
 
-void vksift_downloadMatches(vksift_Instance instance, vksift_Match_2NN *matches)
+uint32_t vksift_ext_getMatchesNumberBatch(vksift_Instance instance, uint32_t pair)
 {
-  vksift_Instance inst = instance;
-  wait_match(inst);
-  if (inst->curr_nb_matches > 0)
+  wait_match(instance);
+  if (pair >= instance->match_slots_used)
   {
-    HIP_CHECK(vksift_hip_memcpy_d2h(matches, inst->d_matches, (size_t)inst->curr_nb_matches * MATCH_BYTES, inst->stream), "match read-back");
+    logError(LOG_TAG, "vksift_ext_getMatchesNumberBatch() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return 0;
+  }
+  return instance->h_match_n[(size_t)pair * 4];
+}
+
+static void download_matches(vksift_Instance inst, uint32_t pair, vksift_Match_2NN *matches, const char *fn)
+{
+  wait_match(inst);
+  if (pair >= inst->match_slots_used && !(pair == 0 && inst->match_slots_used == 0))
+  {
+    logError(LOG_TAG, "%s error: invalid input.", fn);
+    inst->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  uint32_t n = inst->h_match_n[(size_t)pair * 4];
+  if (n > 0)
+  {
+    HIP_CHECK(vksift_hip_memcpy_d2h(matches, inst->d_matches + (uint64_t)pair * inst->match_slot_stride, (size_t)n * MATCH_BYTES, inst->stream),
+              "match read-back");
     HIP_CHECK(vksift_hip_stream_sync(inst->stream), "match read-back");
   }
   return;
 gpu_error:
-  logError(LOG_TAG, "vksift_downloadMatches() error when downloading SIFT matches from GPU memory.");
-  instance->error_cb(VKSIFT_VULKAN_ERROR);
+  logError(LOG_TAG, "%s error when downloading SIFT matches from GPU memory.", fn);
+  inst->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+void vksift_downloadMatches(vksift_Instance instance, vksift_Match_2NN *matches) { download_matches(instance, 0, matches, "vksift_downloadMatches()"); }
+
+void vksift_ext_downloadMatchesBatch(vksift_Instance instance, uint32_t pair, vksift_Match_2NN *matches)
+{
+  download_matches(instance, pair, matches, "vksift_ext_downloadMatchesBatch()");
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -1214,10 +1324,15 @@ uint32_t vksift_ext_exportDescriptorsDevice(vksift_Instance instance, uint32_t g
   vksift_hip_set_device(inst->device);
   uint32_t n = 0, max_rows = 0;
   HIP_CHECK(wait_all(inst), "stream synchronisation");
-  HIP_CHECK(gather_buffer(inst, gpu_buffer_id, d_descriptors, inst->d_norms, inst->d_match_n + 2, 0u, &max_rows), "descriptor gather");
-  HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n + 2, inst->d_match_n + 2, sizeof(uint32_t), inst->stream), "descriptor gather");
-  HIP_CHECK(vksift_hip_stream_sync(inst->stream), "descriptor gather");
-  n = inst->h_match_n[2];
+  {
+    /* gather into slot 0's A scratch (norms are a by-product), then copy the rows out */
+    HIP_CHECK(gather_buffers(inst, &gpu_buffer_id, 1, 0, false, inst->d_desc_a, 2, 0u, &max_rows), "descriptor gather");
+    HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n + 2, inst->d_match_n + 2, sizeof(uint32_t), inst->stream), "descriptor gather");
+    HIP_CHECK(vksift_hip_stream_sync(inst->stream), "descriptor gather");
+    n = inst->h_match_n[2];
+    HIP_CHECK(vksift_hip_memcpy_d2d(d_descriptors, inst->d_desc_a, (size_t)n * 128u, inst->stream), "descriptor gather");
+    HIP_CHECK(vksift_hip_stream_sync(inst->stream), "descriptor gather");
+  }
   return n;
 gpu_error:
   logError(LOG_TAG, "vksift_ext_exportDescriptorsDevice() error when exporting descriptors.");
