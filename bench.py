@@ -16,8 +16,9 @@ needs no collective); the timed region is bracketed by a barrier + device synchr
 over ranks is reported. PyTorch is used for torch.distributed (RCCL) and device buffers only.
 
 Extra objects on the JSON line:
-  roofline     pyramid+DoG pass (k_blur_tile launches): algorithmic bytes per launch /
-               average launch duration measured with HIP events on the library's own stream
+  roofline     pyramid+DoG pass (k_blur_stream launches): algorithmic bytes per launch /
+               average launch duration measured with HIP events on the library's own stream; "traffic" is the
+               PMC-measured HBM traffic per launch from a separate rocprofv3 --pmc run (profiles/*pmc*.json), if present
   cpu_baseline the CPU oracle (a scalar C port of the same algorithm) timed on a bounded sample, rank 0, N=1
 """
 import argparse
@@ -40,7 +41,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step and per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step and per GPU")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-match", action="store_true", help="detect only (BASELINE config 3 style runs)")
@@ -71,6 +72,21 @@ def cpu_baseline(frames, do_match):
                   + ("+self-match" if do_match else "") + f", {nfeat // max(len(frames), 1)} features/frame, {dt:.1f} s wall, "
                   + f"host has {os.cpu_count()} logical cores",
     }
+
+
+def pmc_traffic(w, h, batch):
+    """HBM bytes per k_blur_stream launch measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE in separate passes,
+    gfx950 FETCH_SIZE correction applied: see profiles/README.md). Only valid for the workload it was measured on."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if (d.get("width"), d.get("height"), d.get("batch")) == (w, h, batch):
+                return d["hbm_bytes_per_blur_launch"]
+        except Exception:
+            pass
+    return None
 
 
 def main():
@@ -164,12 +180,12 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_blur_tile (pyramid + DoG pass)",
+                "kernel": "k_blur_stream (pyramid + DoG pass)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": pmc_traffic(W, H, B),
                 "algorithmic_bytes_per_launch": alg_per_launch,
                 "avg_launch_us": avg_launch_s * 1e6,
                 "launches_per_step": launches / max(acc["nb_calls"], 1),

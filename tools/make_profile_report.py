@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Turn a gpurun_out/<tag>/ capture (bench.json, trace/, pmc_fetch/, pmc_write/) into the committed files under
+profiles/: <tag>_bench.json, <tag>_kernel_stats.csv, <tag>_kernel_summary.txt, <tag>_pmc_traffic.json.
+usage: make_profile_report.py gpurun_out/r01 r01 <width> <height> <batch>"""
+import glob
+import io
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pmc(dirpath, counter):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), dirpath, counter, "k_blur_stream"], capture_output=True, text=True)
+    return json.loads(out.stdout)
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    w, h, batch = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    if os.path.exists(os.path.join(src, "bench.json")):
+        shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+    for p in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(src, "trace"), "k_blur_stream"],
+                          capture_output=True, text=True).stdout
+    open(os.path.join(dst, f"{tag}_kernel_summary.txt"), "w").write(summ)
+    if os.path.isdir(os.path.join(src, "pmc_fetch")) and os.path.isdir(os.path.join(src, "pmc_write")):
+        f = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
+        wr = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+        calls = sum(v["calls"] for v in f.values())
+        fetch_kb = sum(v["sum"] for v in f.values())
+        write_kb = sum(v["sum"] for v in wr.values())
+        wcalls = sum(v["calls"] for v in wr.values())
+        # FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
+        # stream (MI355X_MICROARCH.md §HBM): doubled before use. WRITE_SIZE is taken as is (uncalibrated).
+        per_launch = (2.0 * fetch_kb / max(calls, 1) + write_kb / max(wcalls, 1)) * 1024.0
+        rec = {"width": w, "height": h, "batch": batch, "kernel": "k_blur_stream", "launches_fetch_pass": calls, "launches_write_pass": wcalls,
+               "FETCH_SIZE_KiB_sum": fetch_kb, "WRITE_SIZE_KiB_sum": write_kb, "fetch_correction": 2.0,
+               "hbm_bytes_per_blur_launch": per_launch,
+               "per_kernel_FETCH_SIZE": f, "per_kernel_WRITE_SIZE": wr}
+        json.dump(rec, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+        print("traffic per blur launch: %.1f MB" % (per_launch / 1e6))
+    print(summ[:3000])
+
+
+if __name__ == "__main__":
+    main()

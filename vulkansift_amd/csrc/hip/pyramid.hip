@@ -75,6 +75,56 @@ __global__ void __launch_bounds__(256) k_input_blit(const uint8_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Exact 2x up-sampling fast path of the input blit: one thread produces 4 consecutive texels of one
+// output row (one 16-byte store) from a 2-row x 4-column u8 neighbourhood. For a 2:1 blit the Vulkan
+// coordinates u = (x + 0.5)/2 - 0.5 are exact in fp32 and the bilinear weights are exactly 0.25 / 0.75,
+// so this evaluates the same fmaf expressions as k_input_blit (bit-identical) with 8 instead of 16
+// u8 -> float divisions per 4 texels.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_input_blit_2x(const uint8_t *__restrict__ src, int sw, int sh, uint64_t src_img_stride,
+                                                       float *__restrict__ dst, int dw, int dh, int dpitch, uint64_t dst_img_stride)
+{
+  const int xq = blockIdx.x * 64 + (threadIdx.x & 63); // group of 4 output columns
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int x = 4 * xq;
+  if (x >= dw || y >= dh)
+    return;
+  const uint8_t *img = src + (size_t)blockIdx.z * src_img_stride;
+  float *out = dst + (size_t)blockIdx.z * dst_img_stride + (size_t)y * dpitch + x;
+  // rows: v = (y + 0.5)/2 - 0.5 -> fy = floor(v), b = v - fy
+  const float v = ((float)y + 0.5f) * 0.5f - 0.5f;
+  const float fy = floorf(v);
+  const float b = v - fy;
+  const int y0 = clampi((int)fy, 0, sh - 1), y1 = clampi((int)fy + 1, 0, sh - 1);
+  // source columns 2xq-1 .. 2xq+2 cover output columns x .. x+3
+  const int c0 = x / 2 - 1;
+  float t0[4], t1[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    const int c = clampi(c0 + k, 0, sw - 1);
+    t0[k] = (float)img[(size_t)y0 * sw + c] / 255.f;
+    t1[k] = (float)img[(size_t)y1 * sw + c] / 255.f;
+  }
+  float res[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    // output column x+k: even -> (0.25, 0.75) over source (c0 + k/2, c0 + k/2 + 1); odd -> (0.75, 0.25) over (c0 + (k+1)/2, +1)
+    const int i0 = (k + 1) / 2; // index into t[] of the left source texel
+    const float a = (k & 1) ? 0.25f : 0.75f; // weight of the right texel: u - floor(u)
+    const float r0 = fmaf(a, t0[i0 + 1], (1.f - a) * t0[i0]);
+    const float r1 = fmaf(a, t1[i0 + 1], (1.f - a) * t1[i0]);
+    res[k] = fmaf(b, r1, (1.f - b) * r0);
+  }
+  if (x + 3 < dw)
+    *(float4 *)out = make_float4(res[0], res[1], res[2], res[3]);
+  else
+    for (int k = 0; k < 4 && x + k < dw; k++)
+      out[k] = res[k];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused separable blur (+ optional DoG) over a 64x64 output tile staged through LDS.
 //   LDS: s_src[(64+2R)][SS]  source tile with halo (mirrored at the image border)
 //        s_mid[(64+2R)][64]  horizontally blurred rows
@@ -178,17 +228,15 @@ struct StreamArgs
 
 __device__ __forceinline__ int pmod(int v, int m) { return (v + m * 4096) % m; } // v > -4096*m
 
-template <int NT, bool DOG, int NW>
-__global__ void __launch_bounds__(64 * NW) k_blur_stream(StreamArgs a)
+template <int NT, bool DOG, int NR>
+__global__ void __launch_bounds__(64) k_blur_stream(StreamArgs a)
 {
   constexpr int R = NT - 1;
   constexpr int RA = (R + 3) & ~3;
-  constexpr int TW = 128 * NW, NR = 8; // NW waves side by side: 128*NW contiguous columns per workgroup
+  constexpr int TW = 128;
   constexpr int SW = TW + 2 * RA;
   constexpr int CTR_ROWS = R + NR;
-  constexpr int NV4 = SW / 4;          // float4 per staged row
-  constexpr int NTHR = 64 * NW;
-  constexpr int NLD = (NR * NV4 + NTHR - 1) / NTHR; // staging float4 per thread and group
+  constexpr int NV4 = SW / 4;       // float4 per staged row (<= 42 lanes stage, one float4 per row each)
   constexpr int OFS = (RA - R) & 1; // parity fix so that the H-pass window starts on an even float
   constexpr int NP = R + 1 + OFS;   // float2 pairs read per row in the H pass
   constexpr int C0 = R + OFS;       // index of pixel 0's centre inside the window
@@ -196,7 +244,7 @@ __global__ void __launch_bounds__(64 * NW) k_blur_stream(StreamArgs a)
   __shared__ __attribute__((aligned(16))) float s_stage[NR * SW];
   __shared__ __attribute__((aligned(16))) float s_ctr[DOG ? CTR_ROWS * TW : 4];
 
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x;
   const int W = a.w, H = a.h;
   const int x0 = blockIdx.x * TW;
   const int y0 = blockIdx.y * a.seg;
@@ -205,43 +253,32 @@ __global__ void __launch_bounds__(64 * NW) k_blur_stream(StreamArgs a)
   float *dst = a.dst + (size_t)blockIdx.z * a.dst_img_stride;
   float *dog = DOG ? a.dog + (size_t)blockIdx.z * a.dog_img_stride : nullptr;
 
-  // staging assignment: element e = tid + q*NTHR of the group's NR x NV4 float4 grid (row-major)
-  int st_row[NLD], st_c4[NLD];
-  bool st_on[NLD], st_vec[NLD];
-#pragma unroll
-  for (int q = 0; q < NLD; q++)
-  {
-    int e = tid + q * NTHR;
-    st_on[q] = e < NR * NV4;
-    st_row[q] = e / NV4;
-    st_c4[q] = e - st_row[q] * NV4;
-    int gx = x0 - RA + 4 * st_c4[q];
-    st_vec[q] = gx >= 0 && gx + 3 < W;
-  }
+  const int gx4 = x0 - RA + 4 * lane; // first column of this lane's staging float4
+  const bool stager = lane < NV4;
+  const bool vec_ok = gx4 >= 0 && gx4 + 3 < W;
 
-  auto load_elem = [&](int rg, int q) -> float4 {
+  auto load_row = [&](int r) -> float4 {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (st_on[q])
+    if (stager)
     {
-      const float *row = src + (size_t)mirror_idx(rg + st_row[q], H) * a.spitch;
-      const int gx = x0 - RA + 4 * st_c4[q];
-      if (st_vec[q])
-        v = *(const float4 *)(row + gx);
+      const float *row = src + (size_t)mirror_idx(r, H) * a.spitch;
+      if (vec_ok)
+        v = *(const float4 *)(row + gx4);
       else
-        v = make_float4(row[mirror_idx(gx, W)], row[mirror_idx(gx + 1, W)], row[mirror_idx(gx + 2, W)], row[mirror_idx(gx + 3, W)]);
+        v = make_float4(row[mirror_idx(gx4, W)], row[mirror_idx(gx4 + 1, W)], row[mirror_idx(gx4 + 2, W)], row[mirror_idx(gx4 + 3, W)]);
     }
     return v;
   };
 
-  const int lx = 2 * tid; // this lane's first column inside the strip
+  const int lx = 2 * lane; // this lane's first column inside the strip
   const int px = x0 + lx;
   const float k0 = a.taps.k[0];
 
   int rg = y0 - R; // first virtual row of the current group
-  float4 pf[NLD];
+  float4 pf[NR];
 #pragma unroll
-  for (int q = 0; q < NLD; q++)
-    pf[q] = load_elem(rg, q);
+  for (int j = 0; j < NR; j++)
+    pf[j] = load_row(rg + j);
 
   float2 wv[NWIN]; // H rows of virtual rows rg-2R .. rg+NR-1 (this lane's two columns)
 #pragma unroll
@@ -252,13 +289,15 @@ __global__ void __launch_bounds__(64 * NW) k_blur_stream(StreamArgs a)
   {
     // ---- stage the prefetched group, then prefetch the next one
     __syncthreads();
+    if (stager)
+    {
 #pragma unroll
-    for (int q = 0; q < NLD; q++)
-      if (st_on[q])
-        *(v4f *)(s_stage + st_row[q] * SW + 4 * st_c4[q]) = v4f{pf[q].x, pf[q].y, pf[q].z, pf[q].w};
+      for (int j = 0; j < NR; j++)
+        *(v4f *)(s_stage + j * SW + 4 * lane) = v4f{pf[j].x, pf[j].y, pf[j].z, pf[j].w};
+    }
 #pragma unroll
-    for (int q = 0; q < NLD; q++)
-      pf[q] = load_elem(rg + NR, q);
+    for (int j = 0; j < NR; j++)
+      pf[j] = load_row(rg + NR + j);
     __syncthreads();
 
     // ---- horizontal pass of the new rows, into the top of the register window
@@ -283,12 +322,16 @@ __global__ void __launch_bounds__(64 * NW) k_blur_stream(StreamArgs a)
       wv[2 * R + j] = make_float2(acc0, acc1);
       if (DOG)
         *(v2f *)(s_ctr + pmod(rg + j, CTR_ROWS) * TW + lx) = v2f{v[C0], v[C0 + 1]};
+      // keep the rows apart: otherwise the scheduler hoists the LDS reads of all 8 rows (8 x 2NP live registers)
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- vertical pass: output rows yb .. yb+NR-1
     const int yb = rg - R;
     if (yb + NR > y0)
     {
+      size_t orow = (size_t)yb * a.dpitch + px; // running offsets: one 64-bit add per row instead of 16 live addresses
+      size_t grow = (size_t)yb * a.gpitch + px;
 #pragma unroll
       for (int j = 0; j < NR; j++)
       {
@@ -302,7 +345,7 @@ __global__ void __launch_bounds__(64 * NW) k_blur_stream(StreamArgs a)
             acc0 = fmaf(wv[R + j + i].x + wv[R + j - i].x, a.taps.k[i], acc0);
             acc1 = fmaf(wv[R + j + i].y + wv[R + j - i].y, a.taps.k[i], acc1);
           }
-          float *o = dst + (size_t)y * a.dpitch + px;
+          float *o = dst + orow;
           if (px + 1 < W)
             *(float2 *)o = make_float2(acc0, acc1);
           else if (px < W)
@@ -310,13 +353,16 @@ __global__ void __launch_bounds__(64 * NW) k_blur_stream(StreamArgs a)
           if (DOG)
           {
             const v2f c = *(const v2f *)(s_ctr + pmod(y, CTR_ROWS) * TW + lx);
-            float *g = dog + (size_t)y * a.gpitch + px;
+            float *g = dog + grow;
             if (px + 1 < W)
               *(float2 *)g = make_float2(acc0 - c.x, acc1 - c.y);
             else if (px < W)
               g[0] = acc0 - c.x;
           }
         }
+        orow += a.dpitch;
+        grow += a.gpitch;
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- slide the window
@@ -326,24 +372,23 @@ __global__ void __launch_bounds__(64 * NW) k_blur_stream(StreamArgs a)
   }
 }
 
-template <int NT, int NW>
-void launch_stream_nw(const StreamArgs &a, bool with_dog, dim3 grid, hipStream_t s)
-{
-  if (with_dog)
-    hipLaunchKernelGGL((k_blur_stream<NT, true, NW>), grid, dim3(64 * NW), 0, s, a);
-  else
-    hipLaunchKernelGGL((k_blur_stream<NT, false, NW>), grid, dim3(64 * NW), 0, s, a);
-}
-
 template <int NT>
 void launch_stream(const StreamArgs &a, bool with_dog, int nw, dim3 grid, hipStream_t s)
 {
   if (nw == 4)
-    launch_stream_nw<NT, 4>(a, with_dog, grid, s);
-  else if (nw == 2)
-    launch_stream_nw<NT, 2>(a, with_dog, grid, s);
+  {
+    if (with_dog)
+      hipLaunchKernelGGL((k_blur_stream<NT, true, 4>), grid, dim3(64), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_blur_stream<NT, false, 4>), grid, dim3(64), 0, s, a);
+  }
   else
-    launch_stream_nw<NT, 1>(a, with_dog, grid, s);
+  {
+    if (with_dog)
+      hipLaunchKernelGGL((k_blur_stream<NT, true, 8>), grid, dim3(64), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_blur_stream<NT, false, 8>), grid, dim3(64), 0, s, a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,6 +416,13 @@ extern "C"
 
   int vksift_hip_input_blit(const uint8_t *src, uint32_t sw, uint32_t sh, uint64_t src_img_stride, vksift_hip_Plane dst, uint32_t batch, vksift_hip_stream s)
   {
+    if (dst.w == 2 * sw && dst.h == 2 * sh)
+    {
+      dim3 grid2(((dst.w + 3) / 4 + 63) / 64, (dst.h + 3) / 4, batch);
+      hipLaunchKernelGGL(k_input_blit_2x, grid2, dim3(256), 0, (hipStream_t)s, src, (int)sw, (int)sh, src_img_stride, dst.base, (int)dst.w, (int)dst.h,
+                         (int)dst.pitch, dst.img_stride);
+      return (int)hipGetLastError();
+    }
     dim3 grid((dst.w + 63) / 64, (dst.h + 3) / 4, batch);
     hipLaunchKernelGGL(k_input_blit, grid, dim3(256), 0, (hipStream_t)s, src, (int)sw, (int)sh, src_img_stride, dst.base, (int)dst.w, (int)dst.h,
                        (int)dst.pitch, dst.img_stride);
@@ -425,18 +477,15 @@ extern "C"
     a.taps = t;
     /* Row segments: enough workgroups to give every CU ~5 waves, but segments long enough that the 2R-row
      * warm-up stays a small fraction. */
-    static int force_nw = -1;
-    if (force_nw < 0)
+    static int rows_per_group = -1;
+    if (rows_per_group < 0)
     {
-      const char *e = getenv("VKSIFT_BLUR_WAVES"); /* 1, 2 or 4 waves (128 columns each) per workgroup; default by width */
-      force_nw = e ? atoi(e) : 0;
+      const char *e = getenv("VKSIFT_BLUR_ROWS"); /* rows per group of the streaming kernel: 4 or 8 (A/B runs) */
+      rows_per_group = (e && atoi(e) == 4) ? 4 : 8;
     }
-    int nw = 1; /* measured: 1 wave per workgroup (most resident waves per CU) beats 2 or 4 side by side */
-    if (force_nw == 1 || force_nw == 2 || force_nw == 4)
-      nw = force_nw;
-    const uint32_t tw = 128u * (uint32_t)nw;
-    const uint32_t strips = (src.w + tw - 1u) / tw;
-    uint32_t nseg = (1536u / (uint32_t)nw + strips * batch - 1u) / (strips * batch);
+    const int nw = rows_per_group; /* forwarded to launch_stream */
+    const uint32_t strips = (src.w + 127u) / 128u;
+    uint32_t nseg = (1536u + strips * batch - 1u) / (strips * batch);
     uint32_t max_seg = (src.h + 63u) / 64u;
     if (nseg > max_seg)
       nseg = max_seg;

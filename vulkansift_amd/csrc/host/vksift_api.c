@@ -56,6 +56,8 @@ typedef struct
   uint64_t gauss_off[VKSIFT_MAX_OCTAVES];    /* floats from the image's pyramid base */
   uint64_t dog_off[VKSIFT_MAX_OCTAVES];
   uint64_t img_floats; /* floats used by one image */
+  uint64_t seg_off[VKSIFT_MAX_OCTAVES], seg_total;   /* per-octave slices of the segment scratch (elements) */
+  uint64_t cand_off[VKSIFT_MAX_OCTAVES], cand_cap[VKSIFT_MAX_OCTAVES], cand_total;
 } PyrLayout;
 
 struct vksift_Instance_T
@@ -104,6 +106,11 @@ struct vksift_Instance_T
   BufferInfo *bufs;
 
   vksift_hip_stream stream;
+  /* octave-parallel execution inside a stage: octave o >= 1 runs on oct_stream[o] (oct_stream[0] == stream), forked from
+   * and joined back into the main stream with events, so the latency-bound small octaves overlap the large ones */
+  vksift_hip_stream oct_stream[VKSIFT_MAX_OCTAVES];
+  vksift_hip_event ev_fork[4], ev_join[4][VKSIFT_MAX_OCTAVES], ev_oct_ready[VKSIFT_MAX_OCTAVES];
+  bool serial_octaves;
   vksift_hip_event ev_detect, ev_match;
   bool detect_pending, match_pending;
   uint32_t detect_first_buf, detect_count;
@@ -310,18 +317,19 @@ static void compute_layout(vksift_Instance inst, uint32_t w, uint32_t h, PyrLayo
     off += L->plane_stride[o] * (inst->S + 2);
   }
   L->img_floats = off;
-}
-
-static uint64_t seg_count(const PyrLayout *L, uint32_t S)
-{
-  uint64_t mx = 0;
+  uint64_t so = 0, co = 0;
   for (uint32_t o = 0; o < L->n_oct; o++)
   {
-    uint64_t n = (uint64_t)S * L->h[o] * ((L->w[o] + 63) / 64);
-    if (n > mx)
-      mx = n;
+    L->seg_off[o] = so;
+    so += (uint64_t)inst->S * L->h[o] * ((L->w[o] + 63) / 64);
+    L->cand_off[o] = co;
+    /* strict 3x3x3 extrema cannot be denser than 1/4 of the texels; 1/8 (after the contrast pre-filter) is reserved,
+     * excess candidates of a pathological image are dropped in raster order */
+    L->cand_cap[o] = (uint64_t)inst->S * L->w[o] * L->h[o] / 8u + 64u;
+    co += L->cand_cap[o];
   }
-  return mx;
+  L->seg_total = so;
+  L->cand_total = co;
 }
 
 static void set_buffer_sections(vksift_Instance inst, uint32_t buf, uint32_t n_oct, uint32_t w, uint32_t h)
@@ -419,10 +427,8 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   compute_layout(inst, side, side, &L);
   /* Non-square images of the same area need a little more because of the row-pitch padding: keep slack. */
   inst->pyr_img_stride = L.img_floats + L.img_floats / 4 + 4096;
-  inst->seg_cap = seg_count(&L, inst->S) * 2 + 1024;
-  /* strict 3x3x3 extrema cannot be denser than 1/4 of the texels; 1/8 (after the contrast pre-filter) is reserved,
-   * excess candidates of a pathological image are dropped in raster order */
-  inst->cand_cap = (uint64_t)inst->S * L.w[0] * L.h[0] / 8u + 4096u;
+  inst->seg_cap = L.seg_total + L.seg_total / 4 + 1024;
+  inst->cand_cap = L.cand_total + L.cand_total / 4 + 4096u;
   uint32_t caps[VKSIFT_MAX_OCTAVES] = {0};
   vksift_hm_section_caps(config->max_nb_sift_per_buffer, 1, caps);
   inst->ori_cap = config->max_nb_sift_per_buffer; /* a single-octave detection gives the largest section */
@@ -444,7 +450,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   ALLOC_D(inst->d_seg_off, sizeof(uint32_t) * inst->seg_cap * batch_cap);
   ALLOC_D(inst->d_cand_xy, sizeof(uint32_t) * inst->cand_cap * batch_cap);
   ALLOC_D(inst->d_cand_flag, sizeof(uint32_t) * inst->cand_cap * batch_cap);
-  ALLOC_D(inst->d_cand_n, sizeof(uint32_t) * batch_cap);
+  ALLOC_D(inst->d_cand_n, sizeof(uint32_t) * batch_cap * VKSIFT_MAX_OCTAVES);
   ALLOC_D(inst->d_ori_ang, sizeof(float) * VKSIFT_HIP_MAX_ORI * inst->ori_cap * batch_cap);
   ALLOC_D(inst->d_ori_cnt, sizeof(uint32_t) * inst->ori_cap * batch_cap);
   ALLOC_D(inst->d_desc_fp, sizeof(float) * DESC_FP_TAB_MAX);
@@ -462,6 +468,21 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   inst->bufs = (BufferInfo *)calloc(config->sift_buffer_count, sizeof(BufferInfo));
   ok = ok && inst->bufs != NULL;
   inst->stream = vksift_hip_stream_create();
+  inst->oct_stream[0] = inst->stream;
+  for (int o = 1; o < VKSIFT_MAX_OCTAVES; o++)
+    inst->oct_stream[o] = vksift_hip_stream_create();
+  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
+  {
+    inst->ev_oct_ready[o] = vksift_hip_event_create();
+    for (int g = 0; g < 4; g++)
+      inst->ev_join[g][o] = vksift_hip_event_create();
+  }
+  for (int g = 0; g < 4; g++)
+    inst->ev_fork[g] = vksift_hip_event_create();
+  {
+    const char *e = getenv("VKSIFT_SERIAL_OCTAVES"); /* debug: everything on the main stream */
+    inst->serial_octaves = e && e[0] == '1';
+  }
   inst->ev_detect = vksift_hip_event_create();
   inst->ev_match = vksift_hip_event_create();
   inst->ev_staging = vksift_hip_event_create();
@@ -514,6 +535,9 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   assert(*instance_ptr != NULL);
   vksift_Instance inst = *instance_ptr;
   vksift_hip_set_device(inst->device);
+  for (int o = 1; o < VKSIFT_MAX_OCTAVES; o++)
+    if (inst->oct_stream[o])
+      vksift_hip_stream_sync(inst->oct_stream[o]);
   if (inst->stream)
     vksift_hip_stream_sync(inst->stream);
   vksift_hip_free(inst->d_pyr);
@@ -545,6 +569,16 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
     vksift_hip_event_destroy(inst->ev_t[i]);
   vksift_hip_event_destroy(inst->ev_m[0]);
   vksift_hip_event_destroy(inst->ev_m[1]);
+  for (int o = 1; o < VKSIFT_MAX_OCTAVES; o++)
+    vksift_hip_stream_destroy(inst->oct_stream[o]);
+  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
+  {
+    vksift_hip_event_destroy(inst->ev_oct_ready[o]);
+    for (int g = 0; g < 4; g++)
+      vksift_hip_event_destroy(inst->ev_join[g][o]);
+  }
+  for (int g = 0; g < 4; g++)
+    vksift_hip_event_destroy(inst->ev_fork[g]);
   vksift_hip_stream_destroy(inst->stream);
   free(inst);
   *instance_ptr = NULL;
@@ -684,7 +718,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   {
     PyrLayout L;
     compute_layout(inst, w, h, &L);
-    if (L.n_oct == 0 || L.img_floats > inst->pyr_img_stride || seg_count(&L, inst->S) > inst->seg_cap)
+    if (L.n_oct == 0 || L.img_floats > inst->pyr_img_stride || L.seg_total > inst->seg_cap || L.cand_total > inst->cand_cap)
     {
       logError(LOG_TAG, "Failed to fit the scale-space of a %ux%u image in the memory reserved for input_image_max_size", w, h);
       goto gpu_error;
@@ -723,30 +757,45 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   HIP_CHECK(vksift_hip_memset(inst->d_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * count, st),
             "counter reset");
 
-  /* ---- scale-space construction + DoG ---- */
+  /* ---- scale-space construction + DoG ----
+   * Octave o+1 only needs scale S of octave o, so each octave runs on its own stream: the chain of small, latency-bound
+   * launches of the coarse octaves overlaps the bandwidth-bound launches of the fine ones. */
   vksift_hip_range_push("Scale space construction");
   uint32_t nblur = 0;
   const vksift_hip_Plane no_dog = {NULL, 0, 0, 0, 0};
+  const bool par = !inst->serial_octaves && L->n_oct > 1;
   for (uint32_t o = 0; o < L->n_oct; o++)
   {
+    vksift_hip_stream so = par ? inst->oct_stream[o] : st;
     if (o == 0)
     {
       /* blit into the (still unused) layer-1 slot, then seed-blur it into layer 0 */
       vksift_hip_Plane tmp = plane_at(inst, 0, L->gauss_off[0], 1);
-      HIP_CHECK(vksift_hip_input_blit(d_src, w, h, img_bytes, tmp, count, st), "input blit");
-      HIP_CHECK(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), no_dog, &inst->taps[0], inst->ntaps[0], count, st), "seed blur");
+      HIP_CHECK(vksift_hip_input_blit(d_src, w, h, img_bytes, tmp, count, so), "input blit");
+      HIP_CHECK(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), no_dog, &inst->taps[0], inst->ntaps[0], count, so), "seed blur");
       nblur++;
+    }
+    else
+    {
+      if (par)
+        HIP_CHECK(vksift_hip_stream_wait_event(so, inst->ev_oct_ready[o - 1]), "octave dependency");
+      HIP_CHECK(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), count, so), "downsample");
     }
     for (uint32_t s = 1; s < inst->S + 3; s++)
     {
       HIP_CHECK(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), plane_at(inst, o, L->gauss_off[o], s), plane_at(inst, o, L->dog_off[o], s - 1),
-                                &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, st),
+                                &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, so),
                 "blur");
       nblur++;
+      if (par && s == inst->S && o + 1 < L->n_oct)
+        HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], so), "event record");
     }
-    if (o + 1 < L->n_oct)
-      HIP_CHECK(vksift_hip_downsample(plane_at(inst, o, L->gauss_off[o], inst->S), plane_at(inst, o + 1, L->gauss_off[o + 1], 0), count, st), "downsample");
+    if (par && o > 0)
+      HIP_CHECK(vksift_hip_event_record(inst->ev_join[0][o], so), "event record");
   }
+  if (par)
+    for (uint32_t o = 1; o < L->n_oct; o++)
+      HIP_CHECK(vksift_hip_stream_wait_event(st, inst->ev_join[0][o]), "octave join");
   vksift_hip_range_pop();
   inst->last_blur_launches = nblur;
   inst->last_alg_bytes = algorithmic_pyramid_bytes(inst, w, h) * count;
@@ -775,40 +824,52 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     j->cap = b0->sec_cap[o];
     j->found = inst->d_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES + o;
     j->found_img_stride = VKSIFT_MAX_OCTAVES;
-    j->seg_mask = inst->d_seg_mask;
-    j->seg_off = inst->d_seg_off;
+    j->seg_mask = inst->d_seg_mask + L->seg_off[o];
+    j->seg_off = inst->d_seg_off + L->seg_off[o];
     j->seg_img_stride = inst->seg_cap;
-    j->cand_xy = inst->d_cand_xy;
-    j->cand_flag = inst->d_cand_flag;
-    j->cand_n = inst->d_cand_n;
+    j->cand_xy = inst->d_cand_xy + L->cand_off[o];
+    j->cand_flag = inst->d_cand_flag + L->cand_off[o];
+    j->cand_n = inst->d_cand_n + (size_t)o * inst->batch_cap;
     j->cand_img_stride = inst->cand_cap;
-    j->cand_cap = (uint32_t)inst->cand_cap;
-    j->ori_ang = inst->d_ori_ang;
-    j->ori_cnt = inst->d_ori_cnt;
+    j->cand_cap = (uint32_t)L->cand_cap[o];
+    j->ori_ang = inst->d_ori_ang + (size_t)b0->sec_off[o] * VKSIFT_HIP_MAX_ORI;
+    j->ori_cnt = inst->d_ori_cnt + b0->sec_off[o];
     j->ori_img_stride = inst->ori_cap;
     j->max_ori = inst->cfg.max_nb_orientation_per_keypoint;
     j->use_vlfeat = inst->cfg.descriptor_format == VKSIFT_DESCRIPTOR_FORMAT_VLFEAT ? 1u : 0u;
     j->desc_fp_tab = inst->d_desc_fp;
     j->desc_fp_tab_len = inst->desc_fp_len;
   }
-  vksift_hip_range_push("ExtractKeypoints");
-  for (uint32_t o = 0; o < L->n_oct; o++)
-    HIP_CHECK(vksift_hip_extract_keypoints(&jobs[o], count, st), "keypoint extraction");
+  /* Each of the three keypoint stages forks one stream per octave (per-octave scratch, no sharing) and joins back
+   * into the main stream, so stage boundaries (and the stage timings) stay well defined. */
+#define VKSIFT_STAGE(G, NAME, CALL, WHAT)                                                                   \
+  vksift_hip_range_push(NAME);                                                                               \
+  if (par)                                                                                                   \
+    HIP_CHECK(vksift_hip_event_record(inst->ev_fork[G], st), "event record");                               \
+  for (uint32_t o = 0; o < L->n_oct; o++)                                                                    \
+  {                                                                                                          \
+    vksift_hip_stream so = (par && o > 0) ? inst->oct_stream[o] : st;                                        \
+    if (par && o > 0)                                                                                        \
+      HIP_CHECK(vksift_hip_stream_wait_event(so, inst->ev_fork[G]), "octave fork");                          \
+    HIP_CHECK(CALL(&jobs[o], count, so), WHAT);                                                              \
+    if (par && o > 0)                                                                                        \
+      HIP_CHECK(vksift_hip_event_record(inst->ev_join[G][o], so), "event record");                           \
+  }                                                                                                          \
+  if (par)                                                                                                   \
+    for (uint32_t o = 1; o < L->n_oct; o++)                                                                  \
+      HIP_CHECK(vksift_hip_stream_wait_event(st, inst->ev_join[G][o]), "octave join");                       \
   vksift_hip_range_pop();
+
+  VKSIFT_STAGE(1, "ExtractKeypoints", vksift_hip_extract_keypoints, "keypoint extraction")
   if (prof)
     vksift_hip_event_record(inst->ev_t[3], st);
-  vksift_hip_range_push("ComputeOrientation");
-  for (uint32_t o = 0; o < L->n_oct; o++)
-    HIP_CHECK(vksift_hip_orientations(&jobs[o], count, st), "orientation");
-  vksift_hip_range_pop();
+  VKSIFT_STAGE(2, "ComputeOrientation", vksift_hip_orientations, "orientation")
   if (prof)
     vksift_hip_event_record(inst->ev_t[4], st);
-  vksift_hip_range_push("ComputeDescriptors");
-  for (uint32_t o = 0; o < L->n_oct; o++)
-    HIP_CHECK(vksift_hip_descriptors(&jobs[o], count, st), "descriptor");
-  vksift_hip_range_pop();
+  VKSIFT_STAGE(3, "ComputeDescriptors", vksift_hip_descriptors, "descriptor")
   if (prof)
     vksift_hip_event_record(inst->ev_t[5], st);
+#undef VKSIFT_STAGE
 
   /* recCopySIFTCountCmds (sift_detector.c:1261-1291) */
   HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES, inst->d_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES,
