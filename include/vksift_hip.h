@@ -110,7 +110,7 @@ extern "C"
     /* scratch, per image: */
     uint64_t *seg_mask;    /* S*h*nseg words, nseg = ceil(w/64) */
     uint32_t *seg_off;     /* same count */
-    uint64_t seg_img_stride; /* elements between images (both arrays) */
+    uint64_t seg_img_stride; /* elements between images (both arrays); must equal S*h*nseg (contiguous batch) */
     uint32_t *cand_xy;     /* cand_cap packed candidate coordinates */
     uint32_t *cand_flag;   /* cand_cap accept flags */
     uint32_t *cand_n;      /* one counter per image (consecutive) */

@@ -13,6 +13,7 @@
 // oracle/sift_oracle.c:extract_one (fp32, no contraction) so results are bit-exact.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../detmath.h"
 #include "vksift_hip.h"
@@ -177,88 +178,169 @@ struct ExtremaArgs
 // entry replaced by max(left, right) — identical to 26 strict comparisons for finite values. Each DoG plane is read
 // exactly once (20 B per octave pixel at S = 3, coalesced) instead of 27 scattered loads per candidate. The
 // per-segment candidate ballots feed k_segment_scan / k_cand_list; refinement happens later on dense waves.
-template <int S>
-__global__ void __launch_bounds__(64) k_extrema_stream(ExtremaArgs a, int band)
+// lane i <- lane i-1 (lane 0 keeps `edge`), lane i <- lane i+1 (lane 63 keeps `edge`): gfx9 DPP wave shifts, one VALU op
+__device__ __forceinline__ float wave_shr1(float v, float edge)
 {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v, float edge)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// spread the low 32 bits of x to the even bit positions of a 64-bit word
+__device__ __forceinline__ unsigned long long spread32(unsigned long long x)
+{
+  x &= 0xFFFFFFFFull;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+
+template <int S>
+__global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
+{
+  // Each lane owns two adjacent columns (x, x+1): one 8-byte load per layer and row, and only one lane-crossing
+  // operation per pixel pair and side. A wave covers 128 columns = two 64-pixel mask segments.
   constexpr int NL = S + 2;
-  const int lane = threadIdx.x;
-  const int segx = blockIdx.x;
+  const int lane = threadIdx.x & 63;
   const int b = blockIdx.z;
-  const int y0 = blockIdx.y * band;
+  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * band; // 4 independent waves per block, one row band each
+  if (y0 >= a.h)
+    return;
   const int y1 = min(y0 + band, a.h);
-  const int x0 = segx * 64, x = x0 + lane;
+  const int x0 = blockIdx.x * 128, x = x0 + 2 * lane;
   DogView d{a.dog + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
-  const bool xin = x < a.w;
-  const int hx = lane == 0 ? x0 - 1 : x0 + 64;
+  const bool in0 = x < a.w, in1 = x + 1 < a.w;
+  const int hx = lane == 0 ? x0 - 1 : x0 + 128;
   const bool hok = (lane == 0 || lane == 63) && hx >= 0 && hx < a.w;
   const float pre = a.dog_threshold * 0.8f;
+  const int seg0 = blockIdx.x * 2;
+  const bool has_seg1 = seg0 + 1 < a.nseg;
 
-  float hmx[NL][3], hmn[NL][3]; // horizontal 3-max / 3-min of rows (y-1, y, y+1) per layer
-  float ctr[NL][2], lrx[NL][2], lrn[NL][2]; // centre value and max/min(left,right) of rows (y, y+1)
+  // per layer, rows (y-1, y, y+1): horizontal 3-max / 3-min of both columns; rows (y, y+1): centre and max/min(left,right)
+  float hmxA[NL][3], hmnA[NL][3], hmxB[NL][3], hmnB[NL][3];
+  float cA[NL][2], cB[NL][2], lxA[NL][2], lnA[NL][2], lxB[NL][2], lnB[NL][2];
 #pragma unroll
   for (int l = 0; l < NL; l++)
   {
 #pragma unroll
     for (int k = 0; k < 3; k++)
-      hmx[l][k] = hmn[l][k] = 0.f;
-    ctr[l][0] = ctr[l][1] = lrx[l][0] = lrx[l][1] = lrn[l][0] = lrn[l][1] = 0.f;
+      hmxA[l][k] = hmnA[l][k] = hmxB[l][k] = hmnB[l][k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      cA[l][k] = cB[l][k] = lxA[l][k] = lnA[l][k] = lxB[l][k] = lnB[l][k] = 0.f;
   }
 
-  for (int r = y0 - 1; r <= y1; r++)
+  // Software prefetch: the loads of row r+1 are issued before row r is processed (a wave otherwise serialises one HBM
+  // round trip per row). Measured: a two-row look-ahead is slower (register pressure), one row is the sweet spot.
+  struct RowRegs
   {
-    // slide the window and load row r of every layer
+    float va[NL], vb[NL], hv[NL];
+  };
+  auto fetch_row = [&](int r, RowRegs &p) {
 #pragma unroll
     for (int l = 0; l < NL; l++)
     {
-      hmx[l][0] = hmx[l][1], hmx[l][1] = hmx[l][2];
-      hmn[l][0] = hmn[l][1], hmn[l][1] = hmn[l][2];
-      ctr[l][0] = ctr[l][1], lrx[l][0] = lrx[l][1], lrn[l][0] = lrn[l][1];
-    }
-    if (r >= 0 && r < a.h)
-    {
-#pragma unroll
-      for (int l = 0; l < NL; l++)
+      p.va[l] = p.vb[l] = p.hv[l] = 0.f;
+      if (r >= 0 && r < a.h && r <= y1)
       {
         const float *row = d.base + (size_t)l * d.plane + (size_t)r * d.pitch;
-        float v = xin ? row[x] : 0.f;
-        float hv = hok ? row[hx] : 0.f;
-        float left = __shfl_up(v, 1, 64), right = __shfl_down(v, 1, 64);
-        if (lane == 0)
-          left = hv;
-        if (lane == 63)
-          right = hv;
-        float mx = fmaxf(left, right), mn = fminf(left, right);
-        ctr[l][1] = v, lrx[l][1] = mx, lrn[l][1] = mn;
-        hmx[l][2] = fmaxf(mx, v), hmn[l][2] = fminf(mn, v);
+        if (in1)
+        {
+          const float2 t = *(const float2 *)(row + x); // x is even and the pitch a multiple of 64: 8-byte aligned
+          p.va[l] = t.x, p.vb[l] = t.y;
+        }
+        else if (in0)
+          p.va[l] = row[x];
+        if (hok)
+          p.hv[l] = row[hx];
       }
+    }
+  };
+
+  auto process_row = [&](int r, const RowRegs &c) {
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+    {
+      hmxA[l][0] = hmxA[l][1], hmxA[l][1] = hmxA[l][2], hmnA[l][0] = hmnA[l][1], hmnA[l][1] = hmnA[l][2];
+      hmxB[l][0] = hmxB[l][1], hmxB[l][1] = hmxB[l][2], hmnB[l][0] = hmnB[l][1], hmnB[l][1] = hmnB[l][2];
+      cA[l][0] = cA[l][1], cB[l][0] = cB[l][1];
+      lxA[l][0] = lxA[l][1], lnA[l][0] = lnA[l][1], lxB[l][0] = lxB[l][1], lnB[l][0] = lnB[l][1];
+    }
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+    {
+      const float va = c.va[l], vb = c.vb[l], hv = c.hv[l];
+      const float la = wave_shr1(vb, hv); // left neighbour of column x   = previous lane's column x+1
+      const float rb = wave_shl1(va, hv); // right neighbour of column x+1 = next lane's column x
+      const float mxa = fmaxf(la, vb), mna = fminf(la, vb);
+      const float mxb = fmaxf(va, rb), mnb = fminf(va, rb);
+      cA[l][1] = va, cB[l][1] = vb;
+      lxA[l][1] = mxa, lnA[l][1] = mna, lxB[l][1] = mxb, lnB[l][1] = mnb;
+      hmxA[l][2] = fmaxf(mxa, va), hmnA[l][2] = fminf(mna, va);
+      hmxB[l][2] = fmaxf(mxb, vb), hmnB[l][2] = fminf(mnb, vb);
     }
     const int y = r - 1;
     if (y < y0 || y >= y1)
-      continue;
-    const bool interior = x >= 1 && x < a.w - 1 && y >= 1 && y < a.h - 1;
+      return;
+    const bool yin = y >= 1 && y < a.h - 1;
+    const bool intA = yin && x >= 1 && x < a.w - 1;
+    const bool intB = yin && x + 1 < a.w - 1;
 #pragma unroll
     for (int sz = 0; sz < S; sz++)
     {
       const int l = sz + 1;
-      const float c = ctr[l][0];
-      bool cand = interior && fabsf(c) > pre;
-      if (cand)
+      // column x
+      const float ca = cA[l][0];
+      bool candA = intA && fabsf(ca) > pre;
       {
-        float nmx = lrx[l][0], nmn = lrn[l][0];
-        nmx = fmaxf(nmx, fmaxf(hmx[l][0], hmx[l][2]));
-        nmn = fminf(nmn, fminf(hmn[l][0], hmn[l][2]));
+        float nmx = fmaxf(lxA[l][0], fmaxf(hmxA[l][0], hmxA[l][2]));
+        float nmn = fminf(lnA[l][0], fminf(hmnA[l][0], hmnA[l][2]));
 #pragma unroll
         for (int k = 0; k < 3; k++)
         {
-          nmx = fmaxf(nmx, fmaxf(hmx[l - 1][k], hmx[l + 1][k]));
-          nmn = fminf(nmn, fminf(hmn[l - 1][k], hmn[l + 1][k]));
+          nmx = fmaxf(nmx, fmaxf(hmxA[l - 1][k], hmxA[l + 1][k]));
+          nmn = fminf(nmn, fminf(hmnA[l - 1][k], hmnA[l + 1][k]));
         }
-        cand = (c > nmx) || (c < nmn);
+        candA = candA && ((ca > nmx) || (ca < nmn));
       }
-      unsigned long long m = __ballot(cand);
-      if (lane == 0)
-        a.seg_mask[((size_t)sz * a.h + y) * a.nseg + segx + (size_t)b * a.seg_img_stride] = m;
+      // column x+1
+      const float cb = cB[l][0];
+      bool candB = intB && fabsf(cb) > pre;
+      {
+        float nmx = fmaxf(lxB[l][0], fmaxf(hmxB[l][0], hmxB[l][2]));
+        float nmn = fminf(lnB[l][0], fminf(hmnB[l][0], hmnB[l][2]));
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+          nmx = fmaxf(nmx, fmaxf(hmxB[l - 1][k], hmxB[l + 1][k]));
+          nmn = fminf(nmn, fminf(hmnB[l - 1][k], hmnB[l + 1][k]));
+        }
+        candB = candB && ((cb > nmx) || (cb < nmn));
+      }
+      const unsigned long long ma = __ballot(candA), mb = __ballot(candB);
+      if (lane == 0 && (ma | mb) != 0ull) // the mask array was zeroed by a memset: only non-empty ballots are written
+      {
+        // pixel 2i of the wave comes from ma bit i, pixel 2i+1 from mb bit i
+        const size_t base = ((size_t)sz * a.h + y) * a.nseg + (size_t)b * a.seg_img_stride;
+        a.seg_mask[base + seg0] = spread32(ma) | (spread32(mb) << 1);
+        if (has_seg1)
+          a.seg_mask[base + seg0 + 1] = spread32(ma >> 32) | (spread32(mb >> 32) << 1);
+      }
     }
+  };
+
+  RowRegs p0;
+  fetch_row(y0 - 1, p0);
+  for (int r = y0 - 1; r <= y1; r++)
+  {
+    const RowRegs c0 = p0;
+    fetch_row(r + 1, p0);
+    process_row(r, c0);
   }
 }
 
@@ -429,17 +511,26 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   a.found = job->found, a.found_img_stride = job->found_img_stride;
   a.cand_xy = job->cand_xy, a.cand_flag = job->cand_flag, a.cand_n = job->cand_n;
   a.cand_img_stride = job->cand_img_stride, a.cand_cap = job->cand_cap;
+
   hipStream_t hs = (hipStream_t)s;
   const uint32_t nsegs = job->S * job->h * (uint32_t)a.nseg;
 
-  /* 1. candidate ballots */
+  /* 1. candidate ballots: only non-empty 64-pixel segments are stored (scattered 8-byte stores were the bottleneck
+   * of this pass), so the mask array is cleared first. The per-image regions are contiguous (seg_img_stride == nsegs). */
+  if (job->seg_img_stride != nsegs)
+    return (int)hipErrorInvalidValue;
+  {
+    hipError_t me = hipMemsetAsync(a.seg_mask, 0, sizeof(uint64_t) * (size_t)nsegs * batch, hs);
+    if (me != hipSuccess)
+      return (int)me;
+  }
   const int band = 32;
-  dim3 sgrid(a.nseg, (job->h + band - 1) / band, batch);
+  dim3 sgrid((a.nseg + 1) / 2, ((job->h + band - 1) / band + 3) / 4, batch);
   switch (job->S)
   {
 #define VKSIFT_CASE(N)                                                       \
   case N:                                                                    \
-    hipLaunchKernelGGL(k_extrema_stream<N>, sgrid, dim3(64), 0, hs, a, band); \
+    hipLaunchKernelGGL(k_extrema_stream<N>, sgrid, dim3(256), 0, hs, a, band); \
     break;
     VKSIFT_CASE(1) VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9)
     VKSIFT_CASE(10) VKSIFT_CASE(11) VKSIFT_CASE(12) VKSIFT_CASE(13)

@@ -14,6 +14,7 @@
 // "det" math mode operation for operation; exp/atan2/sin/cos come from detmath.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../detmath.h"
 #include "vksift_hip.h"
@@ -305,10 +306,12 @@ __device__ __forceinline__ void desc_accumulate(const DescCtx &c, int cdx, int c
 // per-wave LDS queue; the expensive part (gradient, atan2, exp, 8 fixed-point atomics) then always runs on full
 // 64-lane batches. About half of the window falls outside the rotated grid: the reference evaluates atan/exp for
 // those pixels and then drops the contribution (ComputeDescriptors.comp:189); skipping them changes no bit.
-__global__ void __launch_bounds__(256) k_descriptor(FeatArgs a)
+template <int NWV>
+__global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
 {
+  constexpr int NT_ = 64 * NWV;
   __shared__ uint32_t s_work[128];
-  __shared__ uint32_t s_q[4][128];
+  __shared__ uint32_t s_q[NWV][128];
   const int tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const uint32_t found = a.found[(size_t)b * a.found_img_stride];
@@ -320,8 +323,8 @@ __global__ void __launch_bounds__(256) k_descriptor(FeatArgs a)
   for (uint32_t k = blockIdx.x; k < n1; k += gridDim.x)
   {
     __syncthreads();
-    if (tid < 128)
-      s_work[tid] = 0;
+    for (int i = tid; i < 128; i += NT_)
+      s_work[i] = 0;
     __syncthreads();
 
     const float *rec = (const float *)(feats + (size_t)k * 164);
@@ -346,21 +349,24 @@ __global__ void __launch_bounds__(256) k_descriptor(FeatArgs a)
 
     const int box = 2 * R + 1;
     const int npix = box * box;
-    // walk the window without per-pixel integer division: (dx, dy) advance by 256 pixels per iteration
-    int dy = tid / box - R, dx = tid % box - R;
-    const int step_y = 256 / box, step_x = 256 % box;
+    // Pixel enumeration: thread t walks its own contiguous run [t*niter, (t+1)*niter) of the window, so at any step the
+    // 64 lanes of a wave sit ~niter pixels apart and spread over all 16 spatial cells: the 8 fixed-point LDS atomics of
+    // a step then hit mostly distinct addresses (adjacent pixels would pile onto the same 1-2 cells and serialise).
+    // Integer adds commute, so the result is independent of the enumeration.
+    const int niter = (npix + NT_ - 1) / NT_;
+    int pix = tid * niter;
+    int dy = pix / box - R, dx = pix % box - R;
     uint32_t qn = 0; // queue fill of this wave (wave-uniform)
-    for (int pix0 = 0; pix0 < npix; pix0 += 256)
+    for (int it = 0; it < niter; it++, pix++)
     {
       const int cdx = dx, cdy = dy;
-      dx += step_x;
-      dy += step_y;
+      dx += 1;
       if (dx > R)
       {
-        dx -= box;
+        dx = -R;
         dy += 1;
       }
-      bool ok = pix0 + tid < npix;
+      bool ok = pix < npix;
       const int ix = (int)c.rsx + cdx, iy = (int)c.rsy + cdy;
       ok = ok && !(ix < 1 || ix >= (g.w - 1) || iy < 1 || iy >= (g.h - 1));
       if (ok)
@@ -474,7 +480,18 @@ extern "C"
       blocks = 2048;
     if (blocks == 0)
       blocks = 1;
-    hipLaunchKernelGGL(k_descriptor, dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
+    static int nwv = -1;
+    if (nwv < 0)
+    {
+      const char *e = getenv("VKSIFT_DESC_WAVES"); /* waves per keypoint: 1, 2 or 4 (A/B runs) */
+      nwv = e ? atoi(e) : 4;
+    }
+    if (nwv == 1)
+      hipLaunchKernelGGL(k_descriptor<1>, dim3(blocks, batch), dim3(64), 0, (hipStream_t)s, a);
+    else if (nwv == 2)
+      hipLaunchKernelGGL(k_descriptor<2>, dim3(blocks, batch), dim3(128), 0, (hipStream_t)s, a);
+    else
+      hipLaunchKernelGGL(k_descriptor<4>, dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
     return (int)hipGetLastError();
   }
 }

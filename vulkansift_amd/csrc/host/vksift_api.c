@@ -824,9 +824,13 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     j->cap = b0->sec_cap[o];
     j->found = inst->d_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES + o;
     j->found_img_stride = VKSIFT_MAX_OCTAVES;
-    j->seg_mask = inst->d_seg_mask + L->seg_off[o];
-    j->seg_off = inst->d_seg_off + L->seg_off[o];
-    j->seg_img_stride = inst->seg_cap;
+    /* segment scratch is octave-major: [octave][image][segment], so one octave's masks of the whole batch are contiguous */
+    {
+      const uint64_t nsegs_o = (uint64_t)inst->S * L->h[o] * ((L->w[o] + 63) / 64);
+      j->seg_mask = inst->d_seg_mask + L->seg_off[o] * count;
+      j->seg_off = inst->d_seg_off + L->seg_off[o] * count;
+      j->seg_img_stride = nsegs_o;
+    }
     j->cand_xy = inst->d_cand_xy + L->cand_off[o];
     j->cand_flag = inst->d_cand_flag + L->cand_off[o];
     j->cand_n = inst->d_cand_n + (size_t)o * inst->batch_cap;
