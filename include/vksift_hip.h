@@ -27,6 +27,7 @@ extern "C"
 #endif
 
 #define VKSIFT_HIP_MAX_TAPS 20 /* VKSIFT_DETECTOR_MAX_GAUSSIAN_KERNEL_SIZE, sift_detector.h:9 */
+#define VKSIFT_HIP_MATCH_CHUNKS 8 /* B chunks of the large-N matcher (partial top-2 lists merged exactly) */
 #define VKSIFT_HIP_MAX_ORI 18  /* a 36-bin circular histogram has at most 18 strict local maxima */
 
   typedef void *vksift_hip_stream;
@@ -141,7 +142,7 @@ extern "C"
   int vksift_hip_gather_descriptors(const uint8_t *feats, uint32_t n, uint8_t *desc, vksift_hip_stream s);
   /* Get2NearestNeighbors.comp (sift_matcher.c:246-279) on dense descriptor matrices in HBM, as an exact int8
    * MFMA contraction with a fused top-2 epilogue. desc_a: na rows, desc_b: nb >= 2 rows (callers pad, quirk Q6).
-   * norm_scratch: na + nb u32 of scratch. matches: na records of 20 B {idx_a = a_index_base + row, idx_b1,
+   * norm_scratch: 2*na + nb u32 of scratch, plus 5*na*VKSIFT_HIP_MATCH_CHUNKS u32 when na > 32768. matches: na records of 20 B {idx_a = a_index_base + row, idx_b1,
    * idx_b2, dist1, dist2}; B rows are scanned in index order, so sharding A rows over GPUs (a_index_base =
    * shard offset) gives bit-identical results to a single call. */
   int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
@@ -154,14 +155,16 @@ extern "C"
    * fixed_counts[o] when found_base is NULL), writes the dense descriptor rows in download order, their shifted norms
    * and the row total (n_out_dev[slot*n_slot_stride]); rows below pad_rows_to are zero-filled (quirk Q6). max_rows
    * bounds the launch. match_2nn_async reads {N_A, N_B} of slot i from n_dev[i*n_slot_stride + 0..1].
-   * Slot strides are in bytes for desc/matches and in u32 elements for norms/n. */
+   * Slot strides are in bytes for desc/matches and in u32 elements for norms/n. partial_scratch (may be NULL):
+   * 5*max_na*VKSIFT_HIP_MATCH_CHUNKS u32 used by the B-chunked large-N kernel when nslots == 1. redo: max_na u32 per slot
+   * (same slot stride as the norms) of row flags for the exact scalar replay k_match_redo. */
   int vksift_hip_gather_sections(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, uint32_t nslots, uint32_t nsec,
                                  const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *fixed_counts, const uint32_t *found_base,
                                  uint32_t found_buf_stride, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint64_t desc_slot_stride,
                                  uint32_t *norms, uint64_t norm_slot_stride, uint32_t *n_out_dev, uint32_t n_slot_stride, vksift_hip_stream s);
   int vksift_hip_match_2nn_async(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t max_na, const uint8_t *desc_b, const uint32_t *norm_b,
-                                 const uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t desc_slot_stride, uint64_t norm_slot_stride,
-                                 uint64_t match_slot_stride, uint32_t n_slot_stride, vksift_hip_stream s);
+                                 uint32_t *redo, const uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t desc_slot_stride, uint64_t norm_slot_stride,
+                                 uint64_t match_slot_stride, uint32_t n_slot_stride, uint32_t *partial_scratch, vksift_hip_stream s);
 
 #ifdef __cplusplus
 }

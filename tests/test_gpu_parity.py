@@ -158,3 +158,25 @@ def test_match_largest_regime(vk, oracle):
     a = vk.gen_synthetic_descriptors(41, 33001)
     b = vk.gen_synthetic_descriptors(42, 130)
     _assert_matches_equal(_match_via_api(vk, a, b), oracle.match_2nn(a, b))
+
+
+def test_match_device_pointer_api_chunked(vk, oracle):
+    """vksift_hip_match_2nn_desc on torch tensors: the B-chunked large-N path (na > 32768) with ties across chunk borders"""
+    import torch
+    from vulkansift_amd import multigpu
+    a = vk.gen_synthetic_descriptors(51, 33000)
+    b = vk.gen_synthetic_descriptors(52, 1000)
+    b[1] = b[0]
+    b[700] = b[3]          # duplicate in a later chunk: the earlier index must win
+    b[999] = b[130]
+    a[7] = b[3]
+    a[8] = b[130]
+    rec = multigpu.hip_match_fn(torch.from_numpy(a).cuda(), 100, torch.from_numpy(b).cuda())
+    torch.cuda.synchronize()
+    got = multigpu.records_to_struct(rec.cpu().numpy())
+    ref = oracle.match_2nn(a, b)
+    assert np.array_equal(got["idx_a"], ref["idx_a"] + 100)
+    for name in ("idx_b1", "idx_b2"):
+        assert np.array_equal(got[name], ref[name]), name
+    assert np.array_equal(got["dist_a_b1"].view(np.uint32), ref["dist_a_b1"].view(np.uint32))
+    assert got["idx_b1"][7] == 3 and got["idx_b2"][7] == 700

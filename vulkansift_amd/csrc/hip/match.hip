@@ -11,12 +11,15 @@
 // running top-2 per A row (fused epilogue), lanes are merged once at the end.
 //
 // Bit-exactness with the reference's float comparison (quirk Q8): the shader compares
-// sqrt(float(d2)) values, and two different d2 can round to the same float. A lane sees its B columns
-// in increasing index order, so the integer test d2 < (current second best d2) is a safe pre-filter
-// (sqrt is monotone) and the float comparison is evaluated only on that rare path; cross-lane merges
-// compare (sqrtf(d2), index) lexicographically. Quirk Q7 (d(b0) == d(b1) makes index 1 the best) is an
-// index-priority swap of columns 0 and 1 for that A row. Quirk Q6 (b[0], b[1] read unconditionally):
-// callers pad B to two rows.
+// sqrt(float(d2)) values, and two different d2 can round to the same float — but only for d2 >= 2^22
+// (below, q -> sqrtf(q) is injective, and q < 2^22 <= h implies sqrtf(q) < 2048 <= sqrtf(h)). The MFMA
+// kernels therefore work on integers only: a lane sees its B columns in increasing index order and
+// keeps the two smallest (d2, index) pairs, lanes/chunks are merged lexicographically — identical to
+// the reference's strict-'<' scan whenever every INSERTED candidate has d2 < 2^22 (always true for
+// real SIFT descriptors: |a - b| <= 1024). A row that inserts a larger candidate is flagged and
+// recomputed by k_match_redo, a scalar kernel that replays the reference's float loop verbatim.
+// Quirk Q7 (d(b0) == d(b1) makes index 1 the best) is an index-priority swap of columns 0 and 1 for
+// that A row. Quirk Q6 (b[0], b[1] read unconditionally): callers pad B to two rows.
 //
 // MFMA operand layout used (16x16x64 i8): lane l supplies 16 consecutive K bytes (l>>4)*16.. of A row
 // (l&15) / B row (l&15); since A and B use the same K slicing any K permutation cancels in the dot
@@ -152,6 +155,7 @@ struct SlotStrides
   uint64_t norm_a, norm_b; // u32
   uint64_t matches;        // dwords
   uint32_t n;              // u32 between the {N_A, N_B} pairs
+  uint64_t redo;           // u32
 };
 
 struct Top2
@@ -159,81 +163,50 @@ struct Top2
   uint32_t q1, k1, q2, k2; // squared distances and index keys of best / second
 };
 
-// Below 2^22 the map q -> sqrtf(float(q)) is injective (gap 1/(2 sqrt q) > ulp), so integer order == float
-// order and the correctly rounded sqrtf (a ~20-instruction sequence) is only needed above it.
-constexpr uint32_t Q_EXACT = 1u << 22;
+constexpr uint32_t Q_EXACT = 1u << 22; // below this, integer order of d2 == order of sqrtf(float(d2))
 
-// (sqrtf(q), key) lexicographic order — the order the reference's scan realises
-__device__ __forceinline__ bool lex_less(uint32_t qa, uint32_t ka, uint32_t qb, uint32_t kb)
-{
-  if (qa == qb)
-    return ka < kb;
-  if ((qa | qb) < Q_EXACT)
-    return qa < qb;
-  float da = sqrtf((float)qa), db = sqrtf((float)qb);
-  return da < db || (da == db && ka < kb);
-}
+__device__ __forceinline__ bool lex_less(uint32_t qa, uint32_t ka, uint32_t qb, uint32_t kb) { return qa < qb || (qa == qb && ka < kb); }
 
-// in-lane insertion; keys arrive in increasing order so a tie never displaces a holder.
-// Precondition (pre-filter): q < t.q2 as integers.
+// in-lane insertion; keys arrive in increasing order so a tie never displaces a holder. Precondition: q < t.q2.
 __device__ __forceinline__ void insert_seq(Top2 &t, uint32_t q, uint32_t key)
 {
-  if (t.q2 < Q_EXACT)
-  {
-    // q < q2 < 2^22 and q1 <= q2: pure integer comparison is exact
-    if (q < t.q1)
-    {
-      t.q2 = t.q1, t.k2 = t.k1;
-      t.q1 = q, t.k1 = key;
-    }
-    else
-      t.q2 = q, t.k2 = key;
-    return;
-  }
-  float d = sqrtf((float)q);
-  if (d < sqrtf((float)t.q1))
+  if (q < t.q1)
   {
     t.q2 = t.q1, t.k2 = t.k1;
     t.q1 = q, t.k1 = key;
   }
-  else if (d < sqrtf((float)t.q2))
-  {
+  else
     t.q2 = q, t.k2 = key;
-  }
 }
 
 __device__ __forceinline__ Top2 merge2(const Top2 &a, const Top2 &b)
 {
   Top2 r;
-  if (lex_less(a.q1, a.k1, b.q1, b.k1))
-  {
-    r.q1 = a.q1, r.k1 = a.k1;
-    if (lex_less(a.q2, a.k2, b.q1, b.k1))
-      r.q2 = a.q2, r.k2 = a.k2;
-    else
-      r.q2 = b.q1, r.k2 = b.k1;
-  }
-  else
-  {
-    r.q1 = b.q1, r.k1 = b.k1;
-    if (lex_less(b.q2, b.k2, a.q1, a.k1))
-      r.q2 = b.q2, r.k2 = b.k2;
-    else
-      r.q2 = a.q1, r.k2 = a.k1;
-  }
+  const bool a_first = lex_less(a.q1, a.k1, b.q1, b.k1);
+  const Top2 &w = a_first ? a : b; // winner of the best slot
+  const Top2 &l = a_first ? b : a;
+  r.q1 = w.q1, r.k1 = w.k1;
+  const bool w2 = lex_less(w.q2, w.k2, l.q1, l.k1);
+  r.q2 = w2 ? w.q2 : l.q1;
+  r.k2 = w2 ? w.k2 : l.k1;
   return r;
 }
 
 // AT = 16-row A tiles per wave. Block = 4 waves = 64*AT A rows; B streams through LDS.
+// gridDim.z > 1: B is split into gridDim.z chunks of whole 64-row tiles; every chunk writes its partial top-2 per A row to
+// `partial` ([row][chunk][4], then one flag word per (row, chunk): bit0 = Q7 swap, bit1 = redo) and k_match_merge combines them.
 template <int AT>
 __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
                                                     uint32_t a_index_base, const uint32_t *__restrict__ desc_b, const uint32_t *__restrict__ norm_b,
-                                                    uint32_t nb, uint32_t *__restrict__ matches, const uint32_t *__restrict__ n_dev,
-                                                    uint32_t na_lo, uint32_t na_hi, SlotStrides ss)
+                                                    uint32_t nb, uint32_t *__restrict__ matches, uint32_t *__restrict__ redo,
+                                                    const uint32_t *__restrict__ n_dev, uint32_t na_lo, uint32_t na_hi, SlotStrides ss,
+                                                    uint32_t *__restrict__ partial)
 {
+  const uint32_t nchunks = gridDim.z, chunk = blockIdx.z;
   desc_a += (size_t)blockIdx.y * ss.desc_a, desc_b += (size_t)blockIdx.y * ss.desc_b;
   norm_a += (size_t)blockIdx.y * ss.norm_a, norm_b += (size_t)blockIdx.y * ss.norm_b;
   matches += (size_t)blockIdx.y * ss.matches;
+  redo += (size_t)blockIdx.y * ss.redo;
   if (n_dev)
   {
     n_dev += (size_t)blockIdx.y * ss.n;
@@ -249,173 +222,221 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, grp = lane >> 4;
+  const uint32_t tiles = (nb + BT - 1) / BT, tiles_per_chunk = (tiles + nchunks - 1) / nchunks;
+  const uint32_t tb = chunk * tiles_per_chunk * BT;
+  const uint32_t te = min(nb, tb + tiles_per_chunk * BT);
+
   // the grid may be smaller than the number of 64*AT-row blocks (bounded launch): loop over row blocks
   for (uint32_t rb = blockIdx.x; rb * (64u * AT) < na; rb += gridDim.x)
   {
-  const uint32_t row_base = (rb * 4 + wave) * (16 * AT);
+    const uint32_t row_base = (rb * 4 + wave) * (16 * AT);
 
-  // A fragments (XOR 0x80 -> int8) and norms of the rows this lane accumulates
-  v4i afrag[AT][2];
-  uint32_t an[AT][4];
+    // A fragments (XOR 0x80 -> int8) and norms of the rows this lane accumulates
+    v4i afrag[AT][2];
+    uint32_t an[AT][4];
 #pragma unroll
-  for (int t = 0; t < AT; t++)
-  {
-    uint32_t r = row_base + t * 16 + col;
-    if (r >= na)
-      r = na - 1;
-    const uint4 *p = (const uint4 *)(desc_a + (size_t)r * 32);
-    uint4 v0 = p[grp], v1 = p[4 + grp];
-    afrag[t][0] = v4i{(int)(v0.x ^ 0x80808080u), (int)(v0.y ^ 0x80808080u), (int)(v0.z ^ 0x80808080u), (int)(v0.w ^ 0x80808080u)};
-    afrag[t][1] = v4i{(int)(v1.x ^ 0x80808080u), (int)(v1.y ^ 0x80808080u), (int)(v1.z ^ 0x80808080u), (int)(v1.w ^ 0x80808080u)};
-#pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int t = 0; t < AT; t++)
     {
-      uint32_t rr = row_base + t * 16 + grp * 4 + j;
-      an[t][j] = norm_a[rr < na ? rr : na - 1];
-    }
-  }
-
-  Top2 st[AT][4];
+      uint32_t r = row_base + t * 16 + col;
+      if (r >= na)
+        r = na - 1;
+      const uint4 *p = (const uint4 *)(desc_a + (size_t)r * 32);
+      uint4 v0 = p[grp], v1 = p[4 + grp];
+      afrag[t][0] = v4i{(int)(v0.x ^ 0x80808080u), (int)(v0.y ^ 0x80808080u), (int)(v0.z ^ 0x80808080u), (int)(v0.w ^ 0x80808080u)};
+      afrag[t][1] = v4i{(int)(v1.x ^ 0x80808080u), (int)(v1.y ^ 0x80808080u), (int)(v1.z ^ 0x80808080u), (int)(v1.w ^ 0x80808080u)};
 #pragma unroll
-  for (int t = 0; t < AT; t++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      st[t][j] = Top2{QMAX, QMAX, QMAX, QMAX};
-  uint32_t swap_bits = 0; // bit (t*4+j): d(b0) == d(b1) for that A row (quirk Q7)
-
-  // B tiles are prefetched one tile ahead into registers (2 x 16 B per thread) so that the global-load latency of
-  // tile t+1 hides behind the MFMA + epilogue work of tile t.
-  constexpr int NLD = BT * 8 / 256;
-  uint4 pfb[NLD];
-  uint32_t pfn = 0;
-  auto fetch_tile = [&](uint32_t t0) {
-#pragma unroll
-    for (int q = 0; q < NLD; q++)
-    {
-      int i = threadIdx.x + q * 256;
-      int r = i >> 3, c = i & 7;
-      pfb[q] = make_uint4(0, 0, 0, 0);
-      if (t0 + r < nb)
-        pfb[q] = ((const uint4 *)(desc_b + (size_t)(t0 + r) * 32))[c];
-    }
-    pfn = (threadIdx.x < BT && t0 + threadIdx.x < nb) ? norm_b[t0 + threadIdx.x] : 0u;
-  };
-  fetch_tile(0);
-
-  for (uint32_t t0 = 0; t0 < nb; t0 += BT)
-  {
-    __syncthreads();
-    // stage the prefetched BT rows (zero beyond nb), converting to int8
-#pragma unroll
-    for (int q = 0; q < NLD; q++)
-    {
-      int i = threadIdx.x + q * 256;
-      int r = i >> 3, c = i & 7;
-      uint4 v = pfb[q];
-      v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
-      *(uint4 *)(s_b + r * B_STRIDE + c * 16) = v;
-    }
-    if (threadIdx.x < BT)
-      s_nb[threadIdx.x] = pfn;
-    __syncthreads();
-    if (t0 + BT < nb)
-      fetch_tile(t0 + BT);
-
-#pragma unroll
-    for (int sub = 0; sub < BT / 16; sub++)
-    {
-      const uint32_t bcol = t0 + sub * 16 + col; // B index this lane's outputs belong to
-      if (t0 + sub * 16 >= nb)
-        break;
-      const uint8_t *pb = s_b + (sub * 16 + col) * B_STRIDE + grp * 16;
-      const v4i b0 = *(const v4i *)pb;
-      const v4i b1 = *(const v4i *)(pb + 64);
-      const uint32_t bn = s_nb[sub * 16 + col];
-      const bool first = (t0 == 0 && sub == 0);
-#pragma unroll
-      for (int t = 0; t < AT; t++)
+      for (int j = 0; j < 4; j++)
       {
-        v4i acc = v4i{0, 0, 0, 0};
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[t][0], b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[t][1], b1, acc, 0, 0, 0);
-        uint32_t q[4];
-        bool any = false;
+        uint32_t rr = row_base + t * 16 + grp * 4 + j;
+        an[t][j] = norm_a[rr < na ? rr : na - 1];
+      }
+    }
+
+    Top2 st[AT][4];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+    for (int t = 0; t < AT; t++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        st[t][j] = Top2{QMAX, QMAX, QMAX, QMAX};
+    uint32_t swap_bits = 0;  // bit (t*4+j): d2(b0) == d2(b1) for that A row (quirk Q7)
+    uint32_t risky_bits = 0; // bit (t*4+j): a candidate >= 2^22 was inserted -> the row goes to k_match_redo
+
+    // B tiles are prefetched one tile ahead into registers (2 x 16 B per thread) so that the global-load latency of
+    // tile t+1 hides behind the MFMA + epilogue work of tile t.
+    constexpr int NLD = BT * 8 / 256;
+    uint4 pfb[NLD];
+    uint32_t pfn = 0;
+    auto fetch_tile = [&](uint32_t t0) {
+#pragma unroll
+      for (int q = 0; q < NLD; q++)
+      {
+        int i = threadIdx.x + q * 256;
+        int r = i >> 3, c = i & 7;
+        pfb[q] = make_uint4(0, 0, 0, 0);
+        if (t0 + r < nb)
+          pfb[q] = ((const uint4 *)(desc_b + (size_t)(t0 + r) * 32))[c];
+      }
+      pfn = (threadIdx.x < BT && t0 + threadIdx.x < nb) ? norm_b[t0 + threadIdx.x] : 0u;
+    };
+    fetch_tile(tb);
+
+    for (uint32_t t0 = tb; t0 < te; t0 += BT)
+    {
+      __syncthreads();
+      // stage the prefetched BT rows (zero beyond nb), converting to int8
+#pragma unroll
+      for (int q = 0; q < NLD; q++)
+      {
+        int i = threadIdx.x + q * 256;
+        int r = i >> 3, c = i & 7;
+        uint4 v = pfb[q];
+        v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
+        *(uint4 *)(s_b + r * B_STRIDE + c * 16) = v;
+      }
+      if (threadIdx.x < BT)
+        s_nb[threadIdx.x] = pfn;
+      __syncthreads();
+      if (t0 + BT < te)
+        fetch_tile(t0 + BT);
+
+#pragma unroll
+      for (int sub = 0; sub < BT / 16; sub++)
+      {
+        const uint32_t bcol = t0 + sub * 16 + col; // B index this lane's outputs belong to
+        if (t0 + sub * 16 >= te)
+          break;
+        const uint8_t *pb = s_b + (sub * 16 + col) * B_STRIDE + grp * 16;
+        const v4i b0 = *(const v4i *)pb;
+        const v4i b1 = *(const v4i *)(pb + 64);
+        const uint32_t bn = s_nb[sub * 16 + col];
+        const bool first = (t0 == 0 && sub == 0);
+#pragma unroll
+        for (int t = 0; t < AT; t++)
         {
-          q[j] = bcol < nb ? an[t][j] + bn - 2u * (uint32_t)acc[j] : QMAX;
-          any = any || (q[j] < st[t][j].q2);
-        }
-        if (first)
-        {
-          // quirk Q7: exchange d2(b0) / d2(b1) between the col-0 and col-1 lanes of each row group
+          v4i acc = v4i{0, 0, 0, 0};
+          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[t][0], b0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[t][1], b1, acc, 0, 0, 0);
 #pragma unroll
           for (int j = 0; j < 4; j++)
           {
-            uint32_t other = __shfl_xor(q[j], 1, 64);
-            bool sw = col < 2 && sqrtf((float)q[j]) == sqrtf((float)other);
-            if (sw)
-              swap_bits |= 1u << (t * 4 + j);
-            uint32_t key = (col < 2 && sw) ? (uint32_t)(col ^ 1) : bcol;
-            if (q[j] != QMAX)
-              insert_seq(st[t][j], q[j], key);
+            const uint32_t q = bcol < nb ? an[t][j] + bn - 2u * (uint32_t)acc[j] : QMAX;
+            uint32_t key = bcol;
+            if (first)
+            {
+              // quirk Q7: exchange d2(b0) / d2(b1) between the col-0 and col-1 lanes of each row group
+              const uint32_t other = __shfl_xor(q, 1, 64);
+              const bool sw = col < 2 && q == other;
+              if (sw)
+                swap_bits |= 1u << (t * 4 + j);
+              if (col < 2 && (q >= Q_EXACT || other >= Q_EXACT))
+                risky_bits |= 1u << (t * 4 + j); // the tie test itself needs the float comparison
+              key = sw ? (uint32_t)(col ^ 1) : bcol;
+            }
+            if (q < st[t][j].q2)
+            {
+              if (q >= Q_EXACT)
+                risky_bits |= 1u << (t * 4 + j);
+              insert_seq(st[t][j], q, key);
+            }
           }
         }
-        else if (any)
-        {
+      }
+    }
+
+    // merge the 16 lanes that share A rows (butterfly over the column bits), then lane col==0 writes
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (q[j] < st[t][j].q2)
-              insert_seq(st[t][j], q[j], bcol);
+    for (int m = 1; m < 16; m <<= 1)
+    {
+      risky_bits |= __shfl_xor(risky_bits, m, 64);
+      swap_bits |= __shfl_xor(swap_bits, m, 64);
+    }
+#pragma unroll
+    for (int t = 0; t < AT; t++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        Top2 s = st[t][j];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1)
+        {
+          Top2 o;
+          o.q1 = __shfl_xor(s.q1, m, 64), o.k1 = __shfl_xor(s.k1, m, 64);
+          o.q2 = __shfl_xor(s.q2, m, 64), o.k2 = __shfl_xor(s.k2, m, 64);
+          s = merge2(s, o);
+        }
+        const uint32_t r = row_base + t * 16 + grp * 4 + j;
+        const uint32_t sw = (swap_bits >> (t * 4 + j)) & 1u, rk = (risky_bits >> (t * 4 + j)) & 1u;
+        if (col == 0 && r < na)
+        {
+          if (nchunks > 1)
+          {
+            uint32_t *pp = partial + ((size_t)r * nchunks + chunk) * 4;
+            pp[0] = s.q1, pp[1] = s.k1, pp[2] = s.q2, pp[3] = s.k2;
+            partial[(size_t)na * nchunks * 4 + (size_t)r * nchunks + chunk] = sw | (rk << 1);
+          }
+          else
+          {
+            uint32_t *m = matches + (size_t)r * 5;
+            m[0] = a_index_base + r;
+            m[1] = (sw && s.k1 < 2) ? (s.k1 ^ 1u) : s.k1;
+            m[2] = (sw && s.k2 < 2) ? (s.k2 ^ 1u) : s.k2;
+            m[3] = __float_as_uint(sqrtf((float)s.q1));
+            m[4] = __float_as_uint(sqrtf((float)s.q2));
+            redo[r] = rk;
+          }
         }
       }
-    }
-  }
-
-  // merge the 16 lanes that share A rows (butterfly over the column bits), then lane col==0 writes
-#pragma unroll
-  for (int t = 0; t < AT; t++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-    {
-      Top2 s = st[t][j];
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1)
-      {
-        Top2 o;
-        o.q1 = __shfl_xor(s.q1, m, 64), o.k1 = __shfl_xor(s.k1, m, 64);
-        o.q2 = __shfl_xor(s.q2, m, 64), o.k2 = __shfl_xor(s.k2, m, 64);
-        s = merge2(s, o);
-      }
-      uint32_t r = row_base + t * 16 + grp * 4 + j;
-      if (col == 0 && r < na)
-      {
-        bool sw = (swap_bits >> (t * 4 + j)) & 1u;
-        uint32_t i1 = (sw && s.k1 < 2) ? (s.k1 ^ 1u) : s.k1;
-        uint32_t i2 = (sw && s.k2 < 2) ? (s.k2 ^ 1u) : s.k2;
-        uint32_t *m = matches + (size_t)r * 5;
-        m[0] = a_index_base + r;
-        m[1] = i1;
-        m[2] = i2;
-        m[3] = __float_as_uint(sqrtf((float)s.q1));
-        m[4] = __float_as_uint(sqrtf((float)s.q2));
-      }
-    }
   } // row-block loop
+}
+
+// Exact combination of the per-chunk partial top-2 lists of k_match_mfma (gridDim.z > 1): one thread per A row.
+__global__ void __launch_bounds__(256) k_match_merge(const uint32_t *__restrict__ partial, uint32_t na, uint32_t nchunks, uint32_t a_index_base,
+                                                     uint32_t *__restrict__ matches, uint32_t *__restrict__ redo, const uint32_t *__restrict__ n_dev,
+                                                     uint32_t na_lo, uint32_t na_hi)
+{
+  if (n_dev)
+  {
+    na = n_dev[0];
+    if (na <= na_lo || na > na_hi)
+      return;
+  }
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= na)
+    return;
+  const uint32_t *pp = partial + (size_t)r * nchunks * 4;
+  const uint32_t *fl = partial + (size_t)na * nchunks * 4 + (size_t)r * nchunks;
+  Top2 s{pp[0], pp[1], pp[2], pp[3]};
+  uint32_t flags = fl[0];
+  for (uint32_t c = 1; c < nchunks; c++)
+  {
+    Top2 o{pp[c * 4 + 0], pp[c * 4 + 1], pp[c * 4 + 2], pp[c * 4 + 3]};
+    s = merge2(s, o);
+    flags |= fl[c] & 2u;
+  }
+  const bool sw = flags & 1u;
+  uint32_t *m = matches + (size_t)r * 5;
+  m[0] = a_index_base + r;
+  m[1] = (sw && s.k1 < 2) ? (s.k1 ^ 1u) : s.k1;
+  m[2] = (sw && s.k2 < 2) ? (s.k2 ^ 1u) : s.k2;
+  m[3] = __float_as_uint(sqrtf((float)s.q1));
+  m[4] = __float_as_uint(sqrtf((float)s.q2));
+  redo[r] = (flags >> 1) & 1u;
 }
 
 // Small-problem variant: one workgroup = 16 A rows; its 4 waves each take one 16-row slice of every staged 64-row B
 // tile (wave w sees B indices t0 + 16w + col, increasing over tiles, so the in-lane pre-filter stays valid), and the
-// four partial top-2 lists are merged through LDS with the same (sqrt(d2), index) order. 4x more waves than the
-// row-per-wave kernel for a few thousand features, 4x shorter dependent chain per wave.
+// four partial top-2 lists are merged through LDS. 4x more waves than the row-per-wave kernel for a few thousand
+// features, 4x shorter dependent chain per wave.
 __global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
                                                           uint32_t a_index_base, const uint32_t *__restrict__ desc_b,
                                                           const uint32_t *__restrict__ norm_b, uint32_t nb, uint32_t *__restrict__ matches,
-                                                          const uint32_t *__restrict__ n_dev, uint32_t na_lo, uint32_t na_hi, SlotStrides ss)
+                                                          uint32_t *__restrict__ redo, const uint32_t *__restrict__ n_dev, uint32_t na_lo, uint32_t na_hi,
+                                                          SlotStrides ss)
 {
   desc_a += (size_t)blockIdx.y * ss.desc_a, desc_b += (size_t)blockIdx.y * ss.desc_b;
   norm_a += (size_t)blockIdx.y * ss.norm_a, norm_b += (size_t)blockIdx.y * ss.norm_b;
   matches += (size_t)blockIdx.y * ss.matches;
+  redo += (size_t)blockIdx.y * ss.redo;
   if (n_dev)
   {
     n_dev += (size_t)blockIdx.y * ss.n;
@@ -429,7 +450,7 @@ __global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__rest
   __shared__ __attribute__((aligned(16))) uint8_t s_b[2][BT * B_STRIDE];
   __shared__ uint32_t s_nb[2][BT];
   __shared__ uint32_t s_part[4][16][4];
-  __shared__ uint32_t s_swap;
+  __shared__ uint32_t s_swap, s_risky;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, grp = lane >> 4;
@@ -456,7 +477,7 @@ __global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__rest
 #pragma unroll
   for (int j = 0; j < 4; j++)
     st[j] = Top2{QMAX, QMAX, QMAX, QMAX};
-  uint32_t swap_bits = 0;
+  uint32_t swap_bits = 0, risky_bits = 0;
 
   constexpr int NLD = BT * 8 / 256;
   uint4 pfb[NLD];
@@ -474,6 +495,8 @@ __global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__rest
     pfn = (threadIdx.x < BT && t0 + threadIdx.x < nb) ? norm_b[t0 + threadIdx.x] : 0u;
   };
   fetch_tile(0);
+  if (threadIdx.x == 0)
+    s_swap = 0, s_risky = 0;
 
   int buf = 0;
   for (uint32_t t0 = 0; t0 < nb; t0 += BT, buf ^= 1)
@@ -505,39 +528,38 @@ __global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__rest
       v4i acc = v4i{0, 0, 0, 0};
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[0], b0, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[1], b1, acc, 0, 0, 0);
-      uint32_t q[4];
-      bool any = false;
 #pragma unroll
       for (int j = 0; j < 4; j++)
       {
-        q[j] = bcol < nb ? an[j] + bn - 2u * (uint32_t)acc[j] : QMAX;
-        any = any || (q[j] < st[j].q2);
-      }
-      if (sub0 == 0)
-      {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
+        const uint32_t q = bcol < nb ? an[j] + bn - 2u * (uint32_t)acc[j] : QMAX;
+        uint32_t key = bcol;
+        if (sub0 == 0)
         {
-          uint32_t other = __shfl_xor(q[j], 1, 64);
-          bool sw = col < 2 && sqrtf((float)q[j]) == sqrtf((float)other);
+          const uint32_t other = __shfl_xor(q, 1, 64);
+          const bool sw = col < 2 && q == other;
           if (sw)
             swap_bits |= 1u << j;
-          uint32_t key = (col < 2 && sw) ? (uint32_t)(col ^ 1) : bcol;
-          if (q[j] != QMAX)
-            insert_seq(st[j], q[j], key);
+          if (col < 2 && (q >= Q_EXACT || other >= Q_EXACT))
+            risky_bits |= 1u << j;
+          key = sw ? (uint32_t)(col ^ 1) : bcol;
         }
-      }
-      else if (any)
-      {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (q[j] < st[j].q2)
-            insert_seq(st[j], q[j], bcol);
+        if (q < st[j].q2)
+        {
+          if (q >= Q_EXACT)
+            risky_bits |= 1u << j;
+          insert_seq(st[j], q, key);
+        }
       }
     }
   }
 
   // merge across the 16 lanes of a row group, then across the 4 waves
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1)
+  {
+    risky_bits |= __shfl_xor(risky_bits, m, 64);
+    swap_bits |= __shfl_xor(swap_bits, m, 64);
+  }
 #pragma unroll
   for (int j = 0; j < 4; j++)
   {
@@ -556,11 +578,12 @@ __global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__rest
       s_part[wave][grp * 4 + j][2] = s.q2, s_part[wave][grp * 4 + j][3] = s.k2;
     }
   }
-  if (threadIdx.x == 0)
-    s_swap = 0;
-  __syncthreads();
-  if (wave == 0 && col == 0)
-    atomicOr(&s_swap, swap_bits << (grp * 4));
+  if (col == 0)
+  {
+    atomicOr(&s_risky, risky_bits << (grp * 4));
+    if (wave == 0)
+      atomicOr(&s_swap, swap_bits << (grp * 4));
+  }
   __syncthreads();
   if (threadIdx.x < 16)
   {
@@ -575,16 +598,82 @@ __global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__rest
     const uint32_t r = row_base + rr;
     if (r < na)
     {
-      bool sw = (s_swap >> rr) & 1u;
-      uint32_t i1 = (sw && s.k1 < 2) ? (s.k1 ^ 1u) : s.k1;
-      uint32_t i2 = (sw && s.k2 < 2) ? (s.k2 ^ 1u) : s.k2;
+      const bool sw = (s_swap >> rr) & 1u;
       uint32_t *m = matches + (size_t)r * 5;
       m[0] = a_index_base + r;
-      m[1] = i1;
-      m[2] = i2;
+      m[1] = (sw && s.k1 < 2) ? (s.k1 ^ 1u) : s.k1;
+      m[2] = (sw && s.k2 < 2) ? (s.k2 ^ 1u) : s.k2;
       m[3] = __float_as_uint(sqrtf((float)s.q1));
       m[4] = __float_as_uint(sqrtf((float)s.q2));
+      redo[r] = (s_risky >> rr) & 1u;
     }
+  }
+}
+
+// Exact replay of Get2NearestNeighbors.comp:43-103 for the rows flagged by the MFMA kernels (candidates with
+// d2 >= 2^22, where the reference's float sqrt comparison is not injective). One thread per flagged row, scalar.
+// Never taken for real SIFT descriptors; adversarial inputs just run at scalar speed.
+__global__ void __launch_bounds__(64) k_match_redo(const uint32_t *__restrict__ desc_a, uint32_t na, uint32_t a_index_base,
+                                                   const uint32_t *__restrict__ desc_b, uint32_t nb, uint32_t *__restrict__ matches,
+                                                   const uint32_t *__restrict__ redo, const uint32_t *__restrict__ n_dev, SlotStrides ss)
+{
+  desc_a += (size_t)blockIdx.y * ss.desc_a, desc_b += (size_t)blockIdx.y * ss.desc_b;
+  matches += (size_t)blockIdx.y * ss.matches;
+  redo += (size_t)blockIdx.y * ss.redo;
+  if (n_dev)
+  {
+    n_dev += (size_t)blockIdx.y * ss.n;
+    na = n_dev[0];
+    nb = n_dev[1] < 2u ? 2u : n_dev[1];
+  }
+  for (uint32_t row = blockIdx.x * 64 + threadIdx.x; row < na; row += gridDim.x * 64)
+  {
+    if (!redo[row])
+      continue;
+    uint32_t a[32];
+    uint32_t na2 = 0;
+#pragma unroll
+    for (int j = 0; j < 32; j++)
+    {
+      a[j] = desc_a[(size_t)row * 32 + j];
+      na2 = __builtin_amdgcn_udot4(a[j], a[j], na2, false);
+    }
+    auto dist = [&](uint32_t bi) -> float {
+      const uint32_t *pb = desc_b + (size_t)bi * 32;
+      uint32_t dot = 0, nb2 = 0;
+#pragma unroll
+      for (int j = 0; j < 32; j++)
+      {
+        const uint32_t v = pb[j];
+        dot = __builtin_amdgcn_udot4(a[j], v, dot, false);
+        nb2 = __builtin_amdgcn_udot4(v, v, nb2, false);
+      }
+      return sqrtf((float)(na2 + nb2 - 2u * dot));
+    };
+    float d0 = dist(0), d1 = dist(1);
+    float best_d, second_d;
+    uint32_t best_i, second_i;
+    if (d0 < d1)
+      best_d = d0, best_i = 0, second_d = d1, second_i = 1;
+    else
+      best_d = d1, best_i = 1, second_d = d0, second_i = 0;
+    for (uint32_t bi = 2; bi < nb; bi++)
+    {
+      const float d = dist(bi);
+      if (d < best_d)
+      {
+        second_d = best_d, second_i = best_i;
+        best_d = d, best_i = bi;
+      }
+      else if (d < second_d)
+        second_d = d, second_i = bi;
+    }
+    uint32_t *m = matches + (size_t)row * 5;
+    m[0] = a_index_base + row;
+    m[1] = best_i;
+    m[2] = second_i;
+    m[3] = __float_as_uint(best_d);
+    m[4] = __float_as_uint(second_d);
   }
 }
 
@@ -608,27 +697,31 @@ extern "C"
       return 0;
     if (nb < 2)
       return (int)hipErrorInvalidValue; /* callers pad B to two rows (quirk Q6) */
-    uint32_t *norm_a = norm_scratch, *norm_b = norm_scratch + na;
-    hipLaunchKernelGGL(k_shifted_norms, dim3((na + 255u) / 256u), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, na, norm_a);
-    hipLaunchKernelGGL(k_shifted_norms, dim3((nb + 255u) / 256u), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_b, nb, norm_b);
-    /* Small problems: 16 A rows per wave to fill more CUs; large ones: 64 rows per wave for B-tile reuse. */
+    hipStream_t hs = (hipStream_t)s;
+    uint32_t *norm_a = norm_scratch, *norm_b = norm_scratch + na, *redo = norm_scratch + na + nb;
+    const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
+    const SlotStrides z{0, 0, 0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(k_shifted_norms, dim3((na + 255u) / 256u), dim3(256), 0, hs, da, na, norm_a);
+    hipLaunchKernelGGL(k_shifted_norms, dim3((nb + 255u) / 256u), dim3(256), 0, hs, db, nb, norm_b);
+    /* Small problems: 16 A rows per workgroup with B split over its waves; medium: 16 rows per wave; large: 64 rows per
+     * wave (B-tile reuse) with B split into VKSIFT_HIP_MATCH_CHUNKS chunks across grid.z + exact merge. */
     if (na <= 8192u)
-    {
-      hipLaunchKernelGGL(k_match_mfma_split, dim3((na + 15u) / 16u), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, norm_a, na, a_index_base,
-                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, SlotStrides{0, 0, 0, 0, 0, 0});
-    }
+      hipLaunchKernelGGL(k_match_mfma_split, dim3((na + 15u) / 16u), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
+                         (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z);
     else if (na <= 32768u)
-    {
-      uint32_t blocks = (na + 63u) / 64u;
-      hipLaunchKernelGGL(k_match_mfma<1>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, norm_a, na, a_index_base,
-                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, SlotStrides{0, 0, 0, 0, 0, 0});
-    }
+      hipLaunchKernelGGL(k_match_mfma<1>, dim3((na + 63u) / 64u), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
+                         (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, (uint32_t *)nullptr);
     else
     {
-      uint32_t blocks = (na + 255u) / 256u;
-      hipLaunchKernelGGL(k_match_mfma<4>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc_a, norm_a, na, a_index_base,
-                         (const uint32_t *)desc_b, norm_b, nb, (uint32_t *)matches, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, SlotStrides{0, 0, 0, 0, 0, 0});
+      uint32_t *partial = redo + na;
+      hipLaunchKernelGGL(k_match_mfma<4>, dim3((na + 255u) / 256u, 1, VKSIFT_HIP_MATCH_CHUNKS), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb,
+                         (uint32_t *)matches, redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial);
+      hipLaunchKernelGGL(k_match_merge, dim3((na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial, na, (uint32_t)VKSIFT_HIP_MATCH_CHUNKS,
+                         a_index_base, (uint32_t *)matches, redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
     }
+    uint32_t rblocks = (na + 63u) / 64u;
+    hipLaunchKernelGGL(k_match_redo, dim3(rblocks > 1024u ? 1024u : rblocks), dim3(64), 0, hs, da, na, a_index_base, db, nb, (uint32_t *)matches,
+                       (const uint32_t *)redo, (const uint32_t *)nullptr, z);
     return (int)hipGetLastError();
   }
 
@@ -663,8 +756,9 @@ extern "C"
   }
 
   int vksift_hip_match_2nn_async(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t max_na, const uint8_t *desc_b, const uint32_t *norm_b,
-                                 const uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t desc_slot_stride, uint64_t norm_slot_stride,
-                                 uint64_t match_slot_stride, uint32_t n_slot_stride, vksift_hip_stream s)
+                                 uint32_t *redo, const uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t desc_slot_stride,
+                                 uint64_t norm_slot_stride, uint64_t match_slot_stride, uint32_t n_slot_stride, uint32_t *partial_scratch,
+                                 vksift_hip_stream s)
   {
     if (max_na == 0)
       return 0;
@@ -675,27 +769,43 @@ extern "C"
     ss.norm_a = ss.norm_b = norm_slot_stride;
     ss.matches = match_slot_stride / 4;
     ss.n = n_slot_stride;
+    ss.redo = norm_slot_stride; /* the redo flags live in the same per-slot scratch block as the norms */
     /* The row count is only known on the device: launch for the capacity (surplus workgroups exit at once), one
      * kernel per size regime, each of which returns immediately unless N_A falls in its range:
      *   N_A <= 8192        B-split kernel, 16 A rows per workgroup (keeps a few thousand rows busy on every CU)
      *   8192 < N_A <= 32768 16 A rows per wave
-     *   N_A > 32768         64 A rows per wave (B tile reuse) */
+     *   N_A > 32768         64 A rows per wave (B tile reuse), B-chunked + merged when a single pair is matched */
     const uint32_t S1 = 8192u, S2 = 32768u;
     hipStream_t hs = (hipStream_t)s;
+    const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
     /* regimes 2/3 loop over their row blocks, so their grids stay small even when only the capacity is known */
     auto bounded = [](uint32_t blocks, uint32_t slots) { uint32_t lim = slots >= 8 ? 64u : 1024u; return blocks < lim ? blocks : lim; };
     const uint32_t n1 = max_na < S1 ? max_na : S1;
-    hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u, nslots), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u,
-                       (const uint32_t *)desc_b, norm_b, 0u, (uint32_t *)matches, n_dev, 0u, S1, ss);
+    hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev,
+                       0u, S1, ss);
     if (max_na > S1)
     {
       const uint32_t n2 = max_na < S2 ? max_na : S2;
-      hipLaunchKernelGGL(k_match_mfma<1>, dim3(bounded((n2 + 63u) / 64u, nslots), nslots), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u,
-                         (const uint32_t *)desc_b, norm_b, 0u, (uint32_t *)matches, n_dev, S1, S2, ss);
+      hipLaunchKernelGGL(k_match_mfma<1>, dim3(bounded((n2 + 63u) / 64u, nslots), nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+                         (uint32_t *)matches, redo, n_dev, S1, S2, ss, (uint32_t *)nullptr);
     }
     if (max_na > S2)
-      hipLaunchKernelGGL(k_match_mfma<4>, dim3(bounded((max_na + 255u) / 256u, nslots), nslots), dim3(256), 0, hs, (const uint32_t *)desc_a, norm_a, 0u, 0u,
-                         (const uint32_t *)desc_b, norm_b, 0u, (uint32_t *)matches, n_dev, S2, 0xFFFFFFFFu, ss);
+    {
+      if (nslots == 1 && partial_scratch)
+      {
+        hipLaunchKernelGGL(k_match_mfma<4>, dim3(bounded((max_na + 255u) / 256u, 1), 1, VKSIFT_HIP_MATCH_CHUNKS), dim3(256), 0, hs, da, norm_a, 0u, 0u, db,
+                           norm_b, 0u, (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, partial_scratch);
+        hipLaunchKernelGGL(k_match_merge, dim3((max_na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial_scratch, 0u,
+                           (uint32_t)VKSIFT_HIP_MATCH_CHUNKS, 0u, (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu);
+      }
+      else
+        hipLaunchKernelGGL(k_match_mfma<4>, dim3(bounded((max_na + 255u) / 256u, nslots), nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, (uint32_t *)nullptr);
+    }
+    uint32_t rblocks = (max_na + 63u) / 64u;
+    if (rblocks > 64u)
+      rblocks = 64u;
+    hipLaunchKernelGGL(k_match_redo, dim3(rblocks, nslots), dim3(64), 0, hs, da, 0u, 0u, db, 0u, (uint32_t *)matches, (const uint32_t *)redo, n_dev, ss);
     return (int)hipGetLastError();
   }
 }

@@ -97,6 +97,7 @@ struct vksift_Instance_T
   uint32_t desc_fp_len;
   uint8_t *d_desc_a, *d_desc_b, *d_matches, *h_matches;
   uint32_t *d_norms;
+  uint32_t *d_match_partial; /* partial top-2 lists of the B-chunked large-N matcher (NULL when max_nb <= 32768) */
   uint32_t *d_match_n, *h_match_n; /* per match slot: {N_A, N_B, spare, spare} of the last matching pipeline */
   uint64_t desc_slot_stride, match_slot_stride; /* bytes */
   uint64_t norm_slot_stride;                    /* u32 elements */
@@ -457,12 +458,14 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   /* matching scratch: one slot per batch entry (slot 0 serves vksift_matchFeatures) */
   inst->desc_slot_stride = (((uint64_t)config->max_nb_sift_per_buffer * 128u + 256u) + 255u) & ~(uint64_t)255u;
   inst->match_slot_stride = (((uint64_t)config->max_nb_sift_per_buffer * MATCH_BYTES) + 255u) & ~(uint64_t)255u;
-  inst->norm_slot_stride = 2u * (uint64_t)config->max_nb_sift_per_buffer + 64u;
+  inst->norm_slot_stride = 3u * (uint64_t)config->max_nb_sift_per_buffer + 96u; /* norms of A, norms of B, redo flags */
   ALLOC_D(inst->d_desc_a, inst->desc_slot_stride * batch_cap);
   ALLOC_D(inst->d_desc_b, inst->desc_slot_stride * batch_cap);
   ALLOC_D(inst->d_matches, inst->match_slot_stride * batch_cap);
   ALLOC_D(inst->d_norms, sizeof(uint32_t) * inst->norm_slot_stride * batch_cap);
   ALLOC_D(inst->d_match_n, sizeof(uint32_t) * 4 * batch_cap);
+  if (config->max_nb_sift_per_buffer > 32768u)
+    ALLOC_D(inst->d_match_partial, sizeof(uint32_t) * (size_t)config->max_nb_sift_per_buffer * 5u * VKSIFT_HIP_MATCH_CHUNKS);
   ALLOC_H(inst->h_match_n, sizeof(uint32_t) * 4 * batch_cap);
   inst->h_matches = NULL;
   inst->bufs = (BufferInfo *)calloc(config->sift_buffer_count, sizeof(BufferInfo));
@@ -559,6 +562,7 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_free(inst->d_matches);
   vksift_hip_free(inst->d_norms);
   vksift_hip_free(inst->d_match_n);
+  vksift_hip_free(inst->d_match_partial);
   vksift_hip_host_free(inst->h_match_n);
   vksift_hip_host_free(inst->h_matches);
   free(inst->bufs);
@@ -1129,8 +1133,8 @@ static int match_slots(vksift_Instance inst, const uint32_t *ids_a, const uint32
   const uint32_t *norm_a = inst->d_norms + (uint64_t)first_slot * inst->norm_slot_stride;
   return vksift_hip_match_2nn_async(inst->d_desc_a + (uint64_t)first_slot * inst->desc_slot_stride, norm_a, max_na,
                                     inst->d_desc_b + (uint64_t)first_slot * inst->desc_slot_stride, norm_a + cap + 32u,
-                                    inst->d_match_n + (size_t)first_slot * 4, inst->d_matches + (uint64_t)first_slot * inst->match_slot_stride, count,
-                                    inst->desc_slot_stride, inst->norm_slot_stride, inst->match_slot_stride, 4, inst->stream);
+                                    (uint32_t *)norm_a + 2u * cap + 64u, inst->d_match_n + (size_t)first_slot * 4, inst->d_matches + (uint64_t)first_slot * inst->match_slot_stride, count,
+                                    inst->desc_slot_stride, inst->norm_slot_stride, inst->match_slot_stride, 4, inst->d_match_partial, inst->stream);
 }
 
 static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32_t *ids_b, uint32_t count, const char *fn)
