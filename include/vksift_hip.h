@@ -86,6 +86,16 @@ extern "C"
   int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const float *taps, uint32_t ntaps, uint32_t batch,
                       vksift_hip_stream s);
 
+  /* The whole scale chain of one octave in one launch (pyramid_fused.hip): scales 1..5 and DoG 0..4 from Gaussian plane 0,
+   * i.e. the five H+V GaussianBlur*.comp dispatch pairs and five DifferenceOfGaussian.comp dispatches of
+   * sift_detector.c:927-1001,1039-1079, and (next_g0.base != NULL, exact 2:1 sizes) the NEAREST blit of scale 3 into the
+   * next octave (sift_detector.c:1003-1034). Bit-identical to five vksift_hip_blur calls. Only the default tap set is
+   * compiled: vksift_hip_octave_chain_supported(ntaps, nb_scales) tells whether ntaps[1..5] match.
+   * g0: plane 0 of the octave; planes k follow at k*plane_stride floats, dog0 likewise; taps[s*taps_stride + i]. */
+  int vksift_hip_octave_chain_supported(const uint32_t *ntaps, uint32_t nb_scales);
+  int vksift_hip_octave_chain(vksift_hip_Plane g0, uint64_t plane_stride, float *dog0, vksift_hip_Plane next_g0, const float *taps, uint32_t taps_stride,
+                              uint32_t batch, vksift_hip_stream s);
+
   /* vkCmdBlitImage(NEAREST) of sift_detector.c:1003-1034: dst(x,y) = src(floor((x+.5)*sw/dw), ...). */
   int vksift_hip_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, uint32_t batch, vksift_hip_stream s);
 

@@ -51,6 +51,32 @@ def test_pyramid_bit_exact(vk, oracle, w, h, kw):
 
 
 @pytest.mark.parametrize("w,h,kw", [
+    (323, 211, {}),                                  # odd sizes: ragged last strip, separate down-sample launch, multi-segment
+    (100, 75, {}),                                   # tiny octaves: virtual (mirrored) rows/columns wrap more than once
+    (640, 480, {"use_input_upsampling": False}),     # different seed blur in front of the same chain
+])
+def test_pyramid_fused_chain_all_octaves(vk, oracle, monkeypatch, w, h, kw):
+    """the fused scale-chain kernel (pyramid_fused.hip) forced onto every octave, however small"""
+    monkeypatch.setenv("VKSIFT_CHAIN", "1")
+    monkeypatch.setenv("VKSIFT_CHAIN_MIN_ROWS", "1")
+    vcfg, ocfg = _cfgs(vk, oracle, **kw)
+    img = vk.gen_synthetic_image(9, w, h)
+    with vk.Instance(vcfg) as inst:
+        inst.detectFeatures(img, 0)
+        pyr = oracle.Pyramid(ocfg, img)
+        assert inst.getScaleSpaceNbOctaves() == pyr.nb_octaves
+        for o in range(pyr.nb_octaves):
+            for s in range(6):
+                g = inst.downloadScaleSpaceImage(o, s)
+                ref = pyr.gauss(o, s)
+                assert np.array_equal(g.view(np.uint32), ref.view(np.uint32)), ("gauss", o, s, np.abs(g - ref).max())
+            for s in range(5):
+                d = inst.downloadDoGImage(o, s)
+                ref = pyr.dog(o, s)
+                assert np.array_equal(d.view(np.uint32), ref.view(np.uint32)), ("dog", o, s, np.abs(d - ref).max())
+
+
+@pytest.mark.parametrize("w,h,kw", [
     (320, 240, {}),
     (200, 150, {"use_input_upsampling": False}),
     (320, 240, {"descriptor_format": 1, "max_nb_orientation_per_keypoint": 0}),
@@ -180,3 +206,26 @@ def test_match_device_pointer_api_chunked(vk, oracle):
         assert np.array_equal(got[name], ref[name]), name
     assert np.array_equal(got["dist_a_b1"].view(np.uint32), ref["dist_a_b1"].view(np.uint32))
     assert got["idx_b1"][7] == 3 and got["idx_b2"][7] == 700
+
+
+@pytest.mark.parametrize("na,nb,via_ptr", [(9000, 300, False), (33000, 520, True)])
+def test_match_float_collisions_all_regimes(vk, oracle, na, nb, via_ptr):
+    """d2 >= 2^22 candidates in the 16-rows-per-wave and the B-chunked kernels: flagged rows are replayed by the exact
+    scalar kernel (quirk Q8), all other rows keep the integer MFMA result"""
+    rng = np.random.default_rng(na)
+    a = vk.gen_synthetic_descriptors(61, na)
+    b = vk.gen_synthetic_descriptors(62, nb)
+    ext = slice(0, na, 37)
+    a[ext] = np.where(rng.random((len(range(na)[ext]), 128)) < 0.5, 0, 255).astype(np.uint8)
+    b[::3] = np.where(rng.random((len(range(nb)[::3]), 128)) < 0.5, 0, 255).astype(np.uint8)
+    b[1] = 255 - b[0] // 255 * 255   # first two columns far apart / extreme for some rows
+    ref = oracle.match_2nn(a, b)
+    if via_ptr:
+        import torch
+        from vulkansift_amd import multigpu
+        rec = multigpu.hip_match_fn(torch.from_numpy(a).cuda(), 0, torch.from_numpy(b).cuda())
+        torch.cuda.synchronize()
+        got = multigpu.records_to_struct(rec.cpu().numpy())
+    else:
+        got = _match_via_api(vk, a, b)
+    _assert_matches_equal(got, ref)

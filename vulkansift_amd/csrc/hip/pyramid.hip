@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "vksift_hip.h"
 
@@ -372,10 +373,210 @@ __global__ void __launch_bounds__(64) k_blur_stream(StreamArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_blur_lean: the same streaming algorithm and the same arithmetic as k_blur_stream (NR = 8), rebuilt around the
+// instruction budget. On CDNA a wave issues at most one instruction per 4 cycles whatever its type, and with the
+// 2-4 resident waves per SIMD this kernel gets, every scalar address computation, exec-mask branch and wait of
+// k_blur_stream (~1500 instructions per 8-row group, 600 of them VALU) is on the critical path. Here:
+//   * global accesses are raw buffer instructions: per-lane byte offsets are loop constants, the row offset is one
+//     SGPR; lanes that must not load/store (non-staging lanes, columns >= W) carry an out-of-range offset, so the
+//     hardware drops them — no exec-mask branches, no 64-bit VALU address arithmetic
+//   * mirrored columns are folded into the per-lane load offset (+ a lane-constant "reverse the float4" flag)
+//   * the staging buffer is a ring of NG 8-row groups, so the DoG centres are read back from it (no separate centre
+//     ring, no modulo arithmetic: every LDS offset is group base + compile-time constant)
+//   * the steady state (all 8 rows of a group inside the image and the segment) has no per-row conditions at all
+// Requirements (checked by the launcher, k_blur_stream serves the rest): W % 4 == 0, a single mirror reflection
+// covers every staged column (RA <= W and strips*128 + RA <= 2W).
+// ---------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned BUF_OOB = 0x80000000u; // byte offset beyond any plane: loads return 0, stores are dropped
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base, int pitch, int h)
+{
+  return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, pitch * h * 4, 0x00020000);
+}
+
+template <int NT, bool DOG>
+__global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
+{
+  constexpr int NR = 8;
+  constexpr int R = NT - 1;
+  constexpr int RA = (R + 3) & ~3;
+  constexpr int TW = 128;
+  constexpr int SW = TW + 2 * RA;
+  constexpr int NV4 = SW / 4;
+  constexpr int OFS = (RA - R) & 1;
+  constexpr int NP = R + 1 + OFS;
+  constexpr int C0 = R + OFS;
+  constexpr int NWIN = 2 * R + NR;
+  constexpr int NG = R <= NR ? 2 : 3; // groups kept in the ring: the centres of the rows emitted now are <= R rows old
+  constexpr int GROUP_FLOATS = NR * SW;
+  __shared__ __attribute__((aligned(16))) float s_ring[NG * GROUP_FLOATS];
+
+  const int lane = threadIdx.x;
+  const int W = a.w, H = a.h;
+  const int x0 = blockIdx.x * TW;
+  const int y0 = blockIdx.y * a.seg;
+  const int y1 = min(y0 + a.seg, H);
+  const __amdgpu_buffer_rsrc_t rs = plane_rsrc(a.src + (size_t)blockIdx.z * a.src_img_stride, a.spitch, H);
+  const __amdgpu_buffer_rsrc_t rd = plane_rsrc(a.dst + (size_t)blockIdx.z * a.dst_img_stride, a.dpitch, H);
+  const __amdgpu_buffer_rsrc_t rg_ = plane_rsrc(DOG ? a.dog + (size_t)blockIdx.z * a.dog_img_stride : a.dst, a.gpitch, H);
+
+  // ---- lane constants
+  const int gx4 = x0 - RA + 4 * lane;
+  unsigned ld_off = BUF_OOB;
+  bool rev = false;
+  if (lane < NV4)
+  {
+    if (gx4 >= 0 && gx4 + 3 < W)
+      ld_off = (unsigned)gx4 * 4u;
+    else
+    {
+      ld_off = (unsigned)mirror_idx(gx4 + 3, W) * 4u; // the four virtual columns map to m3+3, m3+2, m3+1, m3
+      rev = true;
+    }
+  }
+  const int px = x0 + 2 * lane;
+  const unsigned st_off = px + 1 < W ? (unsigned)px * 4u : BUF_OOB;
+  const int spitch4 = a.spitch * 4, dpitch4 = a.dpitch * 4, gpitch4 = a.gpitch * 4;
+  const float k0 = a.taps.k[0];
+
+  u32x4 pf[NR];
+  auto prefetch = [&](int r0) {
+    if (r0 >= 0 && r0 + NR <= H)
+    {
+      int so = r0 * spitch4;
+#pragma unroll
+      for (int j = 0; j < NR; j++, so += spitch4)
+        pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, so, 0);
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+        pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, mirror_idx(r0 + j, H) * spitch4, 0);
+    }
+  };
+
+  int rg = y0 - R; // first virtual row of the current group
+  prefetch(rg);
+
+  float2 wv[NWIN];
+#pragma unroll
+  for (int k = 0; k < NWIN; k++)
+    wv[k] = make_float2(0.f, 0.f);
+
+  int gs = 0;              // ring slot of the current group
+  int gs1 = NG - 1;        // slot of the previous group
+  int gs2 = NG - 2;        // slot of the one before (NG == 3 only)
+  for (; rg - R < y1; rg += NR)
+  {
+    // ---- stage the prefetched group into ring slot gs, then prefetch the next group
+    float *grp = s_ring + gs * GROUP_FLOATS;
+    __syncthreads();
+    if (lane < NV4)
+    {
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+      {
+        u32x4 v = pf[j];
+        if (rev)
+          v = u32x4{v.w, v.z, v.y, v.x};
+        *(u32x4 *)(grp + j * SW + 4 * lane) = v;
+      }
+    }
+    prefetch(rg + NR);
+    __syncthreads();
+
+    // ---- horizontal pass of the new rows, into the top of the register window
+    {
+      const float *hb = grp + (RA - R - OFS) + 2 * lane;
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+      {
+        const v2f *p = (const v2f *)(hb + j * SW);
+        float v[2 * NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+        {
+          v2f t = p[q];
+          v[2 * q] = t.x, v[2 * q + 1] = t.y;
+        }
+        float acc0 = v[C0] * k0, acc1 = v[C0 + 1] * k0;
+#pragma unroll
+        for (int i = 1; i < NT; i++)
+        {
+          acc0 = fmaf(v[C0 + i] + v[C0 - i], a.taps.k[i], acc0);
+          acc1 = fmaf(v[C0 + 1 + i] + v[C0 + 1 - i], a.taps.k[i], acc1);
+        }
+        wv[2 * R + j] = make_float2(acc0, acc1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- vertical pass: output rows yb .. yb+NR-1 (source row of output row yb+j: group (j - R) / NR back, row (j - R) mod NR)
+    const int yb = rg - R;
+    if (yb + NR > y0)
+    {
+      const float *c0p = s_ring + gs * GROUP_FLOATS + RA + 2 * lane;
+      const float *c1p = s_ring + gs1 * GROUP_FLOATS + RA + 2 * lane;
+      const float *c2p = s_ring + gs2 * GROUP_FLOATS + RA + 2 * lane;
+      auto vpass = [&](auto checked) {
+        int so_d = yb * dpitch4, so_g = yb * gpitch4;
+#pragma unroll
+        for (int j = 0; j < NR; j++, so_d += dpitch4, so_g += gpitch4)
+        {
+          if (decltype(checked)::value && (yb + j < y0 || yb + j >= y1))
+            continue;
+          float acc0 = wv[R + j].x * k0, acc1 = wv[R + j].y * k0;
+#pragma unroll
+          for (int i = 1; i < NT; i++)
+          {
+            acc0 = fmaf(wv[R + j + i].x + wv[R + j - i].x, a.taps.k[i], acc0);
+            acc1 = fmaf(wv[R + j + i].y + wv[R + j - i].y, a.taps.k[i], acc1);
+          }
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0), __float_as_uint(acc1)}, rd, st_off, so_d, 0);
+          if (DOG)
+          {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int back = j - R;                          // <= 0: rows back from the current group's row 0
+            const int gb = back >= 0 ? 0 : (-back + NR - 1) / NR; // groups back (0, 1 or 2)
+            const int row = back + gb * NR;                  // row inside that group
+            const float *cp = gb == 0 ? c0p : (gb == 1 ? c1p : c2p);
+            const v2f c = *(const v2f *)(cp + row * SW);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0 - c.x), __float_as_uint(acc1 - c.y)}, rg_, st_off, so_g, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (yb >= y0 && yb + NR <= y1)
+        vpass(std::false_type{});
+      else
+        vpass(std::true_type{});
+    }
+    // ---- slide the window, rotate the ring
+#pragma unroll
+    for (int k = 0; k < 2 * R; k++)
+      wv[k] = wv[k + NR];
+    gs2 = gs1;
+    gs1 = gs;
+    gs = gs + 1 == NG ? 0 : gs + 1;
+  }
+}
+
 template <int NT>
 void launch_stream(const StreamArgs &a, bool with_dog, int nw, dim3 grid, hipStream_t s)
 {
-  if (nw == 4)
+  if (nw == 0)
+  {
+    if (with_dog)
+      hipLaunchKernelGGL((k_blur_lean<NT, true>), grid, dim3(64), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_blur_lean<NT, false>), grid, dim3(64), 0, s, a);
+  }
+  else if (nw == 4)
   {
     if (with_dog)
       hipLaunchKernelGGL((k_blur_stream<NT, true, 4>), grid, dim3(64), 0, s, a);
@@ -483,10 +684,30 @@ extern "C"
       const char *e = getenv("VKSIFT_BLUR_ROWS"); /* rows per group of the streaming kernel: 4 or 8 (A/B runs) */
       rows_per_group = (e && atoi(e) == 4) ? 4 : 8;
     }
-    const int nw = rows_per_group; /* forwarded to launch_stream */
+    int nw = rows_per_group; /* forwarded to launch_stream; 0 selects k_blur_lean */
+    {
+      static int lean = -1;
+      if (lean < 0)
+      {
+        const char *e = getenv("VKSIFT_BLUR_LEAN"); /* 0: keep k_blur_stream everywhere (A/B runs) */
+        lean = (e && e[0] == '0') ? 0 : 1;
+      }
+      const uint32_t ra = ((ntaps - 1u) + 3u) & ~3u;
+      const uint32_t nstrips = (src.w + 127u) / 128u;
+      if (lean && (src.w % 4u) == 0 && ra <= src.w && nstrips * 128u + ra <= 2u * src.w && src.pitch == dst.pitch)
+        nw = 0;
+    }
+    static uint32_t wg_target = 0, min_seg_rows = 0;
+    if (!wg_target)
+    {
+      const char *e = getenv("VKSIFT_BLUR_WGS"); /* A/B runs */
+      wg_target = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 1536u;
+      e = getenv("VKSIFT_BLUR_MIN_SEG");
+      min_seg_rows = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 64u;
+    }
     const uint32_t strips = (src.w + 127u) / 128u;
-    uint32_t nseg = (1536u + strips * batch - 1u) / (strips * batch);
-    uint32_t max_seg = (src.h + 63u) / 64u;
+    uint32_t nseg = (wg_target + strips * batch - 1u) / (strips * batch);
+    uint32_t max_seg = (src.h + min_seg_rows - 1u) / min_seg_rows;
     if (nseg > max_seg)
       nseg = max_seg;
     if (nseg < 1)

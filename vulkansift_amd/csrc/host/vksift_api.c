@@ -112,6 +112,8 @@ struct vksift_Instance_T
   vksift_hip_stream oct_stream[VKSIFT_MAX_OCTAVES];
   vksift_hip_event ev_fork[4], ev_join[4][VKSIFT_MAX_OCTAVES], ev_oct_ready[VKSIFT_MAX_OCTAVES];
   bool serial_octaves;
+  bool use_chain;         /* fused per-octave scale chain (pyramid_fused.hip) available for this tap set */
+  uint32_t chain_min_rows; /* octaves shorter than this keep the per-scale kernels (pipeline ramp dominates) */
   vksift_hip_event ev_detect, ev_match;
   bool detect_pending, match_pending;
   uint32_t detect_first_buf, detect_count;
@@ -485,6 +487,12 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   {
     const char *e = getenv("VKSIFT_SERIAL_OCTAVES"); /* debug: everything on the main stream */
     inst->serial_octaves = e && e[0] == '1';
+    /* 1 selects the experimental fused scale-chain kernel (pyramid_fused.hip): bit-identical, but measured slower than the
+     * per-scale kernels on MI355X (VALU-issue bound) -> off by default */
+    e = getenv("VKSIFT_CHAIN");
+    inst->use_chain = (e && e[0] == '1') && vksift_hip_octave_chain_supported(inst->ntaps, inst->S);
+    e = getenv("VKSIFT_CHAIN_MIN_ROWS");
+    inst->chain_min_rows = e ? (uint32_t)atoi(e) : 200u;
   }
   inst->ev_detect = vksift_hip_event_create();
   inst->ev_match = vksift_hip_event_create();
@@ -768,6 +776,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   uint32_t nblur = 0;
   const vksift_hip_Plane no_dog = {NULL, 0, 0, 0, 0};
   const bool par = !inst->serial_octaves && L->n_oct > 1;
+  bool g0_done = false; /* plane 0 of the current octave was already written by the previous octave's chain kernel */
   for (uint32_t o = 0; o < L->n_oct; o++)
   {
     vksift_hip_stream so = par ? inst->oct_stream[o] : st;
@@ -783,17 +792,36 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     {
       if (par)
         HIP_CHECK(vksift_hip_stream_wait_event(so, inst->ev_oct_ready[o - 1]), "octave dependency");
-      HIP_CHECK(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), count, so), "downsample");
+      if (!g0_done)
+        HIP_CHECK(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), count, so), "downsample");
     }
-    for (uint32_t s = 1; s < inst->S + 3; s++)
+    g0_done = false;
+    if (inst->use_chain && L->h[o] >= inst->chain_min_rows)
     {
-      HIP_CHECK(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), plane_at(inst, o, L->gauss_off[o], s), plane_at(inst, o, L->dog_off[o], s - 1),
-                                &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, so),
-                "blur");
+      /* one launch for scales 1..S+2 and all DoG layers; it also seeds the next octave when the sizes are exactly 2:1 */
+      vksift_hip_Plane next = {NULL, 0, 0, 0, 0};
+      if (o + 1 < L->n_oct && L->w[o + 1] * 2 == L->w[o] && L->h[o + 1] * 2 == L->h[o])
+      {
+        next = plane_at(inst, o + 1, L->gauss_off[o + 1], 0);
+        g0_done = true;
+      }
+      HIP_CHECK(vksift_hip_octave_chain(plane_at(inst, o, L->gauss_off[o], 0), L->plane_stride[o], inst->d_pyr + L->dog_off[o], next, inst->taps,
+                                        VKSIFT_MAX_TAPS, count, so),
+                "octave chain");
       nblur++;
-      if (par && s == inst->S && o + 1 < L->n_oct)
+      if (par && o + 1 < L->n_oct)
         HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], so), "event record");
     }
+    else
+      for (uint32_t s = 1; s < inst->S + 3; s++)
+      {
+        HIP_CHECK(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), plane_at(inst, o, L->gauss_off[o], s), plane_at(inst, o, L->dog_off[o], s - 1),
+                                  &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, so),
+                  "blur");
+        nblur++;
+        if (par && s == inst->S && o + 1 < L->n_oct)
+          HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], so), "event record");
+      }
     if (par && o > 0)
       HIP_CHECK(vksift_hip_event_record(inst->ev_join[0][o], so), "event record");
   }
