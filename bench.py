@@ -16,9 +16,12 @@ needs no collective); the timed region is bracketed by a barrier + device synchr
 over ranks is reported. PyTorch is used for torch.distributed (RCCL) and device buffers only.
 
 Extra objects on the JSON line:
-  roofline     pyramid+DoG pass (k_blur_stream launches): algorithmic bytes per launch /
-               average launch duration measured with HIP events on the library's own stream; "traffic" is the
-               PMC-measured HBM traffic per launch from a separate rocprofv3 --pmc run (profiles/*pmc*.json), if present
+  roofline     pyramid+DoG pass of octave 0 (k_input_blit_2x + 6 k_blur_lean launches per step, 77 % of the pyramid's
+               bytes): algorithmic bytes per launch / average launch duration, measured with HIP
+               events recorded on the stream those kernels are launched on (the library's instance stream), inside
+               the timed region; the coarser octaves run concurrently on their own streams and share the HBM
+               bandwidth, so the figure is conservative. "traffic" is the PMC-measured HBM traffic per launch from a
+               separate rocprofv3 --pmc run (profiles/*pmc*.json), if present
   cpu_baseline the CPU oracle (a scalar C port of the same algorithm) timed on a bounded sample, rank 0, N=1
 """
 import argparse
@@ -180,7 +183,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_blur_stream (pyramid + DoG pass)",
+                "kernel": "k_blur_lean (pyramid + DoG pass, octave 0: 1280x960 planes)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

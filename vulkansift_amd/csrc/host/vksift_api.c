@@ -112,6 +112,7 @@ struct vksift_Instance_T
   vksift_hip_stream oct_stream[VKSIFT_MAX_OCTAVES];
   vksift_hip_event ev_fork[4], ev_join[4][VKSIFT_MAX_OCTAVES], ev_oct_ready[VKSIFT_MAX_OCTAVES];
   bool serial_octaves;
+  bool stage_sync;        /* debug: join all octaves at every stage boundary instead of per-octave pipelines */
   bool use_chain;         /* fused per-octave scale chain (pyramid_fused.hip) available for this tap set */
   uint32_t chain_min_rows; /* octaves shorter than this keep the per-scale kernels (pipeline ramp dominates) */
   vksift_hip_event ev_detect, ev_match;
@@ -487,6 +488,8 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   {
     const char *e = getenv("VKSIFT_SERIAL_OCTAVES"); /* debug: everything on the main stream */
     inst->serial_octaves = e && e[0] == '1';
+    e = getenv("VKSIFT_STAGE_SYNC");
+    inst->stage_sync = e && e[0] == '1';
     /* 1 selects the experimental fused scale-chain kernel (pyramid_fused.hip): bit-identical, but measured slower than the
      * per-scale kernels on MI355X (VALU-issue bound) -> off by default */
     e = getenv("VKSIFT_CHAIN");
@@ -660,13 +663,13 @@ static vksift_hip_Plane plane_at(vksift_Instance inst, uint32_t o, uint64_t base
   return p;
 }
 
-static uint64_t algorithmic_pyramid_bytes(vksift_Instance inst, uint32_t w, uint32_t h)
+static uint64_t algorithmic_pyramid_bytes(vksift_Instance inst, uint32_t w, uint32_t h, uint32_t nb_octaves)
 {
   /* (S+3 Gaussian writes + S+2 blur reads + S+2 DoG writes) * 4 B per octave pixel,
    * plus on octave 0: input read (1 B/px of input), up-sample plane write and seed-blur read (4 B each). */
   const PyrLayout *L = &inst->lay;
   uint64_t bytes = 0;
-  for (uint32_t o = 0; o < L->n_oct; o++)
+  for (uint32_t o = 0; o < L->n_oct && o < nb_octaves; o++)
     bytes += (uint64_t)L->w[o] * L->h[o] * 4u * ((inst->S + 3) + (inst->S + 2) + (inst->S + 2));
   bytes += (uint64_t)w * h + (uint64_t)L->w[0] * L->h[0] * 8u;
   return bytes;
@@ -769,71 +772,6 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   HIP_CHECK(vksift_hip_memset(inst->d_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * count, st),
             "counter reset");
 
-  /* ---- scale-space construction + DoG ----
-   * Octave o+1 only needs scale S of octave o, so each octave runs on its own stream: the chain of small, latency-bound
-   * launches of the coarse octaves overlaps the bandwidth-bound launches of the fine ones. */
-  vksift_hip_range_push("Scale space construction");
-  uint32_t nblur = 0;
-  const vksift_hip_Plane no_dog = {NULL, 0, 0, 0, 0};
-  const bool par = !inst->serial_octaves && L->n_oct > 1;
-  bool g0_done = false; /* plane 0 of the current octave was already written by the previous octave's chain kernel */
-  for (uint32_t o = 0; o < L->n_oct; o++)
-  {
-    vksift_hip_stream so = par ? inst->oct_stream[o] : st;
-    if (o == 0)
-    {
-      /* blit into the (still unused) layer-1 slot, then seed-blur it into layer 0 */
-      vksift_hip_Plane tmp = plane_at(inst, 0, L->gauss_off[0], 1);
-      HIP_CHECK(vksift_hip_input_blit(d_src, w, h, img_bytes, tmp, count, so), "input blit");
-      HIP_CHECK(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), no_dog, &inst->taps[0], inst->ntaps[0], count, so), "seed blur");
-      nblur++;
-    }
-    else
-    {
-      if (par)
-        HIP_CHECK(vksift_hip_stream_wait_event(so, inst->ev_oct_ready[o - 1]), "octave dependency");
-      if (!g0_done)
-        HIP_CHECK(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), count, so), "downsample");
-    }
-    g0_done = false;
-    if (inst->use_chain && L->h[o] >= inst->chain_min_rows)
-    {
-      /* one launch for scales 1..S+2 and all DoG layers; it also seeds the next octave when the sizes are exactly 2:1 */
-      vksift_hip_Plane next = {NULL, 0, 0, 0, 0};
-      if (o + 1 < L->n_oct && L->w[o + 1] * 2 == L->w[o] && L->h[o + 1] * 2 == L->h[o])
-      {
-        next = plane_at(inst, o + 1, L->gauss_off[o + 1], 0);
-        g0_done = true;
-      }
-      HIP_CHECK(vksift_hip_octave_chain(plane_at(inst, o, L->gauss_off[o], 0), L->plane_stride[o], inst->d_pyr + L->dog_off[o], next, inst->taps,
-                                        VKSIFT_MAX_TAPS, count, so),
-                "octave chain");
-      nblur++;
-      if (par && o + 1 < L->n_oct)
-        HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], so), "event record");
-    }
-    else
-      for (uint32_t s = 1; s < inst->S + 3; s++)
-      {
-        HIP_CHECK(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), plane_at(inst, o, L->gauss_off[o], s), plane_at(inst, o, L->dog_off[o], s - 1),
-                                  &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, so),
-                  "blur");
-        nblur++;
-        if (par && s == inst->S && o + 1 < L->n_oct)
-          HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], so), "event record");
-      }
-    if (par && o > 0)
-      HIP_CHECK(vksift_hip_event_record(inst->ev_join[0][o], so), "event record");
-  }
-  if (par)
-    for (uint32_t o = 1; o < L->n_oct; o++)
-      HIP_CHECK(vksift_hip_stream_wait_event(st, inst->ev_join[0][o]), "octave join");
-  vksift_hip_range_pop();
-  inst->last_blur_launches = nblur;
-  inst->last_alg_bytes = algorithmic_pyramid_bytes(inst, w, h) * count;
-  if (prof)
-    vksift_hip_event_record(inst->ev_t[2], st);
-
   /* ---- keypoints ---- */
   vksift_hip_OctaveJob jobs[VKSIFT_MAX_OCTAVES];
   const BufferInfo *b0 = &inst->bufs[first_buf];
@@ -876,8 +814,116 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     j->desc_fp_tab = inst->d_desc_fp;
     j->desc_fp_tab_len = inst->desc_fp_len;
   }
-  /* Each of the three keypoint stages forks one stream per octave (per-octave scratch, no sharing) and joins back
-   * into the main stream, so stage boundaries (and the stage timings) stay well defined. */
+
+  /* ---- scale-space construction + DoG, keypoints, orientations, descriptors ----
+   * Octave o+1 only needs scale S of octave o, and everything after the pyramid is per octave (own SIFT-buffer section,
+   * own scratch). Two schedules:
+   *   pipelined (default): octave 0 runs on the instance stream, every other octave runs its whole chain
+   *     pyramid -> ExtractKeypoints -> ComputeOrientation -> ComputeDescriptors on its own stream, started by the
+   *     event "scale S of the previous octave is ready"; the instance stream joins them before the count read-back.
+   *     The latency-bound launch chains of the coarse octaves hide behind the bandwidth-bound work of the fine ones.
+   *     Profiling events then time octave 0's stages (the other octaves overlap them).
+   *   stage-synchronous (VKSIFT_STAGE_SYNC=1): fork per octave inside each stage, join at every stage boundary.
+   *   serial (VKSIFT_SERIAL_OCTAVES=1): everything on the instance stream. */
+  uint32_t nblur = 0;
+  const vksift_hip_Plane no_dog = {NULL, 0, 0, 0, 0};
+  const bool par = !inst->serial_octaves && L->n_oct > 1;
+  const bool pipelined = par && !inst->stage_sync;
+  bool g0_done = false; /* plane 0 of the current octave was already written by the previous octave's chain kernel */
+  if (par)
+    HIP_CHECK(vksift_hip_event_record(inst->ev_fork[0], st), "event record");
+  for (uint32_t o = 0; o < L->n_oct; o++)
+  {
+    vksift_hip_stream so = st;
+    if (par && (o > 0 || !pipelined))
+    {
+      so = inst->oct_stream[o];
+      HIP_CHECK(vksift_hip_stream_wait_event(so, inst->ev_fork[0]), "octave fork");
+    }
+    vksift_hip_range_push("Scale space construction");
+    uint32_t nb_o = 0;
+    if (o == 0)
+    {
+      /* blit into the (still unused) layer-1 slot, then seed-blur it into layer 0 */
+      vksift_hip_Plane tmp = plane_at(inst, 0, L->gauss_off[0], 1);
+      HIP_CHECK(vksift_hip_input_blit(d_src, w, h, img_bytes, tmp, count, so), "input blit");
+      HIP_CHECK(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), no_dog, &inst->taps[0], inst->ntaps[0], count, so), "seed blur");
+      nb_o++;
+    }
+    else
+    {
+      if (par)
+        HIP_CHECK(vksift_hip_stream_wait_event(so, inst->ev_oct_ready[o - 1]), "octave dependency");
+      if (!g0_done)
+        HIP_CHECK(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), count, so), "downsample");
+    }
+    g0_done = false;
+    if (inst->use_chain && L->h[o] >= inst->chain_min_rows)
+    {
+      /* one launch for scales 1..S+2 and all DoG layers; it also seeds the next octave when the sizes are exactly 2:1 */
+      vksift_hip_Plane next = {NULL, 0, 0, 0, 0};
+      if (o + 1 < L->n_oct && L->w[o + 1] * 2 == L->w[o] && L->h[o + 1] * 2 == L->h[o])
+      {
+        next = plane_at(inst, o + 1, L->gauss_off[o + 1], 0);
+        g0_done = true;
+      }
+      HIP_CHECK(vksift_hip_octave_chain(plane_at(inst, o, L->gauss_off[o], 0), L->plane_stride[o], inst->d_pyr + L->dog_off[o], next, inst->taps,
+                                        VKSIFT_MAX_TAPS, count, so),
+                "octave chain");
+      nb_o++;
+      if (par && o + 1 < L->n_oct)
+        HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], so), "event record");
+    }
+    else
+      for (uint32_t s = 1; s < inst->S + 3; s++)
+      {
+        HIP_CHECK(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), plane_at(inst, o, L->gauss_off[o], s), plane_at(inst, o, L->dog_off[o], s - 1),
+                                  &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, so),
+                  "blur");
+        nb_o++;
+        if (par && s == inst->S && o + 1 < L->n_oct)
+          HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], so), "event record");
+      }
+    vksift_hip_range_pop();
+    if (!pipelined || o == 0)
+      nblur += nb_o;
+    if (pipelined)
+    {
+      if (o == 0 && prof)
+        vksift_hip_event_record(inst->ev_t[2], st);
+      vksift_hip_range_push("ExtractKeypoints");
+      HIP_CHECK(vksift_hip_extract_keypoints(&jobs[o], count, so), "keypoint extraction");
+      vksift_hip_range_pop();
+      if (o == 0 && prof)
+        vksift_hip_event_record(inst->ev_t[3], st);
+      vksift_hip_range_push("ComputeOrientation");
+      HIP_CHECK(vksift_hip_orientations(&jobs[o], count, so), "orientation");
+      vksift_hip_range_pop();
+      if (o == 0 && prof)
+        vksift_hip_event_record(inst->ev_t[4], st);
+      vksift_hip_range_push("ComputeDescriptors");
+      HIP_CHECK(vksift_hip_descriptors(&jobs[o], count, so), "descriptor");
+      vksift_hip_range_pop();
+      if (o == 0 && prof)
+        vksift_hip_event_record(inst->ev_t[5], st);
+    }
+    if (par && so != st)
+      HIP_CHECK(vksift_hip_event_record(inst->ev_join[0][o], so), "event record");
+  }
+  if (par)
+    for (uint32_t o = 0; o < L->n_oct; o++)
+      if (o > 0 || !pipelined)
+        HIP_CHECK(vksift_hip_stream_wait_event(st, inst->ev_join[0][o]), "octave join");
+  inst->last_blur_launches = nblur;
+  /* profiling: the pyramid interval is octave 0's when pipelined, the whole pyramid's otherwise */
+  inst->last_alg_bytes = algorithmic_pyramid_bytes(inst, w, h, pipelined ? 1u : L->n_oct) * count;
+
+  if (!pipelined)
+  {
+    if (prof)
+      vksift_hip_event_record(inst->ev_t[2], st);
+    /* Each of the three keypoint stages forks one stream per octave (per-octave scratch, no sharing) and joins back
+     * into the main stream, so stage boundaries (and the stage timings) stay well defined. */
 #define VKSIFT_STAGE(G, NAME, CALL, WHAT)                                                                   \
   vksift_hip_range_push(NAME);                                                                               \
   if (par)                                                                                                   \
@@ -896,16 +942,17 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
       HIP_CHECK(vksift_hip_stream_wait_event(st, inst->ev_join[G][o]), "octave join");                       \
   vksift_hip_range_pop();
 
-  VKSIFT_STAGE(1, "ExtractKeypoints", vksift_hip_extract_keypoints, "keypoint extraction")
-  if (prof)
-    vksift_hip_event_record(inst->ev_t[3], st);
-  VKSIFT_STAGE(2, "ComputeOrientation", vksift_hip_orientations, "orientation")
-  if (prof)
-    vksift_hip_event_record(inst->ev_t[4], st);
-  VKSIFT_STAGE(3, "ComputeDescriptors", vksift_hip_descriptors, "descriptor")
-  if (prof)
-    vksift_hip_event_record(inst->ev_t[5], st);
+    VKSIFT_STAGE(1, "ExtractKeypoints", vksift_hip_extract_keypoints, "keypoint extraction")
+    if (prof)
+      vksift_hip_event_record(inst->ev_t[3], st);
+    VKSIFT_STAGE(2, "ComputeOrientation", vksift_hip_orientations, "orientation")
+    if (prof)
+      vksift_hip_event_record(inst->ev_t[4], st);
+    VKSIFT_STAGE(3, "ComputeDescriptors", vksift_hip_descriptors, "descriptor")
+    if (prof)
+      vksift_hip_event_record(inst->ev_t[5], st);
 #undef VKSIFT_STAGE
+  }
 
   /* recCopySIFTCountCmds (sift_detector.c:1261-1291) */
   HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES, inst->d_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES,
