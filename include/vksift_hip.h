@@ -82,7 +82,8 @@ extern "C"
   /* One Gaussian scale step = the H and V GaussianBlur*.comp dispatches of sift_detector.c:927-1001
    * fused through LDS, plus (dog.base != NULL) the DifferenceOfGaussian.comp layer dst - src
    * (sift_detector.c:1039-1079). taps[0..ntaps) are one-sided direct weights, centre first; the
-   * borders use mirrored-repeat addressing. src and dst must not alias. */
+   * borders use mirrored-repeat addressing. src and dst must not alias. dst.base == NULL (with dog.base != NULL) keeps
+   * only the DoG layer: the last scale of an octave is read by nothing else. */
   int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const float *taps, uint32_t ntaps, uint32_t batch,
                       vksift_hip_stream s);
 

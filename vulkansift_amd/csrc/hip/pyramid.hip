@@ -188,7 +188,8 @@ __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src
       acc = fmaf(p[i * TILE] + p[-i * TILE], taps.k[i], acc);
     if (gx < w)
     {
-      out[(size_t)gy * dpitch + gx] = acc;
+      if (dst)
+        out[(size_t)gy * dpitch + gx] = acc;
       if (gout)
         gout[(size_t)gy * gpitch + gx] = acc - s_src[(rr + R) * SS + lane + R];
     }
@@ -224,6 +225,7 @@ struct StreamArgs
   int spitch, dpitch, gpitch;
   int w, h;
   int seg; // output rows per workgroup (multiple of 8)
+  int xcd_remap; // k_blur_lean: XCD-contiguous work mapping
   Taps taps;
 };
 
@@ -347,7 +349,9 @@ __global__ void __launch_bounds__(64) k_blur_stream(StreamArgs a)
             acc1 = fmaf(wv[R + j + i].y + wv[R + j - i].y, a.taps.k[i], acc1);
           }
           float *o = dst + orow;
-          if (px + 1 < W)
+          if (a.dst == nullptr)
+            ; // caller keeps only the DoG layer of this scale
+          else if (px + 1 < W)
             *(float2 *)o = make_float2(acc0, acc1);
           else if (px < W)
             o[0] = acc0;
@@ -416,12 +420,28 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 
   const int lane = threadIdx.x;
   const int W = a.w, H = a.h;
-  const int x0 = blockIdx.x * TW;
-  const int y0 = blockIdx.y * a.seg;
+  // XCD-aware work mapping: workgroup b is observed to run on XCD b % 8 (each XCD has its own L2). Give every XCD a
+  // contiguous range of the (image, segment, strip) space, strips fastest, so that the workgroups that share halo
+  // columns and warm-up rows run on the same XCD at about the same time and find them in its L2.
+  uint32_t bs = blockIdx.x, bseg = blockIdx.y, bimg = blockIdx.z;
+  {
+    const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
+    if (a.xcd_remap && (total & 7u) == 0)
+    {
+      const uint32_t b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const uint32_t wi = (b & 7u) * (total >> 3) + (b >> 3);
+      bs = wi % gridDim.x;
+      const uint32_t r = wi / gridDim.x;
+      bseg = r % gridDim.y;
+      bimg = r / gridDim.y;
+    }
+  }
+  const int x0 = bs * TW;
+  const int y0 = bseg * a.seg;
   const int y1 = min(y0 + a.seg, H);
-  const __amdgpu_buffer_rsrc_t rs = plane_rsrc(a.src + (size_t)blockIdx.z * a.src_img_stride, a.spitch, H);
-  const __amdgpu_buffer_rsrc_t rd = plane_rsrc(a.dst + (size_t)blockIdx.z * a.dst_img_stride, a.dpitch, H);
-  const __amdgpu_buffer_rsrc_t rg_ = plane_rsrc(DOG ? a.dog + (size_t)blockIdx.z * a.dog_img_stride : a.dst, a.gpitch, H);
+  const __amdgpu_buffer_rsrc_t rs = plane_rsrc(a.src + (size_t)bimg * a.src_img_stride, a.spitch, H);
+  const __amdgpu_buffer_rsrc_t rd = plane_rsrc(a.dst ? a.dst + (size_t)bimg * a.dst_img_stride : a.src, a.dpitch, H);
+  const __amdgpu_buffer_rsrc_t rg_ = plane_rsrc(DOG ? a.dog + (size_t)bimg * a.dog_img_stride : a.dst, a.gpitch, H);
 
   // ---- lane constants
   const int gx4 = x0 - RA + 4 * lane;
@@ -439,6 +459,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   }
   const int px = x0 + 2 * lane;
   const unsigned st_off = px + 1 < W ? (unsigned)px * 4u : BUF_OOB;
+  const unsigned st_off_g = a.dst ? st_off : BUF_OOB; // dst == NULL: the caller keeps only the DoG layer, the hardware drops the store
   const int spitch4 = a.spitch * 4, dpitch4 = a.dpitch * 4, gpitch4 = a.gpitch * 4;
   const float k0 = a.taps.k[0];
 
@@ -536,7 +557,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
             acc0 = fmaf(wv[R + j + i].x + wv[R + j - i].x, a.taps.k[i], acc0);
             acc1 = fmaf(wv[R + j + i].y + wv[R + j - i].y, a.taps.k[i], acc1);
           }
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0), __float_as_uint(acc1)}, rd, st_off, so_d, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0), __float_as_uint(acc1)}, rd, st_off_g, so_d, 0);
           if (DOG)
           {
             constexpr int dummy = 0;
@@ -656,8 +677,10 @@ extern "C"
   int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const float *taps, uint32_t ntaps, uint32_t batch,
                       vksift_hip_stream s)
   {
-    if (ntaps < 1 || ntaps > VKSIFT_HIP_MAX_TAPS || src.base == dst.base)
+    if (ntaps < 1 || ntaps > VKSIFT_HIP_MAX_TAPS || src.base == dst.base || (dst.base == NULL && dog.base == NULL))
       return (int)hipErrorInvalidValue;
+    if (dst.base == NULL)
+      dst.pitch = dog.pitch, dst.img_stride = 0; /* DoG-only call: the blurred scale itself is not stored */
     Taps t;
     for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
       t.k[i] = i < ntaps ? taps[i] : 0.f;
@@ -676,6 +699,15 @@ extern "C"
     a.spitch = (int)src.pitch, a.dpitch = (int)dst.pitch, a.gpitch = (int)dog.pitch;
     a.w = (int)src.w, a.h = (int)src.h;
     a.taps = t;
+    {
+      static int remap = -1;
+      if (remap < 0)
+      {
+        const char *e = getenv("VKSIFT_XCD_REMAP"); /* 0 disables the XCD-contiguous work mapping (A/B runs) */
+        remap = (e && e[0] == '0') ? 0 : 1;
+      }
+      a.xcd_remap = remap;
+    }
     /* Row segments: enough workgroups to give every CU ~5 waves, but segments long enough that the 2R-row
      * warm-up stays a small fraction. */
     static int rows_per_group = -1;
@@ -694,7 +726,7 @@ extern "C"
       }
       const uint32_t ra = ((ntaps - 1u) + 3u) & ~3u;
       const uint32_t nstrips = (src.w + 127u) / 128u;
-      if (lean && (src.w % 4u) == 0 && ra <= src.w && nstrips * 128u + ra <= 2u * src.w && src.pitch == dst.pitch)
+      if (lean && (src.w % 4u) == 0 && ra <= src.w && nstrips * 128u + ra <= 2u * src.w)
         nw = 0;
     }
     static uint32_t wg_target = 0, min_seg_rows = 0;

@@ -112,6 +112,9 @@ struct vksift_Instance_T
   vksift_hip_stream oct_stream[VKSIFT_MAX_OCTAVES];
   vksift_hip_event ev_fork[4], ev_join[4][VKSIFT_MAX_OCTAVES], ev_oct_ready[VKSIFT_MAX_OCTAVES];
   bool serial_octaves;
+  bool lazy_top_scale;    /* do not store Gaussian scale S+2 (only its DoG layer is consumed); re-created on download */
+  bool top_scale_stale[VKSIFT_MAX_OCTAVES];
+  bool coarse_after;      /* coarse octaves start after octave 0's pyramid instead of after its scale S */
   bool stage_sync;        /* debug: join all octaves at every stage boundary instead of per-octave pipelines */
   bool use_chain;         /* fused per-octave scale chain (pyramid_fused.hip) available for this tap set */
   uint32_t chain_min_rows; /* octaves shorter than this keep the per-scale kernels (pipeline ramp dominates) */
@@ -488,6 +491,10 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   {
     const char *e = getenv("VKSIFT_SERIAL_OCTAVES"); /* debug: everything on the main stream */
     inst->serial_octaves = e && e[0] == '1';
+    e = getenv("VKSIFT_LAZY_TOP"); /* 0: always store the last Gaussian scale of every octave */
+    inst->lazy_top_scale = !(e && e[0] == '0');
+    e = getenv("VKSIFT_COARSE_AFTER");
+    inst->coarse_after = e && e[0] == '1';
     e = getenv("VKSIFT_STAGE_SYNC");
     inst->stage_sync = e && e[0] == '1';
     /* 1 selects the experimental fused scale-chain kernel (pyramid_fused.hip): bit-identical, but measured slower than the
@@ -858,6 +865,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
         HIP_CHECK(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), count, so), "downsample");
     }
     g0_done = false;
+    inst->top_scale_stale[o] = false;
     if (inst->use_chain && L->h[o] >= inst->chain_min_rows)
     {
       /* one launch for scales 1..S+2 and all DoG layers; it also seeds the next octave when the sizes are exactly 2:1 */
@@ -877,11 +885,20 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     else
       for (uint32_t s = 1; s < inst->S + 3; s++)
       {
-        HIP_CHECK(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), plane_at(inst, o, L->gauss_off[o], s), plane_at(inst, o, L->dog_off[o], s - 1),
+        vksift_hip_Plane dstp = plane_at(inst, o, L->gauss_off[o], s);
+        inst->top_scale_stale[o] = false;
+        if (s == inst->S + 2 && inst->lazy_top_scale)
+        {
+          /* nothing reads Gaussian scale S+2 (keypoints use scales 1..S, the next octave scale S): keep its DoG layer only;
+           * vksift_downloadScaleSpaceImage() re-creates the plane on demand */
+          dstp.base = NULL;
+          inst->top_scale_stale[o] = true;
+        }
+        HIP_CHECK(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), dstp, plane_at(inst, o, L->dog_off[o], s - 1),
                                   &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, so),
                   "blur");
         nb_o++;
-        if (par && s == inst->S && o + 1 < L->n_oct)
+        if (par && o + 1 < L->n_oct && s == ((inst->coarse_after && o == 0) ? inst->S + 2 : inst->S))
           HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], so), "event record");
       }
     vksift_hip_range_pop();
@@ -1360,6 +1377,15 @@ static void download_plane(vksift_Instance inst, uint8_t octave, uint8_t scale, 
   /* images cannot be read while a detection runs (vulkansift.c:490-491) */
   HIP_CHECK(wait_all(inst), "stream synchronisation");
   const PyrLayout *L = &inst->lay;
+  if (!is_dog && scale == inst->S + 2 && inst->top_scale_stale[octave])
+  {
+    /* the detection pipeline kept only the DoG layer of the last scale: blur it now (image 0, the one this API exposes) */
+    const vksift_hip_Plane no_dog = {NULL, 0, 0, 0, 0};
+    HIP_CHECK(vksift_hip_blur(plane_at(inst, octave, L->gauss_off[octave], scale - 1), plane_at(inst, octave, L->gauss_off[octave], scale), no_dog,
+                              &inst->taps[scale * VKSIFT_MAX_TAPS], inst->ntaps[scale], 1, inst->stream),
+              "top scale blur");
+    inst->top_scale_stale[octave] = false;
+  }
   const float *src = inst->d_pyr + (is_dog ? L->dog_off[octave] : L->gauss_off[octave]) + (uint64_t)scale * L->plane_stride[octave];
   HIP_CHECK(vksift_hip_memcpy2d_d2h(dst, sizeof(float) * L->w[octave], src, sizeof(float) * L->pitch[octave], sizeof(float) * L->w[octave], L->h[octave],
                                     inst->stream),
