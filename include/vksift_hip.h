@@ -87,6 +87,12 @@ extern "C"
   int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const float *taps, uint32_t ntaps, uint32_t batch,
                       vksift_hip_stream s);
 
+  /* vkCmdCopyBufferToImage + vkCmdBlitImage(LINEAR, exact 2:1) + the seed blur (sift_detector.c:881-1001 for octave 0) in one
+   * pass: dst = blur(upsample2x(src / 255)); the up-sampled plane is never written. Bit-identical to vksift_hip_input_blit
+   * followed by vksift_hip_blur. Returns -1 when the shape is not covered (the caller then issues the two separate calls). */
+  int vksift_hip_seed_upsampled(const uint8_t *src, uint32_t sw, uint32_t sh, uint64_t src_img_stride, vksift_hip_Plane dst, const float *taps, uint32_t ntaps,
+                                uint32_t batch, vksift_hip_stream s);
+
   /* The whole scale chain of one octave in one launch (pyramid_fused.hip): scales 1..5 and DoG 0..4 from Gaussian plane 0,
    * i.e. the five H+V GaussianBlur*.comp dispatch pairs and five DifferenceOfGaussian.comp dispatches of
    * sift_detector.c:927-1001,1039-1079, and (next_g0.base != NULL, exact 2:1 sizes) the NEAREST blit of scale 3 into the

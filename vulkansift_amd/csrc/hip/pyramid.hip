@@ -401,7 +401,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base, 
   return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, pitch * h * 4, 0x00020000);
 }
 
-template <int NT, bool DOG>
+// UPS: the source is the u8 input image at half the resolution; the staged rows are produced on the fly by the exact
+// 2:1 LINEAR blit of k_input_blit_2x (same expressions, value/255 through a 256-entry table of the same correctly
+// rounded quotients), i.e. vkCmdCopyBufferToImage + vkCmdBlitImage + the seed blur in one pass: the up-sampled plane
+// never exists in HBM. a.src then points at the u8 images (a.src_img_stride in bytes), a.spitch is the source width.
+template <int NT, bool DOG, bool UPS = false>
 __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 {
   constexpr int NR = 8;
@@ -439,7 +443,9 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   const int x0 = bs * TW;
   const int y0 = bseg * a.seg;
   const int y1 = min(y0 + a.seg, H);
-  const __amdgpu_buffer_rsrc_t rs = plane_rsrc(a.src + (size_t)bimg * a.src_img_stride, a.spitch, H);
+  const __amdgpu_buffer_rsrc_t rs =
+      UPS ? __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)a.src + (size_t)bimg * a.src_img_stride), 0, a.spitch * (H / 2), 0x00020000)
+          : plane_rsrc(a.src + (size_t)bimg * a.src_img_stride, a.spitch, H);
   const __amdgpu_buffer_rsrc_t rd = plane_rsrc(a.dst ? a.dst + (size_t)bimg * a.dst_img_stride : a.src, a.dpitch, H);
   const __amdgpu_buffer_rsrc_t rg_ = plane_rsrc(DOG ? a.dog + (size_t)bimg * a.dog_img_stride : a.dst, a.gpitch, H);
 
@@ -457,6 +463,26 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
       rev = true;
     }
   }
+  // UPS: the 4 output columns X..X+3 (X = real column of the float4 after mirroring) come from the source bytes
+  // X/2-1 .. X/2+2, clamped to the row: one (byte-aligned) dword load + a lane-constant byte permutation
+  unsigned perm_sel = 0x03020100u;
+  __shared__ float s_lut[UPS ? 256 : 1];
+  if (UPS)
+  {
+    for (int i = lane; i < 256; i += 64)
+      s_lut[i] = (float)i / 255.f;
+    if (lane < NV4)
+    {
+      const int X = (int)(ld_off / 4u);
+      const int sw = a.spitch;
+      int cb = X / 2 - 1;
+      if (cb < 0)
+        cb = 0, perm_sel = 0x02010000u; // (b0, b0, b1, b2)
+      else if (cb + 3 > sw - 1)
+        cb = sw - 4, perm_sel = 0x03030201u; // (b1, b2, b3, b3)
+      ld_off = (unsigned)cb;
+    }
+  }
   const int px = x0 + 2 * lane;
   const unsigned st_off = px + 1 < W ? (unsigned)px * 4u : BUF_OOB;
   const unsigned st_off_g = a.dst ? st_off : BUF_OOB; // dst == NULL: the caller keeps only the DoG layer, the hardware drops the store
@@ -464,8 +490,23 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   const float k0 = a.taps.k[0];
 
   u32x4 pf[NR];
+  float vb[NR]; // UPS: vertical weight of the lower source row (wave-uniform)
   auto prefetch = [&](int r0) {
-    if (r0 >= 0 && r0 + NR <= H)
+    if (UPS)
+    {
+      const int sh = H / 2, sw = a.spitch;
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+      {
+        const int ru = mirror_idx(r0 + j, H);
+        const int m = (ru & 1) ? (ru - 1) / 2 : ru / 2 - 1;
+        vb[j] = (ru & 1) ? 0.25f : 0.75f;
+        const int ya = m < 0 ? 0 : m, yb_ = m + 1 > sh - 1 ? sh - 1 : m + 1;
+        pf[j].x = __builtin_amdgcn_raw_buffer_load_b32(rs, ld_off, ya * sw, 0);
+        pf[j].y = __builtin_amdgcn_raw_buffer_load_b32(rs, ld_off, yb_ * sw, 0);
+      }
+    }
+    else if (r0 >= 0 && r0 + NR <= H)
     {
       int so = r0 * spitch4;
 #pragma unroll
@@ -502,6 +543,28 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
       for (int j = 0; j < NR; j++)
       {
         u32x4 v = pf[j];
+        if (UPS)
+        {
+          const unsigned d0 = __builtin_amdgcn_perm(v.x, v.x, perm_sel), d1 = __builtin_amdgcn_perm(v.y, v.y, perm_sel);
+          float t0[4], t1[4], res[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+          {
+            t0[k] = s_lut[(d0 >> (8 * k)) & 0xffu];
+            t1[k] = s_lut[(d1 >> (8 * k)) & 0xffu];
+          }
+          const float b = vb[j];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+          {
+            const int i0 = (k + 1) / 2;              // left source texel of output column X+k
+            const float aw = (k & 1) ? 0.25f : 0.75f; // weight of the right one
+            const float r0 = fmaf(aw, t0[i0 + 1], (1.f - aw) * t0[i0]);
+            const float r1 = fmaf(aw, t1[i0 + 1], (1.f - aw) * t1[i0]);
+            res[k] = fmaf(b, r1, (1.f - b) * r0);
+          }
+          v = u32x4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
+        }
         if (rev)
           v = u32x4{v.w, v.z, v.y, v.x};
         *(u32x4 *)(grp + j * SW + 4 * lane) = v;
@@ -762,6 +825,53 @@ extern "C"
 #undef VKSIFT_CASE
     default:
       return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_seed_upsampled(const uint8_t *src, uint32_t sw, uint32_t sh, uint64_t src_img_stride, vksift_hip_Plane dst, const float *taps, uint32_t ntaps,
+                                uint32_t batch, vksift_hip_stream s)
+  {
+    static int enabled = -1;
+    if (enabled < 0)
+    {
+      const char *e = getenv("VKSIFT_FUSED_SEED"); /* 0: separate blit + seed blur launches (A/B runs) */
+      enabled = (e && e[0] == '0') ? 0 : 1;
+    }
+    const uint32_t W = dst.w, H = dst.h;
+    const uint32_t ra = ((ntaps - 1u) + 3u) & ~3u;
+    const uint32_t strips = (W + 127u) / 128u;
+    if (!enabled || ntaps < 2 || ntaps > VKSIFT_HIP_MAX_TAPS || W != 2 * sw || H != 2 * sh || (W % 4u) != 0 || sw < 4 || ra > W || strips * 128u + ra > 2u * W)
+      return -1; /* not applicable: the caller runs vksift_hip_input_blit + vksift_hip_blur */
+    StreamArgs a;
+    a.src = (const float *)src, a.dst = dst.base, a.dog = NULL;
+    a.src_img_stride = src_img_stride, a.dst_img_stride = dst.img_stride, a.dog_img_stride = 0;
+    a.spitch = (int)sw, a.dpitch = (int)dst.pitch, a.gpitch = (int)dst.pitch;
+    a.w = (int)W, a.h = (int)H;
+    for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
+      a.taps.k[i] = i < ntaps ? taps[i] : 0.f;
+    a.xcd_remap = 1;
+    uint32_t nseg = (1536u + strips * batch - 1u) / (strips * batch);
+    uint32_t max_seg = (H + 63u) / 64u;
+    if (nseg > max_seg)
+      nseg = max_seg;
+    if (nseg < 1)
+      nseg = 1;
+    uint32_t seg = ((H + nseg - 1u) / nseg + 7u) & ~7u;
+    nseg = (H + seg - 1u) / seg;
+    a.seg = (int)seg;
+    dim3 grid(strips, nseg, batch);
+    switch (ntaps)
+    {
+#define VKSIFT_CASE(N)                                                                              \
+  case N:                                                                                           \
+    hipLaunchKernelGGL((k_blur_lean<N, false, true>), grid, dim3(64), 0, (hipStream_t)s, a);       \
+    break;
+      VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9) VKSIFT_CASE(10)
+      VKSIFT_CASE(11) VKSIFT_CASE(12)
+#undef VKSIFT_CASE
+    default:
+      return -1;
     }
     return (int)hipGetLastError();
   }

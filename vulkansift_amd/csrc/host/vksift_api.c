@@ -852,9 +852,19 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     if (o == 0)
     {
       /* blit into the (still unused) layer-1 slot, then seed-blur it into layer 0 */
-      vksift_hip_Plane tmp = plane_at(inst, 0, L->gauss_off[0], 1);
-      HIP_CHECK(vksift_hip_input_blit(d_src, w, h, img_bytes, tmp, count, so), "input blit");
-      HIP_CHECK(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), no_dog, &inst->taps[0], inst->ntaps[0], count, so), "seed blur");
+      int fused = -1;
+      if (L->w[0] == 2 * w && L->h[0] == 2 * h)
+      {
+        fused = vksift_hip_seed_upsampled(d_src, w, h, img_bytes, plane_at(inst, 0, L->gauss_off[0], 0), &inst->taps[0], inst->ntaps[0], count, so);
+        if (fused > 0)
+          HIP_CHECK(fused, "fused up-sampling + seed blur");
+      }
+      if (fused < 0)
+      {
+        vksift_hip_Plane tmp = plane_at(inst, 0, L->gauss_off[0], 1);
+        HIP_CHECK(vksift_hip_input_blit(d_src, w, h, img_bytes, tmp, count, so), "input blit");
+        HIP_CHECK(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), no_dog, &inst->taps[0], inst->ntaps[0], count, so), "seed blur");
+      }
       nb_o++;
     }
     else
