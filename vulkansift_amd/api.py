@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libvulkansift.so")
+# VKSIFT_LIB selects another build of the same library (A/B runs of compiler options); never a different implementation
+LIB_PATH = os.environ.get("VKSIFT_LIB") or os.path.join(_PKG, "lib", "libvulkansift.so")
 
 VKSIFT_SUCCESS, VKSIFT_INVALID_INPUT_ERROR, VKSIFT_VULKAN_ERROR = 0, 1, 2
 VKSIFT_NO_LOG, VKSIFT_LOG_ERROR, VKSIFT_LOG_WARNING, VKSIFT_LOG_INFO, VKSIFT_LOG_DEBUG = range(5)

@@ -55,6 +55,24 @@ def _run(cmd):
         sys.stderr.write(r.stderr)
 
 
+# Per-file code generation options. max-ilp: the default scheduler serialises the independent accumulator chains of the
+# unrolled filters to save registers, which leaves an s_nop after almost every dependent packed-fp32 pair.
+HIP_EXTRA = {}
+
+
+def _extra_flags(src):
+    """VKSIFT_SCHED="pyramid=max-ilp,features=max-ilp" overrides HIP_EXTRA for experiments."""
+    spec = os.environ.get("VKSIFT_SCHED")
+    if spec is None:
+        return HIP_EXTRA.get(src, [])
+    for item in spec.split(","):
+        if "=" in item:
+            name, strat = item.split("=", 1)
+            if os.path.basename(src).split(".")[0] == name and strat:
+                return ["-mllvm", "-amdgpu-sched-strategy=" + strat]
+    return []
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = _all_headers()
@@ -74,7 +92,7 @@ def build(force=False, verbose=False):
         if force or _newer(o, [s] + headers):
             if verbose:
                 print("[hip]", src)
-            _run([HIPCC] + HIPFLAGS + INCLUDES + ["-c", s, "-o", o])
+            _run([HIPCC] + HIPFLAGS + _extra_flags(src) + INCLUDES + ["-c", s, "-o", o])
     if force or _newer(LIB_PATH, objs):
         if verbose:
             print("[ld ]", os.path.relpath(LIB_PATH, ROOT))

@@ -573,28 +573,36 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
     prefetch(rg + NR);
     __syncthreads();
 
-    // ---- horizontal pass of the new rows, into the top of the register window
+    // ---- horizontal pass of the new rows, into the top of the register window. Two rows at a time: their accumulator
+    // chains are independent, so the scheduler can alternate them and the dependent v_pk_add -> v_pk_fma pairs need no
+    // wait states (one row alone leaves an s_nop after almost every packed instruction).
     {
       const float *hb = grp + (RA - R - OFS) + 2 * lane;
 #pragma unroll
-      for (int j = 0; j < NR; j++)
+      for (int j = 0; j < NR; j += 2)
       {
-        const v2f *p = (const v2f *)(hb + j * SW);
-        float v[2 * NP];
+        const v2f *pa = (const v2f *)(hb + j * SW);
+        const v2f *pb = (const v2f *)(hb + (j + 1) * SW);
+        float va[2 * NP], vb2[2 * NP];
 #pragma unroll
         for (int q = 0; q < NP; q++)
         {
-          v2f t = p[q];
-          v[2 * q] = t.x, v[2 * q + 1] = t.y;
+          v2f ta = pa[q], tb = pb[q];
+          va[2 * q] = ta.x, va[2 * q + 1] = ta.y;
+          vb2[2 * q] = tb.x, vb2[2 * q + 1] = tb.y;
         }
-        float acc0 = v[C0] * k0, acc1 = v[C0 + 1] * k0;
+        float a0 = va[C0] * k0, a1 = va[C0 + 1] * k0;
+        float b0 = vb2[C0] * k0, b1 = vb2[C0 + 1] * k0;
 #pragma unroll
         for (int i = 1; i < NT; i++)
         {
-          acc0 = fmaf(v[C0 + i] + v[C0 - i], a.taps.k[i], acc0);
-          acc1 = fmaf(v[C0 + 1 + i] + v[C0 + 1 - i], a.taps.k[i], acc1);
+          a0 = fmaf(va[C0 + i] + va[C0 - i], a.taps.k[i], a0);
+          a1 = fmaf(va[C0 + 1 + i] + va[C0 + 1 - i], a.taps.k[i], a1);
+          b0 = fmaf(vb2[C0 + i] + vb2[C0 - i], a.taps.k[i], b0);
+          b1 = fmaf(vb2[C0 + 1 + i] + vb2[C0 + 1 - i], a.taps.k[i], b1);
         }
-        wv[2 * R + j] = make_float2(acc0, acc1);
+        wv[2 * R + j] = make_float2(a0, a1);
+        wv[2 * R + j + 1] = make_float2(b0, b1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -606,12 +614,27 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
       const float *c0p = s_ring + gs * GROUP_FLOATS + RA + 2 * lane;
       const float *c1p = s_ring + gs1 * GROUP_FLOATS + RA + 2 * lane;
       const float *c2p = s_ring + gs2 * GROUP_FLOATS + RA + 2 * lane;
-      auto vpass = [&](auto checked) {
+      auto centre = [&](int j) -> v2f {
+        const int back = j - R;                               // <= 0: rows back from the current group's row 0
+        const int gb = back >= 0 ? 0 : (-back + NR - 1) / NR; // groups back (0, 1 or 2)
+        const int row = back + gb * NR;                       // row inside that group
+        const float *cp = gb == 0 ? c0p : (gb == 1 ? c1p : c2p);
+        return *(const v2f *)(cp + row * SW);
+      };
+      auto emit = [&](int j, int so_d, int so_g, float acc0, float acc1) {
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0), __float_as_uint(acc1)}, rd, st_off_g, so_d, 0);
+        if (DOG)
+        {
+          const v2f c = centre(j);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0 - c.x), __float_as_uint(acc1 - c.y)}, rg_, st_off, so_g, 0);
+        }
+      };
+      auto vpass_checked = [&]() {
         int so_d = yb * dpitch4, so_g = yb * gpitch4;
 #pragma unroll
         for (int j = 0; j < NR; j++, so_d += dpitch4, so_g += gpitch4)
         {
-          if (decltype(checked)::value && (yb + j < y0 || yb + j >= y1))
+          if (yb + j < y0 || yb + j >= y1)
             continue;
           float acc0 = wv[R + j].x * k0, acc1 = wv[R + j].y * k0;
 #pragma unroll
@@ -620,25 +643,34 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
             acc0 = fmaf(wv[R + j + i].x + wv[R + j - i].x, a.taps.k[i], acc0);
             acc1 = fmaf(wv[R + j + i].y + wv[R + j - i].y, a.taps.k[i], acc1);
           }
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0), __float_as_uint(acc1)}, rd, st_off_g, so_d, 0);
-          if (DOG)
+          emit(j, so_d, so_g, acc0, acc1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      auto vpass_full = [&]() {
+        int so_d = yb * dpitch4, so_g = yb * gpitch4;
+#pragma unroll
+        for (int j = 0; j < NR; j += 2, so_d += 2 * dpitch4, so_g += 2 * gpitch4)
+        {
+          float a0 = wv[R + j].x * k0, a1 = wv[R + j].y * k0;
+          float b0 = wv[R + j + 1].x * k0, b1 = wv[R + j + 1].y * k0;
+#pragma unroll
+          for (int i = 1; i < NT; i++)
           {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int back = j - R;                          // <= 0: rows back from the current group's row 0
-            const int gb = back >= 0 ? 0 : (-back + NR - 1) / NR; // groups back (0, 1 or 2)
-            const int row = back + gb * NR;                  // row inside that group
-            const float *cp = gb == 0 ? c0p : (gb == 1 ? c1p : c2p);
-            const v2f c = *(const v2f *)(cp + row * SW);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0 - c.x), __float_as_uint(acc1 - c.y)}, rg_, st_off, so_g, 0);
+            a0 = fmaf(wv[R + j + i].x + wv[R + j - i].x, a.taps.k[i], a0);
+            a1 = fmaf(wv[R + j + i].y + wv[R + j - i].y, a.taps.k[i], a1);
+            b0 = fmaf(wv[R + j + 1 + i].x + wv[R + j + 1 - i].x, a.taps.k[i], b0);
+            b1 = fmaf(wv[R + j + 1 + i].y + wv[R + j + 1 - i].y, a.taps.k[i], b1);
           }
+          emit(j, so_d, so_g, a0, a1);
+          emit(j + 1, so_d + dpitch4, so_g + gpitch4, b0, b1);
           __builtin_amdgcn_sched_barrier(0);
         }
       };
       if (yb >= y0 && yb + NR <= y1)
-        vpass(std::false_type{});
+        vpass_full();
       else
-        vpass(std::true_type{});
+        vpass_checked();
     }
     // ---- slide the window, rotate the ring
 #pragma unroll
