@@ -13,8 +13,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def pmc(dirpath, counter):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), dirpath, counter, "k_blur_stream"], capture_output=True, text=True)
+KERNEL = "k_blur_lean"
+
+
+def pmc(dirpath, counter, gridx):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), dirpath, counter, KERNEL, str(gridx)], capture_output=True, text=True)
     return json.loads(out.stdout)
 
 
@@ -27,12 +30,14 @@ def main():
         shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
     for p in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats.csv"))
-    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(src, "trace"), "k_blur_stream"],
+    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(src, "trace"), KERNEL],
                           capture_output=True, text=True).stdout
     open(os.path.join(dst, f"{tag}_kernel_summary.txt"), "w").write(summ)
     if os.path.isdir(os.path.join(src, "pmc_fetch")) and os.path.isdir(os.path.join(src, "pmc_write")):
-        f = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
-        wr = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+        # octave-0 launches only (the launches bench.py's roofline is quoted on): grid.x = strips * 64 work-items
+        gridx = ((2 * w + 127) // 128) * 64
+        f = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", gridx)
+        wr = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", gridx)
         calls = sum(v["calls"] for v in f.values())
         fetch_kb = sum(v["sum"] for v in f.values())
         write_kb = sum(v["sum"] for v in wr.values())
@@ -40,7 +45,7 @@ def main():
         # FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
         # stream (MI355X_MICROARCH.md §HBM): doubled before use. WRITE_SIZE is taken as is (uncalibrated).
         per_launch = (2.0 * fetch_kb / max(calls, 1) + write_kb / max(wcalls, 1)) * 1024.0
-        rec = {"width": w, "height": h, "batch": batch, "kernel": "k_blur_stream", "launches_fetch_pass": calls, "launches_write_pass": wcalls,
+        rec = {"width": w, "height": h, "batch": batch, "kernel": KERNEL + " (octave-0 launches)", "launches_fetch_pass": calls, "launches_write_pass": wcalls,
                "FETCH_SIZE_KiB_sum": fetch_kb, "WRITE_SIZE_KiB_sum": write_kb, "fetch_correction": 2.0,
                "hbm_bytes_per_blur_launch": per_launch,
                "per_kernel_FETCH_SIZE": f, "per_kernel_WRITE_SIZE": wr}
