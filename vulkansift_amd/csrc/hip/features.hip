@@ -286,18 +286,24 @@ __device__ __forceinline__ void desc_accumulate(const DescCtx &c, int cdx, int c
   float fbin = c.use_vlfeat ? (ori * 8.f / (2.f * PI_F)) : (-ori * 8.f / (2.f * PI_F));
   int hx = (int)floorf(fhx - 0.5f), hy = (int)floorf(fhy - 0.5f), hb = (int)floorf(fbin);
   float rhx = fhx - ((float)hx + 0.5f), rhy = fhy - ((float)hy + 0.5f), rb = fbin - (float)hb;
+  // The 2x2 spatial cells that fall outside the 4x4 grid (ComputeDescriptors.comp:189 drops them) are redirected to a
+  // per-lane dummy slot behind the histogram instead of being branched around: no exec-mask juggling in the hot loop.
+  const int dummy = 128 + (int)(threadIdx.x & 63);
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
+    {
+      const bool in_grid = (unsigned)(i + hx) < 4u && (unsigned)(j + hy) < 4u;
+      const int cell = (j + hy) * 32 + (i + hx) * 8;
 #pragma unroll
       for (int kk = 0; kk < 2; kk++)
-        if ((i + hx) >= 0 && (i + hx) < 4 && (j + hy) >= 0 && (j + hy) < 4)
-        {
-          int idx = (j + hy) * 32 + (i + hx) * 8 + smod8(kk + hb);
-          float val = fabsf(1.f - (float)i - rhx) * fabsf(1.f - (float)j - rhy) * fabsf(1.f - (float)kk - rb) * mag;
-          atomicAdd(&s_work[idx], (uint32_t)(val * c.fp));
-        }
+      {
+        const int idx = in_grid ? cell + smod8(kk + hb) : dummy;
+        float val = fabsf(1.f - (float)i - rhx) * fabsf(1.f - (float)j - rhy) * fabsf(1.f - (float)kk - rb) * mag;
+        atomicAdd(&s_work[idx], (uint32_t)(val * c.fp));
+      }
+    }
 }
 
 // One 256-thread workgroup per keypoint (the window of a coarse-scale keypoint has up to ~7.5k pixels; a single wave
@@ -310,7 +316,7 @@ template <int NWV>
 __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
 {
   constexpr int NT_ = 64 * NWV;
-  __shared__ uint32_t s_work[128];
+  __shared__ uint32_t s_work[128 + 64]; // histogram + per-lane dummy slots for out-of-grid cells
   __shared__ uint32_t s_q[NWV][128];
   const int tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
@@ -347,37 +353,38 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
     c.fp = a.desc_fp_tab[ti < a.desc_fp_tab_len ? ti : a.desc_fp_tab_len - 1];
     c.rsx = roundf(c.scale_x), c.rsy = roundf(c.scale_y);
 
-    const int box = 2 * R + 1;
-    const int npix = box * box;
+    // The window [-R, R]^2 is clipped to the image interior up front (ComputeDescriptors.comp:151 skips the border texels).
+    const int cxi = (int)c.rsx, cyi = (int)c.rsy;
+    const int dx0 = max(-R, 1 - cxi), dx1 = min(R, g.w - 2 - cxi);
+    const int dy0 = max(-R, 1 - cyi), dy1 = min(R, g.h - 2 - cyi);
+    const int bw = dx1 - dx0 + 1, bh = dy1 - dy0 + 1;
+    const int npix = (bw > 0 && bh > 0) ? bw * bh : 0;
     // Pixel enumeration: thread t walks its own contiguous run [t*niter, (t+1)*niter) of the window, so at any step the
     // 64 lanes of a wave sit ~niter pixels apart and spread over all 16 spatial cells: the 8 fixed-point LDS atomics of
     // a step then hit mostly distinct addresses (adjacent pixels would pile onto the same 1-2 cells and serialise).
     // Integer adds commute, so the result is independent of the enumeration.
+    // Pre-filter: only pixels whose rotated position lies within the 5x5-cell footprint of the 4x4 grid can touch a
+    // bin. The test here is deliberately approximate (fused arithmetic) and conservative (margin): desc_accumulate
+    // re-derives the cells exactly and drops the out-of-grid ones, so a false positive costs a sample slot, never a bit.
     const int niter = (npix + NT_ - 1) / NT_;
     int pix = tid * niter;
-    int dy = pix / box - R, dx = pix % box - R;
+    int dy = dy0 + pix / max(bw, 1), dx = dx0 + pix % max(bw, 1);
+    const float offx = c.rsx - c.scale_x, offy = c.rsy - c.scale_y;
+    const float T = 2.5f + 0.01f;
     uint32_t qn = 0; // queue fill of this wave (wave-uniform)
     for (int it = 0; it < niter; it++, pix++)
     {
       const int cdx = dx, cdy = dy;
       dx += 1;
-      if (dx > R)
+      if (dx > dx1)
       {
-        dx = -R;
+        dx = dx0;
         dy += 1;
       }
-      bool ok = pix < npix;
-      const int ix = (int)c.rsx + cdx, iy = (int)c.rsy + cdy;
-      ok = ok && !(ix < 1 || ix >= (g.w - 1) || iy < 1 || iy >= (g.h - 1));
-      if (ok)
-      {
-        float sdx = (c.rsx + (float)cdx) - c.scale_x;
-        float sdy = (c.rsy + (float)cdy) - c.scale_y;
-        float ox = c.kcos * sdx + c.ksin * sdy;
-        float oy = c.kcos * sdy - c.ksin * sdx;
-        int hx = (int)floorf((ox + 2.f) - 0.5f), hy = (int)floorf((oy + 2.f) - 0.5f);
-        ok = !(hx < -1 || hx > 3 || hy < -1 || hy > 3);
-      }
+      const float fx = (float)cdx + offx, fy = (float)cdy + offy;
+      const float ox = fmaf(c.kcos, fx, c.ksin * fy);
+      const float oy = fmaf(c.kcos, fy, -(c.ksin * fx));
+      const bool ok = pix < npix && fmaxf(fabsf(ox), fabsf(oy)) < T;
       const unsigned long long m = __ballot(ok);
       if (ok)
         q[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(cdx & 0xffff)) | ((uint32_t)cdy << 16);
