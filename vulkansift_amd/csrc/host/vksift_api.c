@@ -60,6 +60,16 @@ typedef struct
   uint64_t cand_off[VKSIFT_MAX_OCTAVES], cand_cap[VKSIFT_MAX_OCTAVES], cand_total;
 } PyrLayout;
 
+/* HIP-event stage timings of one detection (vksift_ext_setProfiling) */
+typedef struct
+{
+  vksift_hip_event ev_t[8];  /* instance stream: start, upload end, pyramid end, extrema end, orientation end, descriptor end, call end */
+  vksift_hip_event ev_pt[2]; /* start / end of octave 0's scale-space construction on its own stream (overlapping detections) */
+  bool valid, accounted, overlap;
+  uint32_t blur_launches;
+  uint64_t alg_bytes;
+} ProfSet;
+
 struct vksift_Instance_T
 {
   vksift_Config cfg;
@@ -79,7 +89,11 @@ struct vksift_Instance_T
   PyrLayout lay;
 
   /* device memory */
-  float *d_pyr;
+  float *d_pyr;            /* pyramid storage of the current detection (= d_pyr_buf[pyr_cur]) */
+  float *d_pyr_buf[2];     /* ping-pong: detection N+1 builds its pyramid while detection N still reads its own */
+  int pyr_cur;
+  bool pyr_pingpong;
+  bool pyr_free_valid[2];
   uint64_t pyr_img_stride; /* floats reserved per image */
   uint8_t *d_input, *h_input;
   uint8_t *d_feats;
@@ -110,6 +124,12 @@ struct vksift_Instance_T
   /* octave-parallel execution inside a stage: octave o >= 1 runs on oct_stream[o] (oct_stream[0] == stream), forked from
    * and joined back into the main stream with events, so the latency-bound small octaves overlap the large ones */
   vksift_hip_stream oct_stream[VKSIFT_MAX_OCTAVES];
+  vksift_hip_stream pyr_stream[VKSIFT_MAX_OCTAVES]; /* scale-space construction of octave o when detections overlap */
+  vksift_hip_event ev_pyr_done[VKSIFT_MAX_OCTAVES];
+  vksift_hip_event ev_pyr_free[2]; /* last reader of pyramid buffer i has finished */
+  vksift_hip_event ev_desc_start;  /* octave 0 of the previous detection has reached its (compute-bound) descriptor stage */
+  bool desc_start_valid;
+  int overlap_gate;                /* 0: next pyramid starts as early as possible, 1: not before the previous descriptor stage */
   vksift_hip_event ev_fork[4], ev_join[4][VKSIFT_MAX_OCTAVES], ev_oct_ready[VKSIFT_MAX_OCTAVES];
   bool serial_octaves;
   bool lazy_top_scale;    /* do not store Gaussian scale S+2 (only its DoG layer is consumed); re-created on download */
@@ -126,10 +146,10 @@ struct vksift_Instance_T
 
   /* profiling */
   bool profiling;
-  vksift_hip_event ev_t[8];
+  ProfSet prof[2]; /* two event sets: the host may enqueue one detection ahead of the one being timed */
+  int prof_cur;
   vksift_hip_event ev_m[2];
-  bool timings_valid, match_timing_valid;
-  bool timings_accounted;
+  bool match_timing_valid;
   double acc_ms[6];
   uint32_t acc_calls;
   uint64_t acc_blur_launches, acc_alg_bytes;
@@ -447,7 +467,17 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   bool ok = true;
 #define ALLOC_D(ptr, bytes) ok = ok && ((ptr = vksift_hip_malloc(bytes)) != NULL)
 #define ALLOC_H(ptr, bytes) ok = ok && ((ptr = vksift_hip_host_malloc(bytes)) != NULL)
-  ALLOC_D(inst->d_pyr, sizeof(float) * inst->pyr_img_stride * batch_cap);
+  {
+    /* 1: two pyramid buffers, so that the scale-space construction of detection N+1 may run under the descriptor and
+     * matching work of detection N. Off by default: on MI355X two large kernels sharing the CUs each slow down by about
+     * what the overlap wins (measured -5 % frames/s), and the second buffer doubles the largest allocation. */
+    const char *e = getenv("VKSIFT_PYR_PINGPONG");
+    inst->pyr_pingpong = e && e[0] == '1';
+  }
+  ALLOC_D(inst->d_pyr_buf[0], sizeof(float) * inst->pyr_img_stride * batch_cap);
+  if (inst->pyr_pingpong)
+    ALLOC_D(inst->d_pyr_buf[1], sizeof(float) * inst->pyr_img_stride * batch_cap);
+  inst->d_pyr = inst->d_pyr_buf[0];
   ALLOC_D(inst->d_input, (size_t)inst->max_image_size * batch_cap);
   ALLOC_H(inst->h_input, (size_t)inst->max_image_size * batch_cap);
   ALLOC_D(inst->d_feats, inst->buf_stride * config->sift_buffer_count);
@@ -476,6 +506,8 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   inst->h_matches = NULL;
   inst->bufs = (BufferInfo *)calloc(config->sift_buffer_count, sizeof(BufferInfo));
   ok = ok && inst->bufs != NULL;
+  /* All streams at the default priority: a high-priority instance stream with low-priority octave streams was measured
+   * 20 % slower on MI355X (11.3k vs 14.1k frames/s). */
   inst->stream = vksift_hip_stream_create();
   inst->oct_stream[0] = inst->stream;
   for (int o = 1; o < VKSIFT_MAX_OCTAVES; o++)
@@ -488,6 +520,20 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   }
   for (int g = 0; g < 4; g++)
     inst->ev_fork[g] = vksift_hip_event_create();
+  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
+  {
+    inst->pyr_stream[o] = vksift_hip_stream_create();
+    inst->ev_pyr_done[o] = vksift_hip_event_create();
+  }
+  inst->ev_desc_start = vksift_hip_event_create();
+  {
+    const char *e = getenv("VKSIFT_OVERLAP_GATE");
+    inst->overlap_gate = e ? atoi(e) : 1;
+  }
+  for (int i = 0; i < 2; i++)
+  {
+    inst->ev_pyr_free[i] = vksift_hip_event_create();
+  }
   {
     const char *e = getenv("VKSIFT_SERIAL_OCTAVES"); /* debug: everything on the main stream */
     inst->serial_octaves = e && e[0] == '1';
@@ -508,7 +554,15 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   inst->ev_match = vksift_hip_event_create();
   inst->ev_staging = vksift_hip_event_create();
   for (int i = 0; i < 8; i++)
-    inst->ev_t[i] = vksift_hip_event_create();
+  {
+    inst->prof[0].ev_t[i] = vksift_hip_event_create();
+    inst->prof[1].ev_t[i] = vksift_hip_event_create();
+  }
+  for (int i = 0; i < 2; i++)
+  {
+    inst->prof[0].ev_pt[i] = vksift_hip_event_create();
+    inst->prof[1].ev_pt[i] = vksift_hip_event_create();
+  }
   inst->ev_m[0] = vksift_hip_event_create();
   inst->ev_m[1] = vksift_hip_event_create();
   ok = ok && inst->stream && inst->ev_detect && inst->ev_match;
@@ -556,12 +610,17 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   assert(*instance_ptr != NULL);
   vksift_Instance inst = *instance_ptr;
   vksift_hip_set_device(inst->device);
-  for (int o = 1; o < VKSIFT_MAX_OCTAVES; o++)
-    if (inst->oct_stream[o])
+  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
+  {
+    if (o > 0 && inst->oct_stream[o])
       vksift_hip_stream_sync(inst->oct_stream[o]);
+    if (inst->pyr_stream[o])
+      vksift_hip_stream_sync(inst->pyr_stream[o]);
+  }
   if (inst->stream)
     vksift_hip_stream_sync(inst->stream);
-  vksift_hip_free(inst->d_pyr);
+  vksift_hip_free(inst->d_pyr_buf[0]);
+  vksift_hip_free(inst->d_pyr_buf[1]);
   vksift_hip_free(inst->d_input);
   vksift_hip_host_free(inst->h_input);
   vksift_hip_free(inst->d_feats);
@@ -588,11 +647,26 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_event_destroy(inst->ev_match);
   vksift_hip_event_destroy(inst->ev_staging);
   for (int i = 0; i < 8; i++)
-    vksift_hip_event_destroy(inst->ev_t[i]);
+  {
+    vksift_hip_event_destroy(inst->prof[0].ev_t[i]);
+    vksift_hip_event_destroy(inst->prof[1].ev_t[i]);
+  }
   vksift_hip_event_destroy(inst->ev_m[0]);
   vksift_hip_event_destroy(inst->ev_m[1]);
   for (int o = 1; o < VKSIFT_MAX_OCTAVES; o++)
     vksift_hip_stream_destroy(inst->oct_stream[o]);
+  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
+  {
+    vksift_hip_stream_destroy(inst->pyr_stream[o]);
+    vksift_hip_event_destroy(inst->ev_pyr_done[o]);
+  }
+  vksift_hip_event_destroy(inst->ev_desc_start);
+  for (int i = 0; i < 2; i++)
+  {
+    vksift_hip_event_destroy(inst->ev_pyr_free[i]);
+    vksift_hip_event_destroy(inst->prof[0].ev_pt[i]);
+    vksift_hip_event_destroy(inst->prof[1].ev_pt[i]);
+  }
   for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
   {
     vksift_hip_event_destroy(inst->ev_oct_ready[o]);
@@ -682,22 +756,29 @@ static uint64_t algorithmic_pyramid_bytes(vksift_Instance inst, uint32_t w, uint
   return bytes;
 }
 
-/* fold the (completed) event timings of the previous detect call into the running sums */
-static void account_timings(vksift_Instance inst)
+/* fold the (completed) event timings of a detect call into the running sums */
+static void account_set(vksift_Instance inst, ProfSet *ps)
 {
-  if (!inst->profiling || !inst->timings_valid || inst->timings_accounted)
+  if (!inst->profiling || !ps->valid || ps->accounted)
     return;
-  vksift_hip_event *e = inst->ev_t;
+  vksift_hip_event *e = ps->ev_t;
   inst->acc_ms[0] += vksift_hip_event_elapsed_ms(e[0], e[1]);
-  inst->acc_ms[1] += vksift_hip_event_elapsed_ms(e[1], e[2]);
+  inst->acc_ms[1] += ps->overlap ? vksift_hip_event_elapsed_ms(ps->ev_pt[0], ps->ev_pt[1]) : vksift_hip_event_elapsed_ms(e[1], e[2]);
   inst->acc_ms[2] += vksift_hip_event_elapsed_ms(e[2], e[3]);
   inst->acc_ms[3] += vksift_hip_event_elapsed_ms(e[3], e[4]);
   inst->acc_ms[4] += vksift_hip_event_elapsed_ms(e[4], e[5]);
   inst->acc_ms[5] += vksift_hip_event_elapsed_ms(e[0], e[6]);
   inst->acc_calls++;
-  inst->acc_blur_launches += inst->last_blur_launches;
-  inst->acc_alg_bytes += inst->last_alg_bytes;
-  inst->timings_accounted = true;
+  inst->acc_blur_launches += ps->blur_launches;
+  inst->acc_alg_bytes += ps->alg_bytes;
+  ps->accounted = true;
+}
+
+/* all detections have completed (caller waited): account both event sets, oldest first */
+static void account_timings(vksift_Instance inst)
+{
+  account_set(inst, &inst->prof[inst->prof_cur ^ 1]);
+  account_set(inst, &inst->prof[inst->prof_cur]);
 }
 
 static void detect_impl(vksift_Instance inst, const uint8_t *const *images, const uint8_t *d_images, uint32_t count, uint32_t w, uint32_t h,
@@ -730,10 +811,18 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     HIP_CHECK(vksift_hip_event_sync(inst->ev_staging), "staging synchronisation");
     inst->staging_pending = false;
   }
-  if (inst->profiling && inst->timings_valid && !inst->timings_accounted)
+  ProfSet *PS = &inst->prof[inst->prof_cur];
+  if (inst->profiling)
   {
-    HIP_CHECK(vksift_hip_event_sync(inst->ev_t[6]), "profiling synchronisation");
-    account_timings(inst);
+    /* recycle the event set of the detection before the previous one: the host never waits for the call it just queued */
+    inst->prof_cur ^= 1;
+    PS = &inst->prof[inst->prof_cur];
+    if (PS->valid && !PS->accounted)
+    {
+      HIP_CHECK(vksift_hip_event_sync(PS->ev_t[6]), "profiling synchronisation");
+      account_set(inst, PS);
+    }
+    PS->valid = false;
   }
 
   if (inst->cur_w != w || inst->cur_h != h)
@@ -758,22 +847,42 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   const bool prof = inst->profiling;
   const size_t img_bytes = (size_t)w * h;
   if (prof)
-    vksift_hip_event_record(inst->ev_t[0], st);
+    vksift_hip_event_record(PS->ev_t[0], st);
+
+  /* Overlapping detections: with two pyramid buffers the scale-space construction of this call does not depend on
+   * anything the previous call (or a matching still in flight) reads or writes, so it runs on its own streams, ordered
+   * only behind the last reader of the pyramid buffer it recycles; everything that touches the SIFT buffers and the
+   * extraction scratch stays in instance-stream order. A caller that issues detect(N+1) right after match(N) gets the
+   * bandwidth-bound pyramid of N+1 under the compute-bound descriptor and matching work of N. */
+  const bool overlap = inst->pyr_pingpong && !inst->serial_octaves && !inst->stage_sync && L->n_oct > 1;
+  PS->overlap = overlap;
+  if (overlap)
+  {
+    inst->pyr_cur ^= 1;
+    inst->d_pyr = inst->d_pyr_buf[inst->pyr_cur];
+    if (inst->pyr_free_valid[inst->pyr_cur])
+      HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream[0], inst->ev_pyr_free[inst->pyr_cur]), "pyramid buffer recycle");
+    /* Pair the bandwidth-bound pyramid with the compute-bound tail of the previous detection (descriptors, matching),
+     * not with its equally bandwidth-bound extraction stage. */
+    if (inst->overlap_gate && inst->desc_start_valid)
+      HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream[0], inst->ev_desc_start), "overlap gate");
+  }
 
   /* stage the images; the caller may reuse its memory as soon as we return (sift_memory.c:943) */
   const uint8_t *d_src = d_images;
   if (images)
   {
+    vksift_hip_stream s_up = overlap ? inst->pyr_stream[0] : st; /* behind the previous reader of d_input either way */
     for (uint32_t i = 0; i < count; i++)
       memcpy(inst->h_input + i * img_bytes, images[i], img_bytes);
-    HIP_CHECK(vksift_hip_memcpy_h2d(inst->d_input, inst->h_input, img_bytes * count, st), "image upload");
-    HIP_CHECK(vksift_hip_event_record(inst->ev_staging, st), "event record");
+    HIP_CHECK(vksift_hip_memcpy_h2d(inst->d_input, inst->h_input, img_bytes * count, s_up), "image upload");
+    HIP_CHECK(vksift_hip_event_record(inst->ev_staging, s_up), "event record");
     inst->staging_pending = true;
     d_src = inst->d_input;
   }
   inst->device_input_last = images == NULL;
   if (prof)
-    vksift_hip_event_record(inst->ev_t[1], st);
+    vksift_hip_event_record(PS->ev_t[1], st);
 
   /* recClearBufferDataCmds (sift_detector.c:1081-1104) */
   HIP_CHECK(vksift_hip_memset(inst->d_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * count, st),
@@ -847,32 +956,38 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
       so = inst->oct_stream[o];
       HIP_CHECK(vksift_hip_stream_wait_event(so, inst->ev_fork[0]), "octave fork");
     }
+    /* sp: stream of this octave's scale-space construction; so: stream of its keypoint stages */
+    vksift_hip_stream sp = overlap ? inst->pyr_stream[o] : so;
+    if (overlap && o > 0 && inst->pyr_free_valid[inst->pyr_cur])
+      HIP_CHECK(vksift_hip_stream_wait_event(sp, inst->ev_pyr_free[inst->pyr_cur]), "pyramid buffer recycle");
     vksift_hip_range_push("Scale space construction");
     uint32_t nb_o = 0;
     if (o == 0)
     {
+      if (overlap && prof)
+        vksift_hip_event_record(PS->ev_pt[0], sp);
       /* blit into the (still unused) layer-1 slot, then seed-blur it into layer 0 */
       int fused = -1;
       if (L->w[0] == 2 * w && L->h[0] == 2 * h)
       {
-        fused = vksift_hip_seed_upsampled(d_src, w, h, img_bytes, plane_at(inst, 0, L->gauss_off[0], 0), &inst->taps[0], inst->ntaps[0], count, so);
+        fused = vksift_hip_seed_upsampled(d_src, w, h, img_bytes, plane_at(inst, 0, L->gauss_off[0], 0), &inst->taps[0], inst->ntaps[0], count, sp);
         if (fused > 0)
           HIP_CHECK(fused, "fused up-sampling + seed blur");
       }
       if (fused < 0)
       {
         vksift_hip_Plane tmp = plane_at(inst, 0, L->gauss_off[0], 1);
-        HIP_CHECK(vksift_hip_input_blit(d_src, w, h, img_bytes, tmp, count, so), "input blit");
-        HIP_CHECK(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), no_dog, &inst->taps[0], inst->ntaps[0], count, so), "seed blur");
+        HIP_CHECK(vksift_hip_input_blit(d_src, w, h, img_bytes, tmp, count, sp), "input blit");
+        HIP_CHECK(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), no_dog, &inst->taps[0], inst->ntaps[0], count, sp), "seed blur");
       }
       nb_o++;
     }
     else
     {
       if (par)
-        HIP_CHECK(vksift_hip_stream_wait_event(so, inst->ev_oct_ready[o - 1]), "octave dependency");
+        HIP_CHECK(vksift_hip_stream_wait_event(sp, inst->ev_oct_ready[o - 1]), "octave dependency");
       if (!g0_done)
-        HIP_CHECK(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), count, so), "downsample");
+        HIP_CHECK(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), count, sp), "downsample");
     }
     g0_done = false;
     inst->top_scale_stale[o] = false;
@@ -886,11 +1001,11 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
         g0_done = true;
       }
       HIP_CHECK(vksift_hip_octave_chain(plane_at(inst, o, L->gauss_off[o], 0), L->plane_stride[o], inst->d_pyr + L->dog_off[o], next, inst->taps,
-                                        VKSIFT_MAX_TAPS, count, so),
+                                        VKSIFT_MAX_TAPS, count, sp),
                 "octave chain");
       nb_o++;
       if (par && o + 1 < L->n_oct)
-        HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], so), "event record");
+        HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], sp), "event record");
     }
     else
       for (uint32_t s = 1; s < inst->S + 3; s++)
@@ -905,34 +1020,46 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
           inst->top_scale_stale[o] = true;
         }
         HIP_CHECK(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), dstp, plane_at(inst, o, L->dog_off[o], s - 1),
-                                  &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, so),
+                                  &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, sp),
                   "blur");
         nb_o++;
         if (par && o + 1 < L->n_oct && s == ((inst->coarse_after && o == 0) ? inst->S + 2 : inst->S))
-          HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], so), "event record");
+          HIP_CHECK(vksift_hip_event_record(inst->ev_oct_ready[o], sp), "event record");
       }
     vksift_hip_range_pop();
     if (!pipelined || o == 0)
       nblur += nb_o;
+    if (overlap)
+    {
+      if (o == 0 && prof)
+        vksift_hip_event_record(PS->ev_pt[1], sp);
+      HIP_CHECK(vksift_hip_event_record(inst->ev_pyr_done[o], sp), "event record");
+      HIP_CHECK(vksift_hip_stream_wait_event(so, inst->ev_pyr_done[o]), "scale space ready");
+    }
     if (pipelined)
     {
       if (o == 0 && prof)
-        vksift_hip_event_record(inst->ev_t[2], st);
+        vksift_hip_event_record(PS->ev_t[2], st);
       vksift_hip_range_push("ExtractKeypoints");
       HIP_CHECK(vksift_hip_extract_keypoints(&jobs[o], count, so), "keypoint extraction");
       vksift_hip_range_pop();
       if (o == 0 && prof)
-        vksift_hip_event_record(inst->ev_t[3], st);
+        vksift_hip_event_record(PS->ev_t[3], st);
       vksift_hip_range_push("ComputeOrientation");
       HIP_CHECK(vksift_hip_orientations(&jobs[o], count, so), "orientation");
       vksift_hip_range_pop();
       if (o == 0 && prof)
-        vksift_hip_event_record(inst->ev_t[4], st);
+        vksift_hip_event_record(PS->ev_t[4], st);
       vksift_hip_range_push("ComputeDescriptors");
+      if (overlap && o == 0)
+      {
+        HIP_CHECK(vksift_hip_event_record(inst->ev_desc_start, st), "event record");
+        inst->desc_start_valid = true;
+      }
       HIP_CHECK(vksift_hip_descriptors(&jobs[o], count, so), "descriptor");
       vksift_hip_range_pop();
       if (o == 0 && prof)
-        vksift_hip_event_record(inst->ev_t[5], st);
+        vksift_hip_event_record(PS->ev_t[5], st);
     }
     if (par && so != st)
       HIP_CHECK(vksift_hip_event_record(inst->ev_join[0][o], so), "event record");
@@ -941,6 +1068,12 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     for (uint32_t o = 0; o < L->n_oct; o++)
       if (o > 0 || !pipelined)
         HIP_CHECK(vksift_hip_stream_wait_event(st, inst->ev_join[0][o]), "octave join");
+  if (overlap)
+  {
+    /* everything that reads this call's pyramid has been joined into the instance stream */
+    HIP_CHECK(vksift_hip_event_record(inst->ev_pyr_free[inst->pyr_cur], st), "event record");
+    inst->pyr_free_valid[inst->pyr_cur] = true;
+  }
   inst->last_blur_launches = nblur;
   /* profiling: the pyramid interval is octave 0's when pipelined, the whole pyramid's otherwise */
   inst->last_alg_bytes = algorithmic_pyramid_bytes(inst, w, h, pipelined ? 1u : L->n_oct) * count;
@@ -948,7 +1081,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   if (!pipelined)
   {
     if (prof)
-      vksift_hip_event_record(inst->ev_t[2], st);
+      vksift_hip_event_record(PS->ev_t[2], st);
     /* Each of the three keypoint stages forks one stream per octave (per-octave scratch, no sharing) and joins back
      * into the main stream, so stage boundaries (and the stage timings) stay well defined. */
 #define VKSIFT_STAGE(G, NAME, CALL, WHAT)                                                                   \
@@ -971,13 +1104,13 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
 
     VKSIFT_STAGE(1, "ExtractKeypoints", vksift_hip_extract_keypoints, "keypoint extraction")
     if (prof)
-      vksift_hip_event_record(inst->ev_t[3], st);
+      vksift_hip_event_record(PS->ev_t[3], st);
     VKSIFT_STAGE(2, "ComputeOrientation", vksift_hip_orientations, "orientation")
     if (prof)
-      vksift_hip_event_record(inst->ev_t[4], st);
+      vksift_hip_event_record(PS->ev_t[4], st);
     VKSIFT_STAGE(3, "ComputeDescriptors", vksift_hip_descriptors, "descriptor")
     if (prof)
-      vksift_hip_event_record(inst->ev_t[5], st);
+      vksift_hip_event_record(PS->ev_t[5], st);
 #undef VKSIFT_STAGE
   }
 
@@ -987,9 +1120,11 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
             "count read-back");
   if (prof)
   {
-    vksift_hip_event_record(inst->ev_t[6], st);
-    inst->timings_valid = true;
-    inst->timings_accounted = false;
+    vksift_hip_event_record(PS->ev_t[6], st);
+    PS->valid = true;
+    PS->accounted = false;
+    PS->blur_launches = inst->last_blur_launches;
+    PS->alg_bytes = inst->last_alg_bytes;
   }
   HIP_CHECK(vksift_hip_event_record(inst->ev_detect, st), "event record");
   inst->detect_pending = true;
@@ -1429,9 +1564,9 @@ void vksift_presentDebugFrame(vksift_Instance instance)
 void vksift_ext_setProfiling(vksift_Instance instance, bool enabled)
 {
   instance->profiling = enabled;
-  instance->timings_valid = false;
+  instance->prof[0].valid = instance->prof[1].valid = false;
+  instance->prof[0].accounted = instance->prof[1].accounted = false;
   instance->match_timing_valid = false;
-  instance->timings_accounted = false;
   memset(instance->acc_ms, 0, sizeof(instance->acc_ms));
   instance->acc_calls = 0;
   instance->acc_blur_launches = 0;
@@ -1468,13 +1603,14 @@ void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext
 void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *out)
 {
   memset(out, 0, sizeof(*out));
-  if (!instance->profiling || !instance->timings_valid)
+  const ProfSet *ps = &instance->prof[instance->prof_cur];
+  if (!instance->profiling || !ps->valid)
     return;
   vksift_hip_set_device(instance->device);
   wait_all(instance);
-  vksift_hip_event *e = instance->ev_t;
+  const vksift_hip_event *e = ps->ev_t;
   out->upload_ms = vksift_hip_event_elapsed_ms(e[0], e[1]);
-  out->pyramid_ms = vksift_hip_event_elapsed_ms(e[1], e[2]);
+  out->pyramid_ms = ps->overlap ? vksift_hip_event_elapsed_ms(ps->ev_pt[0], ps->ev_pt[1]) : vksift_hip_event_elapsed_ms(e[1], e[2]);
   out->extrema_ms = vksift_hip_event_elapsed_ms(e[2], e[3]);
   out->orientation_ms = vksift_hip_event_elapsed_ms(e[3], e[4]);
   out->descriptor_ms = vksift_hip_event_elapsed_ms(e[4], e[5]);
