@@ -12,6 +12,7 @@
 // The arithmetic of refine_texel() is kept operation-for-operation identical to
 // oracle/sift_oracle.c:extract_one (fp32, no contraction) so results are bit-exact.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -188,6 +189,33 @@ __device__ __forceinline__ float wave_shl1(float v, float edge)
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
+// v_max_f32 / v_min_f32 / v_max3_f32 / v_min3_f32 on values known to be finite. fmaxf()/fminf() in IEEE mode first
+// canonicalise both operands (one extra v_max_f32 x, x each) to quieten signalling NaNs; DoG planes never hold NaNs.
+__device__ __forceinline__ float fmax2(float a, float b)
+{
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float fmin2(float a, float b)
+{
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float fmax3(float a, float b, float c)
+{
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fmin3(float a, float b, float c)
+{
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // spread the low 32 bits of x to the even bit positions of a 64-bit word
 __device__ __forceinline__ unsigned long long spread32(unsigned long long x)
 {
@@ -277,12 +305,12 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
       const float va = c.va[l], vb = c.vb[l], hv = c.hv[l];
       const float la = wave_shr1(vb, hv); // left neighbour of column x   = previous lane's column x+1
       const float rb = wave_shl1(va, hv); // right neighbour of column x+1 = next lane's column x
-      const float mxa = fmaxf(la, vb), mna = fminf(la, vb);
-      const float mxb = fmaxf(va, rb), mnb = fminf(va, rb);
+      const float mxa = fmax2(la, vb), mna = fmin2(la, vb);
+      const float mxb = fmax2(va, rb), mnb = fmin2(va, rb);
       cA[l][1] = va, cB[l][1] = vb;
       lxA[l][1] = mxa, lnA[l][1] = mna, lxB[l][1] = mxb, lnB[l][1] = mnb;
-      hmxA[l][2] = fmaxf(mxa, va), hmnA[l][2] = fminf(mna, va);
-      hmxB[l][2] = fmaxf(mxb, vb), hmnB[l][2] = fminf(mnb, vb);
+      hmxA[l][2] = fmax2(mxa, va), hmnA[l][2] = fmin2(mna, va);
+      hmxB[l][2] = fmax2(mxb, vb), hmnB[l][2] = fmin2(mnb, vb);
     }
     const int y = r - 1;
     if (y < y0 || y >= y1)
@@ -298,13 +326,13 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
       const float ca = cA[l][0];
       bool candA = intA && fabsf(ca) > pre;
       {
-        float nmx = fmaxf(lxA[l][0], fmaxf(hmxA[l][0], hmxA[l][2]));
-        float nmn = fminf(lnA[l][0], fminf(hmnA[l][0], hmnA[l][2]));
+        float nmx = fmax3(lxA[l][0], hmxA[l][0], hmxA[l][2]);
+        float nmn = fmin3(lnA[l][0], hmnA[l][0], hmnA[l][2]);
 #pragma unroll
         for (int k = 0; k < 3; k++)
         {
-          nmx = fmaxf(nmx, fmaxf(hmxA[l - 1][k], hmxA[l + 1][k]));
-          nmn = fminf(nmn, fminf(hmnA[l - 1][k], hmnA[l + 1][k]));
+          nmx = fmax3(nmx, hmxA[l - 1][k], hmxA[l + 1][k]);
+          nmn = fmin3(nmn, hmnA[l - 1][k], hmnA[l + 1][k]);
         }
         candA = candA && ((ca > nmx) || (ca < nmn));
       }
@@ -312,13 +340,13 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
       const float cb = cB[l][0];
       bool candB = intB && fabsf(cb) > pre;
       {
-        float nmx = fmaxf(lxB[l][0], fmaxf(hmxB[l][0], hmxB[l][2]));
-        float nmn = fminf(lnB[l][0], fminf(hmnB[l][0], hmnB[l][2]));
+        float nmx = fmax3(lxB[l][0], hmxB[l][0], hmxB[l][2]);
+        float nmn = fmin3(lnB[l][0], hmnB[l][0], hmnB[l][2]);
 #pragma unroll
         for (int k = 0; k < 3; k++)
         {
-          nmx = fmaxf(nmx, fmaxf(hmxB[l - 1][k], hmxB[l + 1][k]));
-          nmn = fminf(nmn, fminf(hmnB[l - 1][k], hmnB[l + 1][k]));
+          nmx = fmax3(nmx, hmxB[l - 1][k], hmxB[l + 1][k]);
+          nmn = fmin3(nmn, hmnB[l - 1][k], hmnB[l + 1][k]);
         }
         candB = candB && ((cb > nmx) || (cb < nmn));
       }
