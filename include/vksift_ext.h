@@ -38,6 +38,22 @@ extern "C"
   VKSIFT_EXPORT uint32_t vksift_ext_getMatchesNumberBatch(vksift_Instance instance, uint32_t pair);
   VKSIFT_EXPORT void vksift_ext_downloadMatchesBatch(vksift_Instance instance, uint32_t pair, vksift_Match_2NN *matches);
 
+  /* ---- GPU-side match filtering ------------------------------------------------------------------
+   * What callers of the reference do on the CPU after vksift_downloadMatches (src/examples/test_sift_match.cpp:90-107,
+   * src/perf/perf_common.cpp:123-169): match A->B and, with cross_check, B->A; keep a match iff it is mutual and passes
+   * Lowe's ratio test d1/d2 < ratio (in both directions when cross-checking). Only the survivors (16 B each, increasing
+   * idx_a) leave the GPU. Asynchronous like vksift_matchFeatures; the forward 2-NN records stay available through
+   * vksift_getMatchesNumber / vksift_downloadMatches (pair 0) and the ...Batch accessors. count <= batch capacity. */
+  typedef struct
+  {
+    uint32_t idx_a, idx_b;
+    float dist_a_b1, dist_a_b2;
+  } vksift_ext_FilteredMatch;
+  VKSIFT_EXPORT void vksift_ext_matchFeaturesFiltered(vksift_Instance instance, uint32_t count, const uint32_t *gpu_buffer_ids_A,
+                                                      const uint32_t *gpu_buffer_ids_B, float ratio, bool cross_check);
+  VKSIFT_EXPORT uint32_t vksift_ext_getFilteredMatchesNumber(vksift_Instance instance, uint32_t pair);
+  VKSIFT_EXPORT void vksift_ext_downloadFilteredMatches(vksift_Instance instance, uint32_t pair, vksift_ext_FilteredMatch *matches);
+
   /* Stage timings (milliseconds, HIP events on the instance stream) of the last detect call.
    * Enabled with vksift_ext_setProfiling(instance, true); disabled by default. Blocking. */
   typedef struct

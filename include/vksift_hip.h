@@ -165,6 +165,14 @@ extern "C"
   int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
                                 uint8_t *matches, vksift_hip_stream s);
 
+  /* Cross-check + Lowe ratio over forward (A->B) and optional reverse (B->A, rev != NULL) 2-NN records, the CPU loop of
+   * src/examples/test_sift_match.cpp:90-107 / src/perf/perf_common.cpp:123-169: keep record i iff d1/d2 < ratio and (with
+   * rev) rev[idx_b1].idx_b1 == i and its own d1/d2 < ratio. n_fwd[slot*n_stride + {0,1}] = {N_A, N_B} on the device.
+   * out: per slot 16-byte records {idx_a, idx_b, dist_a_b1, dist_a_b2} in increasing idx_a order, out_n[slot] their number.
+   * Strides in bytes. */
+  int vksift_hip_filter_matches(const uint8_t *fwd, uint64_t fwd_slot_stride, const uint8_t *rev, uint64_t rev_slot_stride, const uint32_t *n_fwd,
+                                uint32_t n_stride, float ratio, uint32_t nslots, uint8_t *out, uint64_t out_slot_stride, uint32_t *out_n, vksift_hip_stream s);
+
   /* Asynchronous (and batched) matching pipeline used by vksift_matchFeatures / vksift_ext_matchFeaturesBatch — no
    * host round trip for the feature counts. Slot i of a batch handles SIFT buffer buf_ids[i] (feats_base +
    * buf_ids[i]*buf_stride, counters found_base + buf_ids[i]*found_buf_stride); all buffers of one call share the

@@ -96,6 +96,8 @@ def lib():
         L.orc_descriptor.argtypes = [cfgp, C.c_void_p, C.c_uint32, C.c_void_p, u32p]
         L.orc_match_2nn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_match_2nn_desc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_filter_matches.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_filter_matches.restype = C.c_uint32
         for fn in ("orc_dm_expf", "orc_dm_exp2f", "orc_dm_sinf", "orc_dm_cosf"):
             getattr(L, fn).argtypes = [C.c_float]
             getattr(L, fn).restype = C.c_float
@@ -238,3 +240,16 @@ def match_2nn(a, b):
         assert a.dtype == np.uint8 and a.shape[1] == 128 and b.dtype == np.uint8 and b.shape[1] == 128
         lib().orc_match_2nn_desc(a.ctypes.data, len(a), b.ctypes.data, len(b), out.ctypes.data)
     return out
+
+
+def filter_matches(m12, m21=None, ratio=0.75, cross_check=True):
+    """Cross-check + Lowe ratio filter over 2-NN records (reference: test_sift_match.cpp:90-107). Returns (idx_a, idx_b)."""
+    m12 = np.ascontiguousarray(m12)
+    out_a = np.zeros(len(m12), np.uint32)
+    out_b = np.zeros(len(m12), np.uint32)
+    if cross_check:
+        m21 = np.ascontiguousarray(m21)
+        n = lib().orc_filter_matches(m12.ctypes.data, len(m12), m21.ctypes.data, len(m21), ratio, 1, out_a.ctypes.data, out_b.ctypes.data)
+    else:
+        n = lib().orc_filter_matches(m12.ctypes.data, len(m12), None, 0, ratio, 0, out_a.ctypes.data, out_b.ctypes.data)
+    return out_a[:n], out_b[:n]

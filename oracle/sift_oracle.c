@@ -823,6 +823,33 @@ void orc_match_2nn(const orc_Feature *a, uint32_t na, const orc_Feature *b, uint
 }
 void orc_match_2nn_desc(const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb, orc_Match *out) { match_rows(a, 128, na, b, 128, nb, out); }
 
+/* Match filtering as every caller of the reference does it on the CPU after vksift_downloadMatches:
+ * src/examples/test_sift_match.cpp:90-107 and src/perf/perf_common.cpp:123-169 (cross-check: the nearest neighbour of
+ * a's nearest neighbour must be a; Lowe ratio d1/d2 < ratio in both directions), perf_common.cpp:151-163 without
+ * cross-check (ratio test of the forward match only). Output pairs in increasing idx_a order; returns their number. */
+uint32_t orc_filter_matches(const orc_Match *m12, uint32_t n12, const orc_Match *m21, uint32_t n21, float ratio, int cross_check, uint32_t *out_a,
+                            uint32_t *out_b)
+{
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < n12; i++)
+  {
+    const uint32_t j = m12[i].idx_b1;
+    if (cross_check)
+    {
+      if (j >= n21 || m21[j].idx_b1 != i)
+        continue;
+    }
+    if (!((m12[i].dist_a_b1 / m12[i].dist_a_b2) < ratio))
+      continue;
+    if (cross_check && !((m21[j].dist_a_b1 / m21[j].dist_a_b2) < ratio))
+      continue;
+    out_a[n] = m12[i].idx_a;
+    out_b[n] = j;
+    n++;
+  }
+  return n;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* detmath.h entry points exported for tests/test_detmath.py                                   */
 /* ------------------------------------------------------------------------------------------- */

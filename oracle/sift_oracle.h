@@ -104,6 +104,9 @@ extern "C"
   void orc_match_2nn(const orc_Feature *a, uint32_t na, const orc_Feature *b, uint32_t nb, orc_Match *out);
   /* same on bare 128-byte descriptor rows */
   void orc_match_2nn_desc(const uint8_t *a, uint32_t na, const uint8_t *b, uint32_t nb, orc_Match *out);
+  /* cross-check + Lowe ratio filter (test_sift_match.cpp:90-107, perf_common.cpp:123-169) */
+  uint32_t orc_filter_matches(const orc_Match *m12, uint32_t n12, const orc_Match *m21, uint32_t n21, float ratio, int cross_check, uint32_t *out_a,
+                              uint32_t *out_b);
 
   /* detmath.h functions, exported for unit tests */
   float orc_dm_expf(float x);

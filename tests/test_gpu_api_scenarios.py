@@ -257,3 +257,71 @@ def test_batched_match_equals_single_calls(vk, oracle):
             assert np.array_equal(m["idx_b1"], ref["idx_b1"]) and np.array_equal(m["idx_b2"], ref["idx_b2"]), i
         with pytest.raises(vk.VksiftError):
             inst.matchFeaturesBatch([0] * 5, [1] * 5)             # more pairs than the batch capacity
+
+
+def _np_filter(m12, m21, ratio, cross):
+    """independent numpy statement of the CPU loop of the reference's examples (test_sift_match.cpp:90-107)"""
+    keep = []
+    for i in range(len(m12)):
+        j = int(m12["idx_b1"][i])
+        if cross and not (j < len(m21) and int(m21["idx_b1"][j]) == i):
+            continue
+        if not (np.float32(m12["dist_a_b1"][i]) / np.float32(m12["dist_a_b2"][i]) < np.float32(ratio)):
+            continue
+        if cross and not (np.float32(m21["dist_a_b1"][j]) / np.float32(m21["dist_a_b2"][j]) < np.float32(ratio)):
+            continue
+        keep.append((int(m12["idx_a"][i]), j))
+    return np.array(keep, dtype=np.uint32).reshape(-1, 2)
+
+
+@pytest.mark.parametrize("cross,ratio", [(True, 0.75), (False, 0.75), (True, 0.9)])
+def test_filtered_matching_equals_cpu_filter(vk, oracle, cross, ratio):
+    """vksift_ext_matchFeaturesFiltered == 2x vksift_matchFeatures + the reference examples' CPU filter"""
+    rng = np.random.default_rng(5)
+    a = vk.gen_synthetic_descriptors(71, 1500)
+    b = vk.gen_synthetic_descriptors(72, 1300)
+    # plant true correspondences (noisy copies) so that the ratio test has survivors, plus exact duplicates (zero distances)
+    idx = rng.permutation(1300)[:600]
+    noisy = a[:600].astype(np.int32) + rng.integers(-6, 7, (600, 128))
+    b[idx] = np.clip(noisy, 0, 255).astype(np.uint8)
+    b[idx[:5]] = a[:5]
+    b[7] = b[3]
+    fa = np.zeros(len(a), vk.FEATURE_DTYPE)
+    fb = np.zeros(len(b), vk.FEATURE_DTYPE)
+    fa["descriptor"] = a
+    fb["descriptor"] = b
+    with vk.Instance(vk.default_config()) as inst:
+        inst.uploadFeatures(fa, 0)
+        inst.uploadFeatures(fb, 1)
+        inst.matchFeaturesFiltered([0], [1], ratio, cross)
+        got = inst.downloadFilteredMatches(0)
+        fwd = inst.downloadMatches()              # the forward 2-NN records stay available
+        inst.matchFeatures(1, 0)
+        rev = inst.downloadMatches()
+    m12 = oracle.match_2nn(a, b)
+    m21 = oracle.match_2nn(b, a)
+    for name in ("idx_a", "idx_b1", "idx_b2"):
+        assert np.array_equal(fwd[name], m12[name]) and np.array_equal(rev[name], m21[name])
+    ra, rb = oracle.filter_matches(m12, m21, ratio, cross)
+    ref2 = _np_filter(m12, m21, ratio, cross)
+    assert np.array_equal(np.stack([ra, rb], 1).reshape(-1, 2), ref2)      # oracle == independent restatement
+    assert len(got) == len(ra) and len(ra) > 100
+    assert np.array_equal(got["idx_a"], ra) and np.array_equal(got["idx_b"], rb)
+    assert np.array_equal(got["dist_a_b1"].view(np.uint32), m12["dist_a_b1"][ra].view(np.uint32))
+    assert np.array_equal(got["dist_a_b2"].view(np.uint32), m12["dist_a_b2"][ra].view(np.uint32))
+
+
+def test_filtered_matching_batch_after_detection(vk, oracle):
+    """batched filtered matching straight after a batched detection (device-side counts), frame i against frame i+1"""
+    imgs = [vk.gen_synthetic_image(200 + i, 320, 240) for i in range(3)]
+    cfg = vk.default_config(sift_buffer_count=3)
+    with vk.Instance(cfg, batch_capacity=3) as inst:
+        inst.detectFeaturesBatch(imgs, 0)
+        inst.matchFeaturesFiltered([0, 1], [1, 2], 0.8, True)
+        got = [inst.downloadFilteredMatches(p) for p in range(2)]
+        feats = [inst.downloadFeatures(i) for i in range(3)]
+    for p, (ia, ib) in enumerate([(0, 1), (1, 2)]):
+        m12 = oracle.match_2nn(feats[ia], feats[ib])
+        m21 = oracle.match_2nn(feats[ib], feats[ia])
+        ra, rb = oracle.filter_matches(m12, m21, 0.8, True)
+        assert np.array_equal(got[p]["idx_a"], ra) and np.array_equal(got[p]["idx_b"], rb)

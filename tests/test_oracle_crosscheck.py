@@ -102,3 +102,33 @@ def test_extrema_are_strict_26_neighbour_extrema(oracle):
         assert np.all((kps["scale_x"] >= 0) & (kps["scale_x"] < w) & (kps["scale_y"] >= 0) & (kps["scale_y"] < h))
         assert np.all(np.abs(kps["intensity"]) > thr)
     assert total > 5
+
+
+def test_filter_matches_against_numpy_restatement(oracle):
+    """cross-check + Lowe ratio (reference: src/examples/test_sift_match.cpp:90-107) vs an independent numpy loop"""
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 256, (300, 128), dtype=np.uint8)
+    b = rng.integers(0, 256, (260, 128), dtype=np.uint8)
+    idx = rng.permutation(260)[:120]
+    b[idx] = np.clip(a[:120].astype(np.int32) + rng.integers(-5, 6, (120, 128)), 0, 255).astype(np.uint8)
+    b[idx[:3]] = a[:3]                      # zero distances: 0/d2 passes, 0/0 (NaN) must be rejected
+    b[idx[3]] = b[idx[4]] = a[3]            # d1 == d2 == 0 for a[3]
+    m12 = oracle.match_2nn(a, b)
+    m21 = oracle.match_2nn(b, a)
+    for cross in (True, False):
+        for ratio in (0.6, 0.75, 1.5):
+            ra, rb = oracle.filter_matches(m12, m21, ratio, cross)
+            keep = []
+            for i in range(len(m12)):
+                j = int(m12["idx_b1"][i])
+                ok = np.float32(m12["dist_a_b1"][i]) / np.float32(m12["dist_a_b2"][i]) < np.float32(ratio) if m12["dist_a_b2"][i] != 0 or m12["dist_a_b1"][i] != 0 else False
+                if cross:
+                    ok = ok and int(m21["idx_b1"][j]) == i
+                    if ok:
+                        d1, d2 = np.float32(m21["dist_a_b1"][j]), np.float32(m21["dist_a_b2"][j])
+                        ok = (d1 / d2 < np.float32(ratio)) if (d1 != 0 or d2 != 0) else False
+                if ok:
+                    keep.append((i, j))
+            keep = np.array(keep, np.uint32).reshape(-1, 2)
+            assert np.array_equal(ra, keep[:, 0]) and np.array_equal(rb, keep[:, 1]), (cross, ratio)
+    assert 3 not in set(oracle.filter_matches(m12, m21, 0.75, False)[0])     # 0/0 is not < ratio

@@ -69,7 +69,8 @@ FEATURE_DTYPE = np.dtype(
     ]
 )
 MATCH_DTYPE = np.dtype([("idx_a", "<u4"), ("idx_b1", "<u4"), ("idx_b2", "<u4"), ("dist_a_b1", "<f4"), ("dist_a_b2", "<f4")])
-assert FEATURE_DTYPE.itemsize == 164 and MATCH_DTYPE.itemsize == 20
+FILTERED_MATCH_DTYPE = np.dtype([("idx_a", "<u4"), ("idx_b", "<u4"), ("dist_a_b1", "<f4"), ("dist_a_b2", "<f4")])
+assert FEATURE_DTYPE.itemsize == 164 and MATCH_DTYPE.itemsize == 20 and FILTERED_MATCH_DTYPE.itemsize == 16
 
 _lib = None
 
@@ -117,6 +118,10 @@ def lib():
     L.vksift_ext_getMatchesNumberBatch.argtypes = [inst, u32]
     L.vksift_ext_getMatchesNumberBatch.restype = u32
     L.vksift_ext_downloadMatchesBatch.argtypes = [inst, u32, C.c_void_p]
+    L.vksift_ext_matchFeaturesFiltered.argtypes = [inst, u32, C.POINTER(u32), C.POINTER(u32), C.c_float, C.c_bool]
+    L.vksift_ext_getFilteredMatchesNumber.argtypes = [inst, u32]
+    L.vksift_ext_getFilteredMatchesNumber.restype = u32
+    L.vksift_ext_downloadFilteredMatches.argtypes = [inst, u32, C.c_void_p]
     L.vksift_ext_setProfiling.argtypes = [inst, C.c_bool]
     L.vksift_ext_getDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings)]
     L.vksift_ext_getAccumulatedDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.POINTER(u32), C.c_bool]
@@ -273,6 +278,24 @@ class Instance:
         b = (C.c_uint32 * n)(*bufs_b)
         lib().vksift_ext_matchFeaturesBatch(self._h, n, a, b)
         _check_pending()
+
+    def matchFeaturesFiltered(self, bufs_a, bufs_b, ratio=0.75, cross_check=True):
+        """2-NN A->B (+ B->A), cross-check and Lowe ratio on the GPU (vksift_ext_matchFeaturesFiltered)."""
+        n = len(bufs_a)
+        assert n == len(bufs_b)
+        a = (C.c_uint32 * n)(*bufs_a)
+        b = (C.c_uint32 * n)(*bufs_b)
+        lib().vksift_ext_matchFeaturesFiltered(self._h, n, a, b, ratio, cross_check)
+        _check_pending()
+
+    def downloadFilteredMatches(self, pair=0):
+        n = lib().vksift_ext_getFilteredMatchesNumber(self._h, pair)
+        _check_pending()
+        out = np.zeros(n, FILTERED_MATCH_DTYPE)
+        if n:
+            lib().vksift_ext_downloadFilteredMatches(self._h, pair, out.ctypes.data)
+            _check_pending()
+        return out
 
     def getMatchesNumberBatch(self, pair):
         n = lib().vksift_ext_getMatchesNumberBatch(self._h, pair)

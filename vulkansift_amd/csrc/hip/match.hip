@@ -677,6 +677,73 @@ __global__ void __launch_bounds__(64) k_match_redo(const uint32_t *__restrict__ 
   }
 }
 
+// Cross-check + Lowe-ratio filter over the 2-NN records of a forward (A -> B) and, optionally, a reverse (B -> A)
+// matching — what every caller of the reference runs on the CPU after vksift_downloadMatches
+// (src/examples/test_sift_match.cpp:90-107, src/perf/perf_common.cpp:123-169). One 1024-thread workgroup per pair keeps
+// the survivors in increasing idx_a order (ballot + scan compaction, no atomics), 16 B per survivor.
+__global__ void __launch_bounds__(1024) k_filter_matches(const uint32_t *__restrict__ fwd, uint64_t fwd_slot_stride, const uint32_t *__restrict__ rev,
+                                                         uint64_t rev_slot_stride, const uint32_t *__restrict__ n_fwd, uint32_t n_stride, float ratio,
+                                                         uint32_t *__restrict__ out, uint64_t out_slot_stride, uint32_t *__restrict__ out_n)
+{
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const uint32_t slot = blockIdx.x;
+  fwd += (size_t)slot * fwd_slot_stride;
+  if (rev)
+    rev += (size_t)slot * rev_slot_stride;
+  out += (size_t)slot * out_slot_stride;
+  const uint32_t na = n_fwd[(size_t)slot * n_stride], nb = n_fwd[(size_t)slot * n_stride + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0)
+    carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < na; base += 1024)
+  {
+    const uint32_t i = base + threadIdx.x;
+    bool keep = false;
+    uint32_t j = 0, d1 = 0, d2 = 0;
+    if (i < na)
+    {
+      const uint32_t *m = fwd + (size_t)i * 5;
+      j = m[1], d1 = m[3], d2 = m[4];
+      keep = (__uint_as_float(d1) / __uint_as_float(d2)) < ratio;
+      if (rev)
+      {
+        keep = keep && j < nb;
+        if (keep)
+        {
+          const uint32_t *r = rev + (size_t)j * 5;
+          keep = r[1] == i && (__uint_as_float(r[3]) / __uint_as_float(r[4])) < ratio;
+        }
+      }
+    }
+    const unsigned long long bal = __ballot(keep);
+    const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0)
+      wave_tot[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+    for (int wv = 0; wv < 16; wv++)
+    {
+      if (wv < wave)
+        wave_base += wave_tot[wv];
+      total += wave_tot[wv];
+    }
+    const uint32_t carry = carry_s;
+    if (keep)
+    {
+      uint32_t *o = out + (size_t)(carry + wave_base + rank) * 4;
+      o[0] = fwd[(size_t)i * 5], o[1] = j, o[2] = d1, o[3] = d2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      carry_s = carry + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    out_n[slot] = carry_s;
+}
+
 } // namespace
 
 extern "C"
@@ -806,6 +873,16 @@ extern "C"
     if (rblocks > 64u)
       rblocks = 64u;
     hipLaunchKernelGGL(k_match_redo, dim3(rblocks, nslots), dim3(64), 0, hs, da, 0u, 0u, db, 0u, (uint32_t *)matches, (const uint32_t *)redo, n_dev, ss);
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_filter_matches(const uint8_t *fwd, uint64_t fwd_slot_stride, const uint8_t *rev, uint64_t rev_slot_stride, const uint32_t *n_fwd,
+                                uint32_t n_stride, float ratio, uint32_t nslots, uint8_t *out, uint64_t out_slot_stride, uint32_t *out_n, vksift_hip_stream s)
+  {
+    if (nslots < 1)
+      return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_filter_matches, dim3(nslots), dim3(1024), 0, (hipStream_t)s, (const uint32_t *)fwd, fwd_slot_stride / 4, (const uint32_t *)rev,
+                       rev_slot_stride / 4, n_fwd, n_stride, ratio, (uint32_t *)out, out_slot_stride / 4, out_n);
     return (int)hipGetLastError();
   }
 }

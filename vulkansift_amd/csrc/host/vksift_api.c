@@ -61,6 +61,13 @@ typedef struct
 } PyrLayout;
 
 /* HIP-event stage timings of one detection (vksift_ext_setProfiling) */
+/* device scratch of one set of matching slots (slot i serves pair i of a batched call) */
+typedef struct
+{
+  uint8_t *desc_a, *desc_b, *matches;
+  uint32_t *norms, *match_n;
+} MatchScratch;
+
 typedef struct
 {
   vksift_hip_event ev_t[8];  /* instance stream: start, upload end, pyramid end, extrema end, orientation end, descriptor end, call end */
@@ -113,6 +120,12 @@ struct vksift_Instance_T
   uint32_t *d_norms;
   uint32_t *d_match_partial; /* partial top-2 lists of the B-chunked large-N matcher (NULL when max_nb <= 32768) */
   uint32_t *d_match_n, *h_match_n; /* per match slot: {N_A, N_B, spare, spare} of the last matching pipeline */
+  /* filtered matching (vksift_ext_matchFeaturesFiltered): scratch of the reverse (B->A) matching and the survivors; allocated on first use */
+  MatchScratch rev;
+  uint8_t *d_filtered;
+  uint32_t *d_filtered_n, *h_filtered_n;
+  uint64_t filtered_slot_stride;
+  uint32_t filtered_slots_used;
   uint64_t desc_slot_stride, match_slot_stride; /* bytes */
   uint64_t norm_slot_stride;                    /* u32 elements */
   uint32_t match_slots_used;
@@ -640,6 +653,14 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_free(inst->d_norms);
   vksift_hip_free(inst->d_match_n);
   vksift_hip_free(inst->d_match_partial);
+  vksift_hip_free(inst->rev.desc_a);
+  vksift_hip_free(inst->rev.desc_b);
+  vksift_hip_free(inst->rev.matches);
+  vksift_hip_free(inst->rev.norms);
+  vksift_hip_free(inst->rev.match_n);
+  vksift_hip_free(inst->d_filtered);
+  vksift_hip_free(inst->d_filtered_n);
+  vksift_hip_host_free(inst->h_filtered_n);
   vksift_hip_host_free(inst->h_match_n);
   vksift_hip_host_free(inst->h_matches);
   free(inst->bufs);
@@ -1307,14 +1328,14 @@ static bool same_layout(const BufferInfo *x, const BufferInfo *y)
  * The reference physically packs the octave sections (pack_BufferMemory, sift_memory.c:957-1047) after reading the
  * counts on the host; here the gather kernel reads the counters in HBM and walks the sections in the same order, so
  * nothing waits on the host. Returns the launch bound on the row count through *max_rows_out. */
-static int gather_buffers(vksift_Instance inst, const uint32_t *ids, uint32_t count, uint32_t first_slot, bool side_b, uint8_t *d_desc_base,
+static int gather_buffers(vksift_Instance inst, const MatchScratch *ms, const uint32_t *ids, uint32_t count, uint32_t first_slot, bool side_b, uint8_t *d_desc_base,
                           uint32_t n_index, uint32_t pad_rows_to, uint32_t *max_rows_out)
 {
   const BufferInfo *b = &inst->bufs[ids[0]];
   const uint32_t cap = inst->cfg.max_nb_sift_per_buffer;
   uint8_t *d_desc = d_desc_base + (uint64_t)first_slot * inst->desc_slot_stride;
-  uint32_t *d_norm = inst->d_norms + (uint64_t)first_slot * inst->norm_slot_stride + (side_b ? cap + 32u : 0u);
-  uint32_t *d_n = inst->d_match_n + (size_t)first_slot * 4 + n_index;
+  uint32_t *d_norm = ms->norms + (uint64_t)first_slot * inst->norm_slot_stride + (side_b ? cap + 32u : 0u);
+  uint32_t *d_n = ms->match_n + (size_t)first_slot * 4 + n_index;
   uint32_t max_rows = 0;
   int e;
   if (b->nb_sections == 0)
@@ -1355,26 +1376,52 @@ static int gather_buffers(vksift_Instance inst, const uint32_t *ids, uint32_t co
   return e;
 }
 
-static int match_slots(vksift_Instance inst, const uint32_t *ids_a, const uint32_t *ids_b, uint32_t count, uint32_t first_slot)
+static MatchScratch fwd_scratch(vksift_Instance inst)
+{
+  MatchScratch ms = {inst->d_desc_a, inst->d_desc_b, inst->d_matches, inst->d_norms, inst->d_match_n};
+  return ms;
+}
+
+static int match_slots(vksift_Instance inst, const MatchScratch *ms, const uint32_t *ids_a, const uint32_t *ids_b, uint32_t count, uint32_t first_slot)
 {
   const uint32_t cap = inst->cfg.max_nb_sift_per_buffer;
   uint32_t max_na = 0, max_nb = 0;
-  int e = gather_buffers(inst, ids_a, count, first_slot, false, inst->d_desc_a, 0, 0u, &max_na);
+  int e = gather_buffers(inst, ms, ids_a, count, first_slot, false, ms->desc_a, 0, 0u, &max_na);
   if (e)
     return e;
   /* Get2NearestNeighbors.comp:66-67 reads b[0] and b[1] unconditionally (stale memory in the reference when B holds
    * fewer than two features); here the missing rows are defined as all-zero descriptors. */
-  e = gather_buffers(inst, ids_b, count, first_slot, true, inst->d_desc_b, 1, 2u, &max_nb);
+  e = gather_buffers(inst, ms, ids_b, count, first_slot, true, ms->desc_b, 1, 2u, &max_nb);
   if (e)
     return e;
-  const uint32_t *norm_a = inst->d_norms + (uint64_t)first_slot * inst->norm_slot_stride;
-  return vksift_hip_match_2nn_async(inst->d_desc_a + (uint64_t)first_slot * inst->desc_slot_stride, norm_a, max_na,
-                                    inst->d_desc_b + (uint64_t)first_slot * inst->desc_slot_stride, norm_a + cap + 32u,
-                                    (uint32_t *)norm_a + 2u * cap + 64u, inst->d_match_n + (size_t)first_slot * 4, inst->d_matches + (uint64_t)first_slot * inst->match_slot_stride, count,
+  const uint32_t *norm_a = ms->norms + (uint64_t)first_slot * inst->norm_slot_stride;
+  return vksift_hip_match_2nn_async(ms->desc_a + (uint64_t)first_slot * inst->desc_slot_stride, norm_a, max_na,
+                                    ms->desc_b + (uint64_t)first_slot * inst->desc_slot_stride, norm_a + cap + 32u, (uint32_t *)norm_a + 2u * cap + 64u,
+                                    ms->match_n + (size_t)first_slot * 4, ms->matches + (uint64_t)first_slot * inst->match_slot_stride, count,
                                     inst->desc_slot_stride, inst->norm_slot_stride, inst->match_slot_stride, 4, inst->d_match_partial, inst->stream);
 }
 
-static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32_t *ids_b, uint32_t count, const char *fn)
+/* reverse-matching scratch + survivor lists of vksift_ext_matchFeaturesFiltered, allocated on first use */
+static bool ensure_filter_scratch(vksift_Instance inst)
+{
+  if (inst->d_filtered)
+    return true;
+  const uint32_t bc = inst->batch_cap;
+  inst->filtered_slot_stride = (((uint64_t)inst->cfg.max_nb_sift_per_buffer * 16u) + 255u) & ~(uint64_t)255u;
+  bool ok = true;
+  ok = ok && (inst->rev.desc_a = vksift_hip_malloc(inst->desc_slot_stride * bc)) != NULL;
+  ok = ok && (inst->rev.desc_b = vksift_hip_malloc(inst->desc_slot_stride * bc)) != NULL;
+  ok = ok && (inst->rev.matches = vksift_hip_malloc(inst->match_slot_stride * bc)) != NULL;
+  ok = ok && (inst->rev.norms = vksift_hip_malloc(sizeof(uint32_t) * inst->norm_slot_stride * bc)) != NULL;
+  ok = ok && (inst->rev.match_n = vksift_hip_malloc(sizeof(uint32_t) * 4 * bc)) != NULL;
+  ok = ok && (inst->d_filtered_n = vksift_hip_malloc(sizeof(uint32_t) * bc)) != NULL;
+  ok = ok && (inst->h_filtered_n = vksift_hip_host_malloc(sizeof(uint32_t) * bc)) != NULL;
+  ok = ok && (inst->d_filtered = vksift_hip_malloc(inst->filtered_slot_stride * bc)) != NULL;
+  return ok;
+}
+
+static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32_t *ids_b, uint32_t count, const char *fn, bool filter, float ratio,
+                       bool cross_check)
 {
   bool valid = count >= 1 && count <= inst->batch_cap && count <= 64;
   for (uint32_t i = 0; valid && i < count; i++)
@@ -1394,12 +1441,36 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
   bool uniform = true;
   for (uint32_t i = 1; i < count && uniform; i++)
     uniform = same_layout(&inst->bufs[ids_a[0]], &inst->bufs[ids_a[i]]) && same_layout(&inst->bufs[ids_b[0]], &inst->bufs[ids_b[i]]);
+  const MatchScratch fwd = fwd_scratch(inst);
   if (uniform)
-    HIP_CHECK(match_slots(inst, ids_a, ids_b, count, 0), "2-NN matching");
+    HIP_CHECK(match_slots(inst, &fwd, ids_a, ids_b, count, 0), "2-NN matching");
   else
     for (uint32_t i = 0; i < count; i++)
-      HIP_CHECK(match_slots(inst, ids_a + i, ids_b + i, 1, i), "2-NN matching");
+      HIP_CHECK(match_slots(inst, &fwd, ids_a + i, ids_b + i, 1, i), "2-NN matching");
   HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n, inst->d_match_n, sizeof(uint32_t) * 4 * count, inst->stream), "match count read-back");
+  inst->filtered_slots_used = 0;
+  if (filter)
+  {
+    /* the reverse matching, then cross-check + ratio test on the device; only the survivors are read back */
+    if (!ensure_filter_scratch(inst))
+    {
+      logError(LOG_TAG, "%s error: out of device memory for the filtered-matching scratch.", fn);
+      goto gpu_error;
+    }
+    if (cross_check)
+    {
+      if (uniform)
+        HIP_CHECK(match_slots(inst, &inst->rev, ids_b, ids_a, count, 0), "reverse 2-NN matching");
+      else
+        for (uint32_t i = 0; i < count; i++)
+          HIP_CHECK(match_slots(inst, &inst->rev, ids_b + i, ids_a + i, 1, i), "reverse 2-NN matching");
+    }
+    HIP_CHECK(vksift_hip_filter_matches(inst->d_matches, inst->match_slot_stride, cross_check ? inst->rev.matches : NULL, inst->match_slot_stride,
+                                        inst->d_match_n, 4, ratio, count, inst->d_filtered, inst->filtered_slot_stride, inst->d_filtered_n, inst->stream),
+              "match filtering");
+    HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_filtered_n, inst->d_filtered_n, sizeof(uint32_t) * count, inst->stream), "filtered count read-back");
+    inst->filtered_slots_used = count;
+  }
   vksift_hip_range_pop();
   if (inst->profiling)
   {
@@ -1419,12 +1490,24 @@ gpu_error:
 
 void vksift_matchFeatures(vksift_Instance instance, uint32_t gpu_buffer_id_A, uint32_t gpu_buffer_id_B)
 {
-  match_impl(instance, &gpu_buffer_id_A, &gpu_buffer_id_B, 1, "vksift_matchFeatures()");
+  match_impl(instance, &gpu_buffer_id_A, &gpu_buffer_id_B, 1, "vksift_matchFeatures()", false, 0.f, false);
 }
 
 void vksift_ext_matchFeaturesBatch(vksift_Instance instance, uint32_t count, const uint32_t *gpu_buffer_ids_A, const uint32_t *gpu_buffer_ids_B)
 {
-  match_impl(instance, gpu_buffer_ids_A, gpu_buffer_ids_B, count, "vksift_ext_matchFeaturesBatch()");
+  match_impl(instance, gpu_buffer_ids_A, gpu_buffer_ids_B, count, "vksift_ext_matchFeaturesBatch()", false, 0.f, false);
+}
+
+void vksift_ext_matchFeaturesFiltered(vksift_Instance instance, uint32_t count, const uint32_t *gpu_buffer_ids_A, const uint32_t *gpu_buffer_ids_B, float ratio,
+                                      bool cross_check)
+{
+  if (!(ratio > 0.f))
+  {
+    logError(LOG_TAG, "vksift_ext_matchFeaturesFiltered() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  match_impl(instance, gpu_buffer_ids_A, gpu_buffer_ids_B, count, "vksift_ext_matchFeaturesFiltered()", true, ratio, cross_check);
 }
 
 static void wait_match(vksift_Instance inst)
@@ -1481,6 +1564,42 @@ gpu_error:
 }
 
 void vksift_downloadMatches(vksift_Instance instance, vksift_Match_2NN *matches) { download_matches(instance, 0, matches, "vksift_downloadMatches()"); }
+
+uint32_t vksift_ext_getFilteredMatchesNumber(vksift_Instance instance, uint32_t pair)
+{
+  wait_match(instance);
+  if (pair >= instance->filtered_slots_used)
+  {
+    logError(LOG_TAG, "vksift_ext_getFilteredMatchesNumber() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return 0;
+  }
+  return instance->h_filtered_n[pair];
+}
+
+void vksift_ext_downloadFilteredMatches(vksift_Instance instance, uint32_t pair, vksift_ext_FilteredMatch *matches)
+{
+  vksift_Instance inst = instance;
+  wait_match(inst);
+  if (pair >= inst->filtered_slots_used)
+  {
+    logError(LOG_TAG, "vksift_ext_downloadFilteredMatches() error: invalid input.");
+    inst->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  const uint32_t n = inst->h_filtered_n[pair];
+  if (n > 0)
+  {
+    HIP_CHECK(vksift_hip_memcpy_d2h(matches, inst->d_filtered + (uint64_t)pair * inst->filtered_slot_stride, (size_t)n * sizeof(vksift_ext_FilteredMatch),
+                                    inst->stream),
+              "filtered match read-back");
+    HIP_CHECK(vksift_hip_stream_sync(inst->stream), "filtered match read-back");
+  }
+  return;
+gpu_error:
+  logError(LOG_TAG, "vksift_ext_downloadFilteredMatches() error when downloading the filtered matches from GPU memory.");
+  inst->error_cb(VKSIFT_VULKAN_ERROR);
+}
 
 void vksift_ext_downloadMatchesBatch(vksift_Instance instance, uint32_t pair, vksift_Match_2NN *matches)
 {
@@ -1642,7 +1761,8 @@ uint32_t vksift_ext_exportDescriptorsDevice(vksift_Instance instance, uint32_t g
   HIP_CHECK(wait_all(inst), "stream synchronisation");
   {
     /* gather into slot 0's A scratch (norms are a by-product), then copy the rows out */
-    HIP_CHECK(gather_buffers(inst, &gpu_buffer_id, 1, 0, false, inst->d_desc_a, 2, 0u, &max_rows), "descriptor gather");
+    const MatchScratch fwd = fwd_scratch(inst);
+    HIP_CHECK(gather_buffers(inst, &fwd, &gpu_buffer_id, 1, 0, false, inst->d_desc_a, 2, 0u, &max_rows), "descriptor gather");
     HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n + 2, inst->d_match_n + 2, sizeof(uint32_t), inst->stream), "descriptor gather");
     HIP_CHECK(vksift_hip_stream_sync(inst->stream), "descriptor gather");
     n = inst->h_match_n[2];
