@@ -31,6 +31,7 @@ extern "C"
 #define VKSIFT_HIP_MAX_ORI 18  /* a 36-bin circular histogram has at most 18 strict local maxima */
 
   typedef void *vksift_hip_stream;
+  typedef void *vksift_hip_graph; /* an instantiated hipGraph (hipGraphExec_t) */
   typedef void *vksift_hip_event;
 
   /* ------------------------------------------------------------------ runtime (replaces the vkenv directory) */
@@ -54,6 +55,12 @@ extern "C"
   int vksift_hip_event_busy(vksift_hip_event e);
   float vksift_hip_event_elapsed_ms(vksift_hip_event a, vksift_hip_event b);
   int vksift_hip_stream_wait_event(vksift_hip_stream s, vksift_hip_event e);
+  /* hipGraph capture of everything enqueued to s (and to streams forked from it through events) between begin and end;
+   * the launch-bound single-image pipeline (~100 short kernels) is replayed with one vksift_hip_graph_launch. */
+  int vksift_hip_capture_begin(vksift_hip_stream s);
+  int vksift_hip_capture_end(vksift_hip_stream s, vksift_hip_graph *out);
+  int vksift_hip_graph_launch(vksift_hip_graph g, vksift_hip_stream s);
+  void vksift_hip_graph_destroy(vksift_hip_graph g);
   int vksift_hip_memcpy_h2d(void *dst, const void *src, size_t n, vksift_hip_stream s);
   int vksift_hip_memcpy_d2h(void *dst, const void *src, size_t n, vksift_hip_stream s);
   int vksift_hip_memcpy_d2d(void *dst, const void *src, size_t n, vksift_hip_stream s);

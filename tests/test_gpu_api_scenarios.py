@@ -325,3 +325,23 @@ def test_filtered_matching_batch_after_detection(vk, oracle):
         m21 = oracle.match_2nn(feats[ib], feats[ia])
         ra, rb = oracle.filter_matches(m12, m21, 0.8, True)
         assert np.array_equal(got[p]["idx_a"], ra) and np.array_equal(got[p]["idx_b"], rb)
+
+
+def test_graph_replay_gives_identical_results(vk, monkeypatch):
+    """VKSIFT_GRAPH=1: the captured launch sequence is replayed for the second and third detection of the same shape"""
+    imgs = [vk.gen_synthetic_image(300 + i, 320, 240) for i in range(3)]
+    ref = []
+    with vk.Instance(vk.default_config()) as inst:
+        for im in imgs:
+            inst.detectFeatures(im, 0)
+            ref.append(inst.downloadFeatures(0))
+    monkeypatch.setenv("VKSIFT_GRAPH", "1")
+    with vk.Instance(vk.default_config()) as inst:
+        for im, r in zip(imgs, ref):
+            inst.detectFeatures(im, 0)            # 1st call captures, 2nd and 3rd replay (same buffer, same staging pointer)
+            f = inst.downloadFeatures(0)
+            assert f.tobytes() == r.tobytes()
+        inst.detectFeatures(imgs[0], 1)           # another buffer: a second graph
+        assert inst.downloadFeatures(1).tobytes() == ref[0].tobytes()
+        top = inst.downloadScaleSpaceImage(0, 5)  # lazily re-created last scale after a replay
+        assert np.isfinite(top).all() and top.std() > 0

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Single-image latency, the reference's own published measurement (src/perf/perf_runtime.cpp:63-81 through
+src/perf/wrappers/vulkansift_wrapper.cpp:30-33): mean wall-clock of
+    vksift_detectFeatures + vksift_getFeaturesNumber + vksift_downloadFeatures
+for one host image, default config, 10 warm-up + 100 measured runs (docs/Performances.md:22,43).
+Reference figures (other hardware): 640x480 ~4.5-7 ms, 1536x1024 10.6-16.5 ms, 3456x2304 46-73 ms.
+usage: python tools/bench_latency.py [WxH ...]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(w, h, warm=10, runs=100):
+    from vulkansift_amd import api
+    api.lib().vksift_setLogLevel(api.VKSIFT_LOG_ERROR)
+    img = api.gen_synthetic_image(0xABC0 + w, w, h)
+    cfg = api.default_config(input_image_max_size=w * h)
+    with api.Instance(cfg) as inst:
+        n = 0
+        for i in range(warm + runs):
+            if i == warm:
+                t0 = time.perf_counter()
+            inst.detectFeatures(img, 0)
+            n = inst.getFeaturesNumber(0)
+            inst.downloadFeatures(0)
+        dt = (time.perf_counter() - t0) / runs
+    return {"image": f"{w}x{h}", "features": int(n), "latency_ms": dt * 1e3, "frames_per_s": 1.0 / dt}
+
+
+if __name__ == "__main__":
+    sizes = [a for a in sys.argv[1:] if "x" in a] or ["640x480", "1536x1024", "3456x2304"]
+    for sz in sizes:
+        w, h = map(int, sz.split("x"))
+        print(json.dumps(run(w, h)), flush=True)

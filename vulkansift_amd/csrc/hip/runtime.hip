@@ -133,6 +133,30 @@ extern "C"
   }
   int vksift_hip_stream_wait_event(vksift_hip_stream s, vksift_hip_event e) { return (int)hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0); }
 
+  /* ---- hipGraph capture of a launch sequence issued to `s` (and to the streams it forks through events) ---- */
+  int vksift_hip_capture_begin(vksift_hip_stream s) { return (int)hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeRelaxed); }
+  int vksift_hip_capture_end(vksift_hip_stream s, vksift_hip_graph *out)
+  {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    *out = nullptr;
+    hipError_t e = hipStreamEndCapture((hipStream_t)s, &g);
+    if (e != hipSuccess)
+      return (int)e;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess)
+      return (int)e;
+    *out = (vksift_hip_graph)ge;
+    return 0;
+  }
+  int vksift_hip_graph_launch(vksift_hip_graph g, vksift_hip_stream s) { return (int)hipGraphLaunch((hipGraphExec_t)g, (hipStream_t)s); }
+  void vksift_hip_graph_destroy(vksift_hip_graph g)
+  {
+    if (g)
+      (void)hipGraphExecDestroy((hipGraphExec_t)g);
+  }
+
   int vksift_hip_memcpy_h2d(void *dst, const void *src, size_t n, vksift_hip_stream s)
   {
     return n ? (int)hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, (hipStream_t)s) : 0;
