@@ -22,7 +22,8 @@ Extra objects on the JSON line:
                the timed region; the coarser octaves run concurrently on their own streams and share the HBM
                bandwidth, so the figure is conservative. "traffic" is the PMC-measured HBM traffic per launch from a
                separate rocprofv3 --pmc run (profiles/*pmc*.json), if present
-  cpu_baseline the CPU oracle (a scalar C port of the same algorithm) timed on a bounded sample, rank 0, N=1
+  cpu_baseline the CPU oracle (a scalar C port of the same algorithm) timed on a bounded sample (32 frames on 16 host
+               threads, ~25 core-seconds), rank 0, N=1
 """
 import argparse
 import json
@@ -49,30 +50,43 @@ def parse_args():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-match", action="store_true", help="detect only (BASELINE config 3 style runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the workload given to the CPU oracle")
+    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the workload given to the CPU oracle")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="worker threads of the CPU baseline (one frame per thread at a time)")
     return ap.parse_args()
 
 
-def cpu_baseline(frames, do_match):
-    """Time the oracle (scalar C port, 1 thread) on a bounded sample of the same workload."""
+def cpu_baseline(frames, do_match, threads):
+    """Time the oracle (scalar C port of the same algorithm) on a bounded sample of the same workload: one frame per
+    worker thread at a time (the ctypes calls release the GIL, so the threads run on separate host cores). The first
+    frame is also timed alone for the single-thread rate."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
 
     cfg = O.default_config(math_mode=0)
-    t0 = time.perf_counter()
-    nfeat = 0
-    for img in frames:
+
+    def one(img):
         feats, _ = O.detect(cfg, img)
-        nfeat += len(feats)
         if do_match and len(feats) >= 2:
             O.match_2nn(feats, feats)
+        return len(feats)
+
+    t0 = time.perf_counter()
+    n0 = one(frames[0])
+    t_single = time.perf_counter() - t0
+    threads = max(1, min(threads, len(frames)))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        nfeat = list(ex.map(one, frames))
     dt = time.perf_counter() - t0
     return {
         "value": len(frames) / dt,
         "unit": "frames/s",
-        "cores": 1,
+        "cores": threads,
         "kind": "port",
+        "single_thread_value": 1.0 / t_single,
         "sample": f"{len(frames)} of the benchmark's {frames[0].shape[1]}x{frames[0].shape[0]} frames, detect"
-                  + ("+self-match" if do_match else "") + f", {nfeat // max(len(frames), 1)} features/frame, {dt:.1f} s wall, "
+                  + ("+self-match" if do_match else "") + f", {int(np.mean(nfeat))} features/frame, {threads} worker threads x "
+                  + f"{len(frames) // threads} frame(s) each, {dt:.1f} s wall ({dt * threads:.0f} core-seconds); one frame alone {t_single:.2f} s; "
                   + f"host has {os.cpu_count()} logical cores",
     }
 
@@ -198,7 +212,7 @@ def main():
             "last_match_ms": match_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames[: max(1, min(args.cpu_frames, B))], do_match)
+            out["cpu_baseline"] = cpu_baseline(frames[: max(1, min(args.cpu_frames, B))], do_match, args.cpu_threads)
         print(json.dumps(out), flush=True)
 
     if world > 1:
