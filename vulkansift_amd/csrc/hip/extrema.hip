@@ -7,7 +7,7 @@
 //   k_segment_scan   : exclusive prefix sum of popcount(mask) over segments in (scale, y, x) order
 //   k_cand_list      : one thread per segment writes its candidates' packed (x, y, s) at offset + rank
 //   k_refine_flags   : one thread per CANDIDATE (dense waves: no lane idles while a neighbour refines) -> accept flag
-//   k_cand_finalize  : per image: scan of the accept flags, accepted candidates recompute their record and store it
+//   k_chunk_offsets / k_cand_emit : two-level scan of the accept flags, accepted candidates recompute their record and store it
 //                      at their rank (clamped to the section capacity); the un-clamped count goes to found[]
 // The arithmetic of refine_texel() is kept operation-for-operation identical to
 // oracle/sift_oracle.c:extract_one (fp32, no contraction) so results are bit-exact.
@@ -372,114 +372,81 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
   }
 }
 
-// Exclusive scan of popcount(mask) over n segments; one 1024-thread block per image.
+// Exclusive scan of popcount(mask) over the n segments of an image, in two parallel levels (a single workgroup per image
+// made this the longest kernel of a 1080p detection): every 1024-thread workgroup scans one chunk of SEG_CHUNK segments
+// locally and publishes the chunk total; k_chunk_offsets turns the totals of an image into chunk base offsets; the
+// consumer (k_cand_list) adds base + local offset.
+constexpr uint32_t SEG_CHUNK = 4096;
+
 __global__ void __launch_bounds__(1024) k_segment_scan(const uint64_t *__restrict__ mask, uint32_t *__restrict__ off, uint64_t seg_img_stride, uint32_t n,
-                                                       uint32_t *found, uint32_t found_img_stride)
+                                                       uint32_t *__restrict__ chunk_tot, uint64_t chunk_img_stride)
 {
   __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t carry_s;
-  const int b = blockIdx.x;
+  const int b = blockIdx.y;
   mask += (size_t)b * seg_img_stride;
   off += (size_t)b * seg_img_stride;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0)
-    carry_s = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < n; base += 1024)
-  {
-    uint32_t i = base + threadIdx.x;
-    uint32_t v = i < n ? (uint32_t)__popcll(mask[i]) : 0u;
-    // inclusive wave scan
-    uint32_t incl = v;
+  const uint32_t i0 = blockIdx.x * SEG_CHUNK + 4u * threadIdx.x;
+  uint32_t p[4];
 #pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1)
-    {
-      uint32_t t = __shfl_up(incl, dlt, 64);
-      if (lane >= dlt)
-        incl += t;
-    }
-    if (lane == 63)
-      wave_tot[wave] = incl;
-    __syncthreads();
-    uint32_t wave_base = 0;
-    for (int wv = 0; wv < wave; wv++)
+  for (int k = 0; k < 4; k++)
+    p[k] = i0 + k < n ? (uint32_t)__popcll(mask[i0 + k]) : 0u;
+  const uint32_t tsum = p[0] + p[1] + p[2] + p[3];
+  uint32_t incl = tsum;
+#pragma unroll
+  for (int dlt = 1; dlt < 64; dlt <<= 1)
+  {
+    uint32_t t = __shfl_up(incl, dlt, 64);
+    if (lane >= dlt)
+      incl += t;
+  }
+  if (lane == 63)
+    wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t wave_base = 0, total = 0;
+  for (int wv = 0; wv < 16; wv++)
+  {
+    if (wv < wave)
       wave_base += wave_tot[wv];
-    uint32_t carry = carry_s;
-    if (i < n)
-      off[i] = carry + wave_base + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023)
-      carry_s = carry + wave_base + incl;
-    __syncthreads();
+    total += wave_tot[wv];
+  }
+  uint32_t run = wave_base + incl - tsum;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    if (i0 + k < n)
+      off[i0 + k] = run;
+    run += p[k];
   }
   if (threadIdx.x == 0)
-    found[(size_t)b * found_img_stride] = carry_s;
+    chunk_tot[(size_t)b * chunk_img_stride + blockIdx.x] = total;
 }
 
-// One thread per 64-pixel segment: expand its candidate ballot into packed coordinates at offset + rank.
-__global__ void __launch_bounds__(256) k_cand_list(ExtremaArgs a, uint32_t nsegs)
-{
-  const uint32_t seg = blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.y;
-  if (seg >= nsegs)
-    return;
-  unsigned long long m = a.seg_mask[seg + (size_t)b * a.seg_img_stride];
-  if (m == 0ull)
-    return;
-  uint32_t pos = a.seg_off[seg + (size_t)b * a.seg_img_stride];
-  const uint32_t segx = seg % (uint32_t)a.nseg;
-  const uint32_t yy = (seg / (uint32_t)a.nseg) % (uint32_t)a.h;
-  const uint32_t sz = seg / ((uint32_t)a.nseg * (uint32_t)a.h);
-  uint32_t *out = a.cand_xy + (size_t)b * a.cand_img_stride;
-  while (m)
-  {
-    const int bit = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    if (pos < a.cand_cap)
-      out[pos] = (segx * 64u + (uint32_t)bit) | (yy << 14) | ((sz + 1u) << 28);
-    pos++;
-  }
-}
-
-// Dense refinement: thread i of image b refines candidate i. grid-stride, count read from HBM.
-__global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
-{
-  const int b = blockIdx.y;
-  uint32_t n = a.cand_n[b];
-  n = n < a.cand_cap ? n : a.cand_cap;
-  DogView d{a.dog + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
-  const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
-  uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-  {
-    const uint32_t c = xy[i];
-    KpRecord kp;
-    bool ok = refine_texel(d, (int)(c & 0x3fffu), (int)((c >> 14) & 0x3fffu), (int)(c >> 28), a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx,
-                           &kp);
-    flag[i] = ok ? 1u : 0u;
-  }
-}
-
-// Per image: exclusive scan of the accept flags (raster order is preserved), accepted candidates recompute their
-// record (bit-identical) and store it at their rank if it fits the section; found[] gets the un-clamped count.
-__global__ void __launch_bounds__(1024) k_cand_finalize(ExtremaArgs a)
+// In-place exclusive scan of the per-chunk totals of one image (one workgroup per image, the list is short: n / chunk
+// entries); the grand total goes to total_out[b * total_stride]. count_in != NULL: the number of valid entries is
+// ceil(min(count_in[b], count_cap) / per_chunk) (device-side candidate count), else n_entries.
+__global__ void __launch_bounds__(1024) k_chunk_offsets(uint32_t *__restrict__ tot, uint64_t img_stride, uint32_t n_entries, const uint32_t *__restrict__ count_in,
+                                                        uint32_t count_cap, uint32_t per_chunk, uint32_t *__restrict__ total_out, uint32_t total_stride)
 {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
   const int b = blockIdx.x;
+  tot += (size_t)b * img_stride;
+  uint32_t n = n_entries;
+  if (count_in)
+  {
+    uint32_t c = count_in[b];
+    c = c < count_cap ? c : count_cap;
+    n = (c + per_chunk - 1u) / per_chunk;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t n = a.cand_n[b];
-  n = n < a.cand_cap ? n : a.cand_cap;
-  DogView d{a.dog + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
-  const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
-  const uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
   if (threadIdx.x == 0)
     carry_s = 0;
   __syncthreads();
   for (uint32_t base = 0; base < n; base += 1024)
   {
     const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < n ? flag[i] : 0u;
+    const uint32_t v = i < n ? tot[i] : 0u;
     uint32_t incl = v;
 #pragma unroll
     for (int dlt = 1; dlt < 64; dlt <<= 1)
@@ -495,7 +462,103 @@ __global__ void __launch_bounds__(1024) k_cand_finalize(ExtremaArgs a)
     for (int wv = 0; wv < wave; wv++)
       wave_base += wave_tot[wv];
     const uint32_t carry = carry_s;
-    const uint32_t idx = carry + wave_base + incl - v;
+    if (i < n)
+      tot[i] = carry + wave_base + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023)
+      carry_s = carry + wave_base + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    total_out[(size_t)b * total_stride] = carry_s;
+}
+
+// One thread per 64-pixel segment: expand its candidate ballot into packed coordinates at offset + rank.
+__global__ void __launch_bounds__(256) k_cand_list(ExtremaArgs a, uint32_t nsegs)
+{
+  const uint32_t seg = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (seg >= nsegs)
+    return;
+  unsigned long long m = a.seg_mask[seg + (size_t)b * a.seg_img_stride];
+  if (m == 0ull)
+    return;
+  // offset inside the chunk + base of the chunk (k_segment_scan / k_chunk_offsets; the bases sit in the still unused flag array)
+  uint32_t pos = a.seg_off[seg + (size_t)b * a.seg_img_stride] + a.cand_flag[(size_t)b * a.cand_img_stride + seg / SEG_CHUNK];
+  const uint32_t segx = seg % (uint32_t)a.nseg;
+  const uint32_t yy = (seg / (uint32_t)a.nseg) % (uint32_t)a.h;
+  const uint32_t sz = seg / ((uint32_t)a.nseg * (uint32_t)a.h);
+  uint32_t *out = a.cand_xy + (size_t)b * a.cand_img_stride;
+  while (m)
+  {
+    const int bit = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    if (pos < a.cand_cap)
+      out[pos] = (segx * 64u + (uint32_t)bit) | (yy << 14) | ((sz + 1u) << 28);
+    pos++;
+  }
+}
+
+// Dense refinement: thread t of a 256-candidate chunk refines candidate chunk*256 + t (count read from HBM, workgroups
+// stride over the chunks). Besides the accept flags every chunk publishes its number of accepted candidates (into the
+// segment-offset array, free again after k_cand_list) for the two-level scan of k_chunk_offsets / k_cand_emit.
+__global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
+{
+  __shared__ uint32_t s_cnt[4];
+  const int b = blockIdx.y;
+  uint32_t n = a.cand_n[b];
+  n = n < a.cand_cap ? n : a.cand_cap;
+  const uint32_t nch = (n + 255u) / 256u;
+  DogView d{a.dog + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
+  const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
+  uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
+  uint32_t *chunk_sum = a.seg_off + (size_t)b * a.seg_img_stride;
+  for (uint32_t chunk = blockIdx.x; chunk < nch; chunk += gridDim.x)
+  {
+    const uint32_t i = chunk * 256u + threadIdx.x;
+    bool ok = false;
+    if (i < n)
+    {
+      const uint32_t c = xy[i];
+      KpRecord kp;
+      ok = refine_texel(d, (int)(c & 0x3fffu), (int)((c >> 14) & 0x3fffu), (int)(c >> 28), a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
+      flag[i] = ok ? 1u : 0u;
+    }
+    const unsigned long long bal = __ballot(ok);
+    if ((threadIdx.x & 63) == 0)
+      s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0)
+      chunk_sum[chunk] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+  }
+}
+
+// Accepted candidates recompute their record (bit-identical) and store it at chunk base + rank inside the chunk (raster
+// order is preserved) if it fits the section.
+__global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
+{
+  __shared__ uint32_t s_cnt[4];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t n = a.cand_n[b];
+  n = n < a.cand_cap ? n : a.cand_cap;
+  const uint32_t nch = (n + 255u) / 256u;
+  DogView d{a.dog + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
+  const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
+  const uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
+  const uint32_t *chunk_base = a.seg_off + (size_t)b * a.seg_img_stride;
+  for (uint32_t chunk = blockIdx.x; chunk < nch; chunk += gridDim.x)
+  {
+    const uint32_t i = chunk * 256u + threadIdx.x;
+    const bool v = i < n && flag[i] != 0u;
+    const unsigned long long bal = __ballot(v);
+    if (lane == 0)
+      s_cnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t idx = chunk_base[chunk] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    for (int wv = 0; wv < wave; wv++)
+      idx += s_cnt[wv];
     if (v && idx < a.cap)
     {
       const uint32_t c = xy[i];
@@ -513,12 +576,7 @@ __global__ void __launch_bounds__(1024) k_cand_finalize(ExtremaArgs a)
       rec[8] = __float_as_uint(kp.intensity);
     }
     __syncthreads();
-    if (threadIdx.x == 1023)
-      carry_s = carry + wave_base + incl;
-    __syncthreads();
   }
-  if (threadIdx.x == 0)
-    a.found[(size_t)b * a.found_img_stride] = carry_s;
 }
 
 } // namespace
@@ -566,14 +624,23 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   default:
     return (int)hipErrorInvalidValue;
   }
-  /* 2. offsets + candidate count */
-  hipLaunchKernelGGL(k_segment_scan, dim3(batch), dim3(1024), 0, hs, (const uint64_t *)a.seg_mask, a.seg_off, a.seg_img_stride, nsegs, a.cand_n, 1u);
-  /* 3. compact list, 4. dense refinement, 5. accepted -> records */
+  /* 2. offsets + candidate count: chunk-local scan, then the (short) scan of the chunk totals; the totals/bases live at
+   * the start of the flag array until the refinement overwrites it */
+  const uint32_t nchunks = (nsegs + SEG_CHUNK - 1u) / SEG_CHUNK;
+  if (nchunks > a.cand_cap)
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_segment_scan, dim3(nchunks, batch), dim3(1024), 0, hs, (const uint64_t *)a.seg_mask, a.seg_off, a.seg_img_stride, nsegs, a.cand_flag,
+                     a.cand_img_stride);
+  hipLaunchKernelGGL(k_chunk_offsets, dim3(batch), dim3(1024), 0, hs, a.cand_flag, a.cand_img_stride, nchunks, (const uint32_t *)nullptr, 0u, 1u, a.cand_n,
+                     1u);
+  /* 3. compact list, 4. dense refinement (+ per-chunk accept counts), 5. scan of those counts, 6. accepted -> records */
   hipLaunchKernelGGL(k_cand_list, dim3((nsegs + 255u) / 256u, batch), dim3(256), 0, hs, a, nsegs);
   uint32_t rblocks = (a.cand_cap + 255u) / 256u;
   if (rblocks > 512u)
     rblocks = 512u;
   hipLaunchKernelGGL(k_refine_flags, dim3(rblocks, batch), dim3(256), 0, hs, a);
-  hipLaunchKernelGGL(k_cand_finalize, dim3(batch), dim3(1024), 0, hs, a);
+  hipLaunchKernelGGL(k_chunk_offsets, dim3(batch), dim3(1024), 0, hs, a.seg_off, a.seg_img_stride, 0u, (const uint32_t *)a.cand_n, a.cand_cap, 256u, a.found,
+                     a.found_img_stride);
+  hipLaunchKernelGGL(k_cand_emit, dim3(rblocks, batch), dim3(256), 0, hs, a);
   return (int)hipGetLastError();
 }
