@@ -1,7 +1,5 @@
-timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
-pick() { python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$1', round(d['value']), 'fps ms/step', round(d['ms_per_step'],3), 'pyr_ms', round(d['stage_ms_per_step']['pyramid_ms'],3), 'frac', round(d['roofline']['frac'],3))"; }
+pick() { python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$1', round(d['value']), 'fps ms/step', round(d['ms_per_step'],3), 'pyr_ms', round(d['stage_ms_per_step']['pyramid_ms'],3), 'frac', round(d['roofline']['frac'],3), 'match', round(d['last_match_ms'],3))"; }
 $B 2>&1 | pick bench
-$B 2>&1 | pick bench
-python tools/bench_configs.py c3 --batch 32 2>&1 | tail -2 | cut -c1-330
-python tools/bench_latency.py 2>&1 | tail -3
+$B --batch 128 2>&1 | pick bench128

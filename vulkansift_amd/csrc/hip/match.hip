@@ -25,6 +25,7 @@
 // (l&15) / B row (l&15); since A and B use the same K slicing any K permutation cancels in the dot
 // product. Accumulator: lane l holds column (l&15), rows (l>>4)*4 + r, r = 0..3.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "vksift_hip.h"
@@ -839,10 +840,13 @@ extern "C"
     ss.redo = norm_slot_stride; /* the redo flags live in the same per-slot scratch block as the norms */
     /* The row count is only known on the device: launch for the capacity (surplus workgroups exit at once), one
      * kernel per size regime, each of which returns immediately unless N_A falls in its range:
-     *   N_A <= 8192        B-split kernel, 16 A rows per workgroup (keeps a few thousand rows busy on every CU)
-     *   8192 < N_A <= 32768 16 A rows per wave
+     *   N_A <= S1          B-split kernel, 16 A rows per workgroup (keeps a few thousand rows busy on every CU)
+     *   S1 < N_A <= 32768   16 A rows per wave
      *   N_A > 32768         64 A rows per wave (B tile reuse), B-chunked + merged when a single pair is matched */
-    const uint32_t S1 = 8192u, S2 = 32768u;
+    /* The B-split kernel (16 A rows per workgroup) exists to keep every CU busy when ONE pair of a few thousand rows is
+     * matched; a batch of pairs has enough workgroups anyway and runs 24 % faster with 64 rows per workgroup (measured:
+     * 64 pairs of 1.9k x 1.9k, 0.285 -> 0.217 ms). */
+    const uint32_t S1 = nslots >= 8 ? 1024u : 8192u, S2 = 32768u;
     hipStream_t hs = (hipStream_t)s;
     const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
     /* regimes 2/3 loop over their row blocks, so their grids stay small even when only the capacity is known */
