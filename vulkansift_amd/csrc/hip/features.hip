@@ -307,24 +307,25 @@ __device__ __forceinline__ void desc_accumulate(const DescCtx &c, int cdx, int c
 }
 
 // One 256-thread workgroup per keypoint (the window of a coarse-scale keypoint has up to ~7.5k pixels; a single wave
-// would make it the critical path of the whole launch). Each wave first filters its 64 pixels with the cheap tests
-// — inside the image interior, and inside the 4x4 histogram grid after rotation — and compacts the survivors into a
-// per-wave LDS queue; the expensive part (gradient, atan2, exp, 8 fixed-point atomics) then always runs on full
-// 64-lane batches. About half of the window falls outside the rotated grid: the reference evaluates atan/exp for
-// those pixels and then drops the contribution (ComputeDescriptors.comp:189); skipping them changes no bit.
+// would make it the critical path of the whole launch). About half of the window falls outside the rotated 4x4 grid:
+// the reference evaluates atan/exp for those pixels and then drops the contribution (ComputeDescriptors.comp:189);
+// here they are never visited (analytic row spans, see below), which changes no bit. The expensive part (gradient,
+// atan2, exp, 8 fixed-point atomics) runs on full 64-lane batches.
+constexpr int DESC_MAX_ROWS = 256; // window rows handled per pass (R <= 127: every stock configuration); taller windows take several passes
+
 template <int NWV>
 __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
 {
   constexpr int NT_ = 64 * NWV;
   __shared__ uint32_t s_work[128 + 64]; // histogram + per-lane dummy slots for out-of-grid cells
-  __shared__ uint32_t s_q[NWV][128];
+  __shared__ int s_row_lo[DESC_MAX_ROWS];
+  __shared__ uint32_t s_row_pre[DESC_MAX_ROWS + 1];
   const int tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const uint32_t found = a.found[(size_t)b * a.found_img_stride];
   const uint32_t n1 = found < a.cap ? found : a.cap;
   GaussView g{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride};
   uint8_t *feats = a.feats + (size_t)b * a.feat_img_stride;
-  uint32_t *q = s_q[wave];
 
   for (uint32_t k = blockIdx.x; k < n1; k += gridDim.x)
   {
@@ -357,55 +358,112 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
     const int cxi = (int)c.rsx, cyi = (int)c.rsy;
     const int dx0 = max(-R, 1 - cxi), dx1 = min(R, g.w - 2 - cxi);
     const int dy0 = max(-R, 1 - cyi), dy1 = min(R, g.h - 2 - cyi);
-    const int bw = dx1 - dx0 + 1, bh = dy1 - dy0 + 1;
-    const int npix = (bw > 0 && bh > 0) ? bw * bh : 0;
-    // Pixel enumeration: thread t walks its own contiguous run [t*niter, (t+1)*niter) of the window, so at any step the
-    // 64 lanes of a wave sit ~niter pixels apart and spread over all 16 spatial cells: the 8 fixed-point LDS atomics of
-    // a step then hit mostly distinct addresses (adjacent pixels would pile onto the same 1-2 cells and serialise).
-    // Integer adds commute, so the result is independent of the enumeration.
-    // Pre-filter: only pixels whose rotated position lies within the 5x5-cell footprint of the 4x4 grid can touch a
-    // bin. The test here is deliberately approximate (fused arithmetic) and conservative (margin): desc_accumulate
-    // re-derives the cells exactly and drops the out-of-grid ones, so a false positive costs a sample slot, never a bit.
-    const int niter = (npix + NT_ - 1) / NT_;
-    int pix = tid * niter;
-    int dy = dy0 + pix / max(bw, 1), dx = dx0 + pix % max(bw, 1);
+    const int bh = dy1 - dy0 + 1;
+    // Only pixels whose rotated position (ox, oy) lies within the 5x5-cell footprint |ox|, |oy| < 2.5 of the 4x4 grid can
+    // touch a bin (about half of the window). Instead of testing every pixel, each window row gets its span of such
+    // pixels analytically: ox and oy are linear in dx, so {dx : |kcos*fx + ksin*fy| < T and |kcos*fy - ksin*fx| < T} is an
+    // interval. The spans are approximate (fused arithmetic) and conservative (margin): desc_accumulate re-derives the
+    // cells exactly and drops the out-of-grid ones, so a false positive costs a sample slot, never a bit.
+    // Sample enumeration: the concatenated spans form the index space [0, N); wave v owns [v, v+1) * N / NWV and inside it
+    // lane l walks its own contiguous run — at any step the 64 lanes sit a run length apart and spread over all 16 spatial
+    // cells, so the 8 fixed-point LDS atomics of a step hit mostly distinct addresses (row-adjacent samples pile onto
+    // 1-2 cells and serialise: measured 8 % slower). Integer adds commute: the result does not depend on the order.
     const float offx = c.rsx - c.scale_x, offy = c.rsy - c.scale_y;
     const float T = 2.5f + 0.01f;
-    uint32_t qn = 0; // queue fill of this wave (wave-uniform)
-    for (int it = 0; it < niter; it++, pix++)
+    for (int rb = 0; rb < bh; rb += DESC_MAX_ROWS)
     {
-      const int cdx = dx, cdy = dy;
-      dx += 1;
-      if (dx > dx1)
+      const int nrows = min(DESC_MAX_ROWS, bh - rb);
+      __syncthreads();
+      for (int row = tid; row < nrows; row += NT_)
       {
-        dx = dx0;
-        dy += 1;
+        const float fy = (float)(dy0 + rb + row) + offy;
+        float lo = (float)dx0 - 0.5f, hi = (float)dx1 + 0.5f; // in dx
+        // |a * fx + bb| < T for (a, bb) = (kcos, ksin*fy) and (-ksin, kcos*fy); fx = dx + offx
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+        {
+          const float aa = e == 0 ? c.kcos : -c.ksin;
+          const float bb = e == 0 ? c.ksin * fy : c.kcos * fy;
+          if (fabsf(aa) > 1e-12f)
+          {
+            const float ctr = -bb / aa - offx, half = T / fabsf(aa);
+            lo = fmaxf(lo, ctr - half);
+            hi = fminf(hi, ctr + half);
+          }
+          else if (!(fabsf(bb) < T))
+            hi = lo - 2.f; // empty
+        }
+        const int ilo = (int)ceilf(lo - 0.01f), ihi = (int)floorf(hi + 0.01f);
+        const int xl = max(ilo, dx0), xh = min(ihi, dx1);
+        s_row_lo[row] = xl;
+        s_row_pre[row] = xh >= xl ? (uint32_t)(xh - xl + 1) : 0u;
       }
-      const float fx = (float)cdx + offx, fy = (float)cdy + offy;
-      const float ox = fmaf(c.kcos, fx, c.ksin * fy);
-      const float oy = fmaf(c.kcos, fy, -(c.ksin * fx));
-      const bool ok = pix < npix && fmaxf(fabsf(ox), fabsf(oy)) < T;
-      const unsigned long long m = __ballot(ok);
-      if (ok)
-        q[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(cdx & 0xffff)) | ((uint32_t)cdy << 16);
-      qn += (uint32_t)__popcll(m);
-      __builtin_amdgcn_wave_barrier();
-      if (qn >= 64)
+      __syncthreads();
+      if (wave == 0)
       {
-        const uint32_t e = q[lane];
-        desc_accumulate(c, (int)(short)(e & 0xffff), (int)e >> 16, s_work);
-        const uint32_t rest = q[64 + lane];
-        __builtin_amdgcn_wave_barrier();
-        qn -= 64;
-        if ((uint32_t)lane < qn)
-          q[lane] = rest;
-        __builtin_amdgcn_wave_barrier();
+        // exclusive scan of the row counts (nrows <= DESC_MAX_ROWS), total in s_row_pre[nrows]
+        uint32_t carry = 0;
+        for (int base = 0; base < nrows; base += 64)
+        {
+          const int i = base + lane;
+          const uint32_t v = i < nrows ? s_row_pre[i] : 0u;
+          uint32_t incl = v;
+#pragma unroll
+          for (int dlt = 1; dlt < 64; dlt <<= 1)
+          {
+            const uint32_t t = __shfl_up(incl, dlt, 64);
+            if (lane >= dlt)
+              incl += t;
+          }
+          if (i < nrows)
+            s_row_pre[i] = carry + incl - v;
+          carry += __shfl(incl, 63, 64);
+        }
+        if (lane == 0)
+          s_row_pre[nrows] = carry;
       }
-    }
-    if ((uint32_t)lane < qn)
-    {
-      const uint32_t e = q[lane];
-      desc_accumulate(c, (int)(short)(e & 0xffff), (int)e >> 16, s_work);
+      __syncthreads();
+      const uint32_t N = s_row_pre[nrows];
+      const uint32_t per_wave = (N + NWV - 1) / NWV;
+      const uint32_t w0 = min(N, (uint32_t)wave * per_wave), w1 = min(N, w0 + per_wave);
+      const uint32_t run = (w1 - w0 + 63u) / 64u; // samples per lane
+      uint32_t sidx = w0 + (uint32_t)lane * run;
+      const uint32_t send = min(w1, sidx + run);
+      // locate the row of the first sample of this lane's run: largest row with pre[row] <= sidx
+      int row = 0;
+      if (sidx < send)
+      {
+        int lo_r = 0, hi_r = nrows - 1;
+        while (lo_r < hi_r)
+        {
+          const int mid = (lo_r + hi_r + 1) >> 1;
+          if (s_row_pre[mid] <= sidx)
+            lo_r = mid;
+          else
+            hi_r = mid - 1;
+        }
+        row = lo_r;
+        while (s_row_pre[row + 1] <= sidx) // skip empty rows that share the same prefix value
+          row++;
+      }
+      int cdx = s_row_lo[row] + (int)(sidx - s_row_pre[row]);
+      uint32_t row_end = s_row_pre[row + 1];
+      for (uint32_t it = 0; it < run; it++, sidx++)
+      {
+        if (sidx < send)
+        {
+          if (sidx >= row_end)
+          {
+            do
+              row++;
+            while (s_row_pre[row + 1] <= sidx);
+            row_end = s_row_pre[row + 1];
+            cdx = s_row_lo[row];
+          }
+          desc_accumulate(c, cdx, dy0 + rb + row, s_work);
+          cdx++;
+        }
+      }
     }
     __syncthreads();
     if (wave == 0)
