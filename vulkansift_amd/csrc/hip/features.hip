@@ -319,7 +319,8 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
   constexpr int NT_ = 64 * NWV;
   __shared__ uint32_t s_work[128 + 64]; // histogram + per-lane dummy slots for out-of-grid cells
   __shared__ int s_row_lo[DESC_MAX_ROWS];
-  __shared__ uint32_t s_row_pre[DESC_MAX_ROWS + 1];
+  __shared__ uint32_t s_row_cnt[DESC_MAX_ROWS];
+  __shared__ uint32_t s_row_pre[NWV][DESC_MAX_ROWS + 1];
   const int tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const uint32_t found = a.found[(size_t)b * a.found_img_stride];
@@ -329,10 +330,9 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
 
   for (uint32_t k = blockIdx.x; k < n1; k += gridDim.x)
   {
-    __syncthreads();
+    __syncthreads(); // the previous keypoint's epilogue has read the histogram
     for (int i = tid; i < 128; i += NT_)
-      s_work[i] = 0;
-    __syncthreads();
+      s_work[i] = 0; // made visible by the barrier behind the row-span pass below
 
     const float *rec = (const float *)(feats + (size_t)k * 164);
     const uint32_t scale_idx = ((const uint32_t *)rec)[4];
@@ -396,17 +396,18 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
         const int ilo = (int)ceilf(lo - 0.01f), ihi = (int)floorf(hi + 0.01f);
         const int xl = max(ilo, dx0), xh = min(ihi, dx1);
         s_row_lo[row] = xl;
-        s_row_pre[row] = xh >= xl ? (uint32_t)(xh - xl + 1) : 0u;
+        s_row_cnt[row] = xh >= xl ? (uint32_t)(xh - xl + 1) : 0u;
       }
       __syncthreads();
-      if (wave == 0)
       {
-        // exclusive scan of the row counts (nrows <= DESC_MAX_ROWS), total in s_row_pre[nrows]
+        // exclusive scan of the row counts (nrows <= DESC_MAX_ROWS), total in s_row_pre[nrows]. Every wave computes it for
+        // itself from the counts (s_row_cnt is read-only here) into its own copy of the prefix array: no barrier afterwards.
+        uint32_t *pre = s_row_pre[wave];
         uint32_t carry = 0;
         for (int base = 0; base < nrows; base += 64)
         {
           const int i = base + lane;
-          const uint32_t v = i < nrows ? s_row_pre[i] : 0u;
+          const uint32_t v = i < nrows ? s_row_cnt[i] : 0u;
           uint32_t incl = v;
 #pragma unroll
           for (int dlt = 1; dlt < 64; dlt <<= 1)
@@ -416,14 +417,15 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
               incl += t;
           }
           if (i < nrows)
-            s_row_pre[i] = carry + incl - v;
+            pre[i] = carry + incl - v;
           carry += __shfl(incl, 63, 64);
         }
         if (lane == 0)
-          s_row_pre[nrows] = carry;
+          pre[nrows] = carry;
       }
-      __syncthreads();
-      const uint32_t N = s_row_pre[nrows];
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t *s_pre = s_row_pre[wave];
+      const uint32_t N = s_pre[nrows];
       const uint32_t per_wave = (N + NWV - 1) / NWV;
       const uint32_t w0 = min(N, (uint32_t)wave * per_wave), w1 = min(N, w0 + per_wave);
       const uint32_t run = (w1 - w0 + 63u) / 64u; // samples per lane
@@ -437,17 +439,17 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
         while (lo_r < hi_r)
         {
           const int mid = (lo_r + hi_r + 1) >> 1;
-          if (s_row_pre[mid] <= sidx)
+          if (s_pre[mid] <= sidx)
             lo_r = mid;
           else
             hi_r = mid - 1;
         }
         row = lo_r;
-        while (s_row_pre[row + 1] <= sidx) // skip empty rows that share the same prefix value
+        while (s_pre[row + 1] <= sidx) // skip empty rows that share the same prefix value
           row++;
       }
-      int cdx = s_row_lo[row] + (int)(sidx - s_row_pre[row]);
-      uint32_t row_end = s_row_pre[row + 1];
+      int cdx = s_row_lo[row] + (int)(sidx - s_pre[row]);
+      uint32_t row_end = s_pre[row + 1];
       for (uint32_t it = 0; it < run; it++, sidx++)
       {
         if (sidx < send)
@@ -456,8 +458,8 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
           {
             do
               row++;
-            while (s_row_pre[row + 1] <= sidx);
-            row_end = s_row_pre[row + 1];
+            while (s_pre[row + 1] <= sidx);
+            row_end = s_pre[row + 1];
             cdx = s_row_lo[row];
           }
           desc_accumulate(c, cdx, dy0 + rb + row, s_work);
@@ -555,6 +557,8 @@ extern "C"
       hipLaunchKernelGGL(k_descriptor<1>, dim3(blocks, batch), dim3(64), 0, (hipStream_t)s, a);
     else if (nwv == 2)
       hipLaunchKernelGGL(k_descriptor<2>, dim3(blocks, batch), dim3(128), 0, (hipStream_t)s, a);
+    else if (nwv == 8)
+      hipLaunchKernelGGL(k_descriptor<8>, dim3(blocks, batch), dim3(512), 0, (hipStream_t)s, a);
     else
       hipLaunchKernelGGL(k_descriptor<4>, dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
     return (int)hipGetLastError();
