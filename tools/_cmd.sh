@@ -1,2 +1,5 @@
-timeout 800 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for i in 1 2 3; do python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), d['stage_ms_per_step']['descriptor_ms'])"; done
+pick() { python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$1', round(d['value']), 'fps pyr_ms', round(d['stage_ms_per_step']['pyramid_ms'],3), 'frac', round(d['roofline']['frac'],3))"; }
+for i in 1 2 3; do
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | pick default
+VKSIFT_COARSE_AFTER=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | pick coarse_after
+done
