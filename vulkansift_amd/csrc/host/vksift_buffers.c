@@ -1,0 +1,198 @@
+/*
+ * vksift_buffers.c — SIFT-buffer accessors and scale-space inspection (sift_memory.c:1060-1383, vulkansift.c:346-415,464-518)
+ */
+#include "vksift_internal.h"
+
+/* ------------------------------------------------------------------------------------------------ */
+/* feature count / download / upload (sift_memory.c:1060-1272)                                      */
+/* ------------------------------------------------------------------------------------------------ */
+void wait_for_buffer(vksift_Instance inst, uint32_t buf)
+{
+  vksift_hip_set_device(inst->device);
+  if (!inst->bufs[buf].counts_valid || (inst->detect_pending && buf >= inst->detect_first_buf && buf < inst->detect_first_buf + inst->detect_count))
+  {
+    vksift_hip_event_sync(inst->ev_detect);
+    mark_detect_done(inst);
+  }
+  if (inst->match_pending && (buf == inst->match_a || buf == inst->match_b))
+  {
+    vksift_hip_event_sync(inst->ev_match);
+    inst->match_pending = false;
+  }
+}
+
+/* per-section stored counts, clamped to the section capacity (sift_memory.c:1080-1095) */
+uint32_t buffer_counts(vksift_Instance inst, uint32_t buf, uint32_t *cnt, bool log_lost)
+{
+  const BufferInfo *b = &inst->bufs[buf];
+  if (b->is_packed && b->nb_sections == 0)
+    return b->nb_stored;
+  uint32_t sum = 0, lost = 0;
+  const uint32_t *found = inst->h_found + (size_t)buf * VKSIFT_MAX_OCTAVES;
+  for (uint32_t o = 0; o < b->nb_sections; o++)
+  {
+    uint32_t n = found[o];
+    if (n > b->sec_cap[o])
+    {
+      lost += n - b->sec_cap[o];
+      n = b->sec_cap[o];
+    }
+    if (cnt)
+      cnt[o] = n;
+    sum += n;
+  }
+  if (lost > 0 && log_lost)
+    logError(LOG_TAG,
+             "%d feature(s) lost because the SIFT buffer was full, consider increasing "
+             "the maximum number of SIFT features per buffer in the configuration.",
+             lost);
+  return sum;
+}
+
+uint32_t vksift_getFeaturesNumber(vksift_Instance instance, const uint32_t gpu_buffer_id)
+{
+  if (!buffer_idx_valid(instance, gpu_buffer_id))
+  {
+    logError(LOG_TAG, "vksift_getFeaturesNumber() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return 0;
+  }
+  wait_for_buffer(instance, gpu_buffer_id);
+  return buffer_counts(instance, gpu_buffer_id, NULL, true);
+}
+
+void vksift_downloadFeatures(vksift_Instance instance, vksift_Feature *feats_ptr, uint32_t gpu_buffer_id)
+{
+  if (!buffer_idx_valid(instance, gpu_buffer_id))
+  {
+    logError(LOG_TAG, "vksift_downloadFeatures() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  vksift_Instance inst = instance;
+  wait_for_buffer(inst, gpu_buffer_id);
+  const BufferInfo *b = &inst->bufs[gpu_buffer_id];
+  const uint8_t *base = inst->d_feats + (uint64_t)gpu_buffer_id * inst->buf_stride;
+  if (b->nb_sections == 0)
+  {
+    HIP_CHECK(vksift_hip_memcpy_d2h(feats_ptr, base, (size_t)b->nb_stored * FEAT_BYTES, inst->stream), "feature download");
+  }
+  else
+  {
+    uint32_t cnt[VKSIFT_MAX_OCTAVES] = {0};
+    buffer_counts(inst, gpu_buffer_id, cnt, false);
+    uint32_t out = 0;
+    for (uint32_t o = 0; o < b->nb_sections; o++)
+    {
+      HIP_CHECK(vksift_hip_memcpy_d2h((uint8_t *)feats_ptr + (size_t)out * FEAT_BYTES, base + (size_t)b->sec_off[o] * FEAT_BYTES, (size_t)cnt[o] * FEAT_BYTES,
+                                      inst->stream),
+                "feature download");
+      out += cnt[o];
+    }
+  }
+  HIP_CHECK(vksift_hip_stream_sync(inst->stream), "feature download");
+  return;
+gpu_error:
+  logError(LOG_TAG, "vksift_downloadFeatures() error when downloading detection results.");
+  instance->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+void vksift_uploadFeatures(vksift_Instance instance, const vksift_Feature *feats_ptr, const uint32_t nb_feats, const uint32_t gpu_buffer_id)
+{
+  if (!buffer_idx_valid(instance, gpu_buffer_id) || nb_feats > instance->cfg.max_nb_sift_per_buffer)
+  {
+    if (nb_feats > instance->cfg.max_nb_sift_per_buffer)
+      logError(LOG_TAG, "Provided features count (%d) is greater than the configured maximum number of features per GPU buffer size (%d).", nb_feats,
+               instance->cfg.max_nb_sift_per_buffer);
+    logError(LOG_TAG, "vksift_uploadFeatures() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  vksift_Instance inst = instance;
+  wait_for_buffer(inst, gpu_buffer_id);
+  BufferInfo *b = &inst->bufs[gpu_buffer_id];
+  HIP_CHECK(vksift_hip_memcpy_h2d(inst->d_feats + (uint64_t)gpu_buffer_id * inst->buf_stride, feats_ptr, (size_t)nb_feats * FEAT_BYTES, inst->stream),
+            "feature upload");
+  HIP_CHECK(vksift_hip_stream_sync(inst->stream), "feature upload");
+  /* the buffer becomes one packed section (sift_memory.c:1262-1266) */
+  b->is_packed = true;
+  b->nb_stored = nb_feats;
+  b->nb_sections = 0;
+  b->counts_valid = true;
+  return;
+gpu_error:
+  logError(LOG_TAG, "vksift_uploadFeatures() error when uploading SIFT features to GPU memory.");
+  instance->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* scale-space inspection (vulkansift.c:464-518, sift_memory.c:1303-1383)                           */
+/* ------------------------------------------------------------------------------------------------ */
+uint8_t vksift_getScaleSpaceNbOctaves(vksift_Instance instance) { return (uint8_t)instance->lay.n_oct; }
+
+void vksift_getScaleSpaceOctaveResolution(vksift_Instance instance, const uint8_t octave, uint32_t *octave_images_width, uint32_t *octave_images_height)
+{
+  if (octave >= instance->lay.n_oct)
+  {
+    logError(LOG_TAG, "vksift_getScaleSpaceOctaveResolution() error: invalid input. Requested octave idx is %d but the current number of octave is %d",
+             octave, instance->lay.n_oct);
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  *octave_images_width = instance->lay.w[octave];
+  *octave_images_height = instance->lay.h[octave];
+}
+
+static void download_plane(vksift_Instance inst, uint8_t octave, uint8_t scale, bool is_dog, float *dst, const char *fn)
+{
+  uint32_t nscales = inst->S + (is_dog ? 2 : 3);
+  if (octave >= inst->lay.n_oct || scale >= nscales)
+  {
+    if (octave >= inst->lay.n_oct)
+      logError(LOG_TAG, "Requested octave idx is %d but the current number of octaves is %d", octave, inst->lay.n_oct);
+    else
+      logError(LOG_TAG, "Requested scale idx is %d but the number of %s scales is %d", scale, is_dog ? "DoG" : "blurred", nscales);
+    logError(LOG_TAG, "%s error: invalid input.", fn);
+    inst->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  vksift_hip_set_device(inst->device);
+  /* images cannot be read while a detection runs (vulkansift.c:490-491) */
+  HIP_CHECK(wait_all(inst), "stream synchronisation");
+  const PyrLayout *L = &inst->lay;
+  if (!is_dog && scale == inst->S + 2 && inst->top_scale_stale[octave])
+  {
+    /* the detection pipeline kept only the DoG layer of the last scale: blur it now (image 0, the one this API exposes) */
+    const vksift_hip_Plane no_dog = {NULL, 0, 0, 0, 0};
+    HIP_CHECK(vksift_hip_blur(plane_at(inst, octave, L->gauss_off[octave], scale - 1), plane_at(inst, octave, L->gauss_off[octave], scale), no_dog,
+                              &inst->taps[scale * VKSIFT_MAX_TAPS], inst->ntaps[scale], 1, inst->stream),
+              "top scale blur");
+    inst->top_scale_stale[octave] = false;
+  }
+  const float *src = inst->d_pyr + (is_dog ? L->dog_off[octave] : L->gauss_off[octave]) + (uint64_t)scale * L->plane_stride[octave];
+  HIP_CHECK(vksift_hip_memcpy2d_d2h(dst, sizeof(float) * L->w[octave], src, sizeof(float) * L->pitch[octave], sizeof(float) * L->w[octave], L->h[octave],
+                                    inst->stream),
+            "plane download");
+  HIP_CHECK(vksift_hip_stream_sync(inst->stream), "plane download");
+  return;
+gpu_error:
+  logError(LOG_TAG, "%s error when downloading pyramid image from GPU memory.", fn);
+  inst->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+void vksift_downloadScaleSpaceImage(vksift_Instance instance, const uint8_t octave, const uint8_t scale, float *blurred_image)
+{
+  download_plane(instance, octave, scale, false, blurred_image, "vksift_downloadScaleSpaceImage()");
+}
+
+void vksift_downloadDoGImage(vksift_Instance instance, const uint8_t octave, const uint8_t scale, float *dog_image)
+{
+  download_plane(instance, octave, scale, true, dog_image, "vksift_downloadDoGImage()");
+}
+
+void vksift_presentDebugFrame(vksift_Instance instance)
+{
+  (void)instance;
+  logWarning(LOG_TAG, "vksift_presentDebugFrame() was called but instance has no external window configured.");
+}
+

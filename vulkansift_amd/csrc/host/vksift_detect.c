@@ -1,0 +1,584 @@
+/*
+ * vksift_detect.c — the detection pipeline (vulkansift.c:315-344 + sift_memory.c:891-955 + sift_detector.c:1313-1410,1462-1542)
+ */
+#include "vksift_internal.h"
+
+/* ------------------------------------------------------------------------------------------------ */
+/* detection (vulkansift.c:315-344 + sift_memory.c:891-955 + sift_detector.c:1313-1410,1462-1542)   */
+/* ------------------------------------------------------------------------------------------------ */
+vksift_hip_Plane plane_at(vksift_Instance inst, uint32_t o, uint64_t base_off, uint32_t layer)
+{
+  vksift_hip_Plane p;
+  p.base = inst->d_pyr + base_off + (uint64_t)layer * inst->lay.plane_stride[o];
+  p.w = inst->lay.w[o];
+  p.h = inst->lay.h[o];
+  p.pitch = inst->lay.pitch[o];
+  p.img_stride = inst->pyr_img_stride;
+  return p;
+}
+
+static uint64_t algorithmic_pyramid_bytes(vksift_Instance inst, uint32_t w, uint32_t h, uint32_t nb_octaves)
+{
+  /* (S+3 Gaussian writes + S+2 blur reads + S+2 DoG writes) * 4 B per octave pixel,
+   * plus on octave 0: input read (1 B/px of input), up-sample plane write and seed-blur read (4 B each). */
+  const PyrLayout *L = &inst->lay;
+  uint64_t bytes = 0;
+  for (uint32_t o = 0; o < L->n_oct && o < nb_octaves; o++)
+    bytes += (uint64_t)L->w[o] * L->h[o] * 4u * ((inst->S + 3) + (inst->S + 2) + (inst->S + 2));
+  bytes += (uint64_t)w * h + (uint64_t)L->w[0] * L->h[0] * 8u;
+  return bytes;
+}
+
+/* fold the (completed) event timings of a detect call into the running sums */
+void account_set(vksift_Instance inst, ProfSet *ps)
+{
+  if (!inst->profiling || !ps->valid || ps->accounted)
+    return;
+  vksift_hip_event *e = ps->ev_t;
+  inst->acc_ms[0] += vksift_hip_event_elapsed_ms(e[0], e[1]);
+  inst->acc_ms[1] += ps->overlap ? vksift_hip_event_elapsed_ms(ps->ev_pt[0], ps->ev_pt[1]) : vksift_hip_event_elapsed_ms(e[1], e[2]);
+  inst->acc_ms[2] += vksift_hip_event_elapsed_ms(e[2], e[3]);
+  inst->acc_ms[3] += vksift_hip_event_elapsed_ms(e[3], e[4]);
+  inst->acc_ms[4] += vksift_hip_event_elapsed_ms(e[4], e[5]);
+  inst->acc_ms[5] += vksift_hip_event_elapsed_ms(e[0], e[6]);
+  inst->acc_calls++;
+  inst->acc_blur_launches += ps->blur_launches;
+  inst->acc_alg_bytes += ps->alg_bytes;
+  ps->accounted = true;
+}
+
+/* all detections have completed (caller waited): account both event sets, oldest first */
+void account_timings(vksift_Instance inst)
+{
+  account_set(inst, &inst->prof[inst->prof_cur ^ 1]);
+  account_set(inst, &inst->prof[inst->prof_cur]);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* the launch sequence of one detection                                                             */
+/* ------------------------------------------------------------------------------------------------ */
+#define TRY(expr, what)                                                        \
+  do                                                                           \
+  {                                                                            \
+    int _e = (expr);                                                           \
+    if (_e != 0)                                                               \
+    {                                                                          \
+      logError(LOG_TAG, "%s failed: %s", what, vksift_hip_error_string(_e));   \
+      return _e;                                                               \
+    }                                                                          \
+  } while (0)
+
+typedef struct
+{
+  vksift_Instance inst;
+  const PyrLayout *L;
+  ProfSet *PS;
+  bool prof;      /* HIP-event stage timings requested */
+  bool par;       /* octaves on several streams */
+  bool pipelined; /* per-octave chains (default) instead of joins at every stage boundary */
+  bool overlap;   /* pyramid on its own streams and buffer (ping-pong), see detect_impl */
+  bool upload;    /* host images were staged in h_input and have to be copied to d_input */
+  bool capturing; /* the sequence is being captured into a hipGraph: no host-visible events inside */
+  const uint8_t *d_src;
+  uint32_t w, h, count, first_buf;
+  size_t img_bytes;
+  uint32_t nblur;
+  vksift_hip_OctaveJob jobs[VKSIFT_MAX_OCTAVES];
+} DetectCtx;
+
+static void build_jobs(DetectCtx *c)
+{
+  vksift_Instance inst = c->inst;
+  const PyrLayout *L = c->L;
+  const BufferInfo *b0 = &inst->bufs[c->first_buf];
+  for (uint32_t o = 0; o < L->n_oct; o++)
+  {
+    vksift_hip_OctaveJob *j = &c->jobs[o];
+    memset(j, 0, sizeof(*j));
+    j->dog = inst->d_pyr + L->dog_off[o];
+    j->gauss = inst->d_pyr + L->gauss_off[o];
+    j->w = L->w[o], j->h = L->h[o], j->pitch = L->pitch[o];
+    j->plane_stride = L->plane_stride[o];
+    j->img_stride = inst->pyr_img_stride;
+    j->S = inst->S;
+    j->octave_idx = (int32_t)o - (inst->cfg.use_input_upsampling ? 1 : 0);
+    j->seed_sigma = inst->cfg.seed_scale_sigma;
+    j->dog_threshold = inst->cfg.intensity_threshold / (float)inst->S;
+    j->edge_limit = ((inst->cfg.edge_threshold + 1.f) * (inst->cfg.edge_threshold + 1.f)) / inst->cfg.edge_threshold;
+    j->feats = inst->d_feats + (uint64_t)c->first_buf * inst->buf_stride + (uint64_t)b0->sec_off[o] * FEAT_BYTES;
+    j->feat_img_stride = inst->buf_stride;
+    j->cap = b0->sec_cap[o];
+    j->found = inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES + o;
+    j->found_img_stride = VKSIFT_MAX_OCTAVES;
+    /* segment scratch is octave-major: [octave][image][segment], so one octave's masks of the whole batch are contiguous */
+    const uint64_t nsegs_o = (uint64_t)inst->S * L->h[o] * ((L->w[o] + 63) / 64);
+    j->seg_mask = inst->d_seg_mask + L->seg_off[o] * c->count;
+    j->seg_off = inst->d_seg_off + L->seg_off[o] * c->count;
+    j->seg_img_stride = nsegs_o;
+    j->cand_xy = inst->d_cand_xy + L->cand_off[o];
+    j->cand_flag = inst->d_cand_flag + L->cand_off[o];
+    j->cand_n = inst->d_cand_n + (size_t)o * inst->batch_cap;
+    j->cand_img_stride = inst->cand_cap;
+    j->cand_cap = (uint32_t)L->cand_cap[o];
+    j->ori_ang = inst->d_ori_ang + (size_t)b0->sec_off[o] * VKSIFT_HIP_MAX_ORI;
+    j->ori_cnt = inst->d_ori_cnt + b0->sec_off[o];
+    j->ori_img_stride = inst->ori_cap;
+    j->max_ori = inst->cfg.max_nb_orientation_per_keypoint;
+    j->use_vlfeat = inst->cfg.descriptor_format == VKSIFT_DESCRIPTOR_FORMAT_VLFEAT ? 1u : 0u;
+    j->desc_fp_tab = inst->d_desc_fp;
+    j->desc_fp_tab_len = inst->desc_fp_len;
+  }
+}
+
+/* Scale-space construction + DoG of octave o on stream sp (sift_detector.c:881-1079). *g0_done: plane 0 of this octave was
+ * already written by the previous octave's chain kernel; on return it tells the same for the next octave. */
+static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool *g0_done)
+{
+  vksift_Instance inst = c->inst;
+  const PyrLayout *L = c->L;
+  const vksift_hip_Plane no_dog = {NULL, 0, 0, 0, 0};
+  uint32_t nb_o = 0;
+  vksift_hip_range_push("Scale space construction");
+  if (o == 0)
+  {
+    if (c->overlap && c->prof)
+      vksift_hip_event_record(c->PS->ev_pt[0], sp);
+    /* u8 -> fp32 (2x LINEAR blit when up-sampling) + seed blur: one fused pass when the shape allows it, else the blit goes
+     * into the (still unused) layer-1 slot and is seed-blurred into layer 0 */
+    int fused = -1;
+    if (L->w[0] == 2 * c->w && L->h[0] == 2 * c->h)
+    {
+      fused = vksift_hip_seed_upsampled(c->d_src, c->w, c->h, c->img_bytes, plane_at(inst, 0, L->gauss_off[0], 0), &inst->taps[0], inst->ntaps[0], c->count, sp);
+      if (fused > 0)
+        TRY(fused, "fused up-sampling + seed blur");
+    }
+    if (fused < 0)
+    {
+      vksift_hip_Plane tmp = plane_at(inst, 0, L->gauss_off[0], 1);
+      TRY(vksift_hip_input_blit(c->d_src, c->w, c->h, c->img_bytes, tmp, c->count, sp), "input blit");
+      TRY(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), no_dog, &inst->taps[0], inst->ntaps[0], c->count, sp), "seed blur");
+    }
+    nb_o++;
+  }
+  else
+  {
+    if (c->par)
+      TRY(vksift_hip_stream_wait_event(sp, inst->ev_oct_ready[o - 1]), "octave dependency");
+    if (!*g0_done)
+      TRY(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), c->count, sp), "downsample");
+  }
+  *g0_done = false;
+  inst->top_scale_stale[o] = false;
+  if (inst->use_chain && L->h[o] >= inst->chain_min_rows)
+  {
+    /* experimental: one launch for scales 1..S+2 and all DoG layers; it also seeds the next octave when the sizes are exactly 2:1 */
+    vksift_hip_Plane next = {NULL, 0, 0, 0, 0};
+    if (o + 1 < L->n_oct && L->w[o + 1] * 2 == L->w[o] && L->h[o + 1] * 2 == L->h[o])
+    {
+      next = plane_at(inst, o + 1, L->gauss_off[o + 1], 0);
+      *g0_done = true;
+    }
+    TRY(vksift_hip_octave_chain(plane_at(inst, o, L->gauss_off[o], 0), L->plane_stride[o], inst->d_pyr + L->dog_off[o], next, inst->taps, VKSIFT_MAX_TAPS,
+                                c->count, sp),
+        "octave chain");
+    nb_o++;
+    if (c->par && o + 1 < L->n_oct)
+      TRY(vksift_hip_event_record(inst->ev_oct_ready[o], sp), "event record");
+  }
+  else
+  {
+    /* the next octave may start once scale S exists; with coarse_after octave 1 waits for octave 0's whole pyramid */
+    const uint32_t ready_after = (inst->coarse_after && o == 0) ? inst->S + 2 : inst->S;
+    for (uint32_t s = 1; s < inst->S + 3; s++)
+    {
+      vksift_hip_Plane dstp = plane_at(inst, o, L->gauss_off[o], s);
+      if (s == inst->S + 2 && inst->lazy_top_scale)
+      {
+        /* nothing reads Gaussian scale S+2 (keypoints use scales 1..S, the next octave scale S): keep its DoG layer only;
+         * vksift_downloadScaleSpaceImage() re-creates the plane on demand */
+        dstp.base = NULL;
+        inst->top_scale_stale[o] = true;
+      }
+      TRY(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), dstp, plane_at(inst, o, L->dog_off[o], s - 1), &inst->taps[s * VKSIFT_MAX_TAPS],
+                          inst->ntaps[s], c->count, sp),
+          "blur");
+      nb_o++;
+      if (c->par && o + 1 < L->n_oct && s == ready_after)
+        TRY(vksift_hip_event_record(inst->ev_oct_ready[o], sp), "event record");
+    }
+  }
+  vksift_hip_range_pop();
+  if (!c->pipelined || o == 0)
+    c->nblur += nb_o;
+  if (c->overlap && o == 0 && c->prof)
+    vksift_hip_event_record(c->PS->ev_pt[1], sp);
+  return 0;
+}
+
+/* ExtractKeypoints -> ComputeOrientation -> ComputeDescriptors of octave o on stream so (sift_detector.c:1106-1259);
+ * octave 0 carries the stage-timing events */
+static int enqueue_keypoint_chain(DetectCtx *c, uint32_t o, vksift_hip_stream so)
+{
+  vksift_Instance inst = c->inst;
+  const bool timed = o == 0 && c->prof;
+  if (timed)
+    vksift_hip_event_record(c->PS->ev_t[2], inst->stream);
+  vksift_hip_range_push("ExtractKeypoints");
+  TRY(vksift_hip_extract_keypoints(&c->jobs[o], c->count, so), "keypoint extraction");
+  vksift_hip_range_pop();
+  if (timed)
+    vksift_hip_event_record(c->PS->ev_t[3], inst->stream);
+  vksift_hip_range_push("ComputeOrientation");
+  TRY(vksift_hip_orientations(&c->jobs[o], c->count, so), "orientation");
+  vksift_hip_range_pop();
+  if (timed)
+    vksift_hip_event_record(c->PS->ev_t[4], inst->stream);
+  vksift_hip_range_push("ComputeDescriptors");
+  if (c->overlap && o == 0)
+  {
+    TRY(vksift_hip_event_record(inst->ev_desc_start, inst->stream), "event record");
+    inst->desc_start_valid = true;
+  }
+  TRY(vksift_hip_descriptors(&c->jobs[o], c->count, so), "descriptor");
+  vksift_hip_range_pop();
+  if (timed)
+    vksift_hip_event_record(c->PS->ev_t[5], inst->stream);
+  return 0;
+}
+
+/* one keypoint stage of the stage-synchronous / serial schedules: fork one stream per octave, join back */
+static int enqueue_stage(DetectCtx *c, int g, const char *name, int (*call)(const vksift_hip_OctaveJob *, uint32_t, vksift_hip_stream), const char *what)
+{
+  vksift_Instance inst = c->inst;
+  vksift_hip_stream st = inst->stream;
+  vksift_hip_range_push(name);
+  if (c->par)
+    TRY(vksift_hip_event_record(inst->ev_fork[g], st), "event record");
+  for (uint32_t o = 0; o < c->L->n_oct; o++)
+  {
+    vksift_hip_stream so = (c->par && o > 0) ? inst->oct_stream[o] : st;
+    if (c->par && o > 0)
+      TRY(vksift_hip_stream_wait_event(so, inst->ev_fork[g]), "octave fork");
+    TRY(call(&c->jobs[o], c->count, so), what);
+    if (c->par && o > 0)
+      TRY(vksift_hip_event_record(inst->ev_join[g][o], so), "event record");
+  }
+  if (c->par)
+    for (uint32_t o = 1; o < c->L->n_oct; o++)
+      TRY(vksift_hip_stream_wait_event(st, inst->ev_join[g][o]), "octave join");
+  vksift_hip_range_pop();
+  return 0;
+}
+
+/* Everything a detection puts on the GPU, from the image upload to the count read-back: the part a hipGraph captures.
+ *
+ * Octave o+1 only needs scale S of octave o, and everything after the pyramid is per octave (own SIFT-buffer section,
+ * own scratch). Three schedules:
+ *   pipelined (default): octave 0 runs on the instance stream, every other octave runs its whole chain
+ *     pyramid -> ExtractKeypoints -> ComputeOrientation -> ComputeDescriptors on its own stream, started by the
+ *     event "the previous octave's scale S (octave 0: whole pyramid) is ready"; the instance stream joins them before
+ *     the count read-back. The latency-bound launch chains of the coarse octaves hide behind the bandwidth-bound work
+ *     of the fine ones. Profiling events then time octave 0's stages (the other octaves overlap them).
+ *   stage-synchronous (VKSIFT_STAGE_SYNC=1): fork per octave inside each stage, join at every stage boundary.
+ *   serial (VKSIFT_SERIAL_OCTAVES=1): everything on the instance stream. */
+static int enqueue_detection(DetectCtx *c)
+{
+  vksift_Instance inst = c->inst;
+  const PyrLayout *L = c->L;
+  vksift_hip_stream st = inst->stream;
+
+  if (c->upload)
+  {
+    vksift_hip_stream s_up = c->overlap ? inst->pyr_stream[0] : st; /* behind the previous reader of d_input either way */
+    TRY(vksift_hip_memcpy_h2d(inst->d_input, inst->h_input, c->img_bytes * c->count, s_up), "image upload");
+    if (!c->capturing)
+    {
+      /* the pinned staging buffer is free again as soon as this copy has run */
+      TRY(vksift_hip_event_record(inst->ev_staging, s_up), "event record");
+      inst->staging_pending = true;
+    }
+  }
+  if (c->prof)
+    vksift_hip_event_record(c->PS->ev_t[1], st);
+
+  /* recClearBufferDataCmds (sift_detector.c:1081-1104) */
+  TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, st), "counter reset");
+
+  bool g0_done = false;
+  if (c->par)
+    TRY(vksift_hip_event_record(inst->ev_fork[0], st), "event record");
+  for (uint32_t o = 0; o < L->n_oct; o++)
+  {
+    /* so: stream of this octave's keypoint stages; sp: stream of its scale-space construction */
+    vksift_hip_stream so = st;
+    if (c->par && (o > 0 || !c->pipelined))
+    {
+      so = inst->oct_stream[o];
+      TRY(vksift_hip_stream_wait_event(so, inst->ev_fork[0]), "octave fork");
+    }
+    vksift_hip_stream sp = c->overlap ? inst->pyr_stream[o] : so;
+    if (c->overlap && o > 0 && inst->pyr_free_valid[inst->pyr_cur])
+      TRY(vksift_hip_stream_wait_event(sp, inst->ev_pyr_free[inst->pyr_cur]), "pyramid buffer recycle");
+    TRY(enqueue_pyramid(c, o, sp, &g0_done), "scale space construction");
+    if (c->overlap)
+    {
+      TRY(vksift_hip_event_record(inst->ev_pyr_done[o], sp), "event record");
+      TRY(vksift_hip_stream_wait_event(so, inst->ev_pyr_done[o]), "scale space ready");
+    }
+    if (c->pipelined)
+      TRY(enqueue_keypoint_chain(c, o, so), "keypoint stages");
+    if (c->par && so != st)
+      TRY(vksift_hip_event_record(inst->ev_join[0][o], so), "event record");
+  }
+  if (c->par)
+    for (uint32_t o = 0; o < L->n_oct; o++)
+      if (o > 0 || !c->pipelined)
+        TRY(vksift_hip_stream_wait_event(st, inst->ev_join[0][o]), "octave join");
+  if (c->overlap)
+  {
+    /* everything that reads this call's pyramid has been joined into the instance stream */
+    TRY(vksift_hip_event_record(inst->ev_pyr_free[inst->pyr_cur], st), "event record");
+    inst->pyr_free_valid[inst->pyr_cur] = true;
+  }
+  inst->last_blur_launches = c->nblur;
+  /* profiling: the pyramid interval is octave 0's when pipelined, the whole pyramid's otherwise */
+  inst->last_alg_bytes = algorithmic_pyramid_bytes(inst, c->w, c->h, c->pipelined ? 1u : L->n_oct) * c->count;
+
+  if (!c->pipelined)
+  {
+    /* Each of the three keypoint stages forks one stream per octave (per-octave scratch, no sharing) and joins back
+     * into the main stream, so stage boundaries (and the stage timings) stay well defined. */
+    if (c->prof)
+      vksift_hip_event_record(c->PS->ev_t[2], st);
+    TRY(enqueue_stage(c, 1, "ExtractKeypoints", vksift_hip_extract_keypoints, "keypoint extraction"), "keypoint extraction");
+    if (c->prof)
+      vksift_hip_event_record(c->PS->ev_t[3], st);
+    TRY(enqueue_stage(c, 2, "ComputeOrientation", vksift_hip_orientations, "orientation"), "orientation");
+    if (c->prof)
+      vksift_hip_event_record(c->PS->ev_t[4], st);
+    TRY(enqueue_stage(c, 3, "ComputeDescriptors", vksift_hip_descriptors, "descriptor"), "descriptor");
+    if (c->prof)
+      vksift_hip_event_record(c->PS->ev_t[5], st);
+  }
+
+  /* recCopySIFTCountCmds (sift_detector.c:1261-1291) */
+  TRY(vksift_hip_memcpy_d2h(inst->h_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES,
+                            sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, st),
+      "count read-back");
+  return 0;
+}
+
+/* hipGraph replay (VKSIFT_GRAPH=1): the launch sequence depends only on (resolution, batch, first buffer, input pointer) —
+ * counts and candidate lists live on the device — so it is captured once per such key and replayed with a single launch.
+ * Returns the cache entry for the key (hit: ->exec != NULL) or the least recently used entry, emptied (miss). */
+static DetectGraph *graph_lookup(vksift_Instance inst, const DetectCtx *c)
+{
+  DetectGraph *victim = &inst->graphs[0];
+  for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
+  {
+    DetectGraph *g = &inst->graphs[i];
+    if (g->exec && g->w == c->w && g->h == c->h && g->count == c->count && g->first_buf == c->first_buf && g->d_src == c->d_src)
+      return g;
+    if (g->stamp < victim->stamp)
+      victim = g;
+  }
+  vksift_hip_graph_destroy(victim->exec);
+  memset(victim, 0, sizeof(*victim));
+  return victim;
+}
+
+static void detect_impl(vksift_Instance inst, const uint8_t *const *images, const uint8_t *d_images, uint32_t count, uint32_t w, uint32_t h,
+                        uint32_t first_buf, const char *fn)
+{
+  vksift_hip_stream st = inst->stream;
+  bool capturing = false;
+
+  bool valid = count >= 1 && count <= inst->batch_cap && buffer_idx_valid(inst, first_buf) && buffer_idx_valid(inst, first_buf + count - 1) &&
+               resolution_valid(inst, w, h);
+  if (valid)
+  {
+    uint32_t shortest = w < h ? w : h;
+    if (shortest < 16)
+    {
+      logError(LOG_TAG, "Input image %ux%u is too small to build a single octave.", w, h);
+      valid = false;
+    }
+  }
+  if (!valid)
+  {
+    logError(LOG_TAG, "%s error: invalid input.", fn);
+    inst->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+
+  /* The reference makes a new pipeline wait on the host for the running ones (vulkansift.c:326-327) because its
+   * command buffers and staging memory are single-instanced. Here the instance's HIP stream is in-order, so GPU
+   * work is already serialised; the host only has to wait for the resources it is about to overwrite: the pinned
+   * image staging buffer, and (when profiling) the event set of the detection before the previous one. */
+  if (inst->staging_pending && images)
+  {
+    HIP_CHECK(vksift_hip_event_sync(inst->ev_staging), "staging synchronisation");
+    inst->staging_pending = false;
+  }
+  ProfSet *PS = &inst->prof[inst->prof_cur];
+  if (inst->profiling)
+  {
+    /* recycle the older event set: the host never waits for the call it just queued */
+    inst->prof_cur ^= 1;
+    PS = &inst->prof[inst->prof_cur];
+    if (PS->valid && !PS->accounted)
+    {
+      HIP_CHECK(vksift_hip_event_sync(PS->ev_t[6]), "profiling synchronisation");
+      account_set(inst, PS);
+    }
+    PS->valid = false;
+  }
+
+  if (inst->cur_w != w || inst->cur_h != h)
+  {
+    PyrLayout L;
+    compute_layout(inst, w, h, &L);
+    if (L.n_oct == 0 || L.img_floats > inst->pyr_img_stride || L.seg_total > inst->seg_cap || L.cand_total > inst->cand_cap)
+    {
+      logError(LOG_TAG, "Failed to fit the scale-space of a %ux%u image in the memory reserved for input_image_max_size", w, h);
+      goto gpu_error;
+    }
+    inst->lay = L;
+    inst->cur_w = w;
+    inst->cur_h = h;
+  }
+  inst->cur_batch = count;
+  for (uint32_t i = 0; i < count; i++)
+    set_buffer_sections(inst, first_buf + i, inst->lay.n_oct, w, h);
+
+  DetectCtx c;
+  c.inst = inst, c.L = &inst->lay, c.PS = PS;
+  c.prof = inst->profiling;
+  c.par = !inst->serial_octaves && c.L->n_oct > 1;
+  c.pipelined = c.par && !inst->stage_sync;
+  /* Overlapping detections (VKSIFT_PYR_PINGPONG=1): with two pyramid buffers the scale-space construction of this call
+   * does not depend on anything the previous call (or a matching still in flight) reads or writes, so it runs on its own
+   * streams, ordered only behind the last reader of the pyramid buffer it recycles; everything that touches the SIFT
+   * buffers and the extraction scratch stays in instance-stream order. */
+  c.overlap = inst->pyr_pingpong && c.pipelined;
+  c.upload = images != NULL;
+  c.w = w, c.h = h, c.count = count, c.first_buf = first_buf;
+  c.img_bytes = (size_t)w * h;
+  c.nblur = 0;
+  c.capturing = false;
+  PS->overlap = c.overlap;
+  if (c.prof)
+    vksift_hip_event_record(PS->ev_t[0], st);
+  if (c.overlap)
+  {
+    inst->pyr_cur ^= 1;
+    inst->d_pyr = inst->d_pyr_buf[inst->pyr_cur];
+    if (inst->pyr_free_valid[inst->pyr_cur])
+      HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream[0], inst->ev_pyr_free[inst->pyr_cur]), "pyramid buffer recycle");
+    /* pair the bandwidth-bound pyramid with the compute-bound tail of the previous detection (descriptors, matching),
+     * not with its equally bandwidth-bound extraction stage */
+    if (inst->overlap_gate && inst->desc_start_valid)
+      HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream[0], inst->ev_desc_start), "overlap gate");
+  }
+
+  /* stage the images; the caller may reuse its memory as soon as we return (sift_memory.c:943) */
+  c.d_src = d_images;
+  if (images)
+  {
+    for (uint32_t i = 0; i < count; i++)
+      memcpy(inst->h_input + i * c.img_bytes, images[i], c.img_bytes);
+    c.d_src = inst->d_input;
+  }
+  build_jobs(&c);
+
+  /* host-visible events (staging, completion, profiling) stay outside a captured region */
+  DetectGraph *dg = (inst->use_graphs && !c.prof && !c.overlap) ? graph_lookup(inst, &c) : NULL;
+  if (dg && dg->exec)
+  {
+    HIP_CHECK(vksift_hip_graph_launch(dg->exec, st), "detection graph launch");
+    memcpy(inst->top_scale_stale, dg->top_scale_stale, sizeof(inst->top_scale_stale));
+  }
+  else
+  {
+    if (dg)
+    {
+      if (vksift_hip_capture_begin(st) == 0)
+        capturing = c.capturing = true;
+      else
+        dg = NULL;
+    }
+    if (enqueue_detection(&c) != 0)
+      goto gpu_error;
+    if (capturing)
+    {
+      capturing = false;
+      vksift_hip_graph exec = NULL;
+      HIP_CHECK(vksift_hip_capture_end(st, &exec), "detection graph capture");
+      dg->exec = exec;
+      dg->w = w, dg->h = h, dg->count = count, dg->first_buf = first_buf, dg->d_src = c.d_src;
+      memcpy(dg->top_scale_stale, inst->top_scale_stale, sizeof(inst->top_scale_stale));
+      HIP_CHECK(vksift_hip_graph_launch(dg->exec, st), "detection graph launch");
+    }
+  }
+  if (dg)
+    dg->stamp = ++inst->graph_stamp;
+  if (images && dg)
+  {
+    /* graph replay: the upload is a node of the graph, the staging buffer is busy until the graph has run */
+    HIP_CHECK(vksift_hip_event_record(inst->ev_staging, st), "event record");
+    inst->staging_pending = true;
+  }
+  inst->device_input_last = images == NULL;
+  if (c.prof)
+  {
+    vksift_hip_event_record(PS->ev_t[6], st);
+    PS->valid = true;
+    PS->accounted = false;
+    PS->blur_launches = inst->last_blur_launches;
+    PS->alg_bytes = inst->last_alg_bytes;
+  }
+  HIP_CHECK(vksift_hip_event_record(inst->ev_detect, st), "event record");
+  inst->detect_pending = true;
+  inst->detect_first_buf = first_buf;
+  inst->detect_count = count;
+  return;
+
+gpu_error:
+  if (capturing)
+  {
+    vksift_hip_graph dead = NULL;
+    (void)vksift_hip_capture_end(st, &dead);
+    vksift_hip_graph_destroy(dead);
+  }
+  logError(LOG_TAG, "%s error: Failed to start the detection pipeline.", fn);
+  inst->error_cb(VKSIFT_VULKAN_ERROR);
+}
+
+void vksift_detectFeatures(vksift_Instance instance, const uint8_t *image_data, const uint32_t image_width, const uint32_t image_height,
+                           const uint32_t gpu_buffer_id)
+{
+  const uint8_t *imgs[1] = {image_data};
+  vksift_hip_set_device(instance->device);
+  detect_impl(instance, imgs, NULL, 1, image_width, image_height, gpu_buffer_id, "vksift_detectFeatures()");
+}
+
+void vksift_ext_detectFeaturesBatch(vksift_Instance instance, const uint8_t *const *images, uint32_t count, uint32_t image_width, uint32_t image_height,
+                                    uint32_t first_gpu_buffer_id)
+{
+  vksift_hip_set_device(instance->device);
+  detect_impl(instance, images, NULL, count, image_width, image_height, first_gpu_buffer_id, "vksift_ext_detectFeaturesBatch()");
+}
+
+void vksift_ext_detectFeaturesBatchDevice(vksift_Instance instance, const uint8_t *d_images, uint32_t count, uint32_t image_width, uint32_t image_height,
+                                          uint32_t first_gpu_buffer_id)
+{
+  vksift_hip_set_device(instance->device);
+  if (d_images == NULL)
+  {
+    logError(LOG_TAG, "vksift_ext_detectFeaturesBatchDevice() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
+  }
+  detect_impl(instance, NULL, d_images, count, image_width, image_height, first_gpu_buffer_id, "vksift_ext_detectFeaturesBatchDevice()");
+}
+

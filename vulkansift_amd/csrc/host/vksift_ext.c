@@ -1,0 +1,104 @@
+/*
+ * vksift_ext.c — additive extensions of include/vksift_ext.h (profiling accessors, descriptor export, synthetic inputs)
+ */
+#include "vksift_internal.h"
+
+/* ------------------------------------------------------------------------------------------------ */
+/* extensions                                                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+void vksift_ext_setProfiling(vksift_Instance instance, bool enabled)
+{
+  instance->profiling = enabled;
+  instance->prof[0].valid = instance->prof[1].valid = false;
+  instance->prof[0].accounted = instance->prof[1].accounted = false;
+  instance->match_timing_valid = false;
+  memset(instance->acc_ms, 0, sizeof(instance->acc_ms));
+  instance->acc_calls = 0;
+  instance->acc_blur_launches = 0;
+  instance->acc_alg_bytes = 0;
+}
+
+void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *sum, uint32_t *nb_calls, bool reset)
+{
+  memset(sum, 0, sizeof(*sum));
+  *nb_calls = 0;
+  if (!instance->profiling)
+    return;
+  vksift_hip_set_device(instance->device);
+  wait_all(instance);
+  account_timings(instance);
+  sum->upload_ms = (float)instance->acc_ms[0];
+  sum->pyramid_ms = (float)instance->acc_ms[1];
+  sum->extrema_ms = (float)instance->acc_ms[2];
+  sum->orientation_ms = (float)instance->acc_ms[3];
+  sum->descriptor_ms = (float)instance->acc_ms[4];
+  sum->total_ms = (float)instance->acc_ms[5];
+  sum->nb_blur_launches = (uint32_t)instance->acc_blur_launches;
+  sum->pyramid_algorithmic_bytes = instance->acc_alg_bytes;
+  *nb_calls = instance->acc_calls;
+  if (reset)
+  {
+    memset(instance->acc_ms, 0, sizeof(instance->acc_ms));
+    instance->acc_calls = 0;
+    instance->acc_blur_launches = 0;
+    instance->acc_alg_bytes = 0;
+  }
+}
+
+void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *out)
+{
+  memset(out, 0, sizeof(*out));
+  const ProfSet *ps = &instance->prof[instance->prof_cur];
+  if (!instance->profiling || !ps->valid)
+    return;
+  vksift_hip_set_device(instance->device);
+  wait_all(instance);
+  const vksift_hip_event *e = ps->ev_t;
+  out->upload_ms = vksift_hip_event_elapsed_ms(e[0], e[1]);
+  out->pyramid_ms = ps->overlap ? vksift_hip_event_elapsed_ms(ps->ev_pt[0], ps->ev_pt[1]) : vksift_hip_event_elapsed_ms(e[1], e[2]);
+  out->extrema_ms = vksift_hip_event_elapsed_ms(e[2], e[3]);
+  out->orientation_ms = vksift_hip_event_elapsed_ms(e[3], e[4]);
+  out->descriptor_ms = vksift_hip_event_elapsed_ms(e[4], e[5]);
+  out->total_ms = vksift_hip_event_elapsed_ms(e[0], e[6]);
+  out->nb_blur_launches = instance->last_blur_launches;
+  out->pyramid_algorithmic_bytes = instance->last_alg_bytes;
+}
+
+float vksift_ext_getMatchTime(vksift_Instance instance)
+{
+  if (!instance->profiling || !instance->match_timing_valid)
+    return -1.f;
+  vksift_hip_set_device(instance->device);
+  wait_all(instance);
+  return vksift_hip_event_elapsed_ms(instance->ev_m[0], instance->ev_m[1]);
+}
+
+uint32_t vksift_ext_exportDescriptorsDevice(vksift_Instance instance, uint32_t gpu_buffer_id, uint8_t *d_descriptors)
+{
+  if (!buffer_idx_valid(instance, gpu_buffer_id) || d_descriptors == NULL)
+  {
+    logError(LOG_TAG, "vksift_ext_exportDescriptorsDevice() error: invalid input.");
+    instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return 0;
+  }
+  vksift_Instance inst = instance;
+  vksift_hip_set_device(inst->device);
+  uint32_t n = 0, max_rows = 0;
+  HIP_CHECK(wait_all(inst), "stream synchronisation");
+  {
+    /* gather into slot 0's A scratch (norms are a by-product), then copy the rows out */
+    const MatchScratch fwd = fwd_scratch(inst);
+    HIP_CHECK(gather_buffers(inst, &fwd, &gpu_buffer_id, 1, 0, false, inst->d_desc_a, 2, 0u, &max_rows), "descriptor gather");
+    HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n + 2, inst->d_match_n + 2, sizeof(uint32_t), inst->stream), "descriptor gather");
+    HIP_CHECK(vksift_hip_stream_sync(inst->stream), "descriptor gather");
+    n = inst->h_match_n[2];
+    HIP_CHECK(vksift_hip_memcpy_d2d(d_descriptors, inst->d_desc_a, (size_t)n * 128u, inst->stream), "descriptor gather");
+    HIP_CHECK(vksift_hip_stream_sync(inst->stream), "descriptor gather");
+  }
+  return n;
+gpu_error:
+  logError(LOG_TAG, "vksift_ext_exportDescriptorsDevice() error when exporting descriptors.");
+  instance->error_cb(VKSIFT_VULKAN_ERROR);
+  return 0;
+}
+

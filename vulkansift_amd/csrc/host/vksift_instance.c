@@ -1,0 +1,419 @@
+/*
+ * vksift_instance.c — instance creation / destruction, scale-space layout, synchronisation helpers (vulkansift.c:165-313, sift_memory.c:15-87,133-360)
+ */
+#include "vksift_internal.h"
+
+/* ------------------------------------------------------------------------------------------------ */
+/* layout helpers                                                                                   */
+/* ------------------------------------------------------------------------------------------------ */
+static uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+void compute_layout(vksift_Instance inst, uint32_t w, uint32_t h, PyrLayout *L)
+{
+  memset(L, 0, sizeof(*L));
+  L->n_oct = vksift_hm_octaves_for(&inst->cfg, inst->max_octaves, w, h, L->w, L->h);
+  uint64_t off = 0;
+  for (uint32_t o = 0; o < L->n_oct; o++)
+  {
+    L->pitch[o] = round_up(L->w[o], PITCH_ALIGN);
+    L->plane_stride[o] = (uint64_t)L->pitch[o] * L->h[o];
+    L->gauss_off[o] = off;
+    off += L->plane_stride[o] * (inst->S + 3);
+    L->dog_off[o] = off;
+    off += L->plane_stride[o] * (inst->S + 2);
+  }
+  L->img_floats = off;
+  uint64_t so = 0, co = 0;
+  for (uint32_t o = 0; o < L->n_oct; o++)
+  {
+    L->seg_off[o] = so;
+    so += (uint64_t)inst->S * L->h[o] * ((L->w[o] + 63) / 64);
+    L->cand_off[o] = co;
+    /* strict 3x3x3 extrema cannot be denser than 1/4 of the texels; 1/8 (after the contrast pre-filter) is reserved,
+     * excess candidates of a pathological image are dropped in raster order */
+    L->cand_cap[o] = (uint64_t)inst->S * L->w[o] * L->h[o] / 8u + 64u;
+    co += L->cand_cap[o];
+  }
+  L->seg_total = so;
+  L->cand_total = co;
+}
+
+void set_buffer_sections(vksift_Instance inst, uint32_t buf, uint32_t n_oct, uint32_t w, uint32_t h)
+{
+  BufferInfo *b = &inst->bufs[buf];
+  memset(b->sec_off, 0, sizeof(b->sec_off));
+  memset(b->sec_cap, 0, sizeof(b->sec_cap));
+  b->is_packed = false;
+  b->nb_stored = 0;
+  b->nb_sections = n_oct;
+  b->in_w = w;
+  b->in_h = h;
+  b->counts_valid = false;
+  vksift_hm_section_caps(inst->cfg.max_nb_sift_per_buffer, n_oct, b->sec_cap);
+  uint32_t off = 0;
+  for (uint32_t o = 0; o < n_oct; o++)
+  {
+    b->sec_off[o] = off;
+    off += b->sec_cap[o];
+  }
+}
+
+
+/* ------------------------------------------------------------------------------------------------ */
+/* instance                                                                                         */
+/* ------------------------------------------------------------------------------------------------ */
+static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift_Config *config, uint32_t batch_cap)
+{
+  assert(instance_ptr != NULL);
+  assert(*instance_ptr == NULL);
+  assert(config != NULL);
+
+  if (!vksift_g_loaded)
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: GPU runtime not available. vksift_loadVulkan() must be called before using this function.");
+    return VKSIFT_VULKAN_ERROR;
+  }
+  if (!config_is_valid(config))
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: Invalid configuration detected.");
+    return VKSIFT_INVALID_INPUT_ERROR;
+  }
+  if (batch_cap == 0 || batch_cap > config->sift_buffer_count)
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: batch capacity (%u) must be in [1, sift_buffer_count=%u].", batch_cap, config->sift_buffer_count);
+    return VKSIFT_INVALID_INPUT_ERROR;
+  }
+
+  vksift_Instance inst = (vksift_Instance)calloc(1, sizeof(struct vksift_Instance_T));
+  if (!inst)
+    return VKSIFT_VULKAN_ERROR;
+  *instance_ptr = inst;
+  inst->cfg = *config;
+  inst->error_cb = config->on_error_callback_function;
+  inst->S = config->nb_scales_per_octave;
+  inst->batch_cap = batch_cap;
+
+  int ndev = vksift_hip_device_count();
+  int dev = config->gpu_device_index;
+  if (dev < 0)
+    dev = 0; /* all MI355X of a node are identical: "best" = first (reference scores by type/VRAM, vulkan_device.c:394-494) */
+  if (dev >= ndev)
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: gpu_device_index %d but only %d device(s) available", dev, ndev);
+    vksift_destroyInstance(instance_ptr);
+    return VKSIFT_VULKAN_ERROR;
+  }
+  inst->device = dev;
+  if (vksift_hip_set_device(dev) != 0)
+  {
+    vksift_destroyInstance(instance_ptr);
+    return VKSIFT_VULKAN_ERROR;
+  }
+  if (config->pyramid_precision_mode == VKSIFT_PYRAMID_PRECISION_FLOAT16)
+    logWarning(LOG_TAG, "VKSIFT_PYRAMID_PRECISION_FLOAT16 requested: this build keeps the scale-space in fp32 (superset precision).");
+  if (config->use_gpu_debug_functions)
+    logWarning(LOG_TAG, "use_gpu_debug_functions requested: there is no frame presenter in the HIP build; use rocprofv3 / roctx ranges instead.");
+
+  inst->max_octaves = vksift_hm_max_octaves(config, &inst->max_image_size);
+  vksift_hm_blur_taps(config, inst->taps, inst->ntaps);
+
+  /* ---- reserve device memory for the configured maxima (sift_memory.c:133-360 equivalent) ---- */
+  uint32_t side = (uint32_t)ceilf(sqrtf((float)config->input_image_max_size));
+  PyrLayout L;
+  compute_layout(inst, side, side, &L);
+  /* Non-square images of the same area need a little more because of the row-pitch padding: keep slack. */
+  inst->pyr_img_stride = L.img_floats + L.img_floats / 4 + 4096;
+  inst->seg_cap = L.seg_total + L.seg_total / 4 + 1024;
+  inst->cand_cap = L.cand_total + L.cand_total / 4 + 4096u;
+  uint32_t caps[VKSIFT_MAX_OCTAVES] = {0};
+  vksift_hm_section_caps(config->max_nb_sift_per_buffer, 1, caps);
+  inst->ori_cap = config->max_nb_sift_per_buffer; /* a single-octave detection gives the largest section */
+  inst->buf_stride = ((uint64_t)config->max_nb_sift_per_buffer * FEAT_BYTES + 255u) & ~(uint64_t)255u;
+
+  float fp_tab[DESC_FP_TAB_MAX];
+  inst->desc_fp_len = vksift_hm_desc_fp_table(config, fp_tab, DESC_FP_TAB_MAX);
+
+  bool ok = true;
+#define ALLOC_D(ptr, bytes) ok = ok && ((ptr = vksift_hip_malloc(bytes)) != NULL)
+#define ALLOC_H(ptr, bytes) ok = ok && ((ptr = vksift_hip_host_malloc(bytes)) != NULL)
+  {
+    /* 1: two pyramid buffers, so that the scale-space construction of detection N+1 may run under the descriptor and
+     * matching work of detection N. Off by default: on MI355X two large kernels sharing the CUs each slow down by about
+     * what the overlap wins (measured -5 % frames/s), and the second buffer doubles the largest allocation. */
+    const char *e = getenv("VKSIFT_PYR_PINGPONG");
+    inst->pyr_pingpong = e && e[0] == '1';
+  }
+  ALLOC_D(inst->d_pyr_buf[0], sizeof(float) * inst->pyr_img_stride * batch_cap);
+  if (inst->pyr_pingpong)
+    ALLOC_D(inst->d_pyr_buf[1], sizeof(float) * inst->pyr_img_stride * batch_cap);
+  inst->d_pyr = inst->d_pyr_buf[0];
+  ALLOC_D(inst->d_input, (size_t)inst->max_image_size * batch_cap);
+  ALLOC_H(inst->h_input, (size_t)inst->max_image_size * batch_cap);
+  ALLOC_D(inst->d_feats, inst->buf_stride * config->sift_buffer_count);
+  ALLOC_D(inst->d_found, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
+  ALLOC_H(inst->h_found, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
+  ALLOC_D(inst->d_seg_mask, sizeof(uint64_t) * inst->seg_cap * batch_cap);
+  ALLOC_D(inst->d_seg_off, sizeof(uint32_t) * inst->seg_cap * batch_cap);
+  ALLOC_D(inst->d_cand_xy, sizeof(uint32_t) * inst->cand_cap * batch_cap);
+  ALLOC_D(inst->d_cand_flag, sizeof(uint32_t) * inst->cand_cap * batch_cap);
+  ALLOC_D(inst->d_cand_n, sizeof(uint32_t) * batch_cap * VKSIFT_MAX_OCTAVES);
+  ALLOC_D(inst->d_ori_ang, sizeof(float) * VKSIFT_HIP_MAX_ORI * inst->ori_cap * batch_cap);
+  ALLOC_D(inst->d_ori_cnt, sizeof(uint32_t) * inst->ori_cap * batch_cap);
+  ALLOC_D(inst->d_desc_fp, sizeof(float) * DESC_FP_TAB_MAX);
+  /* matching scratch: one slot per batch entry (slot 0 serves vksift_matchFeatures) */
+  inst->desc_slot_stride = (((uint64_t)config->max_nb_sift_per_buffer * 128u + 256u) + 255u) & ~(uint64_t)255u;
+  inst->match_slot_stride = (((uint64_t)config->max_nb_sift_per_buffer * MATCH_BYTES) + 255u) & ~(uint64_t)255u;
+  inst->norm_slot_stride = 3u * (uint64_t)config->max_nb_sift_per_buffer + 96u; /* norms of A, norms of B, redo flags */
+  ALLOC_D(inst->d_desc_a, inst->desc_slot_stride * batch_cap);
+  ALLOC_D(inst->d_desc_b, inst->desc_slot_stride * batch_cap);
+  ALLOC_D(inst->d_matches, inst->match_slot_stride * batch_cap);
+  ALLOC_D(inst->d_norms, sizeof(uint32_t) * inst->norm_slot_stride * batch_cap);
+  ALLOC_D(inst->d_match_n, sizeof(uint32_t) * 4 * batch_cap);
+  if (config->max_nb_sift_per_buffer > 32768u)
+    ALLOC_D(inst->d_match_partial, sizeof(uint32_t) * (size_t)config->max_nb_sift_per_buffer * 5u * VKSIFT_HIP_MATCH_CHUNKS);
+  ALLOC_H(inst->h_match_n, sizeof(uint32_t) * 4 * batch_cap);
+  inst->h_matches = NULL;
+  inst->bufs = (BufferInfo *)calloc(config->sift_buffer_count, sizeof(BufferInfo));
+  ok = ok && inst->bufs != NULL;
+  /* All streams at the default priority: a high-priority instance stream with low-priority octave streams was measured
+   * 20 % slower on MI355X (11.3k vs 14.1k frames/s). */
+  inst->stream = vksift_hip_stream_create();
+  inst->oct_stream[0] = inst->stream;
+  for (int o = 1; o < VKSIFT_MAX_OCTAVES; o++)
+    inst->oct_stream[o] = vksift_hip_stream_create();
+  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
+  {
+    inst->ev_oct_ready[o] = vksift_hip_event_create();
+    for (int g = 0; g < 4; g++)
+      inst->ev_join[g][o] = vksift_hip_event_create();
+  }
+  for (int g = 0; g < 4; g++)
+    inst->ev_fork[g] = vksift_hip_event_create();
+  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
+  {
+    inst->pyr_stream[o] = vksift_hip_stream_create();
+    inst->ev_pyr_done[o] = vksift_hip_event_create();
+  }
+  inst->ev_desc_start = vksift_hip_event_create();
+  {
+    const char *e = getenv("VKSIFT_OVERLAP_GATE");
+    inst->overlap_gate = e ? atoi(e) : 1;
+  }
+  for (int i = 0; i < 2; i++)
+  {
+    inst->ev_pyr_free[i] = vksift_hip_event_create();
+  }
+  {
+    const char *e = getenv("VKSIFT_SERIAL_OCTAVES"); /* debug: everything on the main stream */
+    inst->serial_octaves = e && e[0] == '1';
+    e = getenv("VKSIFT_LAZY_TOP"); /* 0: always store the last Gaussian scale of every octave */
+    inst->lazy_top_scale = !(e && e[0] == '0');
+    /* Octave 1 starts after octave 0's last blur instead of right after its scale S: the two bandwidth-bound pyramids no
+     * longer compete (octave 0 runs 5-8 % faster alone; frames/s unchanged within noise), and the coarse octaves then
+     * overlap octave 0's extraction and descriptor stages. VKSIFT_COARSE_AFTER=0 restores the earliest possible start. */
+    e = getenv("VKSIFT_COARSE_AFTER");
+    inst->coarse_after = !(e && e[0] == '0');
+    /* 1: capture the detection launch sequence in a hipGraph and replay it. Off by default: measured on MI355X / ROCm 7.2 it
+     * buys 6 % on one 640x480 image (0.78 vs 0.83 ms) and loses 10 % from 1536x1024 up (the graph runs the per-octave
+     * branches less concurrently than the streams do). */
+    e = getenv("VKSIFT_GRAPH");
+    inst->use_graphs = e && e[0] == '1';
+    e = getenv("VKSIFT_STAGE_SYNC");
+    inst->stage_sync = e && e[0] == '1';
+    /* 1 selects the experimental fused scale-chain kernel (pyramid_fused.hip): bit-identical, but measured slower than the
+     * per-scale kernels on MI355X (VALU-issue bound) -> off by default */
+    e = getenv("VKSIFT_CHAIN");
+    inst->use_chain = (e && e[0] == '1') && vksift_hip_octave_chain_supported(inst->ntaps, inst->S);
+    e = getenv("VKSIFT_CHAIN_MIN_ROWS");
+    inst->chain_min_rows = e ? (uint32_t)atoi(e) : 200u;
+  }
+  inst->ev_detect = vksift_hip_event_create();
+  inst->ev_match = vksift_hip_event_create();
+  inst->ev_staging = vksift_hip_event_create();
+  for (int i = 0; i < 8; i++)
+  {
+    inst->prof[0].ev_t[i] = vksift_hip_event_create();
+    inst->prof[1].ev_t[i] = vksift_hip_event_create();
+  }
+  for (int i = 0; i < 2; i++)
+  {
+    inst->prof[0].ev_pt[i] = vksift_hip_event_create();
+    inst->prof[1].ev_pt[i] = vksift_hip_event_create();
+  }
+  inst->ev_m[0] = vksift_hip_event_create();
+  inst->ev_m[1] = vksift_hip_event_create();
+  ok = ok && inst->stream && inst->ev_detect && inst->ev_match;
+  if (!ok)
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: Failed to setup the required memory objects");
+    vksift_destroyInstance(instance_ptr);
+    return VKSIFT_VULKAN_ERROR;
+  }
+  memset(inst->h_found, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
+  memset(inst->h_match_n, 0, sizeof(uint32_t) * 4 * batch_cap);
+  if (vksift_hip_memset(inst->d_found, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count, inst->stream) != 0 ||
+      vksift_hip_memcpy_h2d(inst->d_desc_fp, fp_tab, sizeof(float) * inst->desc_fp_len, inst->stream) != 0 || vksift_hip_stream_sync(inst->stream) != 0)
+  {
+    logError(LOG_TAG, "vksift_createInstance() failure: device initialisation failed");
+    vksift_destroyInstance(instance_ptr);
+    return VKSIFT_VULKAN_ERROR;
+  }
+
+  /* default scale-space = the square of maximal area, like the reference (sift_memory.c:644-662) */
+  inst->cur_w = side;
+  inst->cur_h = side;
+  inst->cur_batch = 1;
+  inst->lay = L;
+  for (uint32_t b = 0; b < config->sift_buffer_count; b++)
+  {
+    set_buffer_sections(inst, b, L.n_oct, side, side);
+    inst->bufs[b].counts_valid = true;
+  }
+
+  logInfo(LOG_TAG, "vksift_createInstance() success");
+  return VKSIFT_SUCCESS;
+}
+
+vksift_Result vksift_createInstance(vksift_Instance *instance_ptr, const vksift_Config *config) { return create_instance(instance_ptr, config, 1); }
+
+vksift_Result vksift_ext_createInstanceBatched(vksift_Instance *instance_ptr, const vksift_Config *config, uint32_t batch_capacity)
+{
+  return create_instance(instance_ptr, config, batch_capacity);
+}
+
+void vksift_destroyInstance(vksift_Instance *instance_ptr)
+{
+  assert(instance_ptr != NULL);
+  assert(*instance_ptr != NULL);
+  vksift_Instance inst = *instance_ptr;
+  vksift_hip_set_device(inst->device);
+  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
+  {
+    if (o > 0 && inst->oct_stream[o])
+      vksift_hip_stream_sync(inst->oct_stream[o]);
+    if (inst->pyr_stream[o])
+      vksift_hip_stream_sync(inst->pyr_stream[o]);
+  }
+  if (inst->stream)
+    vksift_hip_stream_sync(inst->stream);
+  vksift_hip_free(inst->d_pyr_buf[0]);
+  vksift_hip_free(inst->d_pyr_buf[1]);
+  vksift_hip_free(inst->d_input);
+  vksift_hip_host_free(inst->h_input);
+  vksift_hip_free(inst->d_feats);
+  vksift_hip_free(inst->d_found);
+  vksift_hip_host_free(inst->h_found);
+  vksift_hip_free(inst->d_seg_mask);
+  vksift_hip_free(inst->d_seg_off);
+  vksift_hip_free(inst->d_cand_xy);
+  vksift_hip_free(inst->d_cand_flag);
+  vksift_hip_free(inst->d_cand_n);
+  vksift_hip_free(inst->d_ori_ang);
+  vksift_hip_free(inst->d_ori_cnt);
+  vksift_hip_free(inst->d_desc_fp);
+  vksift_hip_free(inst->d_desc_a);
+  vksift_hip_free(inst->d_desc_b);
+  vksift_hip_free(inst->d_matches);
+  vksift_hip_free(inst->d_norms);
+  vksift_hip_free(inst->d_match_n);
+  vksift_hip_free(inst->d_match_partial);
+  for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
+    vksift_hip_graph_destroy(inst->graphs[i].exec);
+  vksift_hip_free(inst->rev.desc_a);
+  vksift_hip_free(inst->rev.desc_b);
+  vksift_hip_free(inst->rev.matches);
+  vksift_hip_free(inst->rev.norms);
+  vksift_hip_free(inst->rev.match_n);
+  vksift_hip_free(inst->d_filtered);
+  vksift_hip_free(inst->d_filtered_n);
+  vksift_hip_host_free(inst->h_filtered_n);
+  vksift_hip_host_free(inst->h_match_n);
+  vksift_hip_host_free(inst->h_matches);
+  free(inst->bufs);
+  vksift_hip_event_destroy(inst->ev_detect);
+  vksift_hip_event_destroy(inst->ev_match);
+  vksift_hip_event_destroy(inst->ev_staging);
+  for (int i = 0; i < 8; i++)
+  {
+    vksift_hip_event_destroy(inst->prof[0].ev_t[i]);
+    vksift_hip_event_destroy(inst->prof[1].ev_t[i]);
+  }
+  vksift_hip_event_destroy(inst->ev_m[0]);
+  vksift_hip_event_destroy(inst->ev_m[1]);
+  for (int o = 1; o < VKSIFT_MAX_OCTAVES; o++)
+    vksift_hip_stream_destroy(inst->oct_stream[o]);
+  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
+  {
+    vksift_hip_stream_destroy(inst->pyr_stream[o]);
+    vksift_hip_event_destroy(inst->ev_pyr_done[o]);
+  }
+  vksift_hip_event_destroy(inst->ev_desc_start);
+  for (int i = 0; i < 2; i++)
+  {
+    vksift_hip_event_destroy(inst->ev_pyr_free[i]);
+    vksift_hip_event_destroy(inst->prof[0].ev_pt[i]);
+    vksift_hip_event_destroy(inst->prof[1].ev_pt[i]);
+  }
+  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
+  {
+    vksift_hip_event_destroy(inst->ev_oct_ready[o]);
+    for (int g = 0; g < 4; g++)
+      vksift_hip_event_destroy(inst->ev_join[g][o]);
+  }
+  for (int g = 0; g < 4; g++)
+    vksift_hip_event_destroy(inst->ev_fork[g]);
+  vksift_hip_stream_destroy(inst->stream);
+  free(inst);
+  *instance_ptr = NULL;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* synchronisation helpers (fences of the reference)                                                */
+/* ------------------------------------------------------------------------------------------------ */
+/* The stream is in-order: once the most recent detection has completed, every earlier one has too, so all the
+ * host-side counter mirrors are valid. */
+void mark_detect_done(vksift_Instance inst)
+{
+  inst->detect_pending = false;
+  for (uint32_t b = 0; b < inst->cfg.sift_buffer_count; b++)
+    inst->bufs[b].counts_valid = true;
+}
+bool detect_running(vksift_Instance inst)
+{
+  if (!inst->detect_pending)
+    return false;
+  if (vksift_hip_event_busy(inst->ev_detect) == 1)
+    return true;
+  mark_detect_done(inst);
+  return false;
+}
+bool match_running(vksift_Instance inst)
+{
+  if (!inst->match_pending)
+    return false;
+  if (vksift_hip_event_busy(inst->ev_match) == 1)
+    return true;
+  inst->match_pending = false;
+  return false;
+}
+int wait_all(vksift_Instance inst)
+{
+  vksift_hip_set_device(inst->device);
+  int e = vksift_hip_stream_sync(inst->stream);
+  mark_detect_done(inst);
+  inst->match_pending = false;
+  return e;
+}
+
+bool vksift_isBufferAvailable(vksift_Instance instance, const uint32_t gpu_buffer_id)
+{
+  vksift_hip_set_device(instance->device);
+  if (gpu_buffer_id >= instance->cfg.sift_buffer_count)
+    return true;
+  if (detect_running(instance) && !instance->bufs[gpu_buffer_id].counts_valid)
+    return false;
+  if (match_running(instance) && (gpu_buffer_id == instance->match_a || gpu_buffer_id == instance->match_b))
+    return false;
+  return true;
+}
+

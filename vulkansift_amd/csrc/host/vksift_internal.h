@@ -1,0 +1,220 @@
+/*
+ * vksift_internal.h — private definitions shared by the host translation units behind the vksift_* C API
+ * (vksift_api.c, vksift_instance.c, vksift_detect.c, vksift_buffers.c, vksift_match.c, vksift_ext.c).
+ * Nothing here is part of the public ABI; every function is hidden from the shared library's export table.
+ */
+#ifndef VKSIFT_INTERNAL_H
+#define VKSIFT_INTERNAL_H
+
+#include "vksift_ext.h"
+#include "vksift_hip.h"
+#include "vksift_hostmath.h"
+#include "vksift_log.h"
+#include "vulkansift/vulkansift.h"
+
+#include <assert.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+
+#define VKSIFT_INTERNAL __attribute__((visibility("hidden")))
+
+#define LOG_TAG "VulkanSift"
+
+#define FEAT_BYTES 164u
+#define MATCH_BYTES 20u
+#define PITCH_ALIGN 64u
+#define DESC_FP_TAB_MAX 1024u
+
+typedef struct
+{
+  bool is_packed;       /* true: one section [0, nb_stored) (after upload / after matching) */
+  uint32_t nb_stored;   /* valid when is_packed */
+  uint32_t nb_sections; /* octaves of the detection that last filled the buffer */
+  uint32_t sec_off[VKSIFT_MAX_OCTAVES]; /* in features */
+  uint32_t sec_cap[VKSIFT_MAX_OCTAVES];
+  uint32_t in_w, in_h;  /* resolution of that detection */
+  bool counts_valid;    /* the host mirror of the per-octave counters is up to date */
+} BufferInfo;
+
+typedef struct
+{
+  uint32_t n_oct;
+  uint32_t w[VKSIFT_MAX_OCTAVES], h[VKSIFT_MAX_OCTAVES], pitch[VKSIFT_MAX_OCTAVES];
+  uint64_t plane_stride[VKSIFT_MAX_OCTAVES]; /* floats */
+  uint64_t gauss_off[VKSIFT_MAX_OCTAVES];    /* floats from the image's pyramid base */
+  uint64_t dog_off[VKSIFT_MAX_OCTAVES];
+  uint64_t img_floats; /* floats used by one image */
+  uint64_t seg_off[VKSIFT_MAX_OCTAVES], seg_total;   /* per-octave slices of the segment scratch (elements) */
+  uint64_t cand_off[VKSIFT_MAX_OCTAVES], cand_cap[VKSIFT_MAX_OCTAVES], cand_total;
+} PyrLayout;
+
+/* HIP-event stage timings of one detection (vksift_ext_setProfiling) */
+/* A captured detection launch sequence (hipGraph), valid for one (resolution, batch, first buffer, input pointer) */
+#define VKSIFT_GRAPH_CACHE 8
+typedef struct
+{
+  vksift_hip_graph exec;
+  uint32_t w, h, count, first_buf;
+  const uint8_t *d_src;
+  bool top_scale_stale[VKSIFT_MAX_OCTAVES];
+  uint64_t stamp;
+} DetectGraph;
+
+/* device scratch of one set of matching slots (slot i serves pair i of a batched call) */
+typedef struct
+{
+  uint8_t *desc_a, *desc_b, *matches;
+  uint32_t *norms, *match_n;
+} MatchScratch;
+
+typedef struct
+{
+  vksift_hip_event ev_t[8];  /* instance stream: start, upload end, pyramid end, extrema end, orientation end, descriptor end, call end */
+  vksift_hip_event ev_pt[2]; /* start / end of octave 0's scale-space construction on its own stream (overlapping detections) */
+  bool valid, accounted, overlap;
+  uint32_t blur_launches;
+  uint64_t alg_bytes;
+} ProfSet;
+
+struct vksift_Instance_T
+{
+  vksift_Config cfg;
+  void (*error_cb)(vksift_Result);
+  int device;
+  uint32_t S;
+  uint32_t max_image_size; /* rounded up to a square, sift_memory.c:644-647 */
+  uint32_t max_octaves;
+  uint32_t batch_cap;
+
+  /* blur taps */
+  float taps[(VKSIFT_MAX_SCALES + 3) * VKSIFT_MAX_TAPS];
+  uint32_t ntaps[VKSIFT_MAX_SCALES + 3];
+
+  /* current scale-space */
+  uint32_t cur_w, cur_h, cur_batch;
+  PyrLayout lay;
+
+  /* device memory */
+  float *d_pyr;            /* pyramid storage of the current detection (= d_pyr_buf[pyr_cur]) */
+  float *d_pyr_buf[2];     /* ping-pong: detection N+1 builds its pyramid while detection N still reads its own */
+  int pyr_cur;
+  bool pyr_pingpong;
+  bool pyr_free_valid[2];
+  uint64_t pyr_img_stride; /* floats reserved per image */
+  uint8_t *d_input, *h_input;
+  uint8_t *d_feats;
+  uint64_t buf_stride; /* bytes */
+  uint32_t *d_found, *h_found;
+  uint64_t *d_seg_mask;
+  uint32_t *d_seg_off;
+  uint64_t seg_cap; /* elements reserved per image */
+  uint32_t *d_cand_xy, *d_cand_flag, *d_cand_n;
+  uint64_t cand_cap; /* candidates reserved per image */
+  float *d_ori_ang;
+  uint32_t *d_ori_cnt;
+  uint64_t ori_cap; /* keypoints reserved per image */
+  float *d_desc_fp;
+  uint32_t desc_fp_len;
+  uint8_t *d_desc_a, *d_desc_b, *d_matches, *h_matches;
+  uint32_t *d_norms;
+  uint32_t *d_match_partial; /* partial top-2 lists of the B-chunked large-N matcher (NULL when max_nb <= 32768) */
+  uint32_t *d_match_n, *h_match_n; /* per match slot: {N_A, N_B, spare, spare} of the last matching pipeline */
+  /* filtered matching (vksift_ext_matchFeaturesFiltered): scratch of the reverse (B->A) matching and the survivors; allocated on first use */
+  MatchScratch rev;
+  /* hipGraph replay of the detection launch sequence (latency of small workloads is launch bound) */
+  bool use_graphs;
+  DetectGraph graphs[VKSIFT_GRAPH_CACHE];
+  uint64_t graph_stamp;
+  uint8_t *d_filtered;
+  uint32_t *d_filtered_n, *h_filtered_n;
+  uint64_t filtered_slot_stride;
+  uint32_t filtered_slots_used;
+  uint64_t desc_slot_stride, match_slot_stride; /* bytes */
+  uint64_t norm_slot_stride;                    /* u32 elements */
+  uint32_t match_slots_used;
+  vksift_hip_event ev_staging;      /* host image staging buffer consumed by the H2D copy */
+  bool staging_pending;
+  BufferInfo *bufs;
+
+  vksift_hip_stream stream;
+  /* octave-parallel execution inside a stage: octave o >= 1 runs on oct_stream[o] (oct_stream[0] == stream), forked from
+   * and joined back into the main stream with events, so the latency-bound small octaves overlap the large ones */
+  vksift_hip_stream oct_stream[VKSIFT_MAX_OCTAVES];
+  vksift_hip_stream pyr_stream[VKSIFT_MAX_OCTAVES]; /* scale-space construction of octave o when detections overlap */
+  vksift_hip_event ev_pyr_done[VKSIFT_MAX_OCTAVES];
+  vksift_hip_event ev_pyr_free[2]; /* last reader of pyramid buffer i has finished */
+  vksift_hip_event ev_desc_start;  /* octave 0 of the previous detection has reached its (compute-bound) descriptor stage */
+  bool desc_start_valid;
+  int overlap_gate;                /* 0: next pyramid starts as early as possible, 1: not before the previous descriptor stage */
+  vksift_hip_event ev_fork[4], ev_join[4][VKSIFT_MAX_OCTAVES], ev_oct_ready[VKSIFT_MAX_OCTAVES];
+  bool serial_octaves;
+  bool lazy_top_scale;    /* do not store Gaussian scale S+2 (only its DoG layer is consumed); re-created on download */
+  bool top_scale_stale[VKSIFT_MAX_OCTAVES];
+  bool coarse_after;      /* coarse octaves start after octave 0's pyramid instead of after its scale S */
+  bool stage_sync;        /* debug: join all octaves at every stage boundary instead of per-octave pipelines */
+  bool use_chain;         /* fused per-octave scale chain (pyramid_fused.hip) available for this tap set */
+  uint32_t chain_min_rows; /* octaves shorter than this keep the per-scale kernels (pipeline ramp dominates) */
+  vksift_hip_event ev_detect, ev_match;
+  bool detect_pending, match_pending;
+  uint32_t detect_first_buf, detect_count;
+  uint32_t match_a, match_b;
+  uint32_t curr_nb_matches;
+
+  /* profiling */
+  bool profiling;
+  ProfSet prof[2]; /* two event sets: the host may enqueue one detection ahead of the one being timed */
+  int prof_cur;
+  vksift_hip_event ev_m[2];
+  bool match_timing_valid;
+  double acc_ms[6];
+  uint32_t acc_calls;
+  uint64_t acc_blur_launches, acc_alg_bytes;
+  uint32_t last_blur_launches;
+  uint64_t last_alg_bytes;
+  bool device_input_last;
+};
+
+
+#define HIP_CHECK(expr, what)                                                      \
+  do                                                                               \
+  {                                                                                \
+    int _e = (expr);                                                               \
+    if (_e != 0)                                                                   \
+    {                                                                              \
+      logError(LOG_TAG, "%s failed: %s", what, vksift_hip_error_string(_e));       \
+      goto gpu_error;                                                              \
+    }                                                                              \
+  } while (0)
+
+/* vksift_api.c */
+extern VKSIFT_INTERNAL bool vksift_g_loaded;
+VKSIFT_INTERNAL bool config_is_valid(const vksift_Config *c);
+VKSIFT_INTERNAL void default_error_callback(vksift_Result err);
+VKSIFT_INTERNAL bool buffer_idx_valid(vksift_Instance inst, uint32_t idx);
+VKSIFT_INTERNAL bool resolution_valid(vksift_Instance inst, uint32_t w, uint32_t h);
+
+/* vksift_instance.c */
+VKSIFT_INTERNAL void compute_layout(vksift_Instance inst, uint32_t w, uint32_t h, PyrLayout *L);
+VKSIFT_INTERNAL void set_buffer_sections(vksift_Instance inst, uint32_t buf, uint32_t n_oct, uint32_t w, uint32_t h);
+VKSIFT_INTERNAL void mark_detect_done(vksift_Instance inst);
+VKSIFT_INTERNAL bool detect_running(vksift_Instance inst);
+VKSIFT_INTERNAL bool match_running(vksift_Instance inst);
+VKSIFT_INTERNAL int wait_all(vksift_Instance inst);
+VKSIFT_INTERNAL vksift_hip_Plane plane_at(vksift_Instance inst, uint32_t o, uint64_t base_off, uint32_t layer);
+
+/* vksift_detect.c */
+VKSIFT_INTERNAL void account_set(vksift_Instance inst, ProfSet *ps);
+VKSIFT_INTERNAL void account_timings(vksift_Instance inst);
+
+/* vksift_buffers.c */
+VKSIFT_INTERNAL void wait_for_buffer(vksift_Instance inst, uint32_t buf);
+VKSIFT_INTERNAL uint32_t buffer_counts(vksift_Instance inst, uint32_t buf, uint32_t *cnt, bool log_lost);
+
+/* vksift_match.c */
+VKSIFT_INTERNAL MatchScratch fwd_scratch(vksift_Instance inst);
+VKSIFT_INTERNAL int gather_buffers(vksift_Instance inst, const MatchScratch *ms, const uint32_t *ids, uint32_t count, uint32_t first_slot, bool side_b,
+                                   uint8_t *d_desc_base, uint32_t n_index, uint32_t pad_rows_to, uint32_t *max_rows_out);
+
+#endif
