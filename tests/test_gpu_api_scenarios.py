@@ -345,3 +345,45 @@ def test_graph_replay_gives_identical_results(vk, monkeypatch):
         assert inst.downloadFeatures(1).tobytes() == ref[0].tobytes()
         top = inst.downloadScaleSpaceImage(0, 5)  # lazily re-created last scale after a replay
         assert np.isfinite(top).all() and top.std() > 0
+
+
+_SWITCH_PROBE = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from vulkansift_amd import api as vk
+vk.lib().vksift_setLogLevel(vk.VKSIFT_LOG_ERROR)
+imgs = [vk.gen_synthetic_image(400 + i, 352, 264) for i in range(2)]
+h = hashlib.sha256()
+with vk.Instance(vk.default_config(sift_buffer_count=2), batch_capacity=2) as inst:
+    for rep in range(2):                      # second round: replayed graphs, recycled ping-pong buffers
+        inst.detectFeaturesBatch(imgs, 0)
+        for b in range(2):
+            h.update(inst.downloadFeatures(b).tobytes())
+        inst.matchFeatures(0, 1)
+        h.update(inst.downloadMatches().tobytes())
+    for s in range(6):
+        h.update(inst.downloadScaleSpaceImage(1, s).tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_every_runtime_switch_is_bit_identical(vk):
+    """each optional code path in a fresh process: features, matches and planes must not change by a bit"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variants = [{}, {"VKSIFT_BLUR_LEAN": "0"}, {"VKSIFT_BLUR_LEAN": "0", "VKSIFT_BLUR_ROWS": "4"}, {"VKSIFT_BLUR_KERNEL": "tile"}, {"VKSIFT_FUSED_SEED": "0"},
+                {"VKSIFT_LAZY_TOP": "0"}, {"VKSIFT_XCD_REMAP": "0"}, {"VKSIFT_COARSE_AFTER": "0"}, {"VKSIFT_STAGE_SYNC": "1"}, {"VKSIFT_SERIAL_OCTAVES": "1"},
+                {"VKSIFT_PYR_PINGPONG": "1"}, {"VKSIFT_PYR_PINGPONG": "1", "VKSIFT_OVERLAP_GATE": "0"}, {"VKSIFT_GRAPH": "1"},
+                {"VKSIFT_CHAIN": "1", "VKSIFT_CHAIN_MIN_ROWS": "1"}, {"VKSIFT_CHAIN": "1", "VKSIFT_CHAIN_MIN_ROWS": "1", "VKSIFT_CHAIN_ROWS": "4"},
+                {"VKSIFT_DESC_WAVES": "1"}, {"VKSIFT_DESC_WAVES": "2"}, {"VKSIFT_DESC_WAVES": "8"}]
+    digests = {}
+    for v in variants:
+        env = dict(os.environ)
+        env.update(v)
+        r = subprocess.run([sys.executable, "-c", _SWITCH_PROBE % root], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, (v, r.stdout[-2000:], r.stderr[-2000:])
+        digests[str(v)] = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1]
+    assert len(set(digests.values())) == 1, digests
