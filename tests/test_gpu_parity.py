@@ -229,3 +229,42 @@ def test_match_float_collisions_all_regimes(vk, oracle, na, nb, via_ptr):
     else:
         got = _match_via_api(vk, a, b)
     _assert_matches_equal(got, ref)
+
+
+def test_full_size_1080p_detection_bit_exact(vk, oracle):
+    """BASELINE config 3 resolution (1920x1080, up-sampling ON: 7 octaves, 3840x2160 octave 0): every feature bit-exact"""
+    w, h = 1920, 1080
+    img = vk.gen_synthetic_image(77, w, h)
+    vcfg, ocfg = _cfgs(vk, oracle, input_image_max_size=w * h)
+    with vk.Instance(vcfg) as inst:
+        inst.detectFeatures(img, 0)
+        feats = inst.downloadFeatures(0)
+        assert inst.getScaleSpaceNbOctaves() == 7
+    ref, _ = oracle.detect(ocfg, img)
+    assert len(feats) == len(ref) and len(ref) > 5000
+    assert feats.tobytes() == ref.tobytes()
+
+
+def test_full_size_50k_matcher_properties_and_samples(vk, oracle):
+    """BASELINE config 4 size (50k x 50k, B-chunked MFMA kernel): self-match property on every row + oracle on sampled rows"""
+    import torch
+    from vulkansift_amd import multigpu
+    n = 50000
+    a = vk.gen_synthetic_descriptors(91, n)
+    b = vk.gen_synthetic_descriptors(92, n)
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    # property: A against itself -> every row's best match is itself (or an earlier identical row) at distance 0
+    got = multigpu.records_to_struct(multigpu.hip_match_fn(da, 0, da).cpu().numpy())
+    assert np.all(got["dist_a_b1"] == 0.0)
+    assert np.all(got["idx_b1"] <= np.arange(n))
+    same = np.all(a[got["idx_b1"]] == a, axis=1)
+    assert same.all()
+    assert np.all(got["dist_a_b2"] >= got["dist_a_b1"])
+    # oracle on a sample of rows against the full B
+    got = multigpu.records_to_struct(multigpu.hip_match_fn(da, 0, db).cpu().numpy())
+    rows = np.random.default_rng(1).choice(n, 300, replace=False)
+    ref = oracle.match_2nn(a[rows], b)
+    for name in ("idx_b1", "idx_b2"):
+        assert np.array_equal(got[name][rows], ref[name]), name
+    assert np.array_equal(got["dist_a_b1"][rows].view(np.uint32), ref["dist_a_b1"].view(np.uint32))
+    assert np.array_equal(got["dist_a_b2"][rows].view(np.uint32), ref["dist_a_b2"].view(np.uint32))
