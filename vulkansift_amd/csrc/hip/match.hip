@@ -164,7 +164,24 @@ struct Top2
   uint32_t q1, k1, q2, k2; // squared distances and index keys of best / second
 };
 
-constexpr uint32_t Q_EXACT = 1u << 22; // below this, integer order of d2 == order of sqrtf(float(d2))
+constexpr uint32_t Q_EXACT = 1u << 22;
+constexpr uint32_t SYNC_TILES = 4; // tiles between two exchanges of the row-wide pruning bound (power of two)
+
+// value of lane ((lane & 15) + n) % 16 of the same 16-lane row: one DPP move
+template <int N>
+__device__ __forceinline__ uint32_t row_ror_n(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, false);
+}
+// (m1, m2) <- the two smallest of {m1, m2} of this lane and of the lane N positions further in the row
+template <int N>
+__device__ __forceinline__ void merge_ror(uint32_t &m1, uint32_t &m2)
+{
+  const uint32_t r1 = row_ror_n<N>(m1), r2 = row_ror_n<N>(m2);
+  const uint32_t hi = max(m1, r1);
+  m1 = min(m1, r1);
+  m2 = min(hi, min(m2, r2));
+} // below this, integer order of d2 == order of sqrtf(float(d2))
 
 __device__ __forceinline__ bool lex_less(uint32_t qa, uint32_t ka, uint32_t qb, uint32_t kb) { return qa < qb || (qa == qb && ka < kb); }
 
@@ -259,6 +276,18 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
 #pragma unroll
       for (int j = 0; j < 4; j++)
         st[t][j] = Top2{QMAX, QMAX, QMAX, QMAX};
+    // Row-wide pruning bound. The 16 lanes of a row group each keep the top-2 of their own column subset, and a lane's own
+    // second best is a loose filter (a stream of L columns updates it ~2 ln L times: with 256 results per MFMA pair some
+    // lane passes it almost every time). Every SYNC_TILES tiles the lanes exchange their lists (DPP row rotations) and
+    // take the second smallest d2 of the whole row so far as a common bound: a later candidate that does not beat it
+    // cannot be in the final top-2 (two candidates with smaller-or-equal d2 and smaller index already exist in the
+    // lanes' lists, which all take part in the final merge), so it is dropped before the insertion logic — exact.
+    uint32_t eff[AT][4]; // min(own second best, row-wide bound): what a candidate has to beat
+#pragma unroll
+    for (int t = 0; t < AT; t++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        eff[t][j] = QMAX;
     uint32_t swap_bits = 0;  // bit (t*4+j): d2(b0) == d2(b1) for that A row (quirk Q7)
     uint32_t risky_bits = 0; // bit (t*4+j): a candidate >= 2^22 was inserted -> the row goes to k_match_redo
 
@@ -333,14 +362,31 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
                 risky_bits |= 1u << (t * 4 + j); // the tie test itself needs the float comparison
               key = sw ? (uint32_t)(col ^ 1) : bcol;
             }
-            if (q < st[t][j].q2)
+            if (q < eff[t][j])
             {
               if (q >= Q_EXACT)
                 risky_bits |= 1u << (t * 4 + j);
               insert_seq(st[t][j], q, key);
+              eff[t][j] = min(eff[t][j], st[t][j].q2);
             }
           }
         }
+      }
+      // ---- every SYNC_TILES tiles: tighten the row-wide bound
+      if ((((t0 - tb) / BT) & (SYNC_TILES - 1)) == SYNC_TILES - 1)
+      {
+#pragma unroll
+        for (int t = 0; t < AT; t++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+          {
+            uint32_t m1 = st[t][j].q1, m2 = st[t][j].q2; // two smallest d2 seen by this lane
+            merge_ror<8>(m1, m2);
+            merge_ror<4>(m1, m2);
+            merge_ror<2>(m1, m2);
+            merge_ror<1>(m1, m2);
+            eff[t][j] = min(eff[t][j], m2);
+          }
       }
     }
 
