@@ -27,7 +27,7 @@ extern "C"
 #endif
 
 #define VKSIFT_HIP_MAX_TAPS 20 /* VKSIFT_DETECTOR_MAX_GAUSSIAN_KERNEL_SIZE, sift_detector.h:9 */
-#define VKSIFT_HIP_MATCH_CHUNKS 12 /* B chunks of the large-N matcher (partial top-2 lists merged exactly) */
+#define VKSIFT_HIP_MATCH_CHUNKS 8 /* B chunks of the large-N matcher (partial top-2 lists merged exactly) */
 #define VKSIFT_HIP_MAX_ORI 18  /* a 36-bin circular histogram has at most 18 strict local maxima */
 
   typedef void *vksift_hip_stream;

@@ -167,6 +167,14 @@ struct Top2
 constexpr uint32_t Q_EXACT = 1u << 22;
 constexpr uint32_t SYNC_TILES = 4; // tiles between two exchanges of the row-wide pruning bound (power of two)
 
+// Accumulator-space form of the pruning test (see k_match_mfma): D > acc_threshold(an, eff) is implied by an + par - 2 D < eff.
+// Real accumulators stay above -2^22 (|a'.b'| <= 2^21, bn/2 <= 2^20): ACC_PASS lets all of them through, ACC_DEAD none.
+constexpr int ACC_PASS = -(1 << 29), ACC_DEAD = -(1 << 30);
+__device__ __forceinline__ int acc_threshold(uint32_t an, uint32_t eff)
+{
+  return eff >= (1u << 30) ? ACC_PASS : ((int)an - (int)eff) >> 1;
+}
+
 // value of lane ((lane & 15) + n) % 16 of the same 16-lane row: one DPP move
 template <int N>
 __device__ __forceinline__ uint32_t row_ror_n(uint32_t v)
@@ -288,6 +296,12 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
 #pragma unroll
       for (int j = 0; j < 4; j++)
         eff[t][j] = QMAX;
+    int thr[AT][4]; // eff translated into accumulator space, see the column-block loop
+#pragma unroll
+    for (int t = 0; t < AT; t++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        thr[t][j] = ACC_PASS;
     uint32_t swap_bits = 0;  // bit (t*4+j): d2(b0) == d2(b1) for that A row (quirk Q7)
     uint32_t risky_bits = 0; // bit (t*4+j): a candidate >= 2^22 was inserted -> the row goes to k_match_redo
 
@@ -340,16 +354,24 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
         const v4i b1 = *(const v4i *)(pb + 64);
         const uint32_t bn = s_nb[sub * 16 + col];
         const bool first = (t0 == 0 && sub == 0);
+        // The accumulator starts at -(bn >> 1), so a result is D = a'.b' - (bn >> 1) and d2 = an + (bn & 1) - 2 D. The
+        // common-path test "can this beat eff?" is one signed compare D > thr with thr = floor((an - eff) / 2) kept per state
+        // (conservative by the parity bit; the exact d2 is formed only behind it). Columns >= nb start so low that no
+        // threshold lets them through.
+        const int cinit = bcol < nb ? -(int)(bn >> 1) : ACC_DEAD;
+        const uint32_t par = bn & 1u;
 #pragma unroll
         for (int t = 0; t < AT; t++)
         {
-          v4i acc = v4i{0, 0, 0, 0};
+          v4i acc = v4i{cinit, cinit, cinit, cinit};
           acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[t][0], b0, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[t][1], b1, acc, 0, 0, 0);
 #pragma unroll
           for (int j = 0; j < 4; j++)
           {
-            const uint32_t q = bcol < nb ? an[t][j] + bn - 2u * (uint32_t)acc[j] : QMAX;
+            if (!first && !(acc[j] > thr[t][j]))
+              continue;
+            const uint32_t q = bcol < nb ? an[t][j] + par - 2u * (uint32_t)acc[j] : QMAX;
             uint32_t key = bcol;
             if (first)
             {
@@ -368,6 +390,7 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
                 risky_bits |= 1u << (t * 4 + j);
               insert_seq(st[t][j], q, key);
               eff[t][j] = min(eff[t][j], st[t][j].q2);
+              thr[t][j] = acc_threshold(an[t][j], eff[t][j]);
             }
           }
         }
@@ -386,6 +409,7 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
             merge_ror<2>(m1, m2);
             merge_ror<1>(m1, m2);
             eff[t][j] = min(eff[t][j], m2);
+            thr[t][j] = acc_threshold(an[t][j], eff[t][j]);
           }
       }
     }
@@ -817,7 +841,7 @@ extern "C"
     const SlotStrides z{0, 0, 0, 0, 0, 0, 0};
     hipLaunchKernelGGL(k_shifted_norms, dim3((na + 255u) / 256u), dim3(256), 0, hs, da, na, norm_a);
     hipLaunchKernelGGL(k_shifted_norms, dim3((nb + 255u) / 256u), dim3(256), 0, hs, db, nb, norm_b);
-    /* Small problems: 16 A rows per workgroup with B split over its waves; medium: 16 rows per wave; large: 64 rows per
+    /* Small problems: 16 A rows per workgroup with B split over its waves; medium: 16 rows per wave; large: 32 rows per
      * wave (B-tile reuse) with B split into VKSIFT_HIP_MATCH_CHUNKS chunks across grid.z + exact merge. */
     if (na <= 8192u)
       hipLaunchKernelGGL(k_match_mfma_split, dim3((na + 15u) / 16u), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
@@ -828,7 +852,7 @@ extern "C"
     else
     {
       uint32_t *partial = redo + na;
-      hipLaunchKernelGGL(k_match_mfma<4>, dim3((na + 255u) / 256u, 1, VKSIFT_HIP_MATCH_CHUNKS), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb,
+      hipLaunchKernelGGL(k_match_mfma<2>, dim3((na + 127u) / 128u, 1, VKSIFT_HIP_MATCH_CHUNKS), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb,
                          (uint32_t *)matches, redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial);
       hipLaunchKernelGGL(k_match_merge, dim3((na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial, na, (uint32_t)VKSIFT_HIP_MATCH_CHUNKS,
                          a_index_base, (uint32_t *)matches, redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
@@ -888,7 +912,9 @@ extern "C"
      * kernel per size regime, each of which returns immediately unless N_A falls in its range:
      *   N_A <= S1          B-split kernel, 16 A rows per workgroup (keeps a few thousand rows busy on every CU)
      *   S1 < N_A <= 32768   16 A rows per wave
-     *   N_A > 32768         64 A rows per wave (B tile reuse), B-chunked + merged when a single pair is matched */
+     *   N_A > 32768         32 A rows per wave (B fragment reuse; 64 rows per wave costs too many registers: 2 waves per
+     *                       SIMD cannot hide the LDS / MFMA latencies, measured 1.27 vs 1.05 ms at 50k x 50k), B-chunked +
+     *                       merged when a single pair is matched */
     /* The B-split kernel (16 A rows per workgroup) exists to keep every CU busy when ONE pair of a few thousand rows is
      * matched; a batch of pairs has enough workgroups anyway and runs 24 % faster with 64 rows per workgroup (measured:
      * 64 pairs of 1.9k x 1.9k, 0.285 -> 0.217 ms). */
@@ -910,13 +936,13 @@ extern "C"
     {
       if (nslots == 1 && partial_scratch)
       {
-        hipLaunchKernelGGL(k_match_mfma<4>, dim3(bounded((max_na + 255u) / 256u, 1), 1, VKSIFT_HIP_MATCH_CHUNKS), dim3(256), 0, hs, da, norm_a, 0u, 0u, db,
+        hipLaunchKernelGGL(k_match_mfma<2>, dim3(bounded((max_na + 127u) / 128u, 1), 1, VKSIFT_HIP_MATCH_CHUNKS), dim3(256), 0, hs, da, norm_a, 0u, 0u, db,
                            norm_b, 0u, (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, partial_scratch);
         hipLaunchKernelGGL(k_match_merge, dim3((max_na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial_scratch, 0u,
                            (uint32_t)VKSIFT_HIP_MATCH_CHUNKS, 0u, (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu);
       }
       else
-        hipLaunchKernelGGL(k_match_mfma<4>, dim3(bounded((max_na + 255u) / 256u, nslots), nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+        hipLaunchKernelGGL(k_match_mfma<2>, dim3(bounded((max_na + 127u) / 128u, nslots), nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
                            (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, (uint32_t *)nullptr);
     }
     uint32_t rblocks = (max_na + 63u) / 64u;
