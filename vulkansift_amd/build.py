@@ -58,7 +58,11 @@ def _run(cmd):
 
 # Per-file code generation options. max-ilp: the default scheduler serialises the independent accumulator chains of the
 # unrolled filters to save registers, which leaves an s_nop after almost every dependent packed-fp32 pair.
-HIP_EXTRA = {}
+HIP_EXTRA = {
+    # MFMA results straight into VGPRs: the matcher's epilogue reads every accumulator element once, and the default AGPR
+    # form costs one v_accvgpr_read per element (2 of ~18 VALU instructions per MFMA) for nothing — it has registers to spare
+    "hip/match.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+}
 
 
 def _extra_flags(src):
