@@ -33,8 +33,30 @@ def run(w, h, warm=10, runs=100):
     return {"image": f"{w}x{h}", "features": int(n), "latency_ms": dt * 1e3, "frames_per_s": 1.0 / dt}
 
 
+def run_match(w, h, warm=10, runs=100):
+    """vksift_matchFeatures + vksift_getMatchesNumber + vksift_downloadMatches of two detected images (the reference's
+    src/examples/test_sift_match.cpp flow; it publishes no matching time)."""
+    from vulkansift_amd import api
+    img1, img2 = api.gen_synthetic_image(0xABD0 + w, w, h), api.gen_synthetic_image(0xABE0 + w, w, h)
+    cfg = api.default_config(input_image_max_size=w * h)
+    with api.Instance(cfg) as inst:
+        inst.detectFeatures(img1, 0)
+        inst.detectFeatures(img2, 1)
+        n1, n2 = inst.getFeaturesNumber(0), inst.getFeaturesNumber(1)
+        for i in range(warm + runs):
+            if i == warm:
+                t0 = time.perf_counter()
+            inst.matchFeatures(0, 1)
+            inst.downloadMatches()
+        dt = (time.perf_counter() - t0) / runs
+    return {"match": f"{n1}x{n2} features ({w}x{h} images)", "latency_ms": dt * 1e3}
+
+
 if __name__ == "__main__":
     sizes = [a for a in sys.argv[1:] if "x" in a] or ["640x480", "1536x1024", "3456x2304"]
     for sz in sizes:
         w, h = map(int, sz.split("x"))
         print(json.dumps(run(w, h)), flush=True)
+    for sz in sizes:
+        w, h = map(int, sz.split("x"))
+        print(json.dumps(run_match(w, h)), flush=True)
