@@ -610,7 +610,15 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
     if (me != hipSuccess)
       return (int)me;
   }
-  const int band = 32;
+  static int band_env = -1;
+  if (band_env < 0)
+  {
+    const char *e = getenv("VKSIFT_EXTREMA_BAND"); /* rows per wave of the streaming extrema pass (A/B runs) */
+    band_env = (e && atoi(e) >= 8) ? atoi(e) : 0;
+  }
+  /* 32 rows per wave on the large octaves (3 % halo rows); 16 on the small ones, whose launches are latency bound and
+   * gain more from twice the waves (serial kernel time of the coarse octaves -40 %) */
+  const int band = band_env ? band_env : (job->h > 256u ? 32 : 16);
   dim3 sgrid((a.nseg + 1) / 2, ((job->h + band - 1) / band + 3) / 4, batch);
   switch (job->S)
   {
