@@ -825,16 +825,20 @@ extern "C"
         nw = 0;
     }
     static uint32_t wg_target = 0, min_seg_rows = 0;
+    static bool min_seg_env = false;
     if (!wg_target)
     {
       const char *e = getenv("VKSIFT_BLUR_WGS"); /* A/B runs */
       wg_target = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 1536u;
       e = getenv("VKSIFT_BLUR_MIN_SEG");
-      min_seg_rows = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 64u;
+      min_seg_env = e && atoi(e) > 0;
+      min_seg_rows = min_seg_env ? (uint32_t)atoi(e) : 64u;
     }
     const uint32_t strips = (src.w + 127u) / 128u;
     uint32_t nseg = (wg_target + strips * batch - 1u) / (strips * batch);
-    uint32_t max_seg = (src.h + min_seg_rows - 1u) / min_seg_rows;
+    /* small octaves are launch-latency bound: shorter segments (more waves) shorten each launch */
+    const uint32_t seg_rows = (src.h <= 256u && min_seg_rows > 32u && !min_seg_env) ? 32u : min_seg_rows;
+    uint32_t max_seg = (src.h + seg_rows - 1u) / seg_rows;
     if (nseg > max_seg)
       nseg = max_seg;
     if (nseg < 1)
