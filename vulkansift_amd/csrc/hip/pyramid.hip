@@ -837,7 +837,14 @@ extern "C"
     const uint32_t strips = (src.w + 127u) / 128u;
     uint32_t nseg = (wg_target + strips * batch - 1u) / (strips * batch);
     /* small octaves are launch-latency bound: shorter segments (more waves) shorten each launch */
-    const uint32_t seg_rows = (src.h <= 256u && min_seg_rows > 32u && !min_seg_env) ? 32u : min_seg_rows;
+    uint32_t seg_rows = min_seg_rows;
+    if (!min_seg_env)
+    {
+      /* launches that cannot fill the GPU with 64-row segments (small octaves, small batches) are latency bound: the
+       * shorter the row march of a wave, the shorter the launch — the extra halo rows cost nothing there */
+      const uint32_t waves64 = strips * batch * ((src.h + 63u) / 64u);
+      seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u);
+    }
     uint32_t max_seg = (src.h + seg_rows - 1u) / seg_rows;
     if (nseg > max_seg)
       nseg = max_seg;

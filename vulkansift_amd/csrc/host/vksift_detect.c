@@ -188,7 +188,9 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool 
   else
   {
     /* the next octave may start once scale S exists; with coarse_after octave 1 waits for octave 0's whole pyramid */
-    const uint32_t ready_after = (inst->coarse_after && o == 0) ? inst->S + 2 : inst->S;
+    /* (only for workloads large enough to be bandwidth bound: for a small image the octave chain is the latency) */
+    const bool big = (uint64_t)c->count * c->w * c->h >= (4u << 20);
+    const uint32_t ready_after = (inst->coarse_after && big && o == 0) ? inst->S + 2 : inst->S;
     for (uint32_t s = 1; s < inst->S + 3; s++)
     {
       vksift_hip_Plane dstp = plane_at(inst, o, L->gauss_off[o], s);
