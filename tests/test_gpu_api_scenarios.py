@@ -376,7 +376,7 @@ def test_every_runtime_switch_is_bit_identical(vk):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     variants = [{}, {"VKSIFT_BLUR_LEAN": "0"}, {"VKSIFT_BLUR_LEAN": "0", "VKSIFT_BLUR_ROWS": "4"}, {"VKSIFT_BLUR_KERNEL": "tile"}, {"VKSIFT_FUSED_SEED": "0"},
                 {"VKSIFT_LAZY_TOP": "0"}, {"VKSIFT_XCD_REMAP": "0"}, {"VKSIFT_COARSE_AFTER": "0"}, {"VKSIFT_STAGE_SYNC": "1"}, {"VKSIFT_SERIAL_OCTAVES": "1"},
-                {"VKSIFT_PYR_PINGPONG": "1"}, {"VKSIFT_PYR_PINGPONG": "1", "VKSIFT_OVERLAP_GATE": "0"}, {"VKSIFT_GRAPH": "1"},
+                {"VKSIFT_PYR_PINGPONG": "1"}, {"VKSIFT_PYR_PINGPONG": "1", "VKSIFT_OVERLAP_GATE": "0"}, {"VKSIFT_GRAPH": "1"}, {"VKSIFT_GRAPH": "0"},
                 {"VKSIFT_CHAIN": "1", "VKSIFT_CHAIN_MIN_ROWS": "1"}, {"VKSIFT_CHAIN": "1", "VKSIFT_CHAIN_MIN_ROWS": "1", "VKSIFT_CHAIN_ROWS": "4"},
                 {"VKSIFT_DESC_WAVES": "1"}, {"VKSIFT_DESC_WAVES": "2"}, {"VKSIFT_DESC_WAVES": "8"}]
     digests = {}

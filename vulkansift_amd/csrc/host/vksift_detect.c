@@ -494,7 +494,8 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   build_jobs(&c);
 
   /* host-visible events (staging, completion, profiling) stay outside a captured region */
-  DetectGraph *dg = (inst->use_graphs && !c.prof && !c.overlap) ? graph_lookup(inst, &c) : NULL;
+  const bool replay = inst->use_graphs && !c.prof && !c.overlap && (uint64_t)count * w * h <= inst->graph_max_pixels;
+  DetectGraph *dg = replay ? graph_lookup(inst, &c) : NULL;
   if (dg && dg->exec)
   {
     HIP_CHECK(vksift_hip_graph_launch(dg->exec, st), "detection graph launch");

@@ -213,11 +213,13 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
      * overlap octave 0's extraction and descriptor stages. VKSIFT_COARSE_AFTER=0 restores the earliest possible start. */
     e = getenv("VKSIFT_COARSE_AFTER");
     inst->coarse_after = !(e && e[0] == '0');
-    /* 1: capture the detection launch sequence in a hipGraph and replay it. Off by default: measured on MI355X / ROCm 7.2 it
-     * buys 6 % on one 640x480 image (0.78 vs 0.83 ms) and loses 10 % from 1536x1024 up (the graph runs the per-octave
-     * branches less concurrently than the streams do). */
+    /* hipGraph capture + replay of the detection launch sequence. Measured on MI355X / ROCm 7.2: 10 % faster for one
+     * 640x480 image (0.58 vs 0.65 ms), 12 % slower from 1536x1024 up (the graph runs the per-octave branches less
+     * concurrently than the streams do) -> by default only small workloads are replayed (graph_max_pixels).
+     * VKSIFT_GRAPH=0 never, =1 always. */
     e = getenv("VKSIFT_GRAPH");
-    inst->use_graphs = e && e[0] == '1';
+    inst->use_graphs = !(e && e[0] == '0');
+    inst->graph_max_pixels = (e && e[0] == '1') ? ~(uint64_t)0 : (uint64_t)640 * 480;
     e = getenv("VKSIFT_STAGE_SYNC");
     inst->stage_sync = e && e[0] == '1';
     /* 1 selects the experimental fused scale-chain kernel (pyramid_fused.hip): bit-identical, but measured slower than the

@@ -125,6 +125,7 @@ struct vksift_Instance_T
   MatchScratch rev;
   /* hipGraph replay of the detection launch sequence (latency of small workloads is launch bound) */
   bool use_graphs;
+  uint64_t graph_max_pixels; /* detections of at most this many input pixels (batch total) are replayed from a graph */
   DetectGraph graphs[VKSIFT_GRAPH_CACHE];
   uint64_t graph_stamp;
   uint8_t *d_filtered;
