@@ -500,9 +500,16 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   {
     HIP_CHECK(vksift_hip_graph_launch(dg->exec, st), "detection graph launch");
     memcpy(inst->top_scale_stale, dg->top_scale_stale, sizeof(inst->top_scale_stale));
+    inst->graph_miss_run = 0;
   }
   else
   {
+    if (dg && ++inst->graph_miss_run > 4u * VKSIFT_GRAPH_CACHE)
+    {
+      /* the caller keeps changing shape / buffer / input pointer: captures would only add cost */
+      inst->use_graphs = false;
+      dg = NULL;
+    }
     if (dg)
     {
       if (vksift_hip_capture_begin(st) == 0)

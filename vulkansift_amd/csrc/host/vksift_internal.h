@@ -128,6 +128,7 @@ struct vksift_Instance_T
   uint64_t graph_max_pixels; /* detections of at most this many input pixels (batch total) are replayed from a graph */
   DetectGraph graphs[VKSIFT_GRAPH_CACHE];
   uint64_t graph_stamp;
+  uint32_t graph_miss_run; /* consecutive cache misses: a caller that never repeats a key gets no replays, only capture costs */
   uint8_t *d_filtered;
   uint32_t *d_filtered_n, *h_filtered_n;
   uint64_t filtered_slot_stride;
