@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): SIFT detect+match frames/s on 640x480 frames with ~2k keypoints.
-One "step" = one pass of the hot path over one batch of `--batch` (default 64) synthetic 640x480 frames that are
+One "step" = one pass of the hot path over one batch of `--batch` (default 128) synthetic 640x480 frames that are
 already resident in HBM: batched detection (default vksift_Config: 2x up-sampling, automatic octave
 count = 5, 3 scales/octave) followed by the 2-NN self-match of every frame (matchFeatures(i, i) of BASELINE
 config 2, issued through the batched extension vksift_ext_matchFeaturesBatch). Every step recomputes everything; nothing is cached between steps.
@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step and per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="frames per step and per GPU")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-match", action="store_true", help="detect only (BASELINE config 3 style runs)")
