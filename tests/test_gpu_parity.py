@@ -29,6 +29,8 @@ def _cfgs(vk, oracle, **kw):
     (320, 240, {}),
     (200, 150, {"use_input_upsampling": False}),
     (257, 131, {"use_hardware_interpolated_blur": False}),
+    (368, 224, {"nb_scales_per_octave": 2}),          # largest kernels: 20 one-sided taps (radius 19 > two 8-row groups)
+    (368, 224, {"nb_scales_per_octave": 1, "seed_scale_sigma": 2.4}),
 ])
 def test_pyramid_bit_exact(vk, oracle, w, h, kw):
     vcfg, ocfg = _cfgs(vk, oracle, **kw)
@@ -268,3 +270,50 @@ def test_full_size_50k_matcher_properties_and_samples(vk, oracle):
         assert np.array_equal(got[name][rows], ref[name]), name
     assert np.array_equal(got["dist_a_b1"][rows].view(np.uint32), ref["dist_a_b1"].view(np.uint32))
     assert np.array_equal(got["dist_a_b2"][rows].view(np.uint32), ref["dist_a_b2"].view(np.uint32))
+
+
+def test_randomised_detection_parity(vk, oracle):
+    """random resolutions x random configurations (seeded): every feature byte equals the oracle's"""
+    rng = np.random.default_rng(2024)
+    for case in range(36):
+        w, h = int(rng.integers(48, 420)), int(rng.integers(48, 320))
+        kw = {}
+        if rng.random() < 0.4:
+            kw["use_input_upsampling"] = False
+        if rng.random() < 0.3:
+            kw["use_hardware_interpolated_blur"] = False
+        if rng.random() < 0.4:
+            kw["nb_scales_per_octave"] = int(rng.choice([2, 4, 5]))
+        if rng.random() < 0.3:
+            kw["descriptor_format"] = 1
+        if rng.random() < 0.3:
+            kw["max_nb_orientation_per_keypoint"] = int(rng.choice([0, 1, 2]))
+        if rng.random() < 0.3:
+            kw["nb_octaves"] = int(rng.integers(1, 4))
+        if rng.random() < 0.3:
+            kw["intensity_threshold"] = float(rng.choice([0.02, 0.06]))
+        vcfg, ocfg = _cfgs(vk, oracle, **kw)
+        img = vk.gen_synthetic_image(1000 + case, w, h)
+        with vk.Instance(vcfg) as inst:
+            inst.detectFeatures(img, 0)
+            feats = inst.downloadFeatures(0)
+        ref, _ = oracle.detect(ocfg, img)
+        assert len(feats) == len(ref), (case, w, h, kw, len(feats), len(ref))
+        assert feats.tobytes() == ref.tobytes(), (case, w, h, kw)
+
+
+def test_randomised_matcher_parity(vk, oracle):
+    """random (N_A, N_B) incl. tiny and ragged sizes, duplicates and near-duplicates: all five record fields bit-exact"""
+    rng = np.random.default_rng(77)
+    for case in range(30):
+        na, nb = int(rng.integers(1, 2600)), int(rng.integers(2, 2600))
+        a = vk.gen_synthetic_descriptors(2000 + case, na)
+        b = vk.gen_synthetic_descriptors(3000 + case, nb)
+        k = int(rng.integers(0, min(na, nb) // 2 + 1))
+        if k:
+            idx = rng.permutation(nb)[:k]
+            b[idx] = np.clip(a[:k].astype(np.int32) + rng.integers(-3, 4, (k, 128)), 0, 255).astype(np.uint8)
+            b[idx[: k // 3]] = a[: k // 3]           # exact duplicates -> zero distances and ties
+        if nb > 4 and rng.random() < 0.5:
+            b[1] = b[0]                               # quirk Q7
+        _assert_matches_equal(_match_via_api(vk, a, b), oracle.match_2nn(a, b))

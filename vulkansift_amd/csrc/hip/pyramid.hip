@@ -418,7 +418,8 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   constexpr int NP = R + 1 + OFS;
   constexpr int C0 = R + OFS;
   constexpr int NWIN = 2 * R + NR;
-  constexpr int NG = R <= NR ? 2 : 3; // groups kept in the ring: the centres of the rows emitted now are <= R rows old
+  constexpr int NG = (R + NR - 1) / NR + 1; // groups kept in the ring: the centres of the rows emitted now are up to R rows old
+  static_assert(NG <= 4, "ring bookkeeping below handles up to 3 groups back (R <= 24)");
   constexpr int GROUP_FLOATS = NR * SW;
   __shared__ __attribute__((aligned(16))) float s_ring[NG * GROUP_FLOATS];
 
@@ -531,7 +532,8 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 
   int gs = 0;              // ring slot of the current group
   int gs1 = NG - 1;        // slot of the previous group
-  int gs2 = NG - 2;        // slot of the one before (NG == 3 only)
+  int gs2 = NG >= 3 ? NG - 2 : 0; // slot of the one before (NG >= 3)
+  int gs3 = NG >= 4 ? NG - 3 : 0; // and of the one before that (NG == 4)
   for (; rg - R < y1; rg += NR)
   {
     // ---- stage the prefetched group into ring slot gs, then prefetch the next group
@@ -614,11 +616,12 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
       const float *c0p = s_ring + gs * GROUP_FLOATS + RA + 2 * lane;
       const float *c1p = s_ring + gs1 * GROUP_FLOATS + RA + 2 * lane;
       const float *c2p = s_ring + gs2 * GROUP_FLOATS + RA + 2 * lane;
+      const float *c3p = s_ring + gs3 * GROUP_FLOATS + RA + 2 * lane;
       auto centre = [&](int j) -> v2f {
         const int back = j - R;                               // <= 0: rows back from the current group's row 0
         const int gb = back >= 0 ? 0 : (-back + NR - 1) / NR; // groups back (0, 1 or 2)
         const int row = back + gb * NR;                       // row inside that group
-        const float *cp = gb == 0 ? c0p : (gb == 1 ? c1p : c2p);
+        const float *cp = gb == 0 ? c0p : (gb == 1 ? c1p : (gb == 2 ? c2p : c3p));
         return *(const v2f *)(cp + row * SW);
       };
       auto emit = [&](int j, int so_d, int so_g, float acc0, float acc1) {
@@ -676,6 +679,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 #pragma unroll
     for (int k = 0; k < 2 * R; k++)
       wv[k] = wv[k + NR];
+    gs3 = gs2;
     gs2 = gs1;
     gs1 = gs;
     gs = gs + 1 == NG ? 0 : gs + 1;
