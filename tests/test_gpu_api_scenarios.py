@@ -387,3 +387,59 @@ def test_every_runtime_switch_is_bit_identical(vk):
         assert r.returncode == 0, (v, r.stdout[-2000:], r.stderr[-2000:])
         digests[str(v)] = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1]
     assert len(set(digests.values())) == 1, digests
+
+
+@pytest.mark.parametrize("seed", [99, 100, 101])
+def test_random_operation_sequences_follow_the_model(vk, oracle, seed):
+    """3 x 250 random API calls on one instance (detections of changing resolution into changing buffers, batched detections,
+    uploads, matches, filtered matches, accessors in any order): every observable result must equal a trivial model built
+    from the oracle — stresses the host bookkeeping (pending events, section tables, graph cache, staging reuse)"""
+    rng = np.random.default_rng(seed)
+    sizes = [(320, 240), (320, 240), (256, 192), (400, 300), (200, 160)]
+    imgs = [vk.gen_synthetic_image(700 + i, w, h) for i, (w, h) in enumerate(sizes)]
+    ocfg = oracle.default_config(math_mode=1)
+    ref = [oracle.detect(ocfg, im)[0] for im in imgs]
+    nbuf = 4
+    model = {b: np.zeros(0, vk.FEATURE_DTYPE) for b in range(nbuf)}
+    last_match = None
+    cfg = vk.default_config(sift_buffer_count=nbuf, input_image_max_size=400 * 300)
+    with vk.Instance(cfg, batch_capacity=2) as inst:
+        for step in range(250):
+            op = rng.choice(["detect", "batch", "upload", "count", "download", "match", "filtered", "avail"], p=[0.25, 0.1, 0.1, 0.1, 0.15, 0.15, 0.1, 0.05])
+            if op == "detect":
+                k, b = int(rng.integers(len(imgs))), int(rng.integers(nbuf))
+                inst.detectFeatures(imgs[k], b)
+                model[b] = ref[k]
+            elif op == "batch":
+                b = int(rng.integers(nbuf - 1))
+                inst.detectFeaturesBatch([imgs[0], imgs[1]], b)
+                model[b], model[b + 1] = ref[0], ref[1]
+            elif op == "upload":
+                k, b = int(rng.integers(len(imgs))), int(rng.integers(nbuf))
+                n = int(rng.integers(0, len(ref[k]) + 1))
+                inst.uploadFeatures(ref[k][:n].copy(), b)
+                model[b] = ref[k][:n]
+            elif op == "count":
+                b = int(rng.integers(nbuf))
+                assert inst.getFeaturesNumber(b) == len(model[b]), (step, op, b)
+            elif op == "download":
+                b = int(rng.integers(nbuf))
+                assert inst.downloadFeatures(b).tobytes() == model[b].tobytes(), (step, op, b)
+            elif op in ("match", "filtered"):
+                a, b = int(rng.integers(nbuf)), int(rng.integers(nbuf))
+                if len(model[a]) == 0 or len(model[b]) < 2:
+                    continue
+                m12 = oracle.match_2nn(model[a], model[b])
+                if op == "match":
+                    inst.matchFeatures(a, b)
+                    got = inst.downloadMatches()
+                    assert got.tobytes() == m12.tobytes(), (step, op, a, b)
+                elif len(model[a]) >= 2:
+                    inst.matchFeaturesFiltered([a], [b], 0.8, True)
+                    got = inst.downloadFilteredMatches(0)
+                    ra, rb = oracle.filter_matches(m12, oracle.match_2nn(model[b], model[a]), 0.8, True)
+                    assert np.array_equal(got["idx_a"], ra) and np.array_equal(got["idx_b"], rb), (step, op, a, b)
+            else:
+                b = int(rng.integers(nbuf))
+                inst.getFeaturesNumber(b)           # waits for anything pending on b
+                assert inst.isBufferAvailable(b)

@@ -317,3 +317,29 @@ def test_randomised_matcher_parity(vk, oracle):
         if nb > 4 and rng.random() < 0.5:
             b[1] = b[0]                               # quirk Q7
         _assert_matches_equal(_match_via_api(vk, a, b), oracle.match_2nn(a, b))
+
+
+def test_randomised_detection_parity_wide(vk, oracle):
+    """second distribution: larger images, continuous parameters (sigmas, thresholds), batches of random size"""
+    rng = np.random.default_rng(4242)
+    for case in range(12):
+        w, h = int(rng.integers(200, 900)), int(rng.integers(150, 640))
+        kw = {"seed_scale_sigma": float(np.float32(rng.uniform(1.3, 2.6))), "input_image_blur_level": float(np.float32(rng.uniform(0.3, 0.6))),
+              "intensity_threshold": float(np.float32(rng.uniform(0.015, 0.08))), "edge_threshold": float(np.float32(rng.uniform(5.0, 15.0)))}
+        if rng.random() < 0.5:
+            kw["use_input_upsampling"] = False
+        if rng.random() < 0.5:
+            kw["nb_scales_per_octave"] = int(rng.integers(1, 7))
+        if rng.random() < 0.3:
+            kw["use_hardware_interpolated_blur"] = False
+        nb = int(rng.integers(1, 4))
+        vcfg, ocfg = _cfgs(vk, oracle, input_image_max_size=w * h, **kw)
+        vcfg.sift_buffer_count = nb
+        imgs = [vk.gen_synthetic_image(5000 + 10 * case + i, w, h) for i in range(nb)]
+        with vk.Instance(vcfg, batch_capacity=nb) as inst:
+            inst.detectFeaturesBatch(imgs, 0)
+            feats = [inst.downloadFeatures(i) for i in range(nb)]
+        for i in range(nb):
+            ref, _ = oracle.detect(ocfg, imgs[i])
+            assert len(feats[i]) == len(ref), (case, i, w, h, kw, len(feats[i]), len(ref))
+            assert feats[i].tobytes() == ref.tobytes(), (case, i, w, h, kw)
