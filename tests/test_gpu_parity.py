@@ -343,3 +343,16 @@ def test_randomised_detection_parity_wide(vk, oracle):
             ref, _ = oracle.detect(ocfg, imgs[i])
             assert len(feats[i]) == len(ref), (case, i, w, h, kw, len(feats[i]), len(ref))
             assert feats[i].tobytes() == ref.tobytes(), (case, i, w, h, kw)
+
+
+def test_reference_large_image_size_bit_exact(vk, oracle):
+    """3456x2304, the largest size of the reference's published benchmark (docs/Performances.md:27): 8 octaves, ~50 k features"""
+    w, h = 3456, 2304
+    img = vk.gen_synthetic_image(3456, w, h)
+    vcfg, ocfg = _cfgs(vk, oracle, input_image_max_size=w * h)
+    with vk.Instance(vcfg) as inst:
+        inst.detectFeatures(img, 0)
+        feats = inst.downloadFeatures(0)
+    ref, _ = oracle.detect(ocfg, img)
+    assert len(feats) == len(ref) and len(ref) > 30000
+    assert feats.tobytes() == ref.tobytes()
