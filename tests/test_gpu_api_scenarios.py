@@ -378,7 +378,8 @@ def test_every_runtime_switch_is_bit_identical(vk):
                 {"VKSIFT_LAZY_TOP": "0"}, {"VKSIFT_XCD_REMAP": "0"}, {"VKSIFT_COARSE_AFTER": "0"}, {"VKSIFT_STAGE_SYNC": "1"}, {"VKSIFT_SERIAL_OCTAVES": "1"},
                 {"VKSIFT_PYR_PINGPONG": "1"}, {"VKSIFT_PYR_PINGPONG": "1", "VKSIFT_OVERLAP_GATE": "0"}, {"VKSIFT_GRAPH": "1"}, {"VKSIFT_GRAPH": "0"},
                 {"VKSIFT_CHAIN": "1", "VKSIFT_CHAIN_MIN_ROWS": "1"}, {"VKSIFT_CHAIN": "1", "VKSIFT_CHAIN_MIN_ROWS": "1", "VKSIFT_CHAIN_ROWS": "4"},
-                {"VKSIFT_DESC_WAVES": "1"}, {"VKSIFT_DESC_WAVES": "2"}, {"VKSIFT_DESC_WAVES": "8"}]
+                {"VKSIFT_DESC_WAVES": "1"}, {"VKSIFT_DESC_WAVES": "2"}, {"VKSIFT_DESC_WAVES": "8"},
+                {"VKSIFT_EXTREMA_LEAN": "0"}, {"VKSIFT_EXTREMA_SLOTS": "4", "VKSIFT_EXTREMA_STRIP_MAJOR": "0"}, {"VKSIFT_EXTREMA_BAND": "8"}]
     digests = {}
     for v in variants:
         env = dict(os.environ)

@@ -372,6 +372,164 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_extrema_lean — the production form of the streaming pass above (same mapping, same masks, same results), rebuilt
+// around what bounds it. The pass is a pure stream (20 B per octave pixel at S = 3, no reuse beyond a 3-row window), so
+// its speed is the number of bytes a CU keeps in flight: the generic kernel holds the horizontal 3-max AND 3-min of three
+// rows per layer and column (~100 live registers of window state, one row of loads in flight, and ~700 issued
+// instructions per row — 64-bit per-lane address arithmetic, exec-mask branches around every load, window moves).
+//   * the window holds the RAW texels (3 rows x (2 columns + 1 halo) per layer — they serve max and min alike); the
+//     vertical 3-max / 3-min of a column is formed first, its left / right neighbours then come from ONE lane shift per
+//     side, layer and sign. 60-75 registers of state: 4 waves per SIMD with two rows of loads in flight each.
+//   * raw buffer loads straight into the window slots: lane-constant byte offset (out-of-range for lanes that must not
+//     load: the hardware returns 0), the row offset is one SGPR, one resource per layer — no VALU address arithmetic,
+//     no branches. The row loop is unrolled over the NSLOT window slots, so the window rotates by renaming.
+//   * rows are clamped and columns are not masked: values outside the image only ever reach the test of non-interior
+//     texels, which the (lane-constant) column masks and the scalar row range remove
+//   * the comparisons are ballots combined on the scalar unit; the (rare) store of a non-empty ballot interleaves the
+//     two column masks with two more ballots instead of 100 scalar bit operations
+// 26 strict comparisons == centre above the max / below the min of: the own layer's 8 neighbours
+// (max3(left column's vertical max, right column's vertical max, max(up, down))) and the full 3x3 of both adjacent layers.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+constexpr unsigned EXT_OOB = 0x80000000u;
+
+template <int S, int NSLOT>
+__global__ void __launch_bounds__(256, 4) k_extrema_lean(ExtremaArgs a, int band, int strip_major)
+{
+  constexpr int NL = S + 2;
+  constexpr int AHEAD = NSLOT - 3; // rows of loads in flight behind the 3-row window
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 4 independent waves per block, one row band each
+  const int b = blockIdx.z;
+  int bx = blockIdx.x, by = blockIdx.y * 4 + wv;
+  if (strip_major)
+  {
+    // the 4 waves of a block take 4 adjacent strips of one band (strips fastest over the flattened wave index)
+    const unsigned id = (blockIdx.y * gridDim.x + blockIdx.x) * 4u + (unsigned)wv, ns = (unsigned)(a.nseg + 1) / 2u;
+    by = (int)(id / ns), bx = (int)(id - (unsigned)by * ns);
+  }
+  const int y0 = by * band;
+  if (y0 >= a.h)
+    return;
+  const int y1 = min(y0 + band, a.h);
+  const int x0 = bx * 128, x = x0 + 2 * lane;
+  const float *img = a.dog + (size_t)b * a.img_stride;
+  const int pitch4 = a.pitch * 4;
+  __amdgpu_buffer_rsrc_t rs[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++)
+    rs[l] = __builtin_amdgcn_make_buffer_rsrc((void *)(img + (size_t)l * a.plane_stride), 0, a.pitch * a.h * 4, 0x00020000);
+  // the pitch is a multiple of 64 floats, x is even: the pair (x, x+1) is inside the row or entirely outside
+  const unsigned off2 = x < a.pitch ? (unsigned)x * 4u : EXT_OOB;
+  const int hx = lane == 0 ? x0 - 1 : x0 + 128;
+  const unsigned offh = ((lane == 0 || lane == 63) && hx >= 0 && hx < a.pitch) ? (unsigned)hx * 4u : EXT_OOB;
+  const unsigned long long colA = __ballot(x >= 1 && x < a.w - 1), colB = __ballot(x + 1 < a.w - 1);
+  const float pre = a.dog_threshold * 0.8f;
+  const int seg0 = bx * 2;
+  const bool has_seg1 = seg0 + 1 < a.nseg;
+  const int ylo = max(y0, 1), yhi = min(y1, a.h - 1); // rows tested by this wave
+  const bool odd = lane & 1;
+  const unsigned half = (unsigned)lane >> 1;
+
+  u32x2_t wv2[NSLOT][NL]; // columns x, x+1
+  unsigned wh[NSLOT][NL]; // halo column (lanes 0 and 63)
+  auto fetch_row = [&](int r, auto SLOT) {
+    constexpr int slot = decltype(SLOT)::value;
+    const int rr = min(max(r, 0), a.h - 1);
+    const int so = rr * pitch4;
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+    {
+      wv2[slot][l] = __builtin_amdgcn_raw_buffer_load_b64(rs[l], off2, so, 0);
+      wh[slot][l] = __builtin_amdgcn_raw_buffer_load_b32(rs[l], offh, so, 0);
+    }
+  };
+
+  // Row r has just become the newest row of the window (slot P); the centre row is y = r - 1. Slot (P + 1 + AHEAD - 1) ...
+  // receives row r + AHEAD: it held row r - 3, which no later test reads.
+  auto phase = [&](auto PC, int r) {
+    constexpr int P = decltype(PC)::value;
+    constexpr int sn = P, sm = (P + NSLOT - 1) % NSLOT, so_ = (P + NSLOT - 2) % NSLOT, sf = (P + AHEAD) % NSLOT;
+    if (r + AHEAD <= y1)
+      fetch_row(r + AHEAD, std::integral_constant<int, sf>{});
+    const int y = r - 1;
+    if (y < ylo || y >= yhi)
+      return;
+    float ownxA[S], ownnA[S], ownxB[S], ownnB[S], fullxA[NL], fullnA[NL], fullxB[NL], fullnB[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+    {
+      const float ao = __uint_as_float(wv2[so_][l].x), am = __uint_as_float(wv2[sm][l].x), an = __uint_as_float(wv2[sn][l].x);
+      const float bo = __uint_as_float(wv2[so_][l].y), bm = __uint_as_float(wv2[sm][l].y), bn = __uint_as_float(wv2[sn][l].y);
+      const float ho = __uint_as_float(wh[so_][l]), hm = __uint_as_float(wh[sm][l]), hn = __uint_as_float(wh[sn][l]);
+      const float vxa = fmax3(ao, am, an), vna = fmin3(ao, am, an);
+      const float vxb = fmax3(bo, bm, bn), vnb = fmin3(bo, bm, bn);
+      const float vxh = fmax3(ho, hm, hn), vnh = fmin3(ho, hm, hn);
+      const float Lx = wave_shr1(vxb, vxh), Ln = wave_shr1(vnb, vnh); // column x-1 = previous lane's column x+1
+      const float Rx = wave_shl1(vxa, vxh), Rn = wave_shl1(vna, vnh); // column x+2 = next lane's column x
+      if (l >= 1 && l <= S)
+      {
+        ownxA[l - 1] = fmax3(Lx, vxb, fmax2(ao, an)), ownnA[l - 1] = fmin3(Ln, vnb, fmin2(ao, an));
+        ownxB[l - 1] = fmax3(vxa, Rx, fmax2(bo, bn)), ownnB[l - 1] = fmin3(vna, Rn, fmin2(bo, bn));
+      }
+      fullxA[l] = fmax3(Lx, vxa, vxb), fullnA[l] = fmin3(Ln, vna, vnb);
+      fullxB[l] = fmax3(vxa, vxb, Rx), fullnB[l] = fmin3(vna, vnb, Rn);
+    }
+#pragma unroll
+    for (int sz = 0; sz < S; sz++)
+    {
+      const int l = sz + 1;
+      const float ca = __uint_as_float(wv2[sm][l].x), cb = __uint_as_float(wv2[sm][l].y);
+      const float nxa = fmax3(ownxA[sz], fullxA[l - 1], fullxA[l + 1]), nna = fmin3(ownnA[sz], fullnA[l - 1], fullnA[l + 1]);
+      const float nxb = fmax3(ownxB[sz], fullxB[l - 1], fullxB[l + 1]), nnb = fmin3(ownnB[sz], fullnB[l - 1], fullnB[l + 1]);
+      const unsigned long long ma = (__ballot(ca > nxa) | __ballot(ca < nna)) & __ballot(fabsf(ca) > pre) & colA;
+      const unsigned long long mb = (__ballot(cb > nxb) | __ballot(cb < nnb)) & __ballot(fabsf(cb) > pre) & colB;
+      if ((ma | mb) != 0ull) // the mask array was zeroed by a memset: only non-empty ballots are written
+      {
+        // pixel 2i of the wave comes from ma bit i, pixel 2i+1 from mb bit i: lane j of a segment looks up its own bit
+        const unsigned lo = odd ? (unsigned)mb : (unsigned)ma, hi = odd ? (unsigned)(mb >> 32) : (unsigned)(ma >> 32);
+        const unsigned long long m0 = __ballot((lo >> half) & 1u), m1 = __ballot((hi >> half) & 1u);
+        if (lane == 0)
+        {
+          const size_t base = ((size_t)sz * a.h + y) * a.nseg + (size_t)b * a.seg_img_stride;
+          a.seg_mask[base + seg0] = m0;
+          if (has_seg1)
+            a.seg_mask[base + seg0 + 1] = m1;
+        }
+      }
+    }
+  };
+
+  // rows y0-1 .. y0-2+AHEAD are in flight before the loop; phase k handles row r = y0 - 1 + k
+  if (AHEAD >= 1)
+    fetch_row(y0 - 1, std::integral_constant<int, 0>{});
+  if (AHEAD >= 2)
+    fetch_row(y0, std::integral_constant<int, 1 % NSLOT>{});
+  int r = y0 - 1;
+  for (;;)
+  {
+    phase(std::integral_constant<int, 0>{}, r);
+    if (++r > y1)
+      break;
+    phase(std::integral_constant<int, 1>{}, r);
+    if (++r > y1)
+      break;
+    phase(std::integral_constant<int, 2>{}, r);
+    if (++r > y1)
+      break;
+    phase(std::integral_constant<int, 3>{}, r);
+    if (++r > y1)
+      break;
+    if (NSLOT > 4)
+    {
+      phase(std::integral_constant<int, 4 % NSLOT>{}, r);
+      if (++r > y1)
+        break;
+    }
+  }
+}
+
 // Exclusive scan of popcount(mask) over the n segments of an image, in two parallel levels (a single workgroup per image
 // made this the longest kernel of a 1080p detection): every 1024-thread workgroup scans one chunk of SEG_CHUNK segments
 // locally and publishes the chunk total; k_chunk_offsets turns the totals of an image into chunk base offsets; the
@@ -620,11 +778,36 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
    * gain more from twice the waves (serial kernel time of the coarse octaves -40 %) */
   const int band = band_env ? band_env : (job->h > 256u ? 32 : 16);
   dim3 sgrid((a.nseg + 1) / 2, ((job->h + band - 1) / band + 3) / 4, batch);
+  static int lean_env = -1;
+  if (lean_env < 0)
+  {
+    const char *e = getenv("VKSIFT_EXTREMA_LEAN"); /* 0: the generic streaming kernel (A/B runs) */
+    lean_env = e ? atoi(e) : 1;
+  }
+  static int sm_env = -1;
+  if (sm_env < 0)
+  {
+    const char *e = getenv("VKSIFT_EXTREMA_STRIP_MAJOR"); /* 1: the 4 waves of a block take adjacent strips (-5 %), 0: adjacent bands */
+    sm_env = e ? atoi(e) : 1;
+  }
+  static int occ_env = -1;
+  if (occ_env < 0)
+  {
+    const char *e = getenv("VKSIFT_EXTREMA_SLOTS"); /* window slots: 4 = one row of loads in flight, 5 = two */
+    occ_env = e ? atoi(e) : 5;
+  }
+  /* the lean kernel addresses a plane with 32-bit byte offsets */
+  const bool lean = lean_env && (uint64_t)job->pitch * job->h * 4u < 0x80000000ull;
   switch (job->S)
   {
-#define VKSIFT_CASE(N)                                                       \
-  case N:                                                                    \
-    hipLaunchKernelGGL(k_extrema_stream<N>, sgrid, dim3(256), 0, hs, a, band); \
+#define VKSIFT_CASE(N)                                                         \
+  case N:                                                                      \
+    if (lean && occ_env == 4)                                                  \
+      hipLaunchKernelGGL((k_extrema_lean<N, 4>), sgrid, dim3(256), 0, hs, a, band, sm_env); \
+    else if (lean)                                                  \
+      hipLaunchKernelGGL((k_extrema_lean<N, 5>), sgrid, dim3(256), 0, hs, a, band, sm_env); \
+    else                                                                       \
+      hipLaunchKernelGGL(k_extrema_stream<N>, sgrid, dim3(256), 0, hs, a, band); \
     break;
     VKSIFT_CASE(1) VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9)
     VKSIFT_CASE(10) VKSIFT_CASE(11) VKSIFT_CASE(12) VKSIFT_CASE(13)
