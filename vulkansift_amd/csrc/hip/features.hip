@@ -522,6 +522,21 @@ FeatArgs make_args(const vksift_hip_OctaveJob *job)
   return a;
 }
 
+// grid sizing only (the kernels stride over the real, device-side count): a generous estimate of the keypoints of an octave
+uint32_t expected_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch)
+{
+  static int div = -1;
+  if (div < 0)
+  {
+    const char *e = getenv("VKSIFT_FEAT_GRID_DIV"); /* pixels per expected keypoint (A/B runs); 0 = capacity-sized grids */
+    div = e ? atoi(e) : 512;
+  }
+  if (div <= 0 || batch < 8u) /* a handful of images: idle workgroups cost nothing, keep the full parallelism */
+    return 0xFFFFFFFFu;
+  const uint64_t n = (uint64_t)job->w * job->h / (uint32_t)div;
+  return n < 32u ? 32u : (n > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n);
+}
+
 } // namespace
 
 extern "C"
@@ -529,7 +544,11 @@ extern "C"
   int vksift_hip_orientations(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s)
   {
     FeatArgs a = make_args(job);
-    uint32_t blocks = (job->cap + 3) / 4;
+    /* The keypoint count is only known on the device; the grid is sized for a dense octave (one keypoint per 512 pixels,
+     * twice the usual yield) and strides over whatever is there. Sizing it by the section capacity alone launched 131 k
+     * workgroups per stage on the coarse octaves for a few hundred keypoints: 40-70 us of pure dispatch each. */
+    const uint32_t dense = expected_keypoints(job, batch);
+    uint32_t blocks = ((job->cap < dense ? job->cap : dense) + 3) / 4;
     if (blocks > 1024)
       blocks = 1024;
     if (blocks == 0)
@@ -542,7 +561,8 @@ extern "C"
   int vksift_hip_descriptors(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s)
   {
     FeatArgs a = make_args(job);
-    uint32_t blocks = job->cap;
+    const uint32_t dense = expected_keypoints(job, batch);
+    uint32_t blocks = job->cap < dense ? job->cap : dense;
     if (blocks > 2048)
       blocks = 2048;
     if (blocks == 0)
