@@ -364,6 +364,11 @@ with vk.Instance(vk.default_config(sift_buffer_count=2), batch_capacity=2) as in
         h.update(inst.downloadMatches().tobytes())
     for s in range(6):
         h.update(inst.downloadScaleSpaceImage(1, s).tobytes())
+imgs8 = [vk.gen_synthetic_image(500 + i, 208, 160) for i in range(8)]
+with vk.Instance(vk.default_config(sift_buffer_count=8), batch_capacity=8) as inst:   # batches of 8 and more size their grids differently
+    inst.detectFeaturesBatch(imgs8, 0)
+    for b in range(8):
+        h.update(inst.downloadFeatures(b).tobytes())
 print("DIGEST", h.hexdigest())
 """
 
