@@ -94,6 +94,13 @@ extern "C"
   int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const float *taps, uint32_t ntaps, uint32_t batch,
                       vksift_hip_stream s);
 
+  /* vksift_hip_blur that also seeds the next octave: next(x, y) = dst(2x+1, 2y+1), the vkCmdBlitImage(NEAREST) of
+   * sift_detector.c:1003-1034 for exactly halved sizes, stored from the registers that hold the blurred rows (the separate
+   * pass re-reads the whole plane). Bit-identical to vksift_hip_blur + vksift_hip_downsample. Returns -1 without launching
+   * anything when the shape or the selected kernel does not cover it: the caller then issues the two separate calls. */
+  int vksift_hip_blur_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, vksift_hip_Plane next, const float *taps, uint32_t ntaps,
+                                 uint32_t batch, vksift_hip_stream s);
+
   /* vkCmdCopyBufferToImage + vkCmdBlitImage(LINEAR, exact 2:1) + the seed blur (sift_detector.c:881-1001 for octave 0) in one
    * pass: dst = blur(upsample2x(src / 255)); the up-sampled plane is never written. Bit-identical to vksift_hip_input_blit
    * followed by vksift_hip_blur. Returns -1 when the shape is not covered (the caller then issues the two separate calls). */

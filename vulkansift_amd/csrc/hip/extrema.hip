@@ -693,10 +693,12 @@ __global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
 }
 
 // Accepted candidates recompute their record (bit-identical) and store it at chunk base + rank inside the chunk (raster
-// order is preserved) if it fits the section.
+// order is preserved) if it fits the section. About one candidate in six is accepted: the accepted ones of a chunk are
+// first compacted through LDS, so the recomputation runs on dense lanes (one wave per chunk instead of four sparse ones).
 __global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
 {
   __shared__ uint32_t s_cnt[4];
+  __shared__ uint32_t s_list[256];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t n = a.cand_n[b];
@@ -714,12 +716,17 @@ __global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
     if (lane == 0)
       s_cnt[wave] = (uint32_t)__popcll(bal);
     __syncthreads();
-    uint32_t idx = chunk_base[chunk] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
     for (int wv = 0; wv < wave; wv++)
-      idx += s_cnt[wv];
-    if (v && idx < a.cap)
+      rank += s_cnt[wv];
+    const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (v)
+      s_list[rank] = xy[i];
+    __syncthreads();
+    const uint32_t idx = chunk_base[chunk] + threadIdx.x;
+    if (threadIdx.x < total && idx < a.cap)
     {
-      const uint32_t c = xy[i];
+      const uint32_t c = s_list[threadIdx.x];
       KpRecord kp;
       refine_texel(d, (int)(c & 0x3fffu), (int)((c >> 14) & 0x3fffu), (int)(c >> 28), a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
       uint32_t *rec = (uint32_t *)(a.feats + (size_t)b * a.feat_img_stride + (size_t)idx * 164);

@@ -226,6 +226,9 @@ struct StreamArgs
   int w, h;
   int seg; // output rows per workgroup (multiple of 8)
   int xcd_remap; // k_blur_lean: XCD-contiguous work mapping
+  float *ds;     // k_blur_lean: also store the NEAREST 2:1 resample (odd rows, odd columns) of the result here (next octave's seed), or NULL
+  uint64_t ds_img_stride;
+  int ds_pitch;
   Taps taps;
 };
 
@@ -449,6 +452,8 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
           : plane_rsrc(a.src + (size_t)bimg * a.src_img_stride, a.spitch, H);
   const __amdgpu_buffer_rsrc_t rd = plane_rsrc(a.dst ? a.dst + (size_t)bimg * a.dst_img_stride : a.src, a.dpitch, H);
   const __amdgpu_buffer_rsrc_t rg_ = plane_rsrc(DOG ? a.dog + (size_t)bimg * a.dog_img_stride : a.dst, a.gpitch, H);
+  const bool has_ds = !UPS && a.ds != nullptr;
+  const __amdgpu_buffer_rsrc_t rds = plane_rsrc(has_ds ? a.ds + (size_t)bimg * a.ds_img_stride : a.src, has_ds ? a.ds_pitch : a.spitch, has_ds ? H / 2 : H);
 
   // ---- lane constants
   const int gx4 = x0 - RA + 4 * lane;
@@ -488,6 +493,8 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   const unsigned st_off = px + 1 < W ? (unsigned)px * 4u : BUF_OOB;
   const unsigned st_off_g = a.dst ? st_off : BUF_OOB; // dst == NULL: the caller keeps only the DoG layer, the hardware drops the store
   const int spitch4 = a.spitch * 4, dpitch4 = a.dpitch * 4, gpitch4 = a.gpitch * 4;
+  const unsigned st_off_ds = px + 1 < W ? (unsigned)(px >> 1) * 4u : BUF_OOB; // column px+1 (odd) -> column px/2 of the half-size plane
+  const int dspitch4 = a.ds_pitch * 4;
   const float k0 = a.taps.k[0];
 
   u32x4 pf[NR];
@@ -631,6 +638,10 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
           const v2f c = centre(j);
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0 - c.x), __float_as_uint(acc1 - c.y)}, rg_, st_off, so_g, 0);
         }
+        // vkCmdBlitImage(NEAREST) into the next octave, exact 2:1: destination (x, y) takes source (2x+1, 2y+1). yb is even
+        // (segments start on multiples of 8), so the odd rows are the odd j: a compile-time choice in the unrolled loops
+        if (has_ds && (j & 1))
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1), rds, st_off_ds, ((yb + j) >> 1) * dspitch4, 0);
       };
       auto vpass_checked = [&]() {
         int so_d = yb * dpitch4, so_g = yb * gpitch4;
@@ -773,8 +784,32 @@ extern "C"
     return (int)hipGetLastError();
   }
 
+  static int blur_impl(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, vksift_hip_Plane ds, const float *taps, uint32_t ntaps,
+                       uint32_t batch, vksift_hip_stream s);
+
   int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const float *taps, uint32_t ntaps, uint32_t batch,
                       vksift_hip_stream s)
+  {
+    const vksift_hip_Plane none = {NULL, 0, 0, 0, 0};
+    return blur_impl(src, dst, dog, none, taps, ntaps, batch, s);
+  }
+
+  int vksift_hip_blur_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, vksift_hip_Plane next, const float *taps, uint32_t ntaps,
+                                 uint32_t batch, vksift_hip_stream s)
+  {
+    static int enabled = -1;
+    if (enabled < 0)
+    {
+      const char *e = getenv("VKSIFT_FUSED_DOWNSAMPLE"); /* 0: separate down-sampling launch (A/B runs) */
+      enabled = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!enabled || next.base == NULL || dst.base == NULL || next.w * 2u != src.w || next.h * 2u != src.h)
+      return -1;
+    return blur_impl(src, dst, dog, next, taps, ntaps, batch, s);
+  }
+
+  static int blur_impl(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, vksift_hip_Plane ds, const float *taps, uint32_t ntaps, uint32_t batch,
+                       vksift_hip_stream s)
   {
     if (ntaps < 1 || ntaps > VKSIFT_HIP_MAX_TAPS || src.base == dst.base || (dst.base == NULL && dog.base == NULL))
       return (int)hipErrorInvalidValue;
@@ -790,9 +825,10 @@ extern "C"
       force_tile = (e && e[0] == 't') ? 1 : 0;
     }
     if (ntaps < 2 || force_tile)
-      return blur_tile_launch(src, dst, dog, t, ntaps, batch, s);
+      return ds.base ? -1 : blur_tile_launch(src, dst, dog, t, ntaps, batch, s);
 
     StreamArgs a;
+    a.ds = ds.base, a.ds_img_stride = ds.img_stride, a.ds_pitch = (int)ds.pitch;
     a.src = src.base, a.dst = dst.base, a.dog = dog.base;
     a.src_img_stride = src.img_stride, a.dst_img_stride = dst.img_stride, a.dog_img_stride = dog.img_stride;
     a.spitch = (int)src.pitch, a.dpitch = (int)dst.pitch, a.gpitch = (int)dog.pitch;
@@ -828,6 +864,8 @@ extern "C"
       if (lean && (src.w % 4u) == 0 && ra <= src.w && nstrips * 128u + ra <= 2u * src.w)
         nw = 0;
     }
+    if (ds.base && nw != 0)
+      return -1; /* only k_blur_lean carries the fused down-sampling store */
     static uint32_t wg_target = 0, min_seg_rows = 0;
     static bool min_seg_env = false;
     if (!wg_target)
@@ -891,6 +929,7 @@ extern "C"
     if (!enabled || ntaps < 2 || ntaps > VKSIFT_HIP_MAX_TAPS || W != 2 * sw || H != 2 * sh || (W % 4u) != 0 || sw < 4 || ra > W || strips * 128u + ra > 2u * W)
       return -1; /* not applicable: the caller runs vksift_hip_input_blit + vksift_hip_blur */
     StreamArgs a;
+    a.ds = NULL, a.ds_img_stride = 0, a.ds_pitch = 0;
     a.src = (const float *)src, a.dst = dst.base, a.dog = NULL;
     a.src_img_stride = src_img_stride, a.dst_img_stride = dst.img_stride, a.dog_img_stride = 0;
     a.spitch = (int)sw, a.dpitch = (int)dst.pitch, a.gpitch = (int)dst.pitch;

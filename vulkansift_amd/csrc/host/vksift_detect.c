@@ -201,9 +201,21 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool 
         dstp.base = NULL;
         inst->top_scale_stale[o] = true;
       }
-      TRY(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), dstp, plane_at(inst, o, L->dog_off[o], s - 1), &inst->taps[s * VKSIFT_MAX_TAPS],
-                          inst->ntaps[s], c->count, sp),
-          "blur");
+      int fused_ds = -1;
+      if (s == inst->S && o + 1 < L->n_oct)
+      {
+        /* scale S also seeds the next octave (sift_detector.c:1003-1034): stored by the same pass when the sizes halve exactly */
+        fused_ds = vksift_hip_blur_downsample(plane_at(inst, o, L->gauss_off[o], s - 1), dstp, plane_at(inst, o, L->dog_off[o], s - 1),
+                                              plane_at(inst, o + 1, L->gauss_off[o + 1], 0), &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], c->count, sp);
+        if (fused_ds > 0)
+          TRY(fused_ds, "blur + down-sampling");
+        if (fused_ds == 0)
+          *g0_done = true;
+      }
+      if (fused_ds < 0)
+        TRY(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), dstp, plane_at(inst, o, L->dog_off[o], s - 1), &inst->taps[s * VKSIFT_MAX_TAPS],
+                            inst->ntaps[s], c->count, sp),
+            "blur");
       nb_o++;
       if (c->par && o + 1 < L->n_oct && s == ready_after)
         TRY(vksift_hip_event_record(inst->ev_oct_ready[o], sp), "event record");
