@@ -63,6 +63,9 @@ struct FeatArgs
 // -------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
 {
+  // One wave per keypoint, four independent waves per block: every wave owns its histogram and LDS executes the DS
+  // operations of a wave in program order, so no workgroup barrier is needed (a wave with a 15x15 window does not wait
+  // for a neighbour with a 29x29 one).
   __shared__ uint32_t s_hist[4][36];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
@@ -70,16 +73,14 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
   const uint32_t n0 = found < a.cap ? found : a.cap;
   GaussView g{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride};
   uint8_t *feats = a.feats + (size_t)b * a.feat_img_stride;
+  uint32_t *hist = s_hist[wave];
 
-  for (uint32_t base = blockIdx.x * 4; base < n0; base += gridDim.x * 4)
+  for (uint32_t k = blockIdx.x * 4 + wave; k < n0; k += gridDim.x * 4)
   {
-    const uint32_t k = base + wave;
-    const bool active = k < n0;
     if (lane < 36)
-      s_hist[wave][lane] = 0;
-    __syncthreads();
+      hist[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
     float fp = 0.f;
-    if (active)
     {
       const float *rec = (const float *)(feats + (size_t)k * 164);
       const float scale_x = rec[2], scale_y = rec[3];
@@ -113,9 +114,15 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
       float rsx = roundf(scale_x), rsy = roundf(scale_y);
       int box = 2 * r + 1;
       int npix = box * box;
+      // lane l visits window pixels l, l + 64, ...: (row, column) advance by (64 / box, 64 % box) with at most one carry
+      const int step_q = 64 / box, step_r = 64 - step_q * box;
+      int py = lane / box, px = lane - py * box;
       for (int pix = lane; pix < npix; pix += 64)
       {
-        int dy = (pix / box) - r, dx = (pix % box) - r;
+        const int dy = py - r, dx = px - r;
+        px += step_r, py += step_q;
+        if (px >= box)
+          px -= box, py++;
         int gx = (int)rsx + dx, gy = (int)rsy + dy;
         float sdx = (rsx + (float)dx) - scale_x;
         float sdy = (rsy + (float)dy) - scale_y;
@@ -135,15 +142,14 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
           bin += 36;
         else if (bin >= 36)
           bin -= 36;
-        atomicAdd(&s_hist[wave][bin], (uint32_t)(mag * fp));
+        atomicAdd(&hist[bin], (uint32_t)(mag * fp));
       }
     }
-    __syncthreads();
-    if (active)
+    __builtin_amdgcn_wave_barrier();
     {
       // 3 x 2 box-filter passes in registers (lane i holds bin i), :130-147
       const int li = lane < 36 ? lane : 0;
-      uint32_t hv = s_hist[wave][li];
+      uint32_t hv = hist[li];
       const int lm = (li + 35) % 36, lp = (li + 1) % 36;
 #pragma unroll
       for (int it = 0; it < 6; it++)
@@ -177,7 +183,7 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
       if (lane == 0)
         a.ori_cnt[(size_t)b * a.ori_img_stride + k] = npk < a.max_keep ? npk : a.max_keep;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
