@@ -61,6 +61,7 @@ struct FeatArgs
 // -------------------------------------------------------------------------------------------------
 // Orientation histogram (ComputeOrientation.comp:52-186). grid = (blocks, batch); 4 keypoints/block.
 // -------------------------------------------------------------------------------------------------
+template <bool IMG_FAST>
 __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
 {
   // One wave per keypoint, four independent waves per block: every wave owns its histogram and LDS executes the DS
@@ -68,14 +69,15 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
   // for a neighbour with a 29x29 one).
   __shared__ uint32_t s_hist[4][36];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.y;
+  const int b = IMG_FAST ? blockIdx.x : blockIdx.y;
   const uint32_t found = a.found[(size_t)b * a.found_img_stride];
   const uint32_t n0 = found < a.cap ? found : a.cap;
   GaussView g{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride};
   uint8_t *feats = a.feats + (size_t)b * a.feat_img_stride;
   uint32_t *hist = s_hist[wave];
 
-  for (uint32_t k = blockIdx.x * 4 + wave; k < n0; k += gridDim.x * 4)
+  const uint32_t bk = IMG_FAST ? blockIdx.y : blockIdx.x, nbk = IMG_FAST ? gridDim.y : gridDim.x;
+  for (uint32_t k = bk * 4 + wave; k < n0; k += nbk * 4)
   {
     if (lane < 36)
       hist[lane] = 0;
@@ -257,11 +259,33 @@ __global__ void __launch_bounds__(1024) k_orientation_finalize(FeatArgs a)
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int smod8(int v) { return v & 7; } // floored modulo for a power of two (quirk Q5, OpSMod)
 
+// x / (2*pi) with the result of the IEEE division it replaces, in 3 instructions instead of the 11 of the division
+// expansion: q0 = x * RN(1/c), one exact remainder, one correction (Markstein). Verified exhaustively against x / c for
+// every float in [2^-103, 256] (931 135 489 values, tests/test_host_math.py checks a sample); below 2^-96 the remainder
+// would underflow, so those inputs (never seen in practice) take the division, and zeros keep their sign through x * rc.
+__device__ __forceinline__ float div_2pi(float x)
+{
+  const float c = 2.f * PI_F, rc = 0x1.45f306p-3f;
+  float q = x * rc;
+  if (fabsf(x) >= 0x1p-96f)
+    q = fmaf(fmaf(-q, c, x), rc, q);
+  else if (x != 0.f)
+    q = x / c;
+  return q;
+}
+
+// wrap an angle known to lie in (-2*pi, 4*pi) into [0, 2*pi] (ComputeDescriptors.comp:160-171), as selects
+__device__ __forceinline__ float wrap_2pi(float t)
+{
+  const float up = t + 2.f * PI_F, dn = t - 2.f * PI_F;
+  return t < 0 ? up : (t > (2.f * PI_F) ? dn : t);
+}
+
 // Per-pixel descriptor contribution (ComputeDescriptors.comp:139-197) for window offset (cdx, cdy).
 struct DescCtx
 {
-  const float *layer;
-  int pitch;
+  __amdgpu_buffer_rsrc_t rs; // the keypoint's Gaussian layer
+  int pitch, pitch4;
   float scale_x, scale_y, rsx, rsy, kcos, ksin, kori, fp;
   uint32_t use_vlfeat;
 };
@@ -274,22 +298,21 @@ __device__ __forceinline__ void desc_accumulate(const DescCtx &c, int cdx, int c
   float sdy = (c.rsy + (float)cdy) - c.scale_y;
   float ox = c.kcos * sdx + c.ksin * sdy;
   float oy = c.kcos * sdy - c.ksin * sdx;
-  float gradX = 0.5f * (c.layer[(size_t)iy * c.pitch + ix + 1] - c.layer[(size_t)iy * c.pitch + ix - 1]);
-  float gradY = 0.5f * (c.layer[(size_t)(iy + 1) * c.pitch + ix] - c.layer[(size_t)(iy - 1) * c.pitch + ix]);
-  float ori = dm_atan2f(gradY, gradX);
-  if (ori < 0)
-    ori += 2.f * PI_F;
-  else if (ori > (2.f * PI_F))
-    ori -= 2.f * PI_F;
-  ori = ori - c.kori;
-  if (ori < 0)
-    ori += 2.f * PI_F;
-  else if (ori > (2.f * PI_F))
-    ori -= 2.f * PI_F;
+  // the four taps through the layer's buffer resource: one 32-bit offset (texel (ix-1, iy-1)), the rest is immediate /
+  // scalar offsets (the window is clipped to the image interior, so every tap is in range)
+  const unsigned v0 = (__umul24((unsigned)(iy - 1), (unsigned)c.pitch) + (unsigned)(ix - 1)) * 4u; // sides < 16384: 24-bit factors
+  const float t_up = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c.rs, v0 + 4u, 0, 0));
+  const float t_lf = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c.rs, v0, c.pitch4, 0));
+  const float t_rt = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c.rs, v0 + 8u, c.pitch4, 0));
+  const float t_dn = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c.rs, v0 + 4u, 2 * c.pitch4, 0));
+  float gradX = 0.5f * (t_rt - t_lf);
+  float gradY = 0.5f * (t_dn - t_up);
+  float ori = wrap_2pi(dm_atan2f(gradY, gradX));
+  ori = wrap_2pi(ori - c.kori);
   float mag = dm_expf(es * ((ox * ox) + (oy * oy))) * sqrtf((gradX * gradX) + (gradY * gradY));
 
   float fhx = ox + 2.f, fhy = oy + 2.f;
-  float fbin = c.use_vlfeat ? (ori * 8.f / (2.f * PI_F)) : (-ori * 8.f / (2.f * PI_F));
+  float fbin = div_2pi(c.use_vlfeat ? ori * 8.f : -ori * 8.f);
   int hx = (int)floorf(fhx - 0.5f), hy = (int)floorf(fhy - 0.5f), hb = (int)floorf(fbin);
   float rhx = fhx - ((float)hx + 0.5f), rhy = fhy - ((float)hy + 0.5f), rb = fbin - (float)hb;
   // The 2x2 spatial cells that fall outside the 4x4 grid (ComputeDescriptors.comp:189 drops them) are redirected to a
@@ -319,7 +342,7 @@ __device__ __forceinline__ void desc_accumulate(const DescCtx &c, int cdx, int c
 // atan2, exp, 8 fixed-point atomics) runs on full 64-lane batches.
 constexpr int DESC_MAX_ROWS = 256; // window rows handled per pass (R <= 127: every stock configuration); taller windows take several passes
 
-template <int NWV>
+template <int NWV, bool IMG_FAST>
 __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
 {
   constexpr int NT_ = 64 * NWV;
@@ -328,26 +351,27 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
   __shared__ uint32_t s_row_cnt[DESC_MAX_ROWS];
   __shared__ uint32_t s_row_pre[NWV][DESC_MAX_ROWS + 1];
   const int tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.y;
+  const int b = IMG_FAST ? blockIdx.x : blockIdx.y;
   const uint32_t found = a.found[(size_t)b * a.found_img_stride];
   const uint32_t n1 = found < a.cap ? found : a.cap;
   GaussView g{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride};
   uint8_t *feats = a.feats + (size_t)b * a.feat_img_stride;
 
-  for (uint32_t k = blockIdx.x; k < n1; k += gridDim.x)
+  for (uint32_t k = IMG_FAST ? blockIdx.y : blockIdx.x; k < n1; k += IMG_FAST ? gridDim.y : gridDim.x)
   {
     __syncthreads(); // the previous keypoint's epilogue has read the histogram
     for (int i = tid; i < 128; i += NT_)
       s_work[i] = 0; // made visible by the barrier behind the row-span pass below
 
     const float *rec = (const float *)(feats + (size_t)k * 164);
-    const uint32_t scale_idx = ((const uint32_t *)rec)[4];
+    const uint32_t scale_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const uint32_t *)rec)[4]); // uniform: keeps the resource in SGPRs
     const int octave_idx = ((const int *)rec)[5];
     const float sigma = rec[6];
     DescCtx c;
     c.scale_x = rec[2], c.scale_y = rec[3], c.kori = rec[7];
-    c.layer = g.base + (size_t)scale_idx * g.plane;
-    c.pitch = g.pitch;
+    // planes stay below 2 GiB (vksift_hip_extract_keypoints refuses sides of 16384 and more): 32-bit byte offsets
+    c.rs = __builtin_amdgcn_make_buffer_rsrc((void *)(g.base + (size_t)scale_idx * g.plane), 0, g.pitch * g.h * 4, 0x00020000);
+    c.pitch = g.pitch, c.pitch4 = g.pitch * 4;
     c.use_vlfeat = a.use_vlfeat;
     float scale_factor = dm_pow2i(octave_idx);
     float lambda = 3.0f * (sigma / scale_factor);
@@ -528,6 +552,25 @@ FeatArgs make_args(const vksift_hip_OctaveJob *job)
   return a;
 }
 
+// Work -> workgroup mapping of the per-keypoint kernels. The number of busy workgroups of an image (its keypoint count)
+// is only known on the device and usually a small part of the grid. With the keypoint index fastest the busy ones form
+// a run at the start of every image's row, which the dispatcher's round-robin over XCDs and shader engines can map onto a
+// fraction of the machine (measured on the refinement kernels: 3x); with the image index fastest the busy workgroups
+// are contiguous in dispatch order, and for batches that are multiples of 8 every image stays on one XCD (its pyramid
+// planes in one L2). grid.y is limited to 65535.
+bool img_fast(uint32_t batch, bool descriptor)
+{
+  static int mode = -1;
+  if (mode < 0)
+  {
+    /* bit 0: orientation kernel, bit 1: descriptor kernel. Measured (128 x 640x480): orientation -5 %, descriptor +3 %
+     * (its grid is mostly busy and the keypoint-fastest order spreads the long coarse-scale windows better): default 1 */
+    const char *e = getenv("VKSIFT_IMG_FAST");
+    mode = e ? atoi(e) : 1;
+  }
+  return batch > 1 && ((mode >> (descriptor ? 1 : 0)) & 1);
+}
+
 // grid sizing only (the kernels stride over the real, device-side count): a generous estimate of the keypoints of an octave
 uint32_t expected_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch)
 {
@@ -559,7 +602,10 @@ extern "C"
       blocks = 1024;
     if (blocks == 0)
       blocks = 1;
-    hipLaunchKernelGGL(k_orientation, dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
+    if (img_fast(batch, false))
+      hipLaunchKernelGGL(k_orientation<true>, dim3(batch, blocks), dim3(256), 0, (hipStream_t)s, a);
+    else
+      hipLaunchKernelGGL(k_orientation<false>, dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
     hipLaunchKernelGGL(k_orientation_finalize, dim3(batch), dim3(1024), 0, (hipStream_t)s, a);
     return (int)hipGetLastError();
   }
@@ -579,14 +625,25 @@ extern "C"
       const char *e = getenv("VKSIFT_DESC_WAVES"); /* waves per keypoint: 1, 2 or 4 (A/B runs) */
       nwv = e ? atoi(e) : 4;
     }
+    const bool f = img_fast(batch, true);
+    hipStream_t hs = (hipStream_t)s;
+#define VKSIFT_DESC(N)                                                                          \
+  do                                                                                            \
+  {                                                                                             \
+    if (f)                                                                                      \
+      hipLaunchKernelGGL((k_descriptor<N, true>), dim3(batch, blocks), dim3(64 * N), 0, hs, a);  \
+    else                                                                                        \
+      hipLaunchKernelGGL((k_descriptor<N, false>), dim3(blocks, batch), dim3(64 * N), 0, hs, a); \
+  } while (0)
     if (nwv == 1)
-      hipLaunchKernelGGL(k_descriptor<1>, dim3(blocks, batch), dim3(64), 0, (hipStream_t)s, a);
+      VKSIFT_DESC(1);
     else if (nwv == 2)
-      hipLaunchKernelGGL(k_descriptor<2>, dim3(blocks, batch), dim3(128), 0, (hipStream_t)s, a);
+      VKSIFT_DESC(2);
     else if (nwv == 8)
-      hipLaunchKernelGGL(k_descriptor<8>, dim3(blocks, batch), dim3(512), 0, (hipStream_t)s, a);
+      VKSIFT_DESC(8);
     else
-      hipLaunchKernelGGL(k_descriptor<4>, dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
+      VKSIFT_DESC(4);
+#undef VKSIFT_DESC
     return (int)hipGetLastError();
   }
 }
