@@ -103,6 +103,8 @@ def lib():
             getattr(L, fn).restype = C.c_float
         L.orc_dm_atan2f.argtypes = [C.c_float, C.c_float]
         L.orc_dm_atan2f.restype = C.c_float
+        L.orc_dm_div_2pi.argtypes = [C.c_float]
+        L.orc_dm_div_2pi.restype = C.c_float
         L.orc_dm_ceil_log2f.argtypes = [C.c_float]
         L.orc_dm_ceil_log2f.restype = C.c_int
         _lib = L

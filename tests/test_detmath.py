@@ -64,3 +64,20 @@ def test_ceil_log2_exact(oracle):
     x = np.random.default_rng(4).uniform(1e-3, 1e6, 5000).astype(np.float32)
     got = np.array([L.orc_dm_ceil_log2f(float(v)) for v in x])
     assert np.array_equal(got, np.ceil(np.log2(x.astype(np.float64))).astype(int))
+
+
+def test_div_2pi_matches_ieee_division(oracle):
+    """the kernels' 3-operation x / (2 pi) (detmath.h: dm_div_2pi) against the correctly rounded float32 division it replaces;
+    the full range [2^-103, 256] was checked exhaustively once (931 135 489 values, 0 mismatches) with the same C code"""
+    L = oracle.lib()
+    rng = np.random.default_rng(7)
+    c = np.float32(2.0) * np.float32(np.pi)
+    bits = np.concatenate([rng.integers(0x0c000000, 0x43800000, 60000, dtype=np.int64),        # random floats of the verified range
+                           np.arange(0x40c90fdb - 2000, 0x40c90fdb + 2000, dtype=np.int64),     # around 2 pi
+                           np.arange(0x0f800000 - 300, 0x0f800000 + 300, dtype=np.int64),       # around the 2^-96 guard
+                           rng.integers(1, 0x0c000000, 3000, dtype=np.int64)])                  # below it, denormals included
+    x = bits.astype(np.uint32).view(np.float32)
+    x = np.concatenate([x, -x, np.array([0.0, -0.0, 8 * 6.2831855, 36 * 6.2831855], dtype=np.float32)])
+    got = _vec(L.orc_dm_div_2pi, x)
+    ref = x / c
+    assert got.view(np.uint32).tolist() == ref.view(np.uint32).tolist()

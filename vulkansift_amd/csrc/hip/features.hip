@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
           ori += 2.f * PI_F;
         else if (ori > (2.f * PI_F))
           ori -= 2.f * PI_F;
-        int bin = (int)((ori * 36.f / (2.f * PI_F)));
+        int bin = (int)(dm_div_2pi(ori * 36.f)); // == ori * 36 / (2 pi)
         if (bin < 0)
           bin += 36;
         else if (bin >= 36)
@@ -259,21 +259,6 @@ __global__ void __launch_bounds__(1024) k_orientation_finalize(FeatArgs a)
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int smod8(int v) { return v & 7; } // floored modulo for a power of two (quirk Q5, OpSMod)
 
-// x / (2*pi) with the result of the IEEE division it replaces, in 3 instructions instead of the 11 of the division
-// expansion: q0 = x * RN(1/c), one exact remainder, one correction (Markstein). Verified exhaustively against x / c for
-// every float in [2^-103, 256] (931 135 489 values, tests/test_host_math.py checks a sample); below 2^-96 the remainder
-// would underflow, so those inputs (never seen in practice) take the division, and zeros keep their sign through x * rc.
-__device__ __forceinline__ float div_2pi(float x)
-{
-  const float c = 2.f * PI_F, rc = 0x1.45f306p-3f;
-  float q = x * rc;
-  if (fabsf(x) >= 0x1p-96f)
-    q = fmaf(fmaf(-q, c, x), rc, q);
-  else if (x != 0.f)
-    q = x / c;
-  return q;
-}
-
 // wrap an angle known to lie in (-2*pi, 4*pi) into [0, 2*pi] (ComputeDescriptors.comp:160-171), as selects
 __device__ __forceinline__ float wrap_2pi(float t)
 {
@@ -312,7 +297,7 @@ __device__ __forceinline__ void desc_accumulate(const DescCtx &c, int cdx, int c
   float mag = dm_expf(es * ((ox * ox) + (oy * oy))) * sqrtf((gradX * gradX) + (gradY * gradY));
 
   float fhx = ox + 2.f, fhy = oy + 2.f;
-  float fbin = div_2pi(c.use_vlfeat ? ori * 8.f : -ori * 8.f);
+  float fbin = dm_div_2pi(c.use_vlfeat ? ori * 8.f : -ori * 8.f);
   int hx = (int)floorf(fhx - 0.5f), hy = (int)floorf(fhy - 0.5f), hb = (int)floorf(fbin);
   float rhx = fhx - ((float)hx + 0.5f), rhy = fhy - ((float)hy + 0.5f), rb = fbin - (float)hb;
   // The 2x2 spatial cells that fall outside the 4x4 grid (ComputeDescriptors.comp:189 drops them) are redirected to a
