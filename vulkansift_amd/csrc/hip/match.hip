@@ -157,6 +157,7 @@ struct SlotStrides
   uint64_t matches;        // dwords
   uint32_t n;              // u32 between the {N_A, N_B} pairs
   uint64_t redo;           // u32
+  uint32_t slot_fast;      // k_match_mfma: blockIdx.x is the slot, blockIdx.y the row block
 };
 
 struct Top2
@@ -229,13 +230,16 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
                                                     uint32_t *__restrict__ partial)
 {
   const uint32_t nchunks = gridDim.z, chunk = blockIdx.z;
-  desc_a += (size_t)blockIdx.y * ss.desc_a, desc_b += (size_t)blockIdx.y * ss.desc_b;
-  norm_a += (size_t)blockIdx.y * ss.norm_a, norm_b += (size_t)blockIdx.y * ss.norm_b;
-  matches += (size_t)blockIdx.y * ss.matches;
-  redo += (size_t)blockIdx.y * ss.redo;
+  // ss.slot_fast: grid = (slots, row blocks) — see the batched launch
+  const uint32_t slot = ss.slot_fast ? blockIdx.x : blockIdx.y;
+  const uint32_t rb0 = ss.slot_fast ? blockIdx.y : blockIdx.x, rb_step = ss.slot_fast ? gridDim.y : gridDim.x;
+  desc_a += (size_t)slot * ss.desc_a, desc_b += (size_t)slot * ss.desc_b;
+  norm_a += (size_t)slot * ss.norm_a, norm_b += (size_t)slot * ss.norm_b;
+  matches += (size_t)slot * ss.matches;
+  redo += (size_t)slot * ss.redo;
   if (n_dev)
   {
-    n_dev += (size_t)blockIdx.y * ss.n;
+    n_dev += (size_t)slot * ss.n;
     // asynchronous path: the row counts were produced on the device by k_gather_sections; this instantiation only
     // serves na in (na_lo, na_hi] (the host launches one kernel per regime, the others exit here)
     na = n_dev[0];
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
   const uint32_t te = min(nb, tb + tiles_per_chunk * BT);
 
   // the grid may be smaller than the number of 64*AT-row blocks (bounded launch): loop over row blocks
-  for (uint32_t rb = blockIdx.x; rb * (64u * AT) < na; rb += gridDim.x)
+  for (uint32_t rb = rb0; rb * (64u * AT) < na; rb += rb_step)
   {
     const uint32_t row_base = (rb * 4 + wave) * (16 * AT);
 
@@ -838,7 +842,7 @@ extern "C"
     hipStream_t hs = (hipStream_t)s;
     uint32_t *norm_a = norm_scratch, *norm_b = norm_scratch + na, *redo = norm_scratch + na + nb;
     const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
-    const SlotStrides z{0, 0, 0, 0, 0, 0, 0};
+    const SlotStrides z{0, 0, 0, 0, 0, 0, 0, 0};
     hipLaunchKernelGGL(k_shifted_norms, dim3((na + 255u) / 256u), dim3(256), 0, hs, da, na, norm_a);
     hipLaunchKernelGGL(k_shifted_norms, dim3((nb + 255u) / 256u), dim3(256), 0, hs, db, nb, norm_b);
     /* Small problems: 16 A rows per workgroup with B split over its waves; medium: 16 rows per wave; large: 32 rows per
@@ -908,6 +912,7 @@ extern "C"
     ss.matches = match_slot_stride / 4;
     ss.n = n_slot_stride;
     ss.redo = norm_slot_stride; /* the redo flags live in the same per-slot scratch block as the norms */
+    ss.slot_fast = 0;
     /* The row count is only known on the device: launch for the capacity (surplus workgroups exit at once), one
      * kernel per size regime, each of which returns immediately unless N_A falls in its range:
      *   N_A <= S1          B-split kernel, 16 A rows per workgroup (keeps a few thousand rows busy on every CU)
@@ -929,8 +934,19 @@ extern "C"
     if (max_na > S1)
     {
       const uint32_t n2 = max_na < S2 ? max_na : S2;
-      hipLaunchKernelGGL(k_match_mfma<1>, dim3(bounded((n2 + 63u) / 64u, nslots), nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
-                         (uint32_t *)matches, redo, n_dev, S1, S2, ss, (uint32_t *)nullptr);
+      /* a batch: slot index fastest, so that the busy workgroups (row block < N_A / 64, unknown here) are contiguous in
+       * dispatch order instead of a short run at the start of every slot's row (see features.hip: img_fast) */
+      static int slot_fast = -1;
+      if (slot_fast < 0)
+      {
+        const char *e = getenv("VKSIFT_MATCH_SLOT_FAST");
+        slot_fast = e ? atoi(e) : 1;
+      }
+      SlotStrides s2 = ss;
+      s2.slot_fast = (slot_fast && nslots > 1) ? 1u : 0u;
+      const uint32_t gb = bounded((n2 + 63u) / 64u, nslots);
+      hipLaunchKernelGGL(k_match_mfma<1>, s2.slot_fast ? dim3(nslots, gb) : dim3(gb, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+                         (uint32_t *)matches, redo, n_dev, S1, S2, s2, (uint32_t *)nullptr);
     }
     if (max_na > S2)
     {
