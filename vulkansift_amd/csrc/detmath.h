@@ -56,12 +56,9 @@ DM_FN float dm_rint(float x)
 
 /* e^x. Relative error <= ~1.5 ulp for x in [-87, 87]; returns 0 below -87.3 (the callers only
  * ever scale the result to a <= 2^30 fixed-point integer, so the flushed tail is always 0). */
-DM_FN float dm_expf(float x)
+/* dm_expf for -87.3 <= x <= 88.7 (no range handling, straight-line code): same operations, same bits */
+DM_FN float dm_expf_core(float x)
 {
-  if (x < -87.3f)
-    return 0.f;
-  if (x > 88.7f)
-    x = 88.7f;
   float n = dm_rint(x * 0x1.715476p+0f); /* x / ln2 */
   float r = fmaf(n, -0x1.62e400p-1f, x);  /* ln2 high part: 12 trailing zero bits -> n*hi exact */
   r = fmaf(n, -0x1.7f7d1cp-20f, r);       /* ln2 low part */
@@ -75,6 +72,15 @@ DM_FN float dm_expf(float x)
   /* split the scaling so that ni in [-126-..,128] never builds an out-of-range exponent field */
   int h = ni / 2;
   return (e * dm_pow2i(h)) * dm_pow2i(ni - h);
+}
+
+DM_FN float dm_expf(float x)
+{
+  if (x < -87.3f)
+    return 0.f;
+  if (x > 88.7f)
+    x = 88.7f;
+  return dm_expf_core(x);
 }
 
 /* 2^x for |x| < 120. Relative error <= ~1 ulp. */
@@ -115,9 +121,9 @@ DM_FN float dm_atan2f(float y, float x)
   float ax = fabsf(x), ay = fabsf(y);
   float mx = ax > ay ? ax : ay;
   float mn = ax > ay ? ay : ax;
-  if (mx == 0.f)
-    return 0.f;
-  float a = mn / mx; /* in [0,1] */
+  /* atan2(+-0, +-0) = +0: with the divisor replaced by 1 the straight-line path below yields exactly that
+   * (a = 0, t = +0, neither x < 0 nor y < 0 holds for a signed zero) — no early return, no branch in the kernels */
+  float a = mn / (mx == 0.f ? 1.f : mx); /* in [0,1] */
   float z = a * a;
   float p = -0x1.f76bccp-11f;
   p = fmaf(p, z, 0x1.9eb02ep-8f);

@@ -275,16 +275,25 @@ struct DescCtx
   uint32_t use_vlfeat;
 };
 
-__device__ __forceinline__ void desc_accumulate(const DescCtx &c, int cdx, int cdy, uint32_t *s_work)
+// The contribution of one window pixel in two straight-line halves (no branch in either, so that the scheduler can
+// interleave the halves of two samples): desc_sample() = taps, gradient, angle, weight; desc_scatter() = bins + atomics.
+struct DescSample
+{
+  float ox, oy, mag;
+  float xb; // 8 * relative orientation, before the division by 2*pi
+};
+
+__device__ __forceinline__ DescSample desc_sample(const DescCtx &c, int cdx, int cdy)
 {
   const float es = -1.f / (2.f * 2 * 2);
   const int ix = (int)c.rsx + cdx, iy = (int)c.rsy + cdy;
   float sdx = (c.rsx + (float)cdx) - c.scale_x;
   float sdy = (c.rsy + (float)cdy) - c.scale_y;
-  float ox = c.kcos * sdx + c.ksin * sdy;
-  float oy = c.kcos * sdy - c.ksin * sdx;
+  DescSample r;
+  r.ox = c.kcos * sdx + c.ksin * sdy;
+  r.oy = c.kcos * sdy - c.ksin * sdx;
   // the four taps through the layer's buffer resource: one 32-bit offset (texel (ix-1, iy-1)), the rest is immediate /
-  // scalar offsets (the window is clipped to the image interior, so every tap is in range)
+  // scalar offsets (the window is clipped to the image interior, so every tap of a live sample is in range)
   const unsigned v0 = (__umul24((unsigned)(iy - 1), (unsigned)c.pitch) + (unsigned)(ix - 1)) * 4u; // sides < 16384: 24-bit factors
   const float t_up = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c.rs, v0 + 4u, 0, 0));
   const float t_lf = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c.rs, v0, c.pitch4, 0));
@@ -294,30 +303,55 @@ __device__ __forceinline__ void desc_accumulate(const DescCtx &c, int cdx, int c
   float gradY = 0.5f * (t_dn - t_up);
   float ori = wrap_2pi(dm_atan2f(gradY, gradX));
   ori = wrap_2pi(ori - c.kori);
-  float mag = dm_expf(es * ((ox * ox) + (oy * oy))) * sqrtf((gradX * gradX) + (gradY * gradY));
+  // |ox|, |oy| < 4 for every enumerated sample: the exponent is in [-4, 0], no range handling needed
+  r.mag = dm_expf_core(es * ((r.ox * r.ox) + (r.oy * r.oy))) * sqrtf((gradX * gradX) + (gradY * gradY));
+  r.xb = c.use_vlfeat ? ori * 8.f : -ori * 8.f;
+  return r;
+}
 
-  float fhx = ox + 2.f, fhy = oy + 2.f;
-  float fbin = dm_div_2pi(c.use_vlfeat ? ori * 8.f : -ori * 8.f);
+__device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample &r, float fbin, bool live, uint32_t *s_work)
+{
+  float fhx = r.ox + 2.f, fhy = r.oy + 2.f;
   int hx = (int)floorf(fhx - 0.5f), hy = (int)floorf(fhy - 0.5f), hb = (int)floorf(fbin);
   float rhx = fhx - ((float)hx + 0.5f), rhy = fhy - ((float)hy + 0.5f), rb = fbin - (float)hb;
   // The 2x2 spatial cells that fall outside the 4x4 grid (ComputeDescriptors.comp:189 drops them) are redirected to a
   // per-lane dummy slot behind the histogram instead of being branched around: no exec-mask juggling in the hot loop.
-  const int dummy = 128 + (int)(threadIdx.x & 63);
+  // All offsets in bytes: a cell is 32 bytes, so cell | bin needs no shift and no add.
+  // (Packed v_pk_mul_f32 for the weight products was measured 9 % slower despite 6 % fewer instructions.)
+  const unsigned dummy = (128u + (threadIdx.x & 63u)) * 4u;
+  const unsigned bin4[2] = {(unsigned)smod8(hb) * 4u, (unsigned)smod8(hb + 1) * 4u};
+  char *base = (char *)s_work;
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
     {
-      const bool in_grid = (unsigned)(i + hx) < 4u && (unsigned)(j + hy) < 4u;
-      const int cell = (j + hy) * 32 + (i + hx) * 8;
+      const bool in_grid = live && (unsigned)(i + hx) < 4u && (unsigned)(j + hy) < 4u;
+      const unsigned cell = (unsigned)((j + hy) * 128 + (i + hx) * 32);
 #pragma unroll
       for (int kk = 0; kk < 2; kk++)
       {
-        const int idx = in_grid ? cell + smod8(kk + hb) : dummy;
-        float val = fabsf(1.f - (float)i - rhx) * fabsf(1.f - (float)j - rhy) * fabsf(1.f - (float)kk - rb) * mag;
-        atomicAdd(&s_work[idx], (uint32_t)(val * c.fp));
+        float val = fabsf(1.f - (float)i - rhx) * fabsf(1.f - (float)j - rhy) * fabsf(1.f - (float)kk - rb) * r.mag;
+        atomicAdd((uint32_t *)(base + (in_grid ? (cell | bin4[kk]) : dummy)), (uint32_t)(val * c.fp));
       }
     }
+}
+
+// x / (2*pi) for two samples: the 3-operation form of dm_div_2pi (detmath.h) unconditionally, and one wave-uniform test
+// for the inputs it does not cover (non-zero magnitudes below 2^-96: never seen, they take the IEEE division)
+__device__ __forceinline__ void desc_fbin2(float xa, float xb, float *fa, float *fb)
+{
+  const float c2 = 2.f * PI_F, rc = 0x1.45f306p-3f;
+  float qa = xa * rc, qb = xb * rc;
+  const float ra = fmaf(fmaf(-qa, c2, xa), rc, qa), rb = fmaf(fmaf(-qb, c2, xb), rc, qb);
+  const bool za = fabsf(xa) < 0x1p-96f, zb = fabsf(xb) < 0x1p-96f; // zeros keep x * rc (their sign survives)
+  qa = za ? qa : ra, qb = zb ? qb : rb;
+  if (__builtin_expect(__ballot((za && xa != 0.f) || (zb && xb != 0.f)) != 0ull, 0))
+  {
+    qa = (za && xa != 0.f) ? xa / c2 : qa;
+    qb = (zb && xb != 0.f) ? xb / c2 : qb;
+  }
+  *fa = qa, *fb = qb;
 }
 
 // One 256-thread workgroup per keypoint (the window of a coarse-scale keypoint has up to ~7.5k pixels; a single wave
@@ -465,11 +499,19 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
       }
       int cdx = s_row_lo[row] + (int)(sidx - s_pre[row]);
       uint32_t row_end = s_pre[row + 1];
-      for (uint32_t it = 0; it < run; it++, sidx++)
+      // Two samples per iteration: their (straight-line) contribution code is independent, so the scheduler interleaves
+      // the two dependency chains instead of padding every compare -> select and transcendental with wait states. A lane
+      // whose run has ended carries a dead sample: the taps go through the buffer resource (any offset is safe) and
+      // every contribution is redirected to the lane's dummy slot.
+      for (uint32_t it = 0; it < run; it += 2)
       {
-        if (sidx < send)
+        int sx[2], sy[2];
+        bool live[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++, sidx++)
         {
-          if (sidx >= row_end)
+          live[u] = sidx < send;
+          if (live[u] && sidx >= row_end)
           {
             do
               row++;
@@ -477,9 +519,14 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
             row_end = s_pre[row + 1];
             cdx = s_row_lo[row];
           }
-          desc_accumulate(c, cdx, dy0 + rb + row, s_work);
+          sx[u] = cdx, sy[u] = dy0 + rb + row;
           cdx++;
         }
+        const DescSample s0 = desc_sample(c, sx[0], sy[0]), s1 = desc_sample(c, sx[1], sy[1]);
+        float f0, f1;
+        desc_fbin2(s0.xb, s1.xb, &f0, &f1);
+        desc_scatter(c, s0, f0, live[0], s_work);
+        desc_scatter(c, s1, f1, live[1], s_work);
       }
     }
     __syncthreads();
