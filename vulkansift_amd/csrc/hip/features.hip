@@ -54,6 +54,7 @@ struct FeatArgs
   uint64_t ori_img_stride;
   uint32_t max_keep; // orientations kept per keypoint (1..18)
   uint32_t use_vlfeat;
+  uint32_t desc_equal_split;
   const float *desc_fp_tab;
   uint32_t desc_fp_tab_len;
 };
@@ -475,11 +476,22 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
       __builtin_amdgcn_wave_barrier();
       const uint32_t *s_pre = s_row_pre[wave];
       const uint32_t N = s_pre[nrows];
-      const uint32_t per_wave = (N + NWV - 1) / NWV;
-      const uint32_t w0 = min(N, (uint32_t)wave * per_wave), w1 = min(N, w0 + per_wave);
-      const uint32_t run = (w1 - w0 + 63u) / 64u; // samples per lane
-      uint32_t sidx = w0 + (uint32_t)lane * run;
-      const uint32_t send = min(w1, sidx + run);
+      // The N samples need T = ceil(N / 64) wave-steps; they are dealt out to the waves in whole steps (the first T % NWV
+      // waves take one more), so only the last step of the last wave has idle lanes. Splitting N into NWV equal parts
+      // first and rounding each up to whole steps cost up to NWV - 1 extra steps (11 % of a typical 25-step keypoint).
+      const uint32_t T = (N + 63u) / 64u, tq = T / NWV, tr = T % NWV;
+      uint32_t run = tq + ((uint32_t)wave < tr ? 1u : 0u); // samples per lane = steps of this wave
+      const uint32_t step0 = (uint32_t)wave * tq + min((uint32_t)wave, tr);
+      uint32_t sidx = min(N, step0 * 64u + (uint32_t)lane * run);
+      uint32_t send = min(N, sidx + run);
+      if (a.desc_equal_split) // A/B: the previous distribution
+      {
+        const uint32_t per_wave = (N + NWV - 1) / NWV;
+        const uint32_t w0 = min(N, (uint32_t)wave * per_wave), w1 = min(N, w0 + per_wave);
+        run = (w1 - w0 + 63u) / 64u;
+        sidx = w0 + (uint32_t)lane * run;
+        send = min(w1, sidx + run);
+      }
       // locate the row of the first sample of this lane's run: largest row with pre[row] <= sidx
       int row = 0;
       if (sidx < send)
@@ -503,30 +515,39 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
       // the two dependency chains instead of padding every compare -> select and transcendental with wait states. A lane
       // whose run has ended carries a dead sample: the taps go through the buffer resource (any offset is safe) and
       // every contribution is redirected to the lane's dummy slot.
-      for (uint32_t it = 0; it < run; it += 2)
+      auto next_sample = [&](int &sx, int &sy, bool &live) {
+        live = sidx < send;
+        if (live && sidx >= row_end)
+        {
+          do
+            row++;
+          while (s_pre[row + 1] <= sidx);
+          row_end = s_pre[row + 1];
+          cdx = s_row_lo[row];
+        }
+        sx = cdx, sy = dy0 + rb + row;
+        cdx++, sidx++;
+      };
+      uint32_t it = 0;
+      for (; it + 1 < run; it += 2)
       {
         int sx[2], sy[2];
         bool live[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++, sidx++)
-        {
-          live[u] = sidx < send;
-          if (live[u] && sidx >= row_end)
-          {
-            do
-              row++;
-            while (s_pre[row + 1] <= sidx);
-            row_end = s_pre[row + 1];
-            cdx = s_row_lo[row];
-          }
-          sx[u] = cdx, sy[u] = dy0 + rb + row;
-          cdx++;
-        }
+        next_sample(sx[0], sy[0], live[0]);
+        next_sample(sx[1], sy[1], live[1]);
         const DescSample s0 = desc_sample(c, sx[0], sy[0]), s1 = desc_sample(c, sx[1], sy[1]);
         float f0, f1;
         desc_fbin2(s0.xb, s1.xb, &f0, &f1);
         desc_scatter(c, s0, f0, live[0], s_work);
         desc_scatter(c, s1, f1, live[1], s_work);
+      }
+      if (it < run) // odd number of steps
+      {
+        int sx, sy;
+        bool live;
+        next_sample(sx, sy, live);
+        const DescSample s0 = desc_sample(c, sx, sy);
+        desc_scatter(c, s0, dm_div_2pi(s0.xb), live, s_work);
       }
     }
     __syncthreads();
@@ -580,6 +601,15 @@ FeatArgs make_args(const vksift_hip_OctaveJob *job)
   uint32_t mk = job->max_ori == 0 ? VKSIFT_HIP_MAX_ORI : job->max_ori;
   a.max_keep = mk > VKSIFT_HIP_MAX_ORI ? VKSIFT_HIP_MAX_ORI : mk;
   a.use_vlfeat = job->use_vlfeat;
+  {
+    static int eq = -1;
+    if (eq < 0)
+    {
+      const char *e = getenv("VKSIFT_DESC_EQUAL_SPLIT");
+      eq = (e && e[0] == '1') ? 1 : 0;
+    }
+    a.desc_equal_split = (uint32_t)eq;
+  }
   a.desc_fp_tab = job->desc_fp_tab, a.desc_fp_tab_len = job->desc_fp_tab_len;
   return a;
 }
