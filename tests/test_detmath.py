@@ -81,3 +81,14 @@ def test_div_2pi_matches_ieee_division(oracle):
     got = _vec(L.orc_dm_div_2pi, x)
     ref = x / c
     assert got.view(np.uint32).tolist() == ref.view(np.uint32).tolist()
+
+
+def test_branch_free_exp_is_the_same_function(oracle):
+    """dm_expf_nb (kernels: clamp + select) against dm_expf (oracle: early returns), bit for bit, range ends included"""
+    L = oracle.lib()
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.uniform(-100, 100, 40000), rng.uniform(-12, 0, 20000), [-87.3, -87.30001, -87.29999, 88.7, 88.70001, 0.0, -0.0, -1e30, 1e30]])
+    x = x.astype(np.float32)
+    a = _vec(L.orc_dm_expf, x)
+    b = _vec(L.orc_dm_expf_nb, x)
+    assert a.view(np.uint32).tolist() == b.view(np.uint32).tolist()

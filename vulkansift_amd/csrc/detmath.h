@@ -74,6 +74,13 @@ DM_FN float dm_expf_core(float x)
   return (e * dm_pow2i(h)) * dm_pow2i(ni - h);
 }
 
+/* dm_expf without branches (kernels): clamp, evaluate, select — the same bits for every x */
+DM_FN float dm_expf_nb(float x)
+{
+  const float e = dm_expf_core(x < -87.3f ? -87.3f : (x > 88.7f ? 88.7f : x));
+  return x < -87.3f ? 0.f : e;
+}
+
 DM_FN float dm_expf(float x)
 {
   if (x < -87.3f)

@@ -59,6 +59,13 @@ struct FeatArgs
   uint32_t desc_fp_tab_len;
 };
 
+// wrap an angle known to lie in (-2*pi, 4*pi) into [0, 2*pi] (ComputeDescriptors.comp:160-171), as selects
+__device__ __forceinline__ float wrap_2pi(float t)
+{
+  const float up = t + 2.f * PI_F, dn = t - 2.f * PI_F;
+  return t < 0 ? up : (t > (2.f * PI_F) ? dn : t);
+}
+
 // -------------------------------------------------------------------------------------------------
 // Orientation histogram (ComputeOrientation.comp:52-186). grid = (blocks, batch); 4 keypoints/block.
 // -------------------------------------------------------------------------------------------------
@@ -134,12 +141,8 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
           continue; // quirk Q2 ('&&')
         float gradX = 0.5f * (ldg(g, layer, gx + 1, gy) - ldg(g, layer, gx - 1, gy));
         float gradY = 0.5f * (ldg(g, layer, gx, gy + 1) - ldg(g, layer, gx, gy - 1));
-        float mag = dm_expf(d2 * es) * sqrtf((gradX * gradX) + (gradY * gradY));
-        float ori = dm_atan2f(gradY, gradX);
-        if (ori < 0)
-          ori += 2.f * PI_F;
-        else if (ori > (2.f * PI_F))
-          ori -= 2.f * PI_F;
+        float mag = dm_expf_nb(d2 * es) * sqrtf((gradX * gradX) + (gradY * gradY));
+        float ori = wrap_2pi(dm_atan2f(gradY, gradX));
         int bin = (int)(dm_div_2pi(ori * 36.f)); // == ori * 36 / (2 pi)
         if (bin < 0)
           bin += 36;
@@ -260,12 +263,6 @@ __global__ void __launch_bounds__(1024) k_orientation_finalize(FeatArgs a)
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int smod8(int v) { return v & 7; } // floored modulo for a power of two (quirk Q5, OpSMod)
 
-// wrap an angle known to lie in (-2*pi, 4*pi) into [0, 2*pi] (ComputeDescriptors.comp:160-171), as selects
-__device__ __forceinline__ float wrap_2pi(float t)
-{
-  const float up = t + 2.f * PI_F, dn = t - 2.f * PI_F;
-  return t < 0 ? up : (t > (2.f * PI_F) ? dn : t);
-}
 
 // Per-pixel descriptor contribution (ComputeDescriptors.comp:139-197) for window offset (cdx, cdy).
 struct DescCtx
