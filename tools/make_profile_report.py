@@ -28,8 +28,22 @@ def main():
     os.makedirs(dst, exist_ok=True)
     if os.path.exists(os.path.join(src, "bench.json")):
         shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
-    for p in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    csvs = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    for p in csvs:
         shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    if not csvs:
+        # this rocprofv3 writes a rocpd database instead of csv files: rebuild the --stats table from its kernel records
+        import sqlite3
+        from collections import defaultdict
+        rows = defaultdict(list)
+        for dbp in glob.glob(os.path.join(src, "trace", "**", "*.db"), recursive=True):
+            for name, st, en in sqlite3.connect(dbp).execute("select name, start, end from kernels"):
+                rows[name].append(en - st)
+        tot = sum(sum(v) for v in rows.values()) or 1
+        with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+            f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
+            for name, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+                f.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (name, len(v), sum(v), sum(v) / len(v), 100.0 * sum(v) / tot, min(v), max(v)))
     summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(src, "trace"), KERNEL],
                           capture_output=True, text=True).stdout
     open(os.path.join(dst, f"{tag}_kernel_summary.txt"), "w").write(summ)
