@@ -871,7 +871,7 @@ extern "C"
     if (!wg_target)
     {
       const char *e = getenv("VKSIFT_BLUR_WGS"); /* A/B runs */
-      wg_target = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 1536u;
+      wg_target = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 10240u; /* ~40 waves per CU over the launch: segments of ~120 rows at 128 x 1280x960 (2560 long-lived waves left the slowest CU to set the time: -5 % per launch) */
       e = getenv("VKSIFT_BLUR_MIN_SEG");
       min_seg_env = e && atoi(e) > 0;
       min_seg_rows = min_seg_env ? (uint32_t)atoi(e) : 64u;
