@@ -356,3 +356,25 @@ def test_reference_large_image_size_bit_exact(vk, oracle):
     ref, _ = oracle.detect(ocfg, img)
     assert len(feats) == len(ref) and len(ref) > 30000
     assert feats.tobytes() == ref.tobytes()
+
+
+@pytest.mark.parametrize("nb,w,h,kw", [(9, 256, 192, {}), (16, 208, 160, {"use_input_upsampling": False, "nb_scales_per_octave": 2}),
+                                       (11, 320, 200, {"max_nb_sift_per_buffer": 300})])
+def test_large_batch_detection_and_self_match_bit_exact(vk, oracle, nb, w, h, kw):
+    """batches of 8 images and more take their own launch shapes (estimated feature-stage grids, image-fastest work order,
+    slot-fastest batched matcher): every image against the oracle, including a buffer capacity small enough to clamp"""
+    vcfg, ocfg = _cfgs(vk, oracle, input_image_max_size=w * h, **kw)
+    vcfg.sift_buffer_count = nb
+    imgs = [vk.gen_synthetic_image(7000 + i, w, h) for i in range(nb)]
+    with vk.Instance(vcfg, batch_capacity=nb) as inst:
+        inst.detectFeaturesBatch(imgs, 0)
+        feats = [inst.downloadFeatures(i) for i in range(nb)]
+        pairs = [(i, (i + 1) % nb) for i in range(nb)]
+        inst.matchFeaturesBatch([a for a, _ in pairs], [b for _, b in pairs])
+        got = [inst.downloadMatchesBatch(k) for k in range(nb)]
+    refs = [oracle.detect(ocfg, im)[0] for im in imgs]
+    for i in range(nb):
+        assert len(feats[i]) == len(refs[i]), (i, len(feats[i]), len(refs[i]))
+        assert feats[i].tobytes() == refs[i].tobytes(), i
+    for (a, b), m in zip(pairs, got):
+        _assert_matches_equal(m, oracle.match_2nn(refs[a], refs[b]))
