@@ -678,12 +678,15 @@ extern "C"
       blocks = 2048;
     if (blocks == 0)
       blocks = 1;
-    static int nwv = -1;
-    if (nwv < 0)
+    /* waves per keypoint: 4 keep the critical path of a single image short; a batch has keypoints to spare and runs
+     * 3-4 % faster with 2 (less redundant per-keypoint work, measured under the overlapped batch schedule) */
+    static int nwv_env = -1;
+    if (nwv_env < 0)
     {
-      const char *e = getenv("VKSIFT_DESC_WAVES"); /* waves per keypoint: 1, 2 or 4 (A/B runs) */
-      nwv = e ? atoi(e) : 4;
+      const char *e = getenv("VKSIFT_DESC_WAVES"); /* 1, 2, 4 or 8 (A/B runs) */
+      nwv_env = e ? atoi(e) : 0;
     }
+    const int nwv = nwv_env ? nwv_env : (batch >= 8u ? 2 : 4);
     const bool f = img_fast(batch, true);
     hipStream_t hs = (hipStream_t)s;
 #define VKSIFT_DESC(N)                                                                          \
