@@ -378,3 +378,23 @@ def test_large_batch_detection_and_self_match_bit_exact(vk, oracle, nb, w, h, kw
         assert feats[i].tobytes() == refs[i].tobytes(), i
     for (a, b), m in zip(pairs, got):
         _assert_matches_equal(m, oracle.match_2nn(refs[a], refs[b]))
+
+
+@pytest.mark.parametrize("w,h", [(139, 356), (64, 800), (800, 64), (1100, 90)])
+def test_narrow_images_within_the_configured_area_are_accepted(vk, oracle, w, h):
+    """any w x h <= input_image_max_size must work (the reference re-creates its images per resolution, sift_memory.c:362-452):
+    the row padding of a narrow image needs more scratch than the square reservation, which then grows on demand"""
+    vcfg, ocfg = _cfgs(vk, oracle, input_image_max_size=w * h)
+    img = vk.gen_synthetic_image(w * 7 + h, w, h)
+    sq = vk.gen_synthetic_image(5, 128, 128)
+    with vk.Instance(vcfg) as inst:
+        inst.detectFeatures(sq, 0)                 # a square image first: the reservation is in use, then outgrown
+        inst.detectFeatures(img, 0)
+        feats = inst.downloadFeatures(0)
+        top = inst.downloadScaleSpaceImage(0, 1)
+        inst.detectFeatures(sq, 0)                 # and back
+        again = inst.downloadFeatures(0)
+    ref, _ = oracle.detect(ocfg, img)
+    assert feats.tobytes() == ref.tobytes()
+    assert np.isfinite(top).all()
+    assert again.tobytes() == oracle.detect(ocfg, sq)[0].tobytes()

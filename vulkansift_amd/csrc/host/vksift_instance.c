@@ -400,6 +400,53 @@ bool match_running(vksift_Instance inst)
   inst->match_pending = false;
   return false;
 }
+/* The reservation made at creation covers a square image of input_image_max_size pixels plus 25 %. A narrow image of the
+ * same area can need more (every row is padded to 64 floats on every octave: 139x356 needs 1.5x). The reference re-creates
+ * its images for every new input resolution (sift_memory.c:362-452); here the per-image scratch grows, once, to what the
+ * new layout needs. All work of the instance is drained first; captured launch graphs hold the old addresses and are dropped. */
+int grow_image_scratch(vksift_Instance inst, const PyrLayout *L)
+{
+  if (wait_all(inst) != 0)
+    return -1;
+  for (uint32_t o = 0; o < VKSIFT_MAX_OCTAVES; o++)
+  {
+    if (o > 0 && inst->oct_stream[o])
+      vksift_hip_stream_sync(inst->oct_stream[o]);
+    if (inst->pyr_stream[o])
+      vksift_hip_stream_sync(inst->pyr_stream[o]);
+  }
+  for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
+  {
+    vksift_hip_graph_destroy(inst->graphs[i].exec);
+    memset(&inst->graphs[i], 0, sizeof(inst->graphs[i]));
+  }
+  const uint64_t pyr = L->img_floats + L->img_floats / 4 + 4096, seg = L->seg_total + L->seg_total / 4 + 1024, cand = L->cand_total + L->cand_total / 4 + 4096u;
+  const uint64_t new_pyr = pyr > inst->pyr_img_stride ? pyr : inst->pyr_img_stride;
+  const uint64_t new_seg = seg > inst->seg_cap ? seg : inst->seg_cap, new_cand = cand > inst->cand_cap ? cand : inst->cand_cap;
+  const uint64_t n = inst->batch_cap;
+  /* old blocks first: the pyramid is the largest allocation of the instance, two generations of it may not fit */
+  vksift_hip_free(inst->d_pyr_buf[0]);
+  vksift_hip_free(inst->d_pyr_buf[1]);
+  vksift_hip_free(inst->d_seg_mask);
+  vksift_hip_free(inst->d_seg_off);
+  vksift_hip_free(inst->d_cand_xy);
+  vksift_hip_free(inst->d_cand_flag);
+  inst->d_pyr_buf[1] = NULL;
+  inst->d_pyr_buf[0] = vksift_hip_malloc(sizeof(float) * new_pyr * n);
+  if (inst->pyr_pingpong)
+    inst->d_pyr_buf[1] = vksift_hip_malloc(sizeof(float) * new_pyr * n);
+  inst->d_seg_mask = vksift_hip_malloc(sizeof(uint64_t) * new_seg * n);
+  inst->d_seg_off = vksift_hip_malloc(sizeof(uint32_t) * new_seg * n);
+  inst->d_cand_xy = vksift_hip_malloc(sizeof(uint32_t) * new_cand * n);
+  inst->d_cand_flag = vksift_hip_malloc(sizeof(uint32_t) * new_cand * n);
+  inst->pyr_img_stride = new_pyr, inst->seg_cap = new_seg, inst->cand_cap = new_cand;
+  inst->d_pyr = inst->d_pyr_buf[inst->pyr_pingpong ? inst->pyr_cur : 0];
+  inst->pyr_free_valid[0] = inst->pyr_free_valid[1] = false;
+  inst->cur_w = inst->cur_h = 0; /* no scale-space to download until the next detection */
+  const bool ok = inst->d_pyr_buf[0] && (!inst->pyr_pingpong || inst->d_pyr_buf[1]) && inst->d_seg_mask && inst->d_seg_off && inst->d_cand_xy && inst->d_cand_flag;
+  return ok ? 0 : -1;
+}
+
 int wait_all(vksift_Instance inst)
 {
   vksift_hip_set_device(inst->device);

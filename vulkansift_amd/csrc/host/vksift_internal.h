@@ -204,6 +204,7 @@ VKSIFT_INTERNAL void mark_detect_done(vksift_Instance inst);
 VKSIFT_INTERNAL bool detect_running(vksift_Instance inst);
 VKSIFT_INTERNAL bool match_running(vksift_Instance inst);
 VKSIFT_INTERNAL int wait_all(vksift_Instance inst);
+VKSIFT_INTERNAL int grow_image_scratch(vksift_Instance inst, const PyrLayout *L);
 VKSIFT_INTERNAL vksift_hip_Plane plane_at(vksift_Instance inst, uint32_t o, uint64_t base_off, uint32_t layer);
 
 /* vksift_detect.c */
