@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extra randomised detection / matching parity against the oracle with fresh seeds (the committed tests use fixed ones).
-usage (on the GPU box): python tools/fuzz_parity.py <seed> <cases>"""
+usage (on the GPU box): python tools/fuzz_parity.py <seed> <cases> [max_side]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,10 +9,11 @@ from vulkansift_amd import api as vk
 from oracle import oracle
 vk.lib().vksift_setLogLevel(vk.VKSIFT_LOG_ERROR)
 seed, cases = int(sys.argv[1]), int(sys.argv[2])
+max_side = int(sys.argv[3]) if len(sys.argv) > 3 else 1100
 rng = np.random.default_rng(seed)
 bad = 0
 for case in range(cases):
-    w, h = int(rng.integers(64, 1100)), int(rng.integers(64, 800))
+    w, h = int(rng.integers(64, max_side)), int(rng.integers(64, max(65, max_side * 3 // 4)))
     kw = {"seed_scale_sigma": float(np.float32(rng.uniform(1.2, 2.8))), "input_image_blur_level": float(np.float32(rng.uniform(0.3, 0.6))),
           "intensity_threshold": float(np.float32(rng.uniform(0.01, 0.08))), "edge_threshold": float(np.float32(rng.uniform(4.0, 16.0)))}
     if rng.random() < 0.5:
