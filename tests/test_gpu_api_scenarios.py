@@ -395,7 +395,13 @@ def test_every_runtime_switch_is_bit_identical(vk):
     assert len(set(digests.values())) == 1, digests
 
 
-@pytest.mark.parametrize("seed", [99, 100, 101])
+def _sequence_seeds():
+    import os
+    extra = os.environ.get("VKSIFT_TEST_SEQUENCE_SEEDS")       # e.g. "7,8,9": more sequences for a longer soak
+    return [99, 100, 101] + ([int(x) for x in extra.split(",")] if extra else [])
+
+
+@pytest.mark.parametrize("seed", _sequence_seeds())
 def test_random_operation_sequences_follow_the_model(vk, oracle, seed):
     """3 x 250 random API calls on one instance (detections of changing resolution into changing buffers, batched detections,
     uploads, matches, filtered matches, accessors in any order): every observable result must equal a trivial model built
