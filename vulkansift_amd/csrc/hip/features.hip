@@ -94,10 +94,11 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
     {
       const float *rec = (const float *)(feats + (size_t)k * 164);
       const float scale_x = rec[2], scale_y = rec[3];
-      const uint32_t scale_idx = ((const uint32_t *)rec)[4];
+      const uint32_t scale_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const uint32_t *)rec)[4]); // one keypoint per wave
       const int octave_idx = ((const int *)rec)[5];
       const float sigma = rec[6];
-      const float *layer = g.base + (size_t)scale_idx * g.plane;
+      // planes stay below 2 GiB (vksift_hip_extract_keypoints refuses sides of 16384 and more)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(g.base + (size_t)scale_idx * g.plane), 0, g.pitch * g.h * 4, 0x00020000);
 
       float scale_factor = dm_pow2i(octave_idx);
       float lambda = 1.5f * (sigma / scale_factor);
@@ -139,8 +140,17 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
         float d2 = (sdx * sdx) + (sdy * sdy);
         if ((gx < 1 || gx >= (g.w - 1) || gy < 1 || gy >= (g.h - 1)) && (d2 > (float)(r * r)))
           continue; // quirk Q2 ('&&')
-        float gradX = 0.5f * (ldg(g, layer, gx + 1, gy) - ldg(g, layer, gx - 1, gy));
-        float gradY = 0.5f * (ldg(g, layer, gx, gy + 1) - ldg(g, layer, gx, gy - 1));
+        // imageLoad semantics (0 outside the image, quirk Q2 relies on it) through the layer's buffer resource: a tap
+        // outside the image gets an out-of-range offset, which the hardware answers with 0 — no branches, 32-bit offsets
+        const bool xin = (unsigned)gx < (unsigned)g.w, yin = (unsigned)gy < (unsigned)g.h;
+        // (each row offset from its own, in-range, row index: the 24-bit multiply must not see a negative row)
+        const unsigned o0 = (__umul24((unsigned)gy, (unsigned)g.pitch) + (unsigned)gx) * 4u;
+        const unsigned o_r = (yin && (unsigned)(gx + 1) < (unsigned)g.w) ? o0 + 4u : 0x80000000u;
+        const unsigned o_l = (yin && (unsigned)(gx - 1) < (unsigned)g.w) ? o0 - 4u : 0x80000000u;
+        const unsigned o_d = (xin && (unsigned)(gy + 1) < (unsigned)g.h) ? (__umul24((unsigned)(gy + 1), (unsigned)g.pitch) + (unsigned)gx) * 4u : 0x80000000u;
+        const unsigned o_u = (xin && (unsigned)(gy - 1) < (unsigned)g.h) ? (__umul24((unsigned)(gy - 1), (unsigned)g.pitch) + (unsigned)gx) * 4u : 0x80000000u;
+        float gradX = 0.5f * (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_r, 0, 0)) - __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_l, 0, 0)));
+        float gradY = 0.5f * (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_d, 0, 0)) - __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_u, 0, 0)));
         float mag = dm_expf_nb(d2 * es) * sqrtf((gradX * gradX) + (gradY * gradY));
         float ori = wrap_2pi(dm_atan2f(gradY, gradX));
         int bin = (int)(dm_div_2pi(ori * 36.f)); // == ori * 36 / (2 pi)
