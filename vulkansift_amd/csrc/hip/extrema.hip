@@ -401,12 +401,26 @@ __global__ void __launch_bounds__(256, 4) k_extrema_lean(ExtremaArgs a, int band
   constexpr int AHEAD = NSLOT - 3; // rows of loads in flight behind the 3-row window
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 4 independent waves per block, one row band each
-  const int b = blockIdx.z;
+  int b = blockIdx.z;
   int bx = blockIdx.x, by = blockIdx.y * 4 + wv;
   if (strip_major)
   {
     // the 4 waves of a block take 4 adjacent strips of one band (strips fastest over the flattened wave index)
-    const unsigned id = (blockIdx.y * gridDim.x + blockIdx.x) * 4u + (unsigned)wv, ns = (unsigned)(a.nseg + 1) / 2u;
+    unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
+    if (strip_major & 2)
+    {
+      // XCD-contiguous order (workgroup n runs on XCD n % 8, each with its own L2): every XCD takes a contiguous range of the
+      // (image, band, strip) space, so the bands that share halo rows are read through the same L2
+      const unsigned per_img = gridDim.x * gridDim.y, total = per_img * gridDim.z;
+      if ((total & 7u) == 0)
+      {
+        const unsigned n = blk + per_img * blockIdx.z;
+        const unsigned wi = (n & 7u) * (total >> 3) + (n >> 3);
+        b = (int)(wi / per_img);
+        blk = wi - (unsigned)b * per_img;
+      }
+    }
+    const unsigned id = blk * 4u + (unsigned)wv, ns = (unsigned)(a.nseg + 1) / 2u;
     by = (int)(id / ns), bx = (int)(id - (unsigned)by * ns);
   }
   const int y0 = by * band;
@@ -794,8 +808,8 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   static int sm_env = -1;
   if (sm_env < 0)
   {
-    const char *e = getenv("VKSIFT_EXTREMA_STRIP_MAJOR"); /* 1: the 4 waves of a block take adjacent strips (-5 %), 0: adjacent bands */
-    sm_env = e ? atoi(e) : 1;
+    const char *e = getenv("VKSIFT_EXTREMA_STRIP_MAJOR"); /* bit 0: the 4 waves of a block take adjacent strips (-5 %; 0: adjacent bands), bit 1: XCD-contiguous block order (-3 %) */
+    sm_env = e ? atoi(e) : 3;
   }
   static int occ_env = -1;
   if (occ_env < 0)
