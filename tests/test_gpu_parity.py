@@ -398,3 +398,21 @@ def test_narrow_images_within_the_configured_area_are_accepted(vk, oracle, w, h)
     assert feats.tobytes() == ref.tobytes()
     assert np.isfinite(top).all()
     assert again.tobytes() == oracle.detect(ocfg, sq)[0].tobytes()
+
+
+@pytest.mark.parametrize("w,h,ups", [(41, 29, False), (16, 64, True), (16, 70, False), (33, 70, False), (31, 64, False), (24, 48, True)])
+def test_images_too_small_for_an_octave_detect_nothing(vk, oracle, w, h, ups):
+    """nb_octaves = log2(shortest side) - 4 (+1 with up-sampling) (sift_memory.c:22): zero octaves is an empty result, not an
+    error; one octave of a tiny image must match the oracle like any other"""
+    vcfg, ocfg = _cfgs(vk, oracle, input_image_max_size=128 * 128, use_input_upsampling=ups)
+    img = vk.gen_synthetic_image(w + 3 * h, w, h)
+    with vk.Instance(vcfg) as inst:
+        inst.detectFeatures(img, 0)
+        n = inst.getFeaturesNumber(0)
+        feats = inst.downloadFeatures(0)
+        inst.detectFeatures(img, 1)
+        inst.matchFeatures(0, 1)
+        m = inst.downloadMatches()
+    ref, _ = oracle.detect(ocfg, img)
+    assert n == len(ref) and feats.tobytes() == ref.tobytes()
+    assert len(m) == len(ref)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extra randomised detection / matching parity against the oracle with fresh seeds (the committed tests use fixed ones).
-usage (on the GPU box): python tools/fuzz_parity.py <seed> <cases> [max_side]"""
+usage (on the GPU box): python tools/fuzz_parity.py <seed> <cases> [max_side [min_side]]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,16 +10,19 @@ from oracle import oracle
 vk.lib().vksift_setLogLevel(vk.VKSIFT_LOG_ERROR)
 seed, cases = int(sys.argv[1]), int(sys.argv[2])
 max_side = int(sys.argv[3]) if len(sys.argv) > 3 else 1100
+min_side = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 rng = np.random.default_rng(seed)
 bad = 0
 for case in range(cases):
-    w, h = int(rng.integers(64, max_side)), int(rng.integers(64, max(65, max_side * 3 // 4)))
+    w, h = int(rng.integers(min_side, max_side)), int(rng.integers(min_side, max(min_side + 1, max_side * 3 // 4)))
+    if w * h < 1024:      # below the API's minimum image size (vulkansift.c:600)
+        h = 1024 // w + 1
     kw = {"seed_scale_sigma": float(np.float32(rng.uniform(1.2, 2.8))), "input_image_blur_level": float(np.float32(rng.uniform(0.3, 0.6))),
           "intensity_threshold": float(np.float32(rng.uniform(0.01, 0.08))), "edge_threshold": float(np.float32(rng.uniform(4.0, 16.0)))}
     if rng.random() < 0.5:
         kw["use_input_upsampling"] = False
     if rng.random() < 0.5:
-        kw["nb_scales_per_octave"] = int(rng.integers(1, 7))
+        kw["nb_scales_per_octave"] = int(rng.integers(1, 9))
     if rng.random() < 0.3:
         kw["use_hardware_interpolated_blur"] = False
     if rng.random() < 0.3:
@@ -32,7 +35,7 @@ for case in range(cases):
     if w * h * nb > 3_000_000:
         nb = 1
     okw, vkw = {}, {}
-    for k, v in dict(kw, input_image_max_size=w * h).items():   # the oracle's config spells two fields differently
+    for k, v in dict(kw, input_image_max_size=max(w * h, 128 * 128)).items():   # the oracle's config spells two fields differently
         if k in ("use_input_upsampling", "use_hardware_interpolated_blur"):
             okw[k], vkw[k] = int(v), bool(v)
         elif k == "descriptor_format":
@@ -50,7 +53,7 @@ for case in range(cases):
             ms = [inst.downloadMatchesBatch(k) for k in range(nb)]
     refs = [oracle.detect(ocfg, im)[0] for im in imgs]
     ok = all(f.tobytes() == r.tobytes() for f, r in zip(feats, refs))
-    if ok and nb >= 2:
+    if ok and nb >= 2 and min(len(r) for r in refs) >= 2:
         for k in range(nb):
             rm = oracle.match_2nn(refs[k], refs[(k + 1) % nb])
             ok = ok and len(ms[k]) == len(rm) and ms[k].tobytes() == rm.tobytes()

@@ -452,11 +452,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   {
     PyrLayout L;
     compute_layout(inst, w, h, &L);
-    if (L.n_oct == 0)
-    {
-      logError(LOG_TAG, "Failed to lay out the scale-space of a %ux%u image", w, h);
-      goto gpu_error;
-    }
+    /* n_oct == 0 (shortest side below 32 pixels, 16 with up-sampling): no scale-space, the detection finds nothing */
     if ((L.img_floats > inst->pyr_img_stride || L.seg_total > inst->seg_cap || L.cand_total > inst->cand_cap) && grow_image_scratch(inst, &L) != 0)
     {
       logError(LOG_TAG, "Failed to fit the scale-space of a %ux%u image in device memory", w, h);

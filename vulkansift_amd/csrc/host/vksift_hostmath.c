@@ -24,7 +24,9 @@ uint32_t vksift_hm_max_octaves(const vksift_Config *cfg, uint32_t *rounded_max_i
 uint32_t vksift_hm_octaves_for(const vksift_Config *cfg, uint32_t max_octaves, uint32_t w, uint32_t h, uint32_t *ow, uint32_t *oh)
 {
   uint32_t shortest = w < h ? w : h;
-  uint32_t n = (uint32_t)(log2f((float)shortest) - 4 + (cfg->use_input_upsampling ? 1 : 0));
+  /* sift_memory.c:22; an image too small for a single octave has none (the float -> unsigned cast of a negative value is undefined) */
+  const float fn = log2f((float)shortest) - 4 + (cfg->use_input_upsampling ? 1 : 0);
+  uint32_t n = fn >= 1.f ? (uint32_t)fn : 0u;
   if (n > max_octaves)
     n = max_octaves;
   const float first_octave_scale = cfg->use_input_upsampling ? 0.5f : 1.f;
