@@ -317,6 +317,22 @@ __device__ __forceinline__ DescSample desc_sample(const DescCtx &c, int cdx, int
   return r;
 }
 
+// Histogram layout for 64-bit atomics: the two orientation bins a sample touches, hb and hb + 1 (mod 8), are always one
+// aligned 8-byte pair of one of two interleaved copies of a cell — copy A holds the pairs (0,1)(2,3)(4,5)(6,7), copy B the
+// pairs (1,2)(3,4)(5,6)(7,0) — so each of the four cells takes ONE ds_add_u64 instead of two ds_add_u32 (the sums stay below
+// 2^32 by construction of the fixed-point scale, so the low half never carries into the high half). Cell = 64 bytes:
+// [A: 4 pairs][B: 4 pairs]. The epilogue adds the two copies.
+constexpr int DESC_HIST_WORDS = 16 * 16;              // 16 cells x (8 + 8) words
+constexpr int DESC_WORK_WORDS = DESC_HIST_WORDS + 128; // + one 8-byte dummy slot per lane for the out-of-grid cells
+__device__ __forceinline__ uint32_t desc_hist_read(const uint32_t *s_work, int t) // descriptor element t = cell * 8 + bin
+{
+  const int cell = t >> 3, bin = t & 7;
+  const uint32_t a = s_work[cell * 16 + bin];                                  // copy A: pair bin / 2, half bin & 1
+  const int pb = ((bin + 7) & 7) >> 1;                                         // copy B: the pair that starts at the odd bin below
+  const uint32_t bq = s_work[cell * 16 + 8 + pb * 2 + ((bin & 1) ? 0 : 1)];    // odd bins are the low half there
+  return a + bq;
+}
+
 __device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample &r, float fbin, bool live, uint32_t *s_work)
 {
   float fhx = r.ox + 2.f, fhy = r.oy + 2.f;
@@ -324,10 +340,10 @@ __device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample 
   float rhx = fhx - ((float)hx + 0.5f), rhy = fhy - ((float)hy + 0.5f), rb = fbin - (float)hb;
   // The 2x2 spatial cells that fall outside the 4x4 grid (ComputeDescriptors.comp:189 drops them) are redirected to a
   // per-lane dummy slot behind the histogram instead of being branched around: no exec-mask juggling in the hot loop.
-  // All offsets in bytes: a cell is 32 bytes, so cell | bin needs no shift and no add.
   // (Packed v_pk_mul_f32 for the weight products was measured 9 % slower despite 6 % fewer instructions.)
-  const unsigned dummy = (128u + (threadIdx.x & 63u)) * 4u;
-  const unsigned bin4[2] = {(unsigned)smod8(hb) * 4u, (unsigned)smod8(hb + 1) * 4u};
+  const unsigned dummy = (unsigned)DESC_HIST_WORDS * 4u + (threadIdx.x & 63u) * 8u;
+  const unsigned b0 = (unsigned)smod8(hb);
+  const unsigned pair = ((b0 & 1u) ? 32u : 0u) + (b0 >> 1) * 8u; // byte offset of the (hb, hb+1) pair inside a cell
   char *base = (char *)s_work;
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -335,13 +351,11 @@ __device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample 
     for (int j = 0; j < 2; j++)
     {
       const bool in_grid = live && (unsigned)(i + hx) < 4u && (unsigned)(j + hy) < 4u;
-      const unsigned cell = (unsigned)((j + hy) * 128 + (i + hx) * 32);
-#pragma unroll
-      for (int kk = 0; kk < 2; kk++)
-      {
-        float val = fabsf(1.f - (float)i - rhx) * fabsf(1.f - (float)j - rhy) * fabsf(1.f - (float)kk - rb) * r.mag;
-        atomicAdd((uint32_t *)(base + (in_grid ? (cell | bin4[kk]) : dummy)), (uint32_t)(val * c.fp));
-      }
+      const unsigned cell = (unsigned)((j + hy) * 256 + (i + hx) * 64);
+      const float w = fabsf(1.f - (float)i - rhx) * fabsf(1.f - (float)j - rhy);
+      const uint32_t v0 = (uint32_t)((w * fabsf(1.f - 0.f - rb) * r.mag) * c.fp);
+      const uint32_t v1 = (uint32_t)((w * fabsf(1.f - 1.f - rb) * r.mag) * c.fp);
+      atomicAdd((unsigned long long *)(base + (in_grid ? (cell | pair) : dummy)), ((unsigned long long)v1 << 32) | v0);
     }
 }
 
@@ -373,7 +387,7 @@ template <int NWV, bool IMG_FAST>
 __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
 {
   constexpr int NT_ = 64 * NWV;
-  __shared__ uint32_t s_work[128 + 64]; // histogram + per-lane dummy slots for out-of-grid cells
+  __shared__ __attribute__((aligned(8))) uint32_t s_work[DESC_WORK_WORDS]; // see desc_scatter
   __shared__ int s_row_lo[DESC_MAX_ROWS];
   __shared__ uint32_t s_row_cnt[DESC_MAX_ROWS];
   __shared__ uint32_t s_row_pre[NWV][DESC_MAX_ROWS + 1];
@@ -387,7 +401,7 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
   for (uint32_t k = IMG_FAST ? blockIdx.y : blockIdx.x; k < n1; k += IMG_FAST ? gridDim.y : gridDim.x)
   {
     __syncthreads(); // the previous keypoint's epilogue has read the histogram
-    for (int i = tid; i < 128; i += NT_)
+    for (int i = tid; i < DESC_HIST_WORDS; i += NT_)
       s_work[i] = 0; // made visible by the barrier behind the row-span pass below
 
     const float *rec = (const float *)(feats + (size_t)k * 164);
@@ -561,7 +575,7 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
     if (wave == 0)
     {
       // normalise -> clamp at 0.2*norm -> renormalise -> x512 -> u8 (:200-265)
-      uint32_t w0 = s_work[lane], w1 = s_work[lane + 64];
+      uint32_t w0 = desc_hist_read(s_work, lane), w1 = desc_hist_read(s_work, lane + 64);
       uint32_t acc = w0 * w0 + w1 * w1;
 #pragma unroll
       for (int dlt = 32; dlt >= 1; dlt >>= 1)
