@@ -3,7 +3,8 @@
 
   C3  batch of 64 1920x1080 frames, detect only -> pyramid+DoG algorithmic GB/s
   C4  2-NN brute force 50k x 50k descriptors (MFMA int8 formulation) -> time, int8 TOPS
-usage: python tools/bench_configs.py [c3] [c4] [--batch N]
+  C5  one GPU's share of 512 x 1080p detect + pair matching (64 frames, 32 pairs)
+usage: python tools/bench_configs.py [c3] [c4] [c5] [--batch N]
 """
 import json
 import os
@@ -48,6 +49,39 @@ def c3(batch=64, ups=True, steps=5):
     print(json.dumps(out))
 
 
+def c5_share(batch=64, steps=4):
+    """One GPU's share of BASELINE config C5 (512 x 1080p over 8 GPUs = 64 frames per GPU): detect (up-sampling ON) + 2-NN
+    of the 32 consecutive frame pairs. The 8-GPU aggregate is the driver's bench run (weak scaling, no collectives)."""
+    import torch
+    from vulkansift_amd import api
+
+    api.lib().vksift_setLogLevel(api.VKSIFT_LOG_ERROR)
+    W, H = 1920, 1080
+    base = [api.gen_synthetic_image(0x5EED1000 + i, W, H) for i in range(8)]
+    frames = np.stack([base[i % 8] for i in range(batch)])
+    d = torch.from_numpy(frames).cuda()
+    cfg = api.default_config(sift_buffer_count=batch, input_image_max_size=W * H)
+    inst = api.Instance(cfg, batch_capacity=batch)
+    pa, pb = list(range(0, batch, 2)), list(range(1, batch, 2))
+
+    def step():
+        inst.detectFeaturesBatchDevice(d.data_ptr(), batch, W, H, 0)
+        inst.matchFeaturesBatch(pa, pb)
+
+    step()
+    torch.cuda.synchronize()
+    nfeat = [inst.getFeaturesNumber(i) for i in range(8)]
+    nmatch = inst.getMatchesNumberBatch(0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    inst.close()
+    print(json.dumps({"config": "C5 (one GPU's share)", "frames": batch, "pairs": len(pa), "frames_per_s": batch * steps / dt,
+                      "ms_per_batch": dt / steps * 1e3, "features_per_frame": float(np.mean(nfeat)), "matches_pair0": int(nmatch)}))
+
+
 def c4(n=50000, steps=5):
     import torch
     from vulkansift_amd import api, multigpu
@@ -78,3 +112,5 @@ if __name__ == "__main__":
     if not args or "c3" in args:
         c3(batch=batch)
         c3(batch=batch, ups=False)
+    if not args or "c5" in args:
+        c5_share(batch=batch)
