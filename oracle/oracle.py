@@ -107,6 +107,8 @@ def lib():
         L.orc_dm_div_2pi.restype = C.c_float
         L.orc_dm_expf_nb.argtypes = [C.c_float]
         L.orc_dm_expf_nb.restype = C.c_float
+        L.orc_dm_expf_nb_nonpos.argtypes = [C.c_float]
+        L.orc_dm_expf_nb_nonpos.restype = C.c_float
         L.orc_dm_ceil_log2f.argtypes = [C.c_float]
         L.orc_dm_ceil_log2f.restype = C.c_int
         _lib = L

@@ -857,7 +857,8 @@ float orc_dm_expf(float x) { return dm_expf(x); }
 float orc_dm_exp2f(float x) { return dm_exp2f(x); }
 float orc_dm_atan2f(float y, float x) { return dm_atan2f(y, x); }
 float orc_dm_div_2pi(float x) { return dm_div_2pi(x); }
-float orc_dm_expf_nb(float x) { return dm_expf_nb(x); } /* kernel-side helper, exported for tests/test_detmath.py only */ /* kernel-side helper, exported for tests/test_detmath.py only */
+float orc_dm_expf_nb(float x) { return dm_expf_nb(x); }
+float orc_dm_expf_nb_nonpos(float x) { return dm_expf_nb_nonpos(x); } /* kernel-side helper, exported for tests/test_detmath.py only */ /* kernel-side helper, exported for tests/test_detmath.py only */
 float orc_dm_sinf(float t)
 {
   float s, c;

@@ -114,6 +114,7 @@ extern "C"
   float orc_dm_atan2f(float y, float x);
   float orc_dm_div_2pi(float x);
   float orc_dm_expf_nb(float x);
+  float orc_dm_expf_nb_nonpos(float x);
   float orc_dm_sinf(float t);
   float orc_dm_cosf(float t);
   int orc_dm_ceil_log2f(float m);

@@ -74,6 +74,30 @@ DM_FN float dm_expf_core(float x)
   return (e * dm_pow2i(h)) * dm_pow2i(ni - h);
 }
 
+/* dm_expf_core for -87.3 <= x <= 0 (every exponent the kernels form): n = rint(x / ln2) is in [-126, 0], so 2^n is a
+ * normal number and ONE exact power-of-two scaling replaces the split one (e * 2^h is exact, so both forms round the same
+ * real number once): same bits, 6 instructions less. Checked against dm_expf for every float in the range. */
+DM_FN float dm_expf_core_nonpos(float x)
+{
+  float n = dm_rint(x * 0x1.715476p+0f);
+  float r = fmaf(n, -0x1.62e400p-1f, x);
+  r = fmaf(n, -0x1.7f7d1cp-20f, r);
+  float p = 0x1.6d4922p-10f;
+  p = fmaf(p, r, 0x1.121072p-7f);
+  p = fmaf(p, r, 0x1.5554e4p-5f);
+  p = fmaf(p, r, 0x1.5554d8p-3f);
+  p = fmaf(p, r, 0.5f);
+  float e = fmaf(p * r, r, r) + 1.f;
+  return e * dm_pow2i((int)n);
+}
+
+/* dm_expf for x <= 0 without branches (kernels): clamp, evaluate, select — the same bits */
+DM_FN float dm_expf_nb_nonpos(float x)
+{
+  const float e = dm_expf_core_nonpos(x < -87.3f ? -87.3f : x);
+  return x < -87.3f ? 0.f : e;
+}
+
 /* dm_expf without branches (kernels): clamp, evaluate, select — the same bits for every x */
 DM_FN float dm_expf_nb(float x)
 {

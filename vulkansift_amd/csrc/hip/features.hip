@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
         const unsigned o_u = (xin && (unsigned)(gy - 1) < (unsigned)g.h) ? (__umul24((unsigned)(gy - 1), (unsigned)g.pitch) + (unsigned)gx) * 4u : 0x80000000u;
         float gradX = 0.5f * (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_r, 0, 0)) - __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_l, 0, 0)));
         float gradY = 0.5f * (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_d, 0, 0)) - __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_u, 0, 0)));
-        float mag = dm_expf_nb(d2 * es) * sqrtf((gradX * gradX) + (gradY * gradY));
+        float mag = dm_expf_nb_nonpos(d2 * es) /* d2 >= 0 > es */ * sqrtf((gradX * gradX) + (gradY * gradY));
         float ori = wrap_2pi(dm_atan2f(gradY, gradX));
         int bin = (int)(dm_div_2pi(ori * 36.f)); // == ori * 36 / (2 pi)
         if (bin < 0)
@@ -312,7 +312,7 @@ __device__ __forceinline__ DescSample desc_sample(const DescCtx &c, int cdx, int
   float ori = wrap_2pi(dm_atan2f(gradY, gradX));
   ori = wrap_2pi(ori - c.kori);
   // |ox|, |oy| < 4 for every enumerated sample: the exponent is in [-4, 0], no range handling needed
-  r.mag = dm_expf_core(es * ((r.ox * r.ox) + (r.oy * r.oy))) * sqrtf((gradX * gradX) + (gradY * gradY));
+  r.mag = dm_expf_core_nonpos(es * ((r.ox * r.ox) + (r.oy * r.oy))) * sqrtf((gradX * gradX) + (gradY * gradY));
   r.xb = c.use_vlfeat ? ori * 8.f : -ori * 8.f;
   return r;
 }
