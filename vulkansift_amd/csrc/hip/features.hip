@@ -59,11 +59,14 @@ struct FeatArgs
   uint32_t desc_fp_tab_len;
 };
 
-// wrap an angle known to lie in (-2*pi, 4*pi) into [0, 2*pi] (ComputeDescriptors.comp:160-171), as selects
+// ComputeDescriptors.comp:160-171 / ComputeOrientation.comp:100-104 wrap an angle with "if (t < 0) t += 2 pi; else if
+// (t > 2 pi) t -= 2 pi". Both places only ever see t <= 2 pi — atan2 returns (-pi, pi], and the relative orientation is the
+// difference of two angles of [0, 2 pi] (the keypoint orientations are (k/2 + 0.5) * 2 pi / 36 with k/2 <= 35.5) — so the
+// second branch is dead and the wrap is one add, one compare, one select.
 __device__ __forceinline__ float wrap_2pi(float t)
 {
-  const float up = t + 2.f * PI_F, dn = t - 2.f * PI_F;
-  return t < 0 ? up : (t > (2.f * PI_F) ? dn : t);
+  const float up = t + 2.f * PI_F;
+  return t < 0 ? up : t;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -279,8 +282,7 @@ struct DescCtx
 {
   __amdgpu_buffer_rsrc_t rs; // the keypoint's Gaussian layer
   int pitch, pitch4;
-  float scale_x, scale_y, rsx, rsy, kcos, ksin, kori, fp;
-  uint32_t use_vlfeat;
+  float scale_x, scale_y, rsx, rsy, kcos, ksin, kori, fp, bin_scale;
 };
 
 // The contribution of one window pixel in two straight-line halves (no branch in either, so that the scheduler can
@@ -313,7 +315,7 @@ __device__ __forceinline__ DescSample desc_sample(const DescCtx &c, int cdx, int
   ori = wrap_2pi(ori - c.kori);
   // |ox|, |oy| < 4 for every enumerated sample: the exponent is in [-4, 0], no range handling needed
   r.mag = dm_expf_core_nonpos(es * ((r.ox * r.ox) + (r.oy * r.oy))) * sqrtf((gradX * gradX) + (gradY * gradY));
-  r.xb = c.use_vlfeat ? ori * 8.f : -ori * 8.f;
+  r.xb = ori * c.bin_scale; // +8 (VLFeat order) or -8: (-ori) * 8 == ori * (-8) exactly
   return r;
 }
 
@@ -413,7 +415,7 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
     // planes stay below 2 GiB (vksift_hip_extract_keypoints refuses sides of 16384 and more): 32-bit byte offsets
     c.rs = __builtin_amdgcn_make_buffer_rsrc((void *)(g.base + (size_t)scale_idx * g.plane), 0, g.pitch * g.h * 4, 0x00020000);
     c.pitch = g.pitch, c.pitch4 = g.pitch * 4;
-    c.use_vlfeat = a.use_vlfeat;
+    c.bin_scale = a.use_vlfeat ? 8.f : -8.f;
     float scale_factor = dm_pow2i(octave_idx);
     float lambda = 3.0f * (sigma / scale_factor);
     float radius = sqrtf(2.f) * lambda * 5.f * 0.5f;
