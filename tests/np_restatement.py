@@ -133,3 +133,47 @@ def match_2nn(a, b):
                 sd, si = row[j], j
         out.append((i, bi, si, bd, sd))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole pyramid (all octaves), so that tests/np_features.py can run on planes the oracle never touched
+# ---------------------------------------------------------------------------------------------------------------
+def octave_resolutions(w, h, ups=True, nb_octaves=0):
+    """sift_memory.c:15-38: n = (uint)(log2f(min(w, h)) - 4 + ups); w_o = (uint)((1 / (2^o * sf)) * w), sf = 0.5 if ups"""
+    n = int(f32(np.log2(f32(min(w, h)))) - f32(4) + f32(1 if ups else 0))
+    if nb_octaves > 0:
+        n = min(n, nb_octaves)
+    sf = f32(0.5) if ups else f32(1)
+    out = []
+    for o in range(n):
+        k = f32(1) / f32(f32(2 ** o) * sf)
+        out.append((int(f32(k * f32(w))), int(f32(k * f32(h)))))
+    return out
+
+
+def blit_nearest(src, dw, dh):
+    """vkCmdBlitImage NEAREST: dst(x, y) = src(floor((x + .5) * Ws / Wd), floor((y + .5) * Hs / Hd)), in exact rationals"""
+    sh, sw = src.shape
+    xs = ((2 * np.arange(dw) + 1) * sw) // (2 * dw)
+    ys = ((2 * np.arange(dh) + 1) * sh) // (2 * dh)
+    return src[np.ix_(ys, xs)].copy()
+
+
+def build_pyramid(u8, S=3, seed=1.6, in_blur=0.5, ups=True, interpolated=True, nb_octaves=0):
+    """[(gauss (S+3,H,W), dog (S+2,H,W))] per octave: sift_detector.c:893-1037 schedule"""
+    h, w = u8.shape
+    res = octave_resolutions(w, h, ups, nb_octaves)
+    sig = scale_sigmas(S, seed, in_blur, ups)
+    out = []
+    base = upsample2x(u8) if ups else (u8.astype(f32) / f32(255))
+    for o, (ow, oh) in enumerate(res):
+        if o == 0:
+            assert base.shape == (oh, ow)
+            g = [blur(base, sig[0], interpolated)]
+        else:
+            g = [blit_nearest(out[-1][0][S], ow, oh)]      # Gaussian layer S of the previous octave (blur 2 * seed)
+        for s in range(1, S + 3):
+            g.append(blur(g[-1], sig[s], interpolated))
+        g = np.stack(g)
+        out.append((g, (g[1:] - g[:-1]).astype(f32)))
+    return out

@@ -1,0 +1,134 @@
+"""GPU parity at BASELINE.json's configuration sizes, and the float-tolerance claim over several configurations.
+
+* libm tolerance: the HIP path against the oracle with INDEPENDENT math (glibc expf/atan2f/sinf/cosf/powf instead of the
+  detmath.h both sides share in the bit-exact tests) over seven configurations.
+* C3 at its batch size: 64 x 1920x1080 in one batched detection (31 GB pyramid): every image equals the single-image
+  detection byte for byte, four sampled images equal the oracle byte for byte.
+* C5 share: the per-GPU share of config 5 at 8 GPUs (64 x 1080p, up-sampling on, + matching of the consecutive pairs
+  (2i, 2i+1) in both directions as test_sift_match.cpp:67-80 does): oracle on sampled pairs, properties on all.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _key(f):
+    # positions involve no transcendental function -> bit-identical between math back-ends; the half-bin separates
+    # the multi-orientation copies of a keypoint
+    return (int(f["octave_idx"]), int(f["scale_idx"]), float(f["scale_x"]), float(f["scale_y"]),
+            int(round(float(f["orientation"]) * 36 / (2 * np.pi) * 2)))
+
+
+LIBM_CASES = [
+    ("default_640x480", 640, 480, {}, {}),
+    ("vlfeat_unlimited", 480, 360, {"descriptor_format": 1, "max_nb_orientation_per_keypoint": 0}, {"use_vlfeat_format": 1, "max_nb_orientation_per_keypoint": 0}),
+    ("no_upsampling", 640, 480, {"use_input_upsampling": False}, {"use_input_upsampling": 0}),
+    ("two_scales", 400, 300, {"nb_scales_per_octave": 2}, {"nb_scales_per_octave": 2}),
+    ("five_scales", 400, 300, {"nb_scales_per_octave": 5}, {"nb_scales_per_octave": 5}),
+    ("direct_taps", 400, 300, {"use_hardware_interpolated_blur": False}, {"use_hardware_interpolated_blur": 0}),
+    ("1080p", 1920, 1080, {"input_image_max_size": 1920 * 1080}, {}),
+]
+
+
+@pytest.mark.parametrize("name,w,h,vkw,okw", LIBM_CASES, ids=[c[0] for c in LIBM_CASES])
+def test_libm_oracle_within_tolerance_configs(vk, oracle, name, w, h, vkw, okw):
+    """stated tolerance: same keypoint set (>= 99.5 % keyed hits), |dx|+|dy| < 1e-4 px, |dsigma|/sigma < 1e-5,
+    |dtheta| < 1e-4 rad, descriptor RMS / 512 < 1e-3 at the 99th percentile (median < 1e-4)"""
+    img = vk.gen_synthetic_image(900 + len(name), w, h)
+    with vk.Instance(vk.default_config(**vkw)) as inst:
+        inst.detectFeatures(img, 0)
+        got = inst.downloadFeatures(0)
+    ref, _ = oracle.detect(oracle.default_config(math_mode=0, **okw), img)
+    assert len(ref) > 300
+    assert abs(len(got) - len(ref)) <= max(2, len(ref) // 200)
+    rmap = {_key(f): f for f in ref}
+    hit = [(g, rmap[_key(g)]) for g in got if _key(g) in rmap]
+    assert len(hit) >= 0.995 * len(ref)
+    g = np.array([h_[0] for h_ in hit])
+    r = np.array([h_[1] for h_ in hit])
+    assert (np.abs(g["x"] - r["x"]) + np.abs(g["y"] - r["y"])).max() < 1e-4
+    assert np.abs(g["sigma"] / r["sigma"] - 1).max() < 1e-5
+    assert np.abs(g["orientation"] - r["orientation"]).max() < 1e-4
+    rms = np.sqrt(((g["descriptor"].astype(float) - r["descriptor"].astype(float)) ** 2).mean(axis=1)) / 512.0
+    assert np.median(rms) < 1e-4 and np.percentile(rms, 99) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+NB = 64
+W, H = 1920, 1080
+
+
+@pytest.fixture(scope="module")
+def c3_batch(vk):
+    """64 x 1080p through ONE batched detection + the 32 consecutive-pair matches in both directions (C3 and the C5 share)"""
+    imgs = [vk.gen_synthetic_image(0x5EED0000 + i, W, H) for i in range(NB)]
+    cfg = vk.default_config(sift_buffer_count=NB, input_image_max_size=W * H)
+    with vk.Instance(cfg, batch_capacity=NB) as inst:
+        inst.detectFeaturesBatch(imgs, 0)
+        counts = [inst.getFeaturesNumber(i) for i in range(NB)]
+        feats = [inst.downloadFeatures(i) for i in range(NB)]
+        assert inst.getScaleSpaceNbOctaves() == 7
+        plane_crc = zlib.crc32(inst.downloadDoGImage(0, 2).tobytes())     # classic accessors see image 0 of the batch
+        fwd_a = list(range(0, NB, 2))
+        fwd_b = list(range(1, NB, 2))
+        matches = {}
+        inst.matchFeaturesBatch(fwd_a, fwd_b)
+        for k in range(len(fwd_a)):
+            matches[(fwd_a[k], fwd_b[k])] = inst.downloadMatchesBatch(k)
+        inst.matchFeaturesBatch(fwd_b, fwd_a)
+        for k in range(len(fwd_a)):
+            matches[(fwd_b[k], fwd_a[k])] = inst.downloadMatchesBatch(k)
+    return {"imgs": imgs, "counts": counts, "feats": feats, "matches": matches, "plane_crc": plane_crc}
+
+
+def test_c3_batch64_equals_single_image_detection(vk, c3_batch):
+    """all 64 images: the batched launch shapes (grid.z = 64, 31 GB pyramid: offsets beyond 2^32 bytes) give the bytes of the
+    plain single-image vksift_detectFeatures call"""
+    cfg = vk.default_config(input_image_max_size=W * H)
+    with vk.Instance(cfg) as inst:
+        for i in range(NB):
+            inst.detectFeatures(c3_batch["imgs"][i], 0)
+            assert inst.getFeaturesNumber(0) == c3_batch["counts"][i], i
+            single = inst.downloadFeatures(0)
+            assert single.tobytes() == c3_batch["feats"][i].tobytes(), i
+            if i == 0:
+                assert zlib.crc32(inst.downloadDoGImage(0, 2).tobytes()) == c3_batch["plane_crc"]
+    assert min(c3_batch["counts"]) > 5000
+
+
+@pytest.mark.parametrize("i", [0, 21, 42, 63])
+def test_c3_batch64_sampled_images_equal_oracle(oracle, c3_batch, i):
+    ref, _ = oracle.detect(oracle.default_config(math_mode=1), c3_batch["imgs"][i])
+    assert len(ref) == c3_batch["counts"][i]
+    assert c3_batch["feats"][i].tobytes() == ref.tobytes()
+
+
+def test_c5_share_pair_matching_properties(c3_batch):
+    """every pair, both directions: record count = features of A, indices in range and distinct, d1 <= d2, and the
+    reported distances are the true L2 distances of the indexed descriptors"""
+    feats = c3_batch["feats"]
+    assert len(c3_batch["matches"]) == NB
+    for (a, b), m in c3_batch["matches"].items():
+        fa, fb = feats[a], feats[b]
+        assert len(m) == len(fa)
+        assert np.array_equal(m["idx_a"], np.arange(len(fa), dtype=np.uint32))
+        assert m["idx_b1"].max() < len(fb) and m["idx_b2"].max() < len(fb)
+        assert np.all(m["idx_b1"] != m["idx_b2"])
+        assert np.all(m["dist_a_b1"] <= m["dist_a_b2"])
+        da = fa["descriptor"].astype(np.int32)
+        for col, dist in (("idx_b1", "dist_a_b1"), ("idx_b2", "dist_a_b2")):
+            d2 = ((da - fb["descriptor"][m[col]].astype(np.int32)) ** 2).sum(1)
+            assert np.array_equal(np.sqrt(d2.astype(np.float32)), m[dist])
+
+
+@pytest.mark.parametrize("a,b", [(0, 1), (1, 0), (42, 43), (63, 62)])
+def test_c5_share_sampled_pairs_equal_oracle(oracle, c3_batch, a, b):
+    ref = oracle.match_2nn(c3_batch["feats"][a], c3_batch["feats"][b])
+    m = c3_batch["matches"][(a, b)]
+    for name in ("idx_a", "idx_b1", "idx_b2"):
+        assert np.array_equal(m[name], ref[name]), name
+    for name in ("dist_a_b1", "dist_a_b2"):
+        assert np.array_equal(m[name].view(np.uint32), ref[name].view(np.uint32)), name

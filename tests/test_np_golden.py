@@ -1,0 +1,69 @@
+"""Oracle and HIP path against the numpy-only golden fixtures (tests/golden/make_golden_np.py: pyramid, K4, K5, K6
+restated in numpy from the shaders, no C oracle involved). The fixtures are an independent second reading of the
+reference; the tolerances absorb the different evaluation order of the blur (bilinear fetches vs expanded taps:
+planes differ by ~1e-6) and float64-vs-fp32 intermediates."""
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = {
+    "default": dict(),
+    "noups_vlfeat": dict(use_input_upsampling=0, use_vlfeat_format=1, max_nb_orientation_per_keypoint=0, use_hardware_interpolated_blur=0),
+    "s2": dict(nb_scales_per_octave=2),
+}
+
+
+def _check(got, ref):
+    assert len(got) == len(ref), (len(got), len(ref))
+    assert np.array_equal(got["scale_idx"], ref["scale_idx"]) and np.array_equal(got["octave_idx"], ref["octave_idx"])
+    for name in ("scale_x", "scale_y", "x", "y"):
+        assert np.abs(got[name] - ref[name]).max() < 2e-3, name
+    assert np.abs(got["sigma"] / ref["sigma"] - 1).max() < 3e-4
+    assert np.abs(got["intensity"] - ref["intensity"]).max() < 2e-6
+    assert np.abs(got["orientation"] - ref["orientation"]).max() < 1e-4
+    d = got["descriptor"].astype(np.int32) - ref["descriptor"].astype(np.int32)
+    assert np.abs(d).max() <= 2
+    assert (d == 0).mean() > 0.99
+    rms = np.sqrt((d.astype(np.float64) ** 2).sum(1)) / 512.0
+    assert rms.max() < 1e-2 and rms.mean() < 1e-3
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_oracle_matches_numpy_fixture(oracle, case, math_mode):
+    img = np.load(os.path.join(G, "img_192x144.npy"))
+    ref = np.load(os.path.join(G, f"feats_192x144_{case}_np.npy"))
+    got, _ = oracle.detect(oracle.default_config(math_mode=math_mode, **CASES[case]), img)
+    _check(got, ref)
+
+
+def test_fixture_generator_is_reproducible():
+    """the committed files are what make_golden_np.py produces (one config re-run: ~1 s)"""
+    import sys
+    sys.path.insert(0, G)
+    import make_golden_np as M
+
+    img = M.image()
+    assert np.array_equal(img, np.load(os.path.join(G, "img_192x144.npy")))
+    feats, _ = M.detect(img, **M.CONFIGS["noups_vlfeat"])
+    ref = np.load(os.path.join(G, "feats_192x144_noups_vlfeat_np.npy"))
+    assert feats.tobytes() == ref.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_hip_matches_numpy_fixture(vk, case):
+    """the product path (C-ABI -> HIP kernels) against the numpy-only fixture: no oracle on either side"""
+    img = np.load(os.path.join(G, "img_192x144.npy"))
+    ref = np.load(os.path.join(G, f"feats_192x144_{case}_np.npy"))
+    kw = dict(CASES[case])
+    if "use_vlfeat_format" in kw:
+        kw["descriptor_format"] = 1 if kw.pop("use_vlfeat_format") else 0
+    cfg = vk.default_config(**kw)
+    with vk.Instance(cfg) as inst:
+        inst.detectFeatures(img, 0)
+        got = inst.downloadFeatures(0)
+    _check(got, ref)
