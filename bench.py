@@ -213,7 +213,7 @@ def main():
                 "launches_per_step": launches / max(acc["nb_calls"], 1),
             },
             "stage_ms_per_step": {k: acc[k] / max(acc["nb_calls"], 1) for k in
-                                  ("upload_ms", "pyramid_ms", "extrema_ms", "orientation_ms", "descriptor_ms", "total_ms")},
+                                  ("upload_ms", "pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")},
             "last_match_ms": match_ms,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -66,6 +66,7 @@ extern "C"
     float total_ms;
     uint32_t nb_blur_launches;
     uint64_t pyramid_algorithmic_bytes; /* SURVEY.md §8(d) definition, whole batch */
+    float scan_ms;                      /* the streaming extrema scan of octave 0 alone (mask clear + the kernel that reads the S+3 planes) */
   } vksift_ext_DetectTimings;
   VKSIFT_EXPORT void vksift_ext_setProfiling(vksift_Instance instance, bool enabled);
   VKSIFT_EXPORT void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *out);

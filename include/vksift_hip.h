@@ -10,7 +10,8 @@
  *
  * Data layout in HBM:
  *   plane      : fp32, row-major, row pitch `pitch` floats (multiple of 64 floats = 256 B)
- *   octave     : (S+3) Gaussian planes then (S+2) DoG planes, plane stride = pitch*h floats
+ *   octave     : (S+3) Gaussian planes, plane stride = pitch*h floats. DoG planes are not stored: D[s] = G[s+1] - G[s] is
+ *                formed in registers where it is consumed (extrema scan, refinement), bit-identically
  *   batch      : image b of a batched detect lives `img_stride` floats after image b-1
  *   SIFT buffer: per octave section of 164-byte vksift_Feature records; counters live in a
  *                separate u32 array (found[o], un-clamped like nb_elem in the reference)
@@ -87,19 +88,16 @@ extern "C"
                             vksift_hip_stream s);
 
   /* One Gaussian scale step = the H and V GaussianBlur*.comp dispatches of sift_detector.c:927-1001
-   * fused through LDS, plus (dog.base != NULL) the DifferenceOfGaussian.comp layer dst - src
-   * (sift_detector.c:1039-1079). taps[0..ntaps) are one-sided direct weights, centre first; the
-   * borders use mirrored-repeat addressing. src and dst must not alias. dst.base == NULL (with dog.base != NULL) keeps
-   * only the DoG layer: the last scale of an octave is read by nothing else. */
-  int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const float *taps, uint32_t ntaps, uint32_t batch,
-                      vksift_hip_stream s);
+   * fused through LDS. taps[0..ntaps) are one-sided direct weights, centre first; the borders use
+   * mirrored-repeat addressing. src and dst must not alias. */
+  int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, const float *taps, uint32_t ntaps, uint32_t batch, vksift_hip_stream s);
 
   /* vksift_hip_blur that also seeds the next octave: next(x, y) = dst(2x+1, 2y+1), the vkCmdBlitImage(NEAREST) of
    * sift_detector.c:1003-1034 for exactly halved sizes, stored from the registers that hold the blurred rows (the separate
    * pass re-reads the whole plane). Bit-identical to vksift_hip_blur + vksift_hip_downsample. Returns -1 without launching
    * anything when the shape or the selected kernel does not cover it: the caller then issues the two separate calls. */
-  int vksift_hip_blur_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, vksift_hip_Plane next, const float *taps, uint32_t ntaps,
-                                 uint32_t batch, vksift_hip_stream s);
+  int vksift_hip_blur_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane next, const float *taps, uint32_t ntaps, uint32_t batch,
+                                 vksift_hip_stream s);
 
   /* vkCmdCopyBufferToImage + vkCmdBlitImage(LINEAR, exact 2:1) + the seed blur (sift_detector.c:881-1001 for octave 0) in one
    * pass: dst = blur(upsample2x(src / 255)); the up-sampled plane is never written. Bit-identical to vksift_hip_input_blit
@@ -107,24 +105,17 @@ extern "C"
   int vksift_hip_seed_upsampled(const uint8_t *src, uint32_t sw, uint32_t sh, uint64_t src_img_stride, vksift_hip_Plane dst, const float *taps, uint32_t ntaps,
                                 uint32_t batch, vksift_hip_stream s);
 
-  /* The whole scale chain of one octave in one launch (pyramid_fused.hip): scales 1..5 and DoG 0..4 from Gaussian plane 0,
-   * i.e. the five H+V GaussianBlur*.comp dispatch pairs and five DifferenceOfGaussian.comp dispatches of
-   * sift_detector.c:927-1001,1039-1079, and (next_g0.base != NULL, exact 2:1 sizes) the NEAREST blit of scale 3 into the
-   * next octave (sift_detector.c:1003-1034). Bit-identical to five vksift_hip_blur calls. Only the default tap set is
-   * compiled: vksift_hip_octave_chain_supported(ntaps, nb_scales) tells whether ntaps[1..5] match.
-   * g0: plane 0 of the octave; planes k follow at k*plane_stride floats, dog0 likewise; taps[s*taps_stride + i]. */
-  int vksift_hip_octave_chain_supported(const uint32_t *ntaps, uint32_t nb_scales);
-  int vksift_hip_octave_chain(vksift_hip_Plane g0, uint64_t plane_stride, float *dog0, vksift_hip_Plane next_g0, const float *taps, uint32_t taps_stride,
-                              uint32_t batch, vksift_hip_stream s);
-
   /* vkCmdBlitImage(NEAREST) of sift_detector.c:1003-1034: dst(x,y) = src(floor((x+.5)*sw/dw), ...). */
   int vksift_hip_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, uint32_t batch, vksift_hip_stream s);
+
+  /* DifferenceOfGaussian.comp:13-17 for one layer of one image: out (dense w x h) = hi - lo. Only vksift_downloadDoGImage uses
+   * it — the detection path never materialises a DoG plane. */
+  int vksift_hip_dog_plane(const float *lo, const float *hi, uint32_t w, uint32_t h, uint32_t pitch, float *out_dense, vksift_hip_stream s);
 
   /* ------------------------------------------------------------------ keypoints */
   typedef struct
   {
-    float *dog;          /* DoG layer 0 of image 0 of this octave */
-    float *gauss;        /* Gaussian layer 0 of image 0 */
+    float *gauss;        /* Gaussian layer 0 of image 0 of this octave (S+3 layers; DoG layer s = layer s+1 - layer s) */
     uint32_t w, h, pitch;
     uint64_t plane_stride; /* floats between layers */
     uint64_t img_stride;   /* floats between images */
@@ -159,8 +150,9 @@ extern "C"
 
   /* ExtractKeypoints.comp (sift_detector.c:1106-1189) as a deterministic, atomic-free pipeline: streaming
    * 26-neighbour test -> per-64-pixel-segment candidate ballots -> exclusive scan -> compact candidate list ->
-   * dense refinement -> per-image scan + emit in raster order. found[] receives the un-clamped keypoint count. */
-  int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s);
+   * dense refinement -> per-image scan + emit in raster order. found[] receives the un-clamped keypoint count.
+   * scan_done (may be NULL): recorded right after the streaming scan kernel, the one bandwidth-bound launch of the stage. */
+  int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s, vksift_hip_event scan_done);
   /* ComputeOrientation.comp (sift_detector.c:1191-1241): main orientation written in place, extra
    * orientations appended in (keypoint, bin) order; found[] updated. */
   int vksift_hip_orientations(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s);

@@ -343,7 +343,7 @@ def test_graph_replay_gives_identical_results(vk, monkeypatch):
             assert f.tobytes() == r.tobytes()
         inst.detectFeatures(imgs[0], 1)           # another buffer: a second graph
         assert inst.downloadFeatures(1).tobytes() == ref[0].tobytes()
-        top = inst.downloadScaleSpaceImage(0, 5)  # lazily re-created last scale after a replay
+        top = inst.downloadScaleSpaceImage(0, 5)
         assert np.isfinite(top).all() and top.std() > 0
 
 
@@ -379,13 +379,9 @@ def test_every_runtime_switch_is_bit_identical(vk):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    variants = [{}, {"VKSIFT_BLUR_LEAN": "0"}, {"VKSIFT_BLUR_LEAN": "0", "VKSIFT_BLUR_ROWS": "4"}, {"VKSIFT_BLUR_KERNEL": "tile"}, {"VKSIFT_FUSED_SEED": "0"},
-                {"VKSIFT_LAZY_TOP": "0"}, {"VKSIFT_XCD_REMAP": "0"}, {"VKSIFT_COARSE_AFTER": "0"}, {"VKSIFT_STAGE_SYNC": "1"}, {"VKSIFT_SERIAL_OCTAVES": "1"},
-                {"VKSIFT_PYR_PINGPONG": "1"}, {"VKSIFT_PYR_PINGPONG": "1", "VKSIFT_OVERLAP_GATE": "0"}, {"VKSIFT_GRAPH": "1"}, {"VKSIFT_GRAPH": "0"},
-                {"VKSIFT_CHAIN": "1", "VKSIFT_CHAIN_MIN_ROWS": "1"}, {"VKSIFT_CHAIN": "1", "VKSIFT_CHAIN_MIN_ROWS": "1", "VKSIFT_CHAIN_ROWS": "4"},
-                {"VKSIFT_DESC_WAVES": "1"}, {"VKSIFT_DESC_WAVES": "2"}, {"VKSIFT_DESC_WAVES": "8"},
-                {"VKSIFT_EXTREMA_LEAN": "0"}, {"VKSIFT_EXTREMA_SLOTS": "4", "VKSIFT_EXTREMA_STRIP_MAJOR": "0"}, {"VKSIFT_EXTREMA_BAND": "8"}, {"VKSIFT_FEAT_GRID_DIV": "0"}, {"VKSIFT_FEAT_GRID_DIV": "100000"}, {"VKSIFT_FUSED_DOWNSAMPLE": "0"}, {"VKSIFT_IMG_FAST": "0"}, {"VKSIFT_IMG_FAST": "3"}, {"VKSIFT_REFINE_BLOCKS": "3"},
-                {"VKSIFT_DESC_EQUAL_SPLIT": "1"}, {"VKSIFT_EXTREMA_STRIP_MAJOR": "1"}, {"VKSIFT_MATCH_SLOT_FAST": "0"}, {"VKSIFT_BLUR_WGS": "1536"}, {"VKSIFT_PYR_PINGPONG": "0"}]
+    variants = [{}, {"VKSIFT_BLUR_KERNEL": "tile"}, {"VKSIFT_SERIAL_OCTAVES": "1"}, {"VKSIFT_PYR_PINGPONG": "1"}, {"VKSIFT_PYR_PINGPONG": "0"},
+                {"VKSIFT_GRAPH": "1"}, {"VKSIFT_GRAPH": "0"}, {"VKSIFT_DESC_WAVES": "1"}, {"VKSIFT_DESC_WAVES": "2"}, {"VKSIFT_DESC_WAVES": "8"},
+                {"VKSIFT_EXTREMA_LEAN": "0"}]
     digests = {}
     for v in variants:
         env = dict(os.environ)

@@ -53,32 +53,6 @@ def test_pyramid_bit_exact(vk, oracle, w, h, kw):
 
 
 @pytest.mark.parametrize("w,h,kw", [
-    (323, 211, {}),                                  # odd sizes: ragged last strip, separate down-sample launch, multi-segment
-    (100, 75, {}),                                   # tiny octaves: virtual (mirrored) rows/columns wrap more than once
-    (640, 480, {"use_input_upsampling": False}),     # different seed blur in front of the same chain
-])
-def test_pyramid_fused_chain_all_octaves(vk, oracle, monkeypatch, w, h, kw):
-    """the fused scale-chain kernel (pyramid_fused.hip) forced onto every octave, however small"""
-    monkeypatch.setenv("VKSIFT_CHAIN", "1")
-    monkeypatch.setenv("VKSIFT_CHAIN_MIN_ROWS", "1")
-    vcfg, ocfg = _cfgs(vk, oracle, **kw)
-    img = vk.gen_synthetic_image(9, w, h)
-    with vk.Instance(vcfg) as inst:
-        inst.detectFeatures(img, 0)
-        pyr = oracle.Pyramid(ocfg, img)
-        assert inst.getScaleSpaceNbOctaves() == pyr.nb_octaves
-        for o in range(pyr.nb_octaves):
-            for s in range(6):
-                g = inst.downloadScaleSpaceImage(o, s)
-                ref = pyr.gauss(o, s)
-                assert np.array_equal(g.view(np.uint32), ref.view(np.uint32)), ("gauss", o, s, np.abs(g - ref).max())
-            for s in range(5):
-                d = inst.downloadDoGImage(o, s)
-                ref = pyr.dog(o, s)
-                assert np.array_equal(d.view(np.uint32), ref.view(np.uint32)), ("dog", o, s, np.abs(d - ref).max())
-
-
-@pytest.mark.parametrize("w,h,kw", [
     (320, 240, {}),
     (200, 150, {"use_input_upsampling": False}),
     (320, 240, {"descriptor_format": 1, "max_nb_orientation_per_keypoint": 0}),

@@ -1,5 +1,9 @@
 // extrema.hip — DoG extrema detection, sub-pixel refinement and deterministic compaction (gfx950).
 //
+// The DoG planes of the reference (DifferenceOfGaussian.comp: D[z] = G[z+1] - G[z]) are not stored by this build: every
+// DoG value below is formed where it is consumed as ONE fp32 subtraction of two stored Gaussian texels, which is the
+// shader's own expression — bit-identical, and 20 B per octave pixel of HBM writes + 20 B of reads become 24 B of reads.
+//
 // Replaces ExtractKeypoints.comp (dispatch: sift_detector.c:1106-1189). The reference appends
 // keypoints with a global atomicAdd (ExtractKeypoints.comp:208), which makes their order
 // non-deterministic. Here the append is an atomic-free pipeline whose output order is raster (scale, y, x):
@@ -24,18 +28,19 @@ namespace
 
 struct DogView
 {
-  const float *base; // layer 0
+  const float *base; // GAUSSIAN layer 0 of the octave: DoG layer s = Gaussian layer s+1 - Gaussian layer s
   int w, h, pitch;
   size_t plane; // floats between layers
   int S;
 };
 
-// imageLoad with robust out-of-bounds behaviour on the layer axis (quirk Q1): layer S+2 reads 0.
+// imageLoad of the DoG image with robust out-of-bounds behaviour on the layer axis (quirk Q1): layer S+2 reads 0.
 __device__ __forceinline__ float ld(const DogView &d, int s, int x, int y)
 {
   if (s < 0 || s > d.S + 1)
     return 0.f;
-  return d.base[(size_t)s * d.plane + (size_t)y * d.pitch + x];
+  const float *p = d.base + (size_t)s * d.plane + (size_t)y * d.pitch + x;
+  return p[d.plane] - p[0];
 }
 
 struct KpRecord
@@ -45,26 +50,6 @@ struct KpRecord
   int32_t octave_idx;
   float sigma, orientation, intensity;
 };
-
-// 26-neighbour strict extremum test (ExtractKeypoints.comp:56-116).
-__device__ __forceinline__ bool is_extremum(const DogView &d, int s, int x, int y, float c)
-{
-  bool is_max = true, is_min = true;
-#pragma unroll
-  for (int ds = -1; ds <= 1; ds++)
-#pragma unroll
-    for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-      for (int dx = -1; dx <= 1; dx++)
-      {
-        if (!ds && !dy && !dx)
-          continue;
-        float v = d.base[(size_t)(s + ds) * d.plane + (size_t)(y + dy) * d.pitch + (x + dx)];
-        is_max = is_max && (c > v);
-        is_min = is_min && (c < v);
-      }
-  return is_max || is_min;
-}
 
 // Refinement + acceptance tests (ExtractKeypoints.comp:121-224).
 __device__ bool refine_texel(const DogView &d, int x, int y, int s, float dog_threshold, float edge_limit, float seed_sigma, int octave_idx, KpRecord *kp)
@@ -136,22 +121,9 @@ __device__ bool refine_texel(const DogView &d, int x, int y, int s, float dog_th
   return true;
 }
 
-__device__ __forceinline__ bool test_texel(const DogView &d, int x, int y, int s, float dog_threshold, float edge_limit, float seed_sigma, int octave_idx,
-                                           KpRecord *kp)
-{
-  if (!(x >= 1 && x < d.w - 1 && y >= 1 && y < d.h - 1))
-    return false;
-  float c = d.base[(size_t)s * d.plane + (size_t)y * d.pitch + x];
-  if (!(fabsf(c) > dog_threshold * 0.8f))
-    return false;
-  if (!is_extremum(d, s, x, y, c))
-    return false;
-  return refine_texel(d, x, y, s, dog_threshold, edge_limit, seed_sigma, octave_idx, kp);
-}
-
 struct ExtremaArgs
 {
-  const float *dog;
+  const float *gauss; // Gaussian layer 0 of image 0 of the octave (S+3 layers, plane_stride apart)
   int w, h, pitch;
   uint64_t plane_stride, img_stride;
   int S, octave_idx;
@@ -241,7 +213,7 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
     return;
   const int y1 = min(y0 + band, a.h);
   const int x0 = blockIdx.x * 128, x = x0 + 2 * lane;
-  DogView d{a.dog + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
+  DogView d{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
   const bool in0 = x < a.w, in1 = x + 1 < a.w;
   const int hx = lane == 0 ? x0 - 1 : x0 + 128;
   const bool hok = (lane == 0 || lane == 63) && hx >= 0 && hx < a.w;
@@ -276,16 +248,18 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
       p.va[l] = p.vb[l] = p.hv[l] = 0.f;
       if (r >= 0 && r < a.h && r <= y1)
       {
-        const float *row = d.base + (size_t)l * d.plane + (size_t)r * d.pitch;
+        const float *row = d.base + (size_t)l * d.plane + (size_t)r * d.pitch; // Gaussian layer l; layer l+1 one plane further
+        const float *rowu = row + d.plane;
         if (in1)
         {
           const float2 t = *(const float2 *)(row + x); // x is even and the pitch a multiple of 64: 8-byte aligned
-          p.va[l] = t.x, p.vb[l] = t.y;
+          const float2 u = *(const float2 *)(rowu + x);
+          p.va[l] = u.x - t.x, p.vb[l] = u.y - t.y;
         }
         else if (in0)
-          p.va[l] = row[x];
+          p.va[l] = rowu[x] - row[x];
         if (hok)
-          p.hv[l] = row[hx];
+          p.hv[l] = rowu[hx] - row[hx];
       }
     }
   };
@@ -428,11 +402,11 @@ __global__ void __launch_bounds__(256, 4) k_extrema_lean(ExtremaArgs a, int band
     return;
   const int y1 = min(y0 + band, a.h);
   const int x0 = bx * 128, x = x0 + 2 * lane;
-  const float *img = a.dog + (size_t)b * a.img_stride;
+  const float *img = a.gauss + (size_t)b * a.img_stride;
   const int pitch4 = a.pitch * 4;
-  __amdgpu_buffer_rsrc_t rs[NL];
+  __amdgpu_buffer_rsrc_t rs[NL + 1]; // one resource per GAUSSIAN layer
 #pragma unroll
-  for (int l = 0; l < NL; l++)
+  for (int l = 0; l <= NL; l++)
     rs[l] = __builtin_amdgcn_make_buffer_rsrc((void *)(img + (size_t)l * a.plane_stride), 0, a.pitch * a.h * 4, 0x00020000);
   // the pitch is a multiple of 64 floats, x is even: the pair (x, x+1) is inside the row or entirely outside
   const unsigned off2 = x < a.pitch ? (unsigned)x * 4u : EXT_OOB;
@@ -446,17 +420,29 @@ __global__ void __launch_bounds__(256, 4) k_extrema_lean(ExtremaArgs a, int band
   const bool odd = lane & 1;
   const unsigned half = (unsigned)lane >> 1;
 
-  u32x2_t wv2[NSLOT][NL]; // columns x, x+1
-  unsigned wh[NSLOT][NL]; // halo column (lanes 0 and 63)
+  // a slot receives the NL+1 Gaussian texels of a row; when the row becomes the newest row of the window they are turned
+  // into the NL DoG texels in place (entry NL is dead from then on)
+  u32x2_t wv2[NSLOT][NL + 1]; // columns x, x+1
+  unsigned wh[NSLOT][NL + 1]; // halo column (lanes 0 and 63)
   auto fetch_row = [&](int r, auto SLOT) {
     constexpr int slot = decltype(SLOT)::value;
     const int rr = min(max(r, 0), a.h - 1);
     const int so = rr * pitch4;
 #pragma unroll
-    for (int l = 0; l < NL; l++)
+    for (int l = 0; l <= NL; l++)
     {
       wv2[slot][l] = __builtin_amdgcn_raw_buffer_load_b64(rs[l], off2, so, 0);
       wh[slot][l] = __builtin_amdgcn_raw_buffer_load_b32(rs[l], offh, so, 0);
+    }
+  };
+  auto to_dog = [&](auto SLOT) {
+    constexpr int slot = decltype(SLOT)::value;
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+    {
+      wv2[slot][l].x = __float_as_uint(__uint_as_float(wv2[slot][l + 1].x) - __uint_as_float(wv2[slot][l].x));
+      wv2[slot][l].y = __float_as_uint(__uint_as_float(wv2[slot][l + 1].y) - __uint_as_float(wv2[slot][l].y));
+      wh[slot][l] = __float_as_uint(__uint_as_float(wh[slot][l + 1]) - __uint_as_float(wh[slot][l]));
     }
   };
 
@@ -467,6 +453,7 @@ __global__ void __launch_bounds__(256, 4) k_extrema_lean(ExtremaArgs a, int band
     constexpr int sn = P, sm = (P + NSLOT - 1) % NSLOT, so_ = (P + NSLOT - 2) % NSLOT, sf = (P + AHEAD) % NSLOT;
     if (r + AHEAD <= y1)
       fetch_row(r + AHEAD, std::integral_constant<int, sf>{});
+    to_dog(std::integral_constant<int, sn>{}); // row r: Gaussian texels -> DoG texels (every row passes here exactly once)
     const int y = r - 1;
     if (y < ylo || y >= yhi)
       return;
@@ -681,7 +668,7 @@ __global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
   uint32_t n = a.cand_n[b];
   n = n < a.cand_cap ? n : a.cand_cap;
   const uint32_t nch = (n + 255u) / 256u;
-  DogView d{a.dog + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
+  DogView d{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
   const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
   uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
   uint32_t *chunk_sum = a.seg_off + (size_t)b * a.seg_img_stride;
@@ -718,7 +705,7 @@ __global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
   uint32_t n = a.cand_n[b];
   n = n < a.cand_cap ? n : a.cand_cap;
   const uint32_t nch = (n + 255u) / 256u;
-  DogView d{a.dog + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
+  DogView d{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
   const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
   const uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
   const uint32_t *chunk_base = a.seg_off + (size_t)b * a.seg_img_stride;
@@ -760,12 +747,12 @@ __global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
 
 } // namespace
 
-extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s)
+extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s, vksift_hip_event scan_done)
 {
   if (job->w >= 16384u || job->h >= 16384u || job->S > 14u)
     return (int)hipErrorInvalidValue; /* candidate coordinates are packed 14 + 14 + 4 bits */
   ExtremaArgs a;
-  a.dog = job->dog;
+  a.gauss = job->gauss;
   a.w = (int)job->w, a.h = (int)job->h, a.pitch = (int)job->pitch;
   a.plane_stride = job->plane_stride, a.img_stride = job->img_stride;
   a.S = (int)job->S, a.octave_idx = job->octave_idx;
@@ -815,7 +802,7 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   if (occ_env < 0)
   {
     const char *e = getenv("VKSIFT_EXTREMA_SLOTS"); /* window slots: 4 = one row of loads in flight, 5 = two */
-    occ_env = e ? atoi(e) : 5;
+    occ_env = e ? atoi(e) : 4;
   }
   /* the lean kernel addresses a plane with 32-bit byte offsets */
   const bool lean = lean_env && (uint64_t)job->pitch * job->h * 4u < 0x80000000ull;
@@ -836,6 +823,8 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   default:
     return (int)hipErrorInvalidValue;
   }
+  if (scan_done)
+    (void)hipEventRecord((hipEvent_t)scan_done, hs);
   /* 2. offsets + candidate count: chunk-local scan, then the (short) scan of the chunk totals; the totals/bases live at
    * the start of the flag array until the refinement overwrites it */
   const uint32_t nchunks = (nsegs + SEG_CHUNK - 1u) / SEG_CHUNK;

@@ -1,10 +1,13 @@
-// pyramid.hip — Gaussian scale-space construction kernels for gfx950 (wave64, LDS-tiled).
+// pyramid.hip — Gaussian scale-space construction kernels for gfx950 (wave64, LDS-staged, register V-window).
 //
 // Replaces, in the reference (paths relative to src/vulkansift/):
-//   vkCmdCopyBufferToImage + vkCmdBlitImage(LINEAR)   sift_detector.c:881, 909-916   -> k_input_blit
-//   GaussianBlur*.comp H + V dispatches               sift_detector.c:927-1001       -> k_blur_tile (fused)
-//   DifferenceOfGaussian.comp                         sift_detector.c:1039-1079      -> fused into k_blur_tile
-//   vkCmdBlitImage(NEAREST) down-sample               sift_detector.c:1003-1034      -> k_downsample
+//   vkCmdCopyBufferToImage + vkCmdBlitImage(LINEAR)   sift_detector.c:881, 909-916   -> k_input_blit / fused into the seed blur
+//   GaussianBlur*.comp H + V dispatches               sift_detector.c:927-1001       -> k_blur_lean (k_blur_tile: generic fallback)
+//   vkCmdBlitImage(NEAREST) down-sample               sift_detector.c:1003-1034      -> fused into the scale-S blur / k_downsample
+//   DifferenceOfGaussian.comp                         sift_detector.c:1039-1079      -> NOT a pass here: D[s] = G[s+1] - G[s] is one
+//       fp32 subtraction of two stored planes, so the extrema scan and the refinement (extrema.hip) form it on the fly from the
+//       Gaussian planes, bit-identically, and the DoG planes never exist in HBM (20 B per octave pixel less traffic at S = 3).
+//       k_dog_plane materialises one layer on demand for vksift_downloadDoGImage.
 //
 // Arithmetic contract (must stay bit-identical to oracle/sift_oracle.c blur_plane/blit_*):
 //   pass:  acc = centre*k0;  acc = fmaf(t(+i) + t(-i), k[i], acc)  for i = 1..n-1 ascending
@@ -126,17 +129,17 @@ __global__ void __launch_bounds__(256) k_input_blit_2x(const uint8_t *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused separable blur (+ optional DoG) over a 64x64 output tile staged through LDS.
+// Generic fallback: fused separable blur over a 64x64 output tile staged through LDS (any width, any tap count).
 //   LDS: s_src[(64+2R)][SS]  source tile with halo (mirrored at the image border)
 //        s_mid[(64+2R)][64]  horizontally blurred rows
 // 4 waves; lane = column so every LDS access is stride-1 (conflict-free) and every global row
-// access is one 256-byte coalesced segment.
+// access is one 256-byte coalesced segment. Serves the shapes k_blur_lean does not (widths that are not a
+// multiple of 4, images narrower than the halo, 1-tap kernels).
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE = 64;
 
 __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src, uint64_t src_img_stride, int spitch, float *__restrict__ dst,
-                                                   uint64_t dst_img_stride, int dpitch, float *__restrict__ dog, uint64_t dog_img_stride, int gpitch,
-                                                   int w, int h, Taps taps, int ntaps)
+                                                   uint64_t dst_img_stride, int dpitch, int w, int h, Taps taps, int ntaps)
 {
   extern __shared__ float lds[];
   const int R = ntaps - 1;
@@ -151,7 +154,6 @@ __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src
   const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
   const float *in = src + (size_t)blockIdx.z * src_img_stride;
 
-  // stage source tile
   for (int r = wave; r < SH; r += 4)
   {
     int gy = mirror_idx(y0 - R + r, h);
@@ -161,7 +163,6 @@ __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src
   }
   __syncthreads();
 
-  // horizontal pass over all staged rows
   const float k0 = taps.k[0];
   for (int r = wave; r < SH; r += 4)
   {
@@ -173,10 +174,8 @@ __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src
   }
   __syncthreads();
 
-  // vertical pass, 16 output rows per wave
   const int gx = x0 + lane;
   float *out = dst + (size_t)blockIdx.z * dst_img_stride;
-  float *gout = dog ? dog + (size_t)blockIdx.z * dog_img_stride : nullptr;
   for (int rr = wave * 16; rr < wave * 16 + 16; rr++)
   {
     int gy = y0 + rr;
@@ -187,214 +186,48 @@ __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src
     for (int i = 1; i < ntaps; i++)
       acc = fmaf(p[i * TILE] + p[-i * TILE], taps.k[i], acc);
     if (gx < w)
-    {
-      if (dst)
-        out[(size_t)gy * dpitch + gx] = acc;
-      if (gout)
-        gout[(size_t)gy * gpitch + gx] = acc - s_src[(rr + R) * SS + lane + R];
-    }
+      out[(size_t)gy * dpitch + gx] = acc;
   }
 }
-
 // ---------------------------------------------------------------------------------------------
-// Streaming separable blur (+ DoG): the production kernel.
+// k_blur_lean — streaming separable blur, the production kernel.
 //
-// One wave owns a 128-column strip of a row segment [y0, y1) and marches down the "virtual" row
-// sequence r = y0-R .. y1-1+R in groups of NR = 8 rows; virtual row r is fed by source row mirror(r),
-// so the mirrored-repeat border needs no special case anywhere below the loads.
-//   stage   : float4 loads of the next group's source rows (prefetched one group ahead, 16 B/lane,
-//             coalesced, halo RA = R rounded up to 4, mirrored in x at the image edges) -> LDS
-//   H pass  : every lane blurs its 2 pixels of each new row from LDS (ds_read_b64, stride-1 lanes:
-//             conflict free) straight into the register window
-//   V pass  : the register window holds the 2R+8 most recent H rows of the lane's own two columns;
-//             8 output rows are produced per group, then the window shifts by 8 (2R v_mov per pixel
-//             column against 8*4R arithmetic instructions)
-//   DoG     : G - source centre; the centres wait R rows in a small LDS ring written by their own lane
-// Everything is unrolled on the tap count (template): taps sit in SGPRs, inner loops are straight
-// v_add/v_fma chains with 16 independent accumulators per lane. Only the staging buffer is shared
-// between lanes -> one barrier per group. LDS per wave: 8*(128+2RA)*4 + (R+8)*128*4 B (15 KiB at R = 12).
-// HBM traffic per pixel: 4 B read (x (128+2RA)/128 horizontally, x (SEG+2R)/SEG vertically) + 4 B G +
-// 4 B DoG written.
+// One wave owns a 128-column strip of a row segment [y0, y1) and marches down the "virtual" row sequence
+// r = y0-R .. y1-1+R in groups of 8 rows; virtual row r is fed by source row mirror(r), so the mirrored-repeat border
+// needs no special case below the loads.
+//   stage   : float4 loads of the next group's source rows (prefetched one group ahead, 16 B/lane, coalesced, halo
+//             RA = R rounded up to 4, mirrored in x at the image edges) -> LDS
+//   H pass  : every lane blurs its 2 pixels of each new row from LDS (ds_read_b64, stride-1 lanes: conflict free)
+//             straight into the register window
+//   V pass  : the register window holds the 2R+8 most recent H rows of the lane's own two columns; 8 output rows are
+//             produced per group, then the window shifts by 8
+// Everything is unrolled on the tap count (template): taps sit in SGPRs, inner loops are straight v_pk_add/v_pk_fma
+// chains. Built around the instruction budget (a CDNA wave issues at most one instruction per 4 cycles whatever its type):
+//   * global accesses are raw buffer instructions: per-lane byte offsets are loop constants, the row offset is one
+//     SGPR; lanes that must not load/store (non-staging lanes, columns >= W) carry an out-of-range offset, so the
+//     hardware drops them — no exec-mask branches, no 64-bit VALU address arithmetic
+//   * mirrored columns are folded into the per-lane load offset (+ a lane-constant "reverse the float4" flag)
+//   * the steady state (all 8 rows of a group inside the image and the segment) has no per-row conditions at all
+//   * LDS per wave is one 8-row staging group (5 KiB at R = 12): occupancy is set by the registers alone
+// HBM traffic per pixel: 4 B read (x (128+2RA)/128 horizontally, x (SEG+2R)/SEG vertically, mostly L2 hits thanks to the
+// XCD-contiguous work order) + 4 B written.
+// Requirements (checked by the launcher, k_blur_tile serves the rest): W % 4 == 0, a single mirror reflection
+// covers every staged column (RA <= W and strips*128 + RA <= 2W).
 // ---------------------------------------------------------------------------------------------
 struct StreamArgs
 {
   const float *src;
   float *dst;
-  float *dog;
-  uint64_t src_img_stride, dst_img_stride, dog_img_stride;
-  int spitch, dpitch, gpitch;
+  uint64_t src_img_stride, dst_img_stride;
+  int spitch, dpitch;
   int w, h;
-  int seg; // output rows per workgroup (multiple of 8)
-  int xcd_remap; // k_blur_lean: XCD-contiguous work mapping
-  float *ds;     // k_blur_lean: also store the NEAREST 2:1 resample (odd rows, odd columns) of the result here (next octave's seed), or NULL
+  int seg;   // output rows per workgroup (multiple of 8)
+  float *ds; // also store the NEAREST 2:1 resample (odd rows, odd columns) of the result here (next octave's seed), or NULL
   uint64_t ds_img_stride;
   int ds_pitch;
   Taps taps;
 };
 
-__device__ __forceinline__ int pmod(int v, int m) { return (v + m * 4096) % m; } // v > -4096*m
-
-template <int NT, bool DOG, int NR>
-__global__ void __launch_bounds__(64) k_blur_stream(StreamArgs a)
-{
-  constexpr int R = NT - 1;
-  constexpr int RA = (R + 3) & ~3;
-  constexpr int TW = 128;
-  constexpr int SW = TW + 2 * RA;
-  constexpr int CTR_ROWS = R + NR;
-  constexpr int NV4 = SW / 4;       // float4 per staged row (<= 42 lanes stage, one float4 per row each)
-  constexpr int OFS = (RA - R) & 1; // parity fix so that the H-pass window starts on an even float
-  constexpr int NP = R + 1 + OFS;   // float2 pairs read per row in the H pass
-  constexpr int C0 = R + OFS;       // index of pixel 0's centre inside the window
-  constexpr int NWIN = 2 * R + NR;
-  __shared__ __attribute__((aligned(16))) float s_stage[NR * SW];
-  __shared__ __attribute__((aligned(16))) float s_ctr[DOG ? CTR_ROWS * TW : 4];
-
-  const int lane = threadIdx.x;
-  const int W = a.w, H = a.h;
-  const int x0 = blockIdx.x * TW;
-  const int y0 = blockIdx.y * a.seg;
-  const int y1 = min(y0 + a.seg, H);
-  const float *src = a.src + (size_t)blockIdx.z * a.src_img_stride;
-  float *dst = a.dst + (size_t)blockIdx.z * a.dst_img_stride;
-  float *dog = DOG ? a.dog + (size_t)blockIdx.z * a.dog_img_stride : nullptr;
-
-  const int gx4 = x0 - RA + 4 * lane; // first column of this lane's staging float4
-  const bool stager = lane < NV4;
-  const bool vec_ok = gx4 >= 0 && gx4 + 3 < W;
-
-  auto load_row = [&](int r) -> float4 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (stager)
-    {
-      const float *row = src + (size_t)mirror_idx(r, H) * a.spitch;
-      if (vec_ok)
-        v = *(const float4 *)(row + gx4);
-      else
-        v = make_float4(row[mirror_idx(gx4, W)], row[mirror_idx(gx4 + 1, W)], row[mirror_idx(gx4 + 2, W)], row[mirror_idx(gx4 + 3, W)]);
-    }
-    return v;
-  };
-
-  const int lx = 2 * lane; // this lane's first column inside the strip
-  const int px = x0 + lx;
-  const float k0 = a.taps.k[0];
-
-  int rg = y0 - R; // first virtual row of the current group
-  float4 pf[NR];
-#pragma unroll
-  for (int j = 0; j < NR; j++)
-    pf[j] = load_row(rg + j);
-
-  float2 wv[NWIN]; // H rows of virtual rows rg-2R .. rg+NR-1 (this lane's two columns)
-#pragma unroll
-  for (int k = 0; k < NWIN; k++)
-    wv[k] = make_float2(0.f, 0.f);
-
-  for (; rg - R < y1; rg += NR)
-  {
-    // ---- stage the prefetched group, then prefetch the next one
-    __syncthreads();
-    if (stager)
-    {
-#pragma unroll
-      for (int j = 0; j < NR; j++)
-        *(v4f *)(s_stage + j * SW + 4 * lane) = v4f{pf[j].x, pf[j].y, pf[j].z, pf[j].w};
-    }
-#pragma unroll
-    for (int j = 0; j < NR; j++)
-      pf[j] = load_row(rg + NR + j);
-    __syncthreads();
-
-    // ---- horizontal pass of the new rows, into the top of the register window
-#pragma unroll
-    for (int j = 0; j < NR; j++)
-    {
-      const v2f *p = (const v2f *)(s_stage + j * SW + (RA - R - OFS) + lx);
-      float v[2 * NP];
-#pragma unroll
-      for (int q = 0; q < NP; q++)
-      {
-        v2f t = p[q];
-        v[2 * q] = t.x, v[2 * q + 1] = t.y;
-      }
-      float acc0 = v[C0] * k0, acc1 = v[C0 + 1] * k0;
-#pragma unroll
-      for (int i = 1; i < NT; i++)
-      {
-        acc0 = fmaf(v[C0 + i] + v[C0 - i], a.taps.k[i], acc0);
-        acc1 = fmaf(v[C0 + 1 + i] + v[C0 + 1 - i], a.taps.k[i], acc1);
-      }
-      wv[2 * R + j] = make_float2(acc0, acc1);
-      if (DOG)
-        *(v2f *)(s_ctr + pmod(rg + j, CTR_ROWS) * TW + lx) = v2f{v[C0], v[C0 + 1]};
-      // keep the rows apart: otherwise the scheduler hoists the LDS reads of all 8 rows (8 x 2NP live registers)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- vertical pass: output rows yb .. yb+NR-1
-    const int yb = rg - R;
-    if (yb + NR > y0)
-    {
-      size_t orow = (size_t)yb * a.dpitch + px; // running offsets: one 64-bit add per row instead of 16 live addresses
-      size_t grow = (size_t)yb * a.gpitch + px;
-#pragma unroll
-      for (int j = 0; j < NR; j++)
-      {
-        const int y = yb + j;
-        if (y >= y0 && y < y1)
-        {
-          float acc0 = wv[R + j].x * k0, acc1 = wv[R + j].y * k0;
-#pragma unroll
-          for (int i = 1; i < NT; i++)
-          {
-            acc0 = fmaf(wv[R + j + i].x + wv[R + j - i].x, a.taps.k[i], acc0);
-            acc1 = fmaf(wv[R + j + i].y + wv[R + j - i].y, a.taps.k[i], acc1);
-          }
-          float *o = dst + orow;
-          if (a.dst == nullptr)
-            ; // caller keeps only the DoG layer of this scale
-          else if (px + 1 < W)
-            *(float2 *)o = make_float2(acc0, acc1);
-          else if (px < W)
-            o[0] = acc0;
-          if (DOG)
-          {
-            const v2f c = *(const v2f *)(s_ctr + pmod(y, CTR_ROWS) * TW + lx);
-            float *g = dog + grow;
-            if (px + 1 < W)
-              *(float2 *)g = make_float2(acc0 - c.x, acc1 - c.y);
-            else if (px < W)
-              g[0] = acc0 - c.x;
-          }
-        }
-        orow += a.dpitch;
-        grow += a.gpitch;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // ---- slide the window
-#pragma unroll
-    for (int k = 0; k < 2 * R; k++)
-      wv[k] = wv[k + NR];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_blur_lean: the same streaming algorithm and the same arithmetic as k_blur_stream (NR = 8), rebuilt around the
-// instruction budget. On CDNA a wave issues at most one instruction per 4 cycles whatever its type, and with the
-// 2-4 resident waves per SIMD this kernel gets, every scalar address computation, exec-mask branch and wait of
-// k_blur_stream (~1500 instructions per 8-row group, 600 of them VALU) is on the critical path. Here:
-//   * global accesses are raw buffer instructions: per-lane byte offsets are loop constants, the row offset is one
-//     SGPR; lanes that must not load/store (non-staging lanes, columns >= W) carry an out-of-range offset, so the
-//     hardware drops them — no exec-mask branches, no 64-bit VALU address arithmetic
-//   * mirrored columns are folded into the per-lane load offset (+ a lane-constant "reverse the float4" flag)
-//   * the staging buffer is a ring of NG 8-row groups, so the DoG centres are read back from it (no separate centre
-//     ring, no modulo arithmetic: every LDS offset is group base + compile-time constant)
-//   * the steady state (all 8 rows of a group inside the image and the segment) has no per-row conditions at all
-// Requirements (checked by the launcher, k_blur_stream serves the rest): W % 4 == 0, a single mirror reflection
-// covers every staged column (RA <= W and strips*128 + RA <= 2W).
-// ---------------------------------------------------------------------------------------------
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned BUF_OOB = 0x80000000u; // byte offset beyond any plane: loads return 0, stores are dropped
@@ -408,7 +241,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base, 
 // 2:1 LINEAR blit of k_input_blit_2x (same expressions, value/255 through a 256-entry table of the same correctly
 // rounded quotients), i.e. vkCmdCopyBufferToImage + vkCmdBlitImage + the seed blur in one pass: the up-sampled plane
 // never exists in HBM. a.src then points at the u8 images (a.src_img_stride in bytes), a.spitch is the source width.
-template <int NT, bool DOG, bool UPS = false>
+template <int NT, bool UPS>
 __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 {
   constexpr int NR = 8;
@@ -416,15 +249,12 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   constexpr int RA = (R + 3) & ~3;
   constexpr int TW = 128;
   constexpr int SW = TW + 2 * RA;
-  constexpr int NV4 = SW / 4;
-  constexpr int OFS = (RA - R) & 1;
-  constexpr int NP = R + 1 + OFS;
-  constexpr int C0 = R + OFS;
+  constexpr int NV4 = SW / 4;       // float4 per staged row (<= 42 lanes stage, one float4 per row each)
+  constexpr int OFS = (RA - R) & 1; // parity fix so that the H-pass window starts on an even float
+  constexpr int NP = R + 1 + OFS;   // float2 pairs read per row in the H pass
+  constexpr int C0 = R + OFS;       // index of pixel 0's centre inside the window
   constexpr int NWIN = 2 * R + NR;
-  constexpr int NG = (R + NR - 1) / NR + 1; // groups kept in the ring: the centres of the rows emitted now are up to R rows old
-  static_assert(NG <= 4, "ring bookkeeping below handles up to 3 groups back (R <= 24)");
-  constexpr int GROUP_FLOATS = NR * SW;
-  __shared__ __attribute__((aligned(16))) float s_ring[NG * GROUP_FLOATS];
+  __shared__ __attribute__((aligned(16))) float s_grp[NR * SW];
 
   const int lane = threadIdx.x;
   const int W = a.w, H = a.h;
@@ -434,7 +264,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   uint32_t bs = blockIdx.x, bseg = blockIdx.y, bimg = blockIdx.z;
   {
     const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
-    if (a.xcd_remap && (total & 7u) == 0)
+    if ((total & 7u) == 0)
     {
       const uint32_t b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
       const uint32_t wi = (b & 7u) * (total >> 3) + (b >> 3);
@@ -450,10 +280,9 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   const __amdgpu_buffer_rsrc_t rs =
       UPS ? __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)a.src + (size_t)bimg * a.src_img_stride), 0, a.spitch * (H / 2), 0x00020000)
           : plane_rsrc(a.src + (size_t)bimg * a.src_img_stride, a.spitch, H);
-  const __amdgpu_buffer_rsrc_t rd = plane_rsrc(a.dst ? a.dst + (size_t)bimg * a.dst_img_stride : a.src, a.dpitch, H);
-  const __amdgpu_buffer_rsrc_t rg_ = plane_rsrc(DOG ? a.dog + (size_t)bimg * a.dog_img_stride : a.dst, a.gpitch, H);
+  const __amdgpu_buffer_rsrc_t rd = plane_rsrc(a.dst + (size_t)bimg * a.dst_img_stride, a.dpitch, H);
   const bool has_ds = !UPS && a.ds != nullptr;
-  const __amdgpu_buffer_rsrc_t rds = plane_rsrc(has_ds ? a.ds + (size_t)bimg * a.ds_img_stride : a.src, has_ds ? a.ds_pitch : a.spitch, has_ds ? H / 2 : H);
+  const __amdgpu_buffer_rsrc_t rds = plane_rsrc(has_ds ? a.ds + (size_t)bimg * a.ds_img_stride : a.dst, has_ds ? a.ds_pitch : a.dpitch, has_ds ? H / 2 : H);
 
   // ---- lane constants
   const int gx4 = x0 - RA + 4 * lane;
@@ -491,8 +320,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   }
   const int px = x0 + 2 * lane;
   const unsigned st_off = px + 1 < W ? (unsigned)px * 4u : BUF_OOB;
-  const unsigned st_off_g = a.dst ? st_off : BUF_OOB; // dst == NULL: the caller keeps only the DoG layer, the hardware drops the store
-  const int spitch4 = a.spitch * 4, dpitch4 = a.dpitch * 4, gpitch4 = a.gpitch * 4;
+  const int spitch4 = a.spitch * 4, dpitch4 = a.dpitch * 4;
   const unsigned st_off_ds = px + 1 < W ? (unsigned)(px >> 1) * 4u : BUF_OOB; // column px+1 (odd) -> column px/2 of the half-size plane
   const int dspitch4 = a.ds_pitch * 4;
   const float k0 = a.taps.k[0];
@@ -537,14 +365,9 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   for (int k = 0; k < NWIN; k++)
     wv[k] = make_float2(0.f, 0.f);
 
-  int gs = 0;              // ring slot of the current group
-  int gs1 = NG - 1;        // slot of the previous group
-  int gs2 = NG >= 3 ? NG - 2 : 0; // slot of the one before (NG >= 3)
-  int gs3 = NG >= 4 ? NG - 3 : 0; // and of the one before that (NG == 4)
   for (; rg - R < y1; rg += NR)
   {
-    // ---- stage the prefetched group into ring slot gs, then prefetch the next group
-    float *grp = s_ring + gs * GROUP_FLOATS;
+    // ---- stage the prefetched group, then prefetch the next one
     __syncthreads();
     if (lane < NV4)
     {
@@ -576,7 +399,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
         }
         if (rev)
           v = u32x4{v.w, v.z, v.y, v.x};
-        *(u32x4 *)(grp + j * SW + 4 * lane) = v;
+        *(u32x4 *)(s_grp + j * SW + 4 * lane) = v;
       }
     }
     prefetch(rg + NR);
@@ -586,7 +409,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
     // chains are independent, so the scheduler can alternate them and the dependent v_pk_add -> v_pk_fma pairs need no
     // wait states (one row alone leaves an s_nop after almost every packed instruction).
     {
-      const float *hb = grp + (RA - R - OFS) + 2 * lane;
+      const float *hb = s_grp + (RA - R - OFS) + 2 * lane;
 #pragma unroll
       for (int j = 0; j < NR; j += 2)
       {
@@ -616,55 +439,22 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
       }
     }
 
-    // ---- vertical pass: output rows yb .. yb+NR-1 (source row of output row yb+j: group (j - R) / NR back, row (j - R) mod NR)
+    // ---- vertical pass: output rows yb .. yb+NR-1
     const int yb = rg - R;
     if (yb + NR > y0)
     {
-      const float *c0p = s_ring + gs * GROUP_FLOATS + RA + 2 * lane;
-      const float *c1p = s_ring + gs1 * GROUP_FLOATS + RA + 2 * lane;
-      const float *c2p = s_ring + gs2 * GROUP_FLOATS + RA + 2 * lane;
-      const float *c3p = s_ring + gs3 * GROUP_FLOATS + RA + 2 * lane;
-      auto centre = [&](int j) -> v2f {
-        const int back = j - R;                               // <= 0: rows back from the current group's row 0
-        const int gb = back >= 0 ? 0 : (-back + NR - 1) / NR; // groups back (0, 1 or 2)
-        const int row = back + gb * NR;                       // row inside that group
-        const float *cp = gb == 0 ? c0p : (gb == 1 ? c1p : (gb == 2 ? c2p : c3p));
-        return *(const v2f *)(cp + row * SW);
-      };
-      auto emit = [&](int j, int so_d, int so_g, float acc0, float acc1) {
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0), __float_as_uint(acc1)}, rd, st_off_g, so_d, 0);
-        if (DOG)
-        {
-          const v2f c = centre(j);
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0 - c.x), __float_as_uint(acc1 - c.y)}, rg_, st_off, so_g, 0);
-        }
+      auto emit = [&](int j, int so_d, float acc0, float acc1) {
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0), __float_as_uint(acc1)}, rd, st_off, so_d, 0);
         // vkCmdBlitImage(NEAREST) into the next octave, exact 2:1: destination (x, y) takes source (2x+1, 2y+1). yb is even
         // (segments start on multiples of 8), so the odd rows are the odd j: a compile-time choice in the unrolled loops
         if (has_ds && (j & 1))
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1), rds, st_off_ds, ((yb + j) >> 1) * dspitch4, 0);
       };
-      auto vpass_checked = [&]() {
-        int so_d = yb * dpitch4, so_g = yb * gpitch4;
+      if (yb >= y0 && yb + NR <= y1)
+      {
+        int so_d = yb * dpitch4;
 #pragma unroll
-        for (int j = 0; j < NR; j++, so_d += dpitch4, so_g += gpitch4)
-        {
-          if (yb + j < y0 || yb + j >= y1)
-            continue;
-          float acc0 = wv[R + j].x * k0, acc1 = wv[R + j].y * k0;
-#pragma unroll
-          for (int i = 1; i < NT; i++)
-          {
-            acc0 = fmaf(wv[R + j + i].x + wv[R + j - i].x, a.taps.k[i], acc0);
-            acc1 = fmaf(wv[R + j + i].y + wv[R + j - i].y, a.taps.k[i], acc1);
-          }
-          emit(j, so_d, so_g, acc0, acc1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      auto vpass_full = [&]() {
-        int so_d = yb * dpitch4, so_g = yb * gpitch4;
-#pragma unroll
-        for (int j = 0; j < NR; j += 2, so_d += 2 * dpitch4, so_g += 2 * gpitch4)
+        for (int j = 0; j < NR; j += 2, so_d += 2 * dpitch4)
         {
           float a0 = wv[R + j].x * k0, a1 = wv[R + j].y * k0;
           float b0 = wv[R + j + 1].x * k0, b1 = wv[R + j + 1].y * k0;
@@ -676,50 +466,35 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
             b0 = fmaf(wv[R + j + 1 + i].x + wv[R + j + 1 - i].x, a.taps.k[i], b0);
             b1 = fmaf(wv[R + j + 1 + i].y + wv[R + j + 1 - i].y, a.taps.k[i], b1);
           }
-          emit(j, so_d, so_g, a0, a1);
-          emit(j + 1, so_d + dpitch4, so_g + gpitch4, b0, b1);
+          emit(j, so_d, a0, a1);
+          emit(j + 1, so_d + dpitch4, b0, b1);
           __builtin_amdgcn_sched_barrier(0);
         }
-      };
-      if (yb >= y0 && yb + NR <= y1)
-        vpass_full();
+      }
       else
-        vpass_checked();
+      {
+        int so_d = yb * dpitch4;
+#pragma unroll
+        for (int j = 0; j < NR; j++, so_d += dpitch4)
+        {
+          if (yb + j < y0 || yb + j >= y1)
+            continue;
+          float acc0 = wv[R + j].x * k0, acc1 = wv[R + j].y * k0;
+#pragma unroll
+          for (int i = 1; i < NT; i++)
+          {
+            acc0 = fmaf(wv[R + j + i].x + wv[R + j - i].x, a.taps.k[i], acc0);
+            acc1 = fmaf(wv[R + j + i].y + wv[R + j - i].y, a.taps.k[i], acc1);
+          }
+          emit(j, so_d, acc0, acc1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
-    // ---- slide the window, rotate the ring
+    // ---- slide the window
 #pragma unroll
     for (int k = 0; k < 2 * R; k++)
       wv[k] = wv[k + NR];
-    gs3 = gs2;
-    gs2 = gs1;
-    gs1 = gs;
-    gs = gs + 1 == NG ? 0 : gs + 1;
-  }
-}
-
-template <int NT>
-void launch_stream(const StreamArgs &a, bool with_dog, int nw, dim3 grid, hipStream_t s)
-{
-  if (nw == 0)
-  {
-    if (with_dog)
-      hipLaunchKernelGGL((k_blur_lean<NT, true>), grid, dim3(64), 0, s, a);
-    else
-      hipLaunchKernelGGL((k_blur_lean<NT, false>), grid, dim3(64), 0, s, a);
-  }
-  else if (nw == 4)
-  {
-    if (with_dog)
-      hipLaunchKernelGGL((k_blur_stream<NT, true, 4>), grid, dim3(64), 0, s, a);
-    else
-      hipLaunchKernelGGL((k_blur_stream<NT, false, 4>), grid, dim3(64), 0, s, a);
-  }
-  else
-  {
-    if (with_dog)
-      hipLaunchKernelGGL((k_blur_stream<NT, true, 8>), grid, dim3(64), 0, s, a);
-    else
-      hipLaunchKernelGGL((k_blur_stream<NT, false, 8>), grid, dim3(64), 0, s, a);
   }
 }
 
@@ -739,6 +514,17 @@ __global__ void __launch_bounds__(256) k_downsample(const float *__restrict__ sr
   const float *in = src + (size_t)blockIdx.z * src_img_stride;
   float *out = dst + (size_t)blockIdx.z * dst_img_stride;
   out[(size_t)y * dpitch + x] = in[(size_t)yy * spitch + xx];
+}
+
+// DifferenceOfGaussian.comp:13-17 for ONE layer of ONE image, dense w x h output: only vksift_downloadDoGImage needs a DoG plane
+// in memory (the detection path forms the differences in registers).
+__global__ void __launch_bounds__(256) k_dog_plane(const float *__restrict__ lo, const float *__restrict__ hi, int w, int h, int pitch, float *__restrict__ out)
+{
+  int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h)
+    return;
+  out[(size_t)y * w + x] = hi[(size_t)y * pitch + x] - lo[(size_t)y * pitch + x];
 }
 
 } // namespace
@@ -761,8 +547,7 @@ extern "C"
     return (int)hipGetLastError();
   }
 
-  static int blur_tile_launch(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const Taps &t, uint32_t ntaps, uint32_t batch,
-                              vksift_hip_stream s)
+  static int blur_tile_launch(vksift_hip_Plane src, vksift_hip_Plane dst, const Taps &t, uint32_t ntaps, uint32_t batch, vksift_hip_stream s)
   {
     int R = (int)ntaps - 1;
     int SH = TILE + 2 * R, SS = TILE + 2 * R + 1;
@@ -780,129 +565,63 @@ extern "C"
     }
     dim3 grid((src.w + TILE - 1) / TILE, (src.h + TILE - 1) / TILE, batch);
     hipLaunchKernelGGL(k_blur_tile, grid, dim3(256), lds_bytes, (hipStream_t)s, src.base, src.img_stride, (int)src.pitch, dst.base, dst.img_stride,
-                       (int)dst.pitch, dog.base, dog.img_stride, (int)dog.pitch, (int)src.w, (int)src.h, t, (int)ntaps);
+                       (int)dst.pitch, (int)src.w, (int)src.h, t, (int)ntaps);
     return (int)hipGetLastError();
   }
 
-  static int blur_impl(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, vksift_hip_Plane ds, const float *taps, uint32_t ntaps,
-                       uint32_t batch, vksift_hip_stream s);
-
-  int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, const float *taps, uint32_t ntaps, uint32_t batch,
-                      vksift_hip_stream s)
+  /* Row segments of the streaming kernel: enough workgroups to give every CU ~40 waves over the launch (2560 long-lived waves
+   * left the slowest CU to set the time), but segments long enough that the 2R-row warm-up stays a small fraction; launches
+   * that cannot fill the GPU anyway (small octaves, small batches) are latency bound and take shorter marches. */
+  static dim3 stream_grid(uint32_t w, uint32_t h, uint32_t batch, uint32_t wg_target, int *seg_out)
   {
-    const vksift_hip_Plane none = {NULL, 0, 0, 0, 0};
-    return blur_impl(src, dst, dog, none, taps, ntaps, batch, s);
+    const uint32_t strips = (w + 127u) / 128u;
+    uint32_t nseg = (wg_target + strips * batch - 1u) / (strips * batch);
+    const uint32_t waves64 = strips * batch * ((h + 63u) / 64u);
+    const uint32_t seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u);
+    const uint32_t max_seg = (h + seg_rows - 1u) / seg_rows;
+    if (nseg > max_seg)
+      nseg = max_seg;
+    if (nseg < 1)
+      nseg = 1;
+    const uint32_t seg = ((h + nseg - 1u) / nseg + 7u) & ~7u;
+    nseg = (h + seg - 1u) / seg;
+    *seg_out = (int)seg;
+    return dim3(strips, nseg, batch);
   }
 
-  int vksift_hip_blur_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, vksift_hip_Plane next, const float *taps, uint32_t ntaps,
-                                 uint32_t batch, vksift_hip_stream s)
+  static int blur_impl(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane ds, const float *taps, uint32_t ntaps, uint32_t batch, vksift_hip_stream s)
   {
-    static int enabled = -1;
-    if (enabled < 0)
-    {
-      const char *e = getenv("VKSIFT_FUSED_DOWNSAMPLE"); /* 0: separate down-sampling launch (A/B runs) */
-      enabled = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (!enabled || next.base == NULL || dst.base == NULL || next.w * 2u != src.w || next.h * 2u != src.h)
-      return -1;
-    return blur_impl(src, dst, dog, next, taps, ntaps, batch, s);
-  }
-
-  static int blur_impl(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane dog, vksift_hip_Plane ds, const float *taps, uint32_t ntaps, uint32_t batch,
-                       vksift_hip_stream s)
-  {
-    if (ntaps < 1 || ntaps > VKSIFT_HIP_MAX_TAPS || src.base == dst.base || (dst.base == NULL && dog.base == NULL))
+    if (ntaps < 1 || ntaps > VKSIFT_HIP_MAX_TAPS || src.base == dst.base || dst.base == NULL)
       return (int)hipErrorInvalidValue;
-    if (dst.base == NULL)
-      dst.pitch = dog.pitch, dst.img_stride = 0; /* DoG-only call: the blurred scale itself is not stored */
     Taps t;
     for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
       t.k[i] = i < ntaps ? taps[i] : 0.f;
     static int force_tile = -1;
     if (force_tile < 0)
     {
-      const char *e = getenv("VKSIFT_BLUR_KERNEL"); /* "tile" selects the simple 2-D tile kernel (debug / A-B runs) */
+      const char *e = getenv("VKSIFT_BLUR_KERNEL"); /* "tile": the generic fallback kernel everywhere (debugging) */
       force_tile = (e && e[0] == 't') ? 1 : 0;
     }
-    if (ntaps < 2 || force_tile)
-      return ds.base ? -1 : blur_tile_launch(src, dst, dog, t, ntaps, batch, s);
+    const uint32_t ra = ((ntaps - 1u) + 3u) & ~3u;
+    const uint32_t nstrips = (src.w + 127u) / 128u;
+    const bool lean = !force_tile && ntaps >= 2 && (src.w % 4u) == 0 && ra <= src.w && nstrips * 128u + ra <= 2u * src.w;
+    if (!lean)
+      return ds.base ? -1 : blur_tile_launch(src, dst, t, ntaps, batch, s);
 
     StreamArgs a;
     a.ds = ds.base, a.ds_img_stride = ds.img_stride, a.ds_pitch = (int)ds.pitch;
-    a.src = src.base, a.dst = dst.base, a.dog = dog.base;
-    a.src_img_stride = src.img_stride, a.dst_img_stride = dst.img_stride, a.dog_img_stride = dog.img_stride;
-    a.spitch = (int)src.pitch, a.dpitch = (int)dst.pitch, a.gpitch = (int)dog.pitch;
+    a.src = src.base, a.dst = dst.base;
+    a.src_img_stride = src.img_stride, a.dst_img_stride = dst.img_stride;
+    a.spitch = (int)src.pitch, a.dpitch = (int)dst.pitch;
     a.w = (int)src.w, a.h = (int)src.h;
     a.taps = t;
-    {
-      static int remap = -1;
-      if (remap < 0)
-      {
-        const char *e = getenv("VKSIFT_XCD_REMAP"); /* 0 disables the XCD-contiguous work mapping (A/B runs) */
-        remap = (e && e[0] == '0') ? 0 : 1;
-      }
-      a.xcd_remap = remap;
-    }
-    /* Row segments: enough workgroups to give every CU ~5 waves, but segments long enough that the 2R-row
-     * warm-up stays a small fraction. */
-    static int rows_per_group = -1;
-    if (rows_per_group < 0)
-    {
-      const char *e = getenv("VKSIFT_BLUR_ROWS"); /* rows per group of the streaming kernel: 4 or 8 (A/B runs) */
-      rows_per_group = (e && atoi(e) == 4) ? 4 : 8;
-    }
-    int nw = rows_per_group; /* forwarded to launch_stream; 0 selects k_blur_lean */
-    {
-      static int lean = -1;
-      if (lean < 0)
-      {
-        const char *e = getenv("VKSIFT_BLUR_LEAN"); /* 0: keep k_blur_stream everywhere (A/B runs) */
-        lean = (e && e[0] == '0') ? 0 : 1;
-      }
-      const uint32_t ra = ((ntaps - 1u) + 3u) & ~3u;
-      const uint32_t nstrips = (src.w + 127u) / 128u;
-      if (lean && (src.w % 4u) == 0 && ra <= src.w && nstrips * 128u + ra <= 2u * src.w)
-        nw = 0;
-    }
-    if (ds.base && nw != 0)
-      return -1; /* only k_blur_lean carries the fused down-sampling store */
-    static uint32_t wg_target = 0, min_seg_rows = 0;
-    static bool min_seg_env = false;
-    if (!wg_target)
-    {
-      const char *e = getenv("VKSIFT_BLUR_WGS"); /* A/B runs */
-      wg_target = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 10240u; /* ~40 waves per CU over the launch: segments of ~120 rows at 128 x 1280x960 (2560 long-lived waves left the slowest CU to set the time: -5 % per launch) */
-      e = getenv("VKSIFT_BLUR_MIN_SEG");
-      min_seg_env = e && atoi(e) > 0;
-      min_seg_rows = min_seg_env ? (uint32_t)atoi(e) : 64u;
-    }
-    const uint32_t strips = (src.w + 127u) / 128u;
-    uint32_t nseg = (wg_target + strips * batch - 1u) / (strips * batch);
-    /* small octaves are launch-latency bound: shorter segments (more waves) shorten each launch */
-    uint32_t seg_rows = min_seg_rows;
-    if (!min_seg_env)
-    {
-      /* launches that cannot fill the GPU with 64-row segments (small octaves, small batches) are latency bound: the
-       * shorter the row march of a wave, the shorter the launch — the extra halo rows cost nothing there */
-      const uint32_t waves64 = strips * batch * ((src.h + 63u) / 64u);
-      seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u);
-    }
-    uint32_t max_seg = (src.h + seg_rows - 1u) / seg_rows;
-    if (nseg > max_seg)
-      nseg = max_seg;
-    if (nseg < 1)
-      nseg = 1;
-    uint32_t seg = ((src.h + nseg - 1u) / nseg + 7u) & ~7u;
-    nseg = (src.h + seg - 1u) / seg;
-    a.seg = (int)seg;
-    dim3 grid(strips, nseg, batch);
-    const bool with_dog = dog.base != NULL;
+    const dim3 grid = stream_grid(src.w, src.h, batch, 10240u, &a.seg);
     hipStream_t hs = (hipStream_t)s;
     switch (ntaps)
     {
-#define VKSIFT_CASE(N)                    \
-  case N:                                 \
-    launch_stream<N>(a, with_dog, nw, grid, hs); \
+#define VKSIFT_CASE(N)                                                        \
+  case N:                                                                     \
+    hipLaunchKernelGGL((k_blur_lean<N, false>), grid, dim3(64), 0, hs, a);    \
     break;
       VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9) VKSIFT_CASE(10)
       VKSIFT_CASE(11) VKSIFT_CASE(12) VKSIFT_CASE(13) VKSIFT_CASE(14) VKSIFT_CASE(15) VKSIFT_CASE(16) VKSIFT_CASE(17) VKSIFT_CASE(18)
@@ -914,29 +633,36 @@ extern "C"
     return (int)hipGetLastError();
   }
 
+  int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, const float *taps, uint32_t ntaps, uint32_t batch, vksift_hip_stream s)
+  {
+    const vksift_hip_Plane none = {NULL, 0, 0, 0, 0};
+    return blur_impl(src, dst, none, taps, ntaps, batch, s);
+  }
+
+  int vksift_hip_blur_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane next, const float *taps, uint32_t ntaps, uint32_t batch,
+                                 vksift_hip_stream s)
+  {
+    if (next.base == NULL || dst.base == NULL || next.w * 2u != src.w || next.h * 2u != src.h)
+      return -1;
+    return blur_impl(src, dst, next, taps, ntaps, batch, s);
+  }
+
   int vksift_hip_seed_upsampled(const uint8_t *src, uint32_t sw, uint32_t sh, uint64_t src_img_stride, vksift_hip_Plane dst, const float *taps, uint32_t ntaps,
                                 uint32_t batch, vksift_hip_stream s)
   {
-    static int enabled = -1;
-    if (enabled < 0)
-    {
-      const char *e = getenv("VKSIFT_FUSED_SEED"); /* 0: separate blit + seed blur launches (A/B runs) */
-      enabled = (e && e[0] == '0') ? 0 : 1;
-    }
     const uint32_t W = dst.w, H = dst.h;
     const uint32_t ra = ((ntaps - 1u) + 3u) & ~3u;
     const uint32_t strips = (W + 127u) / 128u;
-    if (!enabled || ntaps < 2 || ntaps > VKSIFT_HIP_MAX_TAPS || W != 2 * sw || H != 2 * sh || (W % 4u) != 0 || sw < 4 || ra > W || strips * 128u + ra > 2u * W)
+    if (ntaps < 2 || ntaps > 12 || W != 2 * sw || H != 2 * sh || (W % 4u) != 0 || sw < 4 || ra > W || strips * 128u + ra > 2u * W)
       return -1; /* not applicable: the caller runs vksift_hip_input_blit + vksift_hip_blur */
     StreamArgs a;
     a.ds = NULL, a.ds_img_stride = 0, a.ds_pitch = 0;
-    a.src = (const float *)src, a.dst = dst.base, a.dog = NULL;
-    a.src_img_stride = src_img_stride, a.dst_img_stride = dst.img_stride, a.dog_img_stride = 0;
-    a.spitch = (int)sw, a.dpitch = (int)dst.pitch, a.gpitch = (int)dst.pitch;
+    a.src = (const float *)src, a.dst = dst.base;
+    a.src_img_stride = src_img_stride, a.dst_img_stride = dst.img_stride;
+    a.spitch = (int)sw, a.dpitch = (int)dst.pitch;
     a.w = (int)W, a.h = (int)H;
     for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
       a.taps.k[i] = i < ntaps ? taps[i] : 0.f;
-    a.xcd_remap = 1;
     uint32_t nseg = (1536u + strips * batch - 1u) / (strips * batch);
     uint32_t max_seg = (H + 63u) / 64u;
     if (nseg > max_seg)
@@ -949,9 +675,9 @@ extern "C"
     dim3 grid(strips, nseg, batch);
     switch (ntaps)
     {
-#define VKSIFT_CASE(N)                                                                              \
-  case N:                                                                                           \
-    hipLaunchKernelGGL((k_blur_lean<N, false, true>), grid, dim3(64), 0, (hipStream_t)s, a);       \
+#define VKSIFT_CASE(N)                                                                        \
+  case N:                                                                                     \
+    hipLaunchKernelGGL((k_blur_lean<N, true>), grid, dim3(64), 0, (hipStream_t)s, a);         \
     break;
       VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9) VKSIFT_CASE(10)
       VKSIFT_CASE(11) VKSIFT_CASE(12)
@@ -967,6 +693,13 @@ extern "C"
     dim3 grid((dst.w + 63) / 64, (dst.h + 3) / 4, batch);
     hipLaunchKernelGGL(k_downsample, grid, dim3(256), 0, (hipStream_t)s, src.base, src.img_stride, (int)src.w, (int)src.h, (int)src.pitch, dst.base,
                        dst.img_stride, (int)dst.w, (int)dst.h, (int)dst.pitch);
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_dog_plane(const float *lo, const float *hi, uint32_t w, uint32_t h, uint32_t pitch, float *out_dense, vksift_hip_stream s)
+  {
+    dim3 grid((w + 63) / 64, (h + 3) / 4, 1);
+    hipLaunchKernelGGL(k_dog_plane, grid, dim3(256), 0, (hipStream_t)s, lo, hi, (int)w, (int)h, (int)pitch, out_dense);
     return (int)hipGetLastError();
   }
 }

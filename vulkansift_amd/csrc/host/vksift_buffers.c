@@ -14,10 +14,11 @@ void wait_for_buffer(vksift_Instance inst, uint32_t buf)
     vksift_hip_event_sync(inst->ev_detect);
     mark_detect_done(inst);
   }
-  if (inst->match_pending && (buf == inst->match_a || buf == inst->match_b))
+  if (inst->match_pending && inst->match_busy[buf])
   {
     vksift_hip_event_sync(inst->ev_match);
     inst->match_pending = false;
+    memset(inst->match_busy, 0, sizeof(bool) * inst->cfg.sift_buffer_count);
   }
 }
 
@@ -145,6 +146,7 @@ void vksift_getScaleSpaceOctaveResolution(vksift_Instance instance, const uint8_
 
 static void download_plane(vksift_Instance inst, uint8_t octave, uint8_t scale, bool is_dog, float *dst, const char *fn)
 {
+  float *tmp = NULL;
   uint32_t nscales = inst->S + (is_dog ? 2 : 3);
   if (octave >= inst->lay.n_oct || scale >= nscales)
   {
@@ -160,22 +162,32 @@ static void download_plane(vksift_Instance inst, uint8_t octave, uint8_t scale, 
   /* images cannot be read while a detection runs (vulkansift.c:490-491) */
   HIP_CHECK(wait_all(inst), "stream synchronisation");
   const PyrLayout *L = &inst->lay;
-  if (!is_dog && scale == inst->S + 2 && inst->top_scale_stale[octave])
+  if (inst->d_pyr == NULL || inst->cur_w == 0)
   {
-    /* the detection pipeline kept only the DoG layer of the last scale: blur it now (image 0, the one this API exposes) */
-    const vksift_hip_Plane no_dog = {NULL, 0, 0, 0, 0};
-    HIP_CHECK(vksift_hip_blur(plane_at(inst, octave, L->gauss_off[octave], scale - 1), plane_at(inst, octave, L->gauss_off[octave], scale), no_dog,
-                              &inst->taps[scale * VKSIFT_MAX_TAPS], inst->ntaps[scale], 1, inst->stream),
-              "top scale blur");
-    inst->top_scale_stale[octave] = false;
+    logError(LOG_TAG, "%s error: no scale-space available (no detection since the last resize).", fn);
+    inst->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+    return;
   }
-  const float *src = inst->d_pyr + (is_dog ? L->dog_off[octave] : L->gauss_off[octave]) + (uint64_t)scale * L->plane_stride[octave];
-  HIP_CHECK(vksift_hip_memcpy2d_d2h(dst, sizeof(float) * L->w[octave], src, sizeof(float) * L->pitch[octave], sizeof(float) * L->w[octave], L->h[octave],
-                                    inst->stream),
-            "plane download");
+  const float *src = inst->d_pyr + L->gauss_off[octave] + (uint64_t)scale * L->plane_stride[octave];
+  if (is_dog)
+  {
+    /* DifferenceOfGaussian.comp layer z = G[z+1] - G[z]: the detection path forms these in registers and never stores them;
+     * this (debug) accessor materialises the requested layer of image 0 */
+    tmp = (float *)vksift_hip_malloc(sizeof(float) * (size_t)L->w[octave] * L->h[octave]);
+    if (!tmp)
+      goto gpu_error;
+    HIP_CHECK(vksift_hip_dog_plane(src, src + L->plane_stride[octave], L->w[octave], L->h[octave], L->pitch[octave], tmp, inst->stream), "DoG layer");
+    HIP_CHECK(vksift_hip_memcpy_d2h(dst, tmp, sizeof(float) * (size_t)L->w[octave] * L->h[octave], inst->stream), "plane download");
+  }
+  else
+    HIP_CHECK(vksift_hip_memcpy2d_d2h(dst, sizeof(float) * L->w[octave], src, sizeof(float) * L->pitch[octave], sizeof(float) * L->w[octave], L->h[octave],
+                                      inst->stream),
+              "plane download");
   HIP_CHECK(vksift_hip_stream_sync(inst->stream), "plane download");
+  vksift_hip_free(tmp);
   return;
 gpu_error:
+  vksift_hip_free(tmp);
   logError(LOG_TAG, "%s error when downloading pyramid image from GPU memory.", fn);
   inst->error_cb(VKSIFT_VULKAN_ERROR);
 }

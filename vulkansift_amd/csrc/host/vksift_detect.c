@@ -41,6 +41,7 @@ void account_set(vksift_Instance inst, ProfSet *ps)
   inst->acc_ms[3] += vksift_hip_event_elapsed_ms(e[3], e[4]);
   inst->acc_ms[4] += vksift_hip_event_elapsed_ms(e[4], e[5]);
   inst->acc_ms[5] += vksift_hip_event_elapsed_ms(e[0], e[6]);
+  inst->acc_ms[6] += vksift_hip_event_elapsed_ms(e[2], ps->ev_scan);
   inst->acc_calls++;
   inst->acc_blur_launches += ps->blur_launches;
   inst->acc_alg_bytes += ps->alg_bytes;
@@ -95,7 +96,6 @@ static void build_jobs(DetectCtx *c)
   {
     vksift_hip_OctaveJob *j = &c->jobs[o];
     memset(j, 0, sizeof(*j));
-    j->dog = inst->d_pyr + L->dog_off[o];
     j->gauss = inst->d_pyr + L->gauss_off[o];
     j->w = L->w[o], j->h = L->h[o], j->pitch = L->pitch[o];
     j->plane_stride = L->plane_stride[o];
@@ -130,13 +130,14 @@ static void build_jobs(DetectCtx *c)
   }
 }
 
-/* Scale-space construction + DoG of octave o on stream sp (sift_detector.c:881-1079). *g0_done: plane 0 of this octave was
- * already written by the previous octave's chain kernel; on return it tells the same for the next octave. */
+/* Scale-space construction of octave o on stream sp (sift_detector.c:881-1037). The DoG pass of the reference
+ * (sift_detector.c:1039-1079) has no counterpart: the extrema stage forms D[s] = G[s+1] - G[s] from the Gaussian planes.
+ * *g0_done: plane 0 of this octave was already written by the previous octave's scale-S pass; on return it tells the same
+ * for the next octave. */
 static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool *g0_done)
 {
   vksift_Instance inst = c->inst;
   const PyrLayout *L = c->L;
-  const vksift_hip_Plane no_dog = {NULL, 0, 0, 0, 0};
   uint32_t nb_o = 0;
   vksift_hip_range_push("Scale space construction");
   if (o == 0)
@@ -156,7 +157,13 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool 
     {
       vksift_hip_Plane tmp = plane_at(inst, 0, L->gauss_off[0], 1);
       TRY(vksift_hip_input_blit(c->d_src, c->w, c->h, c->img_bytes, tmp, c->count, sp), "input blit");
-      TRY(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), no_dog, &inst->taps[0], inst->ntaps[0], c->count, sp), "seed blur");
+      TRY(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), &inst->taps[0], inst->ntaps[0], c->count, sp), "seed blur");
+    }
+    /* d_input has been consumed: the next upload (possibly on another stream) may overwrite it after this point */
+    if (!c->capturing)
+    {
+      TRY(vksift_hip_event_record(inst->ev_input_free, sp), "event record");
+      inst->input_free_valid = true;
     }
     nb_o++;
   }
@@ -168,58 +175,29 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool 
       TRY(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), c->count, sp), "downsample");
   }
   *g0_done = false;
-  inst->top_scale_stale[o] = false;
-  if (inst->use_chain && L->h[o] >= inst->chain_min_rows)
+  /* The next octave needs scale S only. For workloads large enough to be bandwidth bound, octave 1 nevertheless waits for
+   * octave 0's whole pyramid: the two bandwidth-bound chains do not compete (octave 0 runs 5-8 % faster alone) and the
+   * coarse octaves then overlap octave 0's extraction and descriptor stages. A small image is latency bound: earliest start. */
+  const bool big = (uint64_t)c->count * c->w * c->h >= (4u << 20);
+  const uint32_t ready_after = (big && o == 0) ? inst->S + 2 : inst->S;
+  for (uint32_t s = 1; s < inst->S + 3; s++)
   {
-    /* experimental: one launch for scales 1..S+2 and all DoG layers; it also seeds the next octave when the sizes are exactly 2:1 */
-    vksift_hip_Plane next = {NULL, 0, 0, 0, 0};
-    if (o + 1 < L->n_oct && L->w[o + 1] * 2 == L->w[o] && L->h[o + 1] * 2 == L->h[o])
+    const vksift_hip_Plane srcp = plane_at(inst, o, L->gauss_off[o], s - 1), dstp = plane_at(inst, o, L->gauss_off[o], s);
+    int fused_ds = -1;
+    if (s == inst->S && o + 1 < L->n_oct)
     {
-      next = plane_at(inst, o + 1, L->gauss_off[o + 1], 0);
-      *g0_done = true;
+      /* scale S also seeds the next octave (sift_detector.c:1003-1034): stored by the same pass when the sizes halve exactly */
+      fused_ds = vksift_hip_blur_downsample(srcp, dstp, plane_at(inst, o + 1, L->gauss_off[o + 1], 0), &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], c->count, sp);
+      if (fused_ds > 0)
+        TRY(fused_ds, "blur + down-sampling");
+      if (fused_ds == 0)
+        *g0_done = true;
     }
-    TRY(vksift_hip_octave_chain(plane_at(inst, o, L->gauss_off[o], 0), L->plane_stride[o], inst->d_pyr + L->dog_off[o], next, inst->taps, VKSIFT_MAX_TAPS,
-                                c->count, sp),
-        "octave chain");
+    if (fused_ds < 0)
+      TRY(vksift_hip_blur(srcp, dstp, &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], c->count, sp), "blur");
     nb_o++;
-    if (c->par && o + 1 < L->n_oct)
+    if (c->par && o + 1 < L->n_oct && s == ready_after)
       TRY(vksift_hip_event_record(inst->ev_oct_ready[o], sp), "event record");
-  }
-  else
-  {
-    /* the next octave may start once scale S exists; with coarse_after octave 1 waits for octave 0's whole pyramid */
-    /* (only for workloads large enough to be bandwidth bound: for a small image the octave chain is the latency) */
-    const bool big = (uint64_t)c->count * c->w * c->h >= (4u << 20);
-    const uint32_t ready_after = (inst->coarse_after && big && o == 0) ? inst->S + 2 : inst->S;
-    for (uint32_t s = 1; s < inst->S + 3; s++)
-    {
-      vksift_hip_Plane dstp = plane_at(inst, o, L->gauss_off[o], s);
-      if (s == inst->S + 2 && inst->lazy_top_scale)
-      {
-        /* nothing reads Gaussian scale S+2 (keypoints use scales 1..S, the next octave scale S): keep its DoG layer only;
-         * vksift_downloadScaleSpaceImage() re-creates the plane on demand */
-        dstp.base = NULL;
-        inst->top_scale_stale[o] = true;
-      }
-      int fused_ds = -1;
-      if (s == inst->S && o + 1 < L->n_oct)
-      {
-        /* scale S also seeds the next octave (sift_detector.c:1003-1034): stored by the same pass when the sizes halve exactly */
-        fused_ds = vksift_hip_blur_downsample(plane_at(inst, o, L->gauss_off[o], s - 1), dstp, plane_at(inst, o, L->dog_off[o], s - 1),
-                                              plane_at(inst, o + 1, L->gauss_off[o + 1], 0), &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], c->count, sp);
-        if (fused_ds > 0)
-          TRY(fused_ds, "blur + down-sampling");
-        if (fused_ds == 0)
-          *g0_done = true;
-      }
-      if (fused_ds < 0)
-        TRY(vksift_hip_blur(plane_at(inst, o, L->gauss_off[o], s - 1), dstp, plane_at(inst, o, L->dog_off[o], s - 1), &inst->taps[s * VKSIFT_MAX_TAPS],
-                            inst->ntaps[s], c->count, sp),
-            "blur");
-      nb_o++;
-      if (c->par && o + 1 < L->n_oct && s == ready_after)
-        TRY(vksift_hip_event_record(inst->ev_oct_ready[o], sp), "event record");
-    }
   }
   vksift_hip_range_pop();
   if (!c->pipelined || o == 0)
@@ -238,7 +216,7 @@ static int enqueue_keypoint_chain(DetectCtx *c, uint32_t o, vksift_hip_stream so
   if (timed)
     vksift_hip_event_record(c->PS->ev_t[2], inst->stream);
   vksift_hip_range_push("ExtractKeypoints");
-  TRY(vksift_hip_extract_keypoints(&c->jobs[o], c->count, so), "keypoint extraction");
+  TRY(vksift_hip_extract_keypoints(&c->jobs[o], c->count, so, timed ? c->PS->ev_scan : NULL), "keypoint extraction");
   vksift_hip_range_pop();
   if (timed)
     vksift_hip_event_record(c->PS->ev_t[3], inst->stream);
@@ -261,6 +239,8 @@ static int enqueue_keypoint_chain(DetectCtx *c, uint32_t o, vksift_hip_stream so
 }
 
 /* one keypoint stage of the stage-synchronous / serial schedules: fork one stream per octave, join back */
+static int extract_untimed(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s) { return vksift_hip_extract_keypoints(job, batch, s, NULL); }
+
 static int enqueue_stage(DetectCtx *c, int g, const char *name, int (*call)(const vksift_hip_OctaveJob *, uint32_t, vksift_hip_stream), const char *what)
 {
   vksift_Instance inst = c->inst;
@@ -287,14 +267,13 @@ static int enqueue_stage(DetectCtx *c, int g, const char *name, int (*call)(cons
 /* Everything a detection puts on the GPU, from the image upload to the count read-back: the part a hipGraph captures.
  *
  * Octave o+1 only needs scale S of octave o, and everything after the pyramid is per octave (own SIFT-buffer section,
- * own scratch). Three schedules:
+ * own scratch). Two schedules:
  *   pipelined (default): octave 0 runs on the instance stream, every other octave runs its whole chain
  *     pyramid -> ExtractKeypoints -> ComputeOrientation -> ComputeDescriptors on its own stream, started by the
  *     event "the previous octave's scale S (octave 0: whole pyramid) is ready"; the instance stream joins them before
  *     the count read-back. The latency-bound launch chains of the coarse octaves hide behind the bandwidth-bound work
  *     of the fine ones. Profiling events then time octave 0's stages (the other octaves overlap them).
- *   stage-synchronous (VKSIFT_STAGE_SYNC=1): fork per octave inside each stage, join at every stage boundary.
- *   serial (VKSIFT_SERIAL_OCTAVES=1): everything on the instance stream. */
+ *   serial (VKSIFT_SERIAL_OCTAVES=1, and single-octave images): everything on the instance stream. */
 static int enqueue_detection(DetectCtx *c)
 {
   vksift_Instance inst = c->inst;
@@ -303,7 +282,10 @@ static int enqueue_detection(DetectCtx *c)
 
   if (c->upload)
   {
-    vksift_hip_stream s_up = c->overlap ? inst->pyr_stream[0] : st; /* behind the previous reader of d_input either way */
+    vksift_hip_stream s_up = c->overlap ? inst->pyr_stream[0] : st;
+    /* behind the previous reader of d_input, whichever stream that detection's seed pass ran on */
+    if (inst->input_free_valid && !c->capturing)
+      TRY(vksift_hip_stream_wait_event(s_up, inst->ev_input_free), "input buffer recycle");
     TRY(vksift_hip_memcpy_h2d(inst->d_input, inst->h_input, c->img_bytes * c->count, s_up), "image upload");
     if (!c->capturing)
     {
@@ -348,9 +330,10 @@ static int enqueue_detection(DetectCtx *c)
     for (uint32_t o = 0; o < L->n_oct; o++)
       if (o > 0 || !c->pipelined)
         TRY(vksift_hip_stream_wait_event(st, inst->ev_join[0][o]), "octave join");
-  if (c->overlap)
+  if (inst->pyr_pingpong && !c->capturing)
   {
-    /* everything that reads this call's pyramid has been joined into the instance stream */
+    /* everything that reads this call's pyramid has been joined into the instance stream (also recorded by the calls that
+     * do not overlap — tiny images, serial mode — so that a later overlapped call never recycles the buffer under them) */
     TRY(vksift_hip_event_record(inst->ev_pyr_free[inst->pyr_cur], st), "event record");
     inst->pyr_free_valid[inst->pyr_cur] = true;
   }
@@ -364,7 +347,7 @@ static int enqueue_detection(DetectCtx *c)
      * into the main stream, so stage boundaries (and the stage timings) stay well defined. */
     if (c->prof)
       vksift_hip_event_record(c->PS->ev_t[2], st);
-    TRY(enqueue_stage(c, 1, "ExtractKeypoints", vksift_hip_extract_keypoints, "keypoint extraction"), "keypoint extraction");
+    TRY(enqueue_stage(c, 1, "ExtractKeypoints", extract_untimed, "keypoint extraction"), "keypoint extraction");
     if (c->prof)
       vksift_hip_event_record(c->PS->ev_t[3], st);
     TRY(enqueue_stage(c, 2, "ComputeOrientation", vksift_hip_orientations, "orientation"), "orientation");
@@ -470,7 +453,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   c.inst = inst, c.L = &inst->lay, c.PS = PS;
   c.prof = inst->profiling;
   c.par = !inst->serial_octaves && c.L->n_oct > 1;
-  c.pipelined = c.par && !inst->stage_sync;
+  c.pipelined = c.par;
   /* Overlapping detections (VKSIFT_PYR_PINGPONG=1): with two pyramid buffers the scale-space construction of this call
    * does not depend on anything the previous call (or a matching still in flight) reads or writes, so it runs on its own
    * streams, ordered only behind the last reader of the pyramid buffer it recycles; everything that touches the SIFT
@@ -492,7 +475,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
       HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream[0], inst->ev_pyr_free[inst->pyr_cur]), "pyramid buffer recycle");
     /* pair the bandwidth-bound pyramid with the compute-bound tail of the previous detection (descriptors, matching),
      * not with its equally bandwidth-bound extraction stage */
-    if (inst->overlap_gate && inst->desc_start_valid)
+    if (inst->desc_start_valid)
       HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream[0], inst->ev_desc_start), "overlap gate");
   }
 
@@ -506,13 +489,13 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   }
   build_jobs(&c);
 
-  /* host-visible events (staging, completion, profiling) stay outside a captured region */
-  const bool replay = inst->use_graphs && !c.prof && !c.overlap && (uint64_t)count * w * h <= inst->graph_max_pixels;
+  /* host-visible events (staging, completion, profiling) stay outside a captured region; a captured graph holds the address
+   * of ONE pyramid buffer, so instances with two (ping-pong) never replay */
+  const bool replay = inst->use_graphs && !c.prof && !inst->pyr_pingpong && (uint64_t)count * w * h <= inst->graph_max_pixels;
   DetectGraph *dg = replay ? graph_lookup(inst, &c) : NULL;
   if (dg && dg->exec)
   {
     HIP_CHECK(vksift_hip_graph_launch(dg->exec, st), "detection graph launch");
-    memcpy(inst->top_scale_stale, dg->top_scale_stale, sizeof(inst->top_scale_stale));
     inst->graph_miss_run = 0;
   }
   else
@@ -539,7 +522,6 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
       HIP_CHECK(vksift_hip_capture_end(st, &exec), "detection graph capture");
       dg->exec = exec;
       dg->w = w, dg->h = h, dg->count = count, dg->first_buf = first_buf, dg->d_src = c.d_src;
-      memcpy(dg->top_scale_stale, inst->top_scale_stale, sizeof(inst->top_scale_stale));
       HIP_CHECK(vksift_hip_graph_launch(dg->exec, st), "detection graph launch");
     }
   }

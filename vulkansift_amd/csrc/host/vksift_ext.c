@@ -33,6 +33,7 @@ void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext
   sum->orientation_ms = (float)instance->acc_ms[3];
   sum->descriptor_ms = (float)instance->acc_ms[4];
   sum->total_ms = (float)instance->acc_ms[5];
+  sum->scan_ms = (float)instance->acc_ms[6];
   sum->nb_blur_launches = (uint32_t)instance->acc_blur_launches;
   sum->pyramid_algorithmic_bytes = instance->acc_alg_bytes;
   *nb_calls = instance->acc_calls;
@@ -60,6 +61,7 @@ void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimi
   out->orientation_ms = vksift_hip_event_elapsed_ms(e[3], e[4]);
   out->descriptor_ms = vksift_hip_event_elapsed_ms(e[4], e[5]);
   out->total_ms = vksift_hip_event_elapsed_ms(e[0], e[6]);
+  out->scan_ms = vksift_hip_event_elapsed_ms(e[2], ps->ev_scan);
   out->nb_blur_launches = instance->last_blur_launches;
   out->pyramid_algorithmic_bytes = instance->last_alg_bytes;
 }

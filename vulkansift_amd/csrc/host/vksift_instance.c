@@ -19,8 +19,6 @@ void compute_layout(vksift_Instance inst, uint32_t w, uint32_t h, PyrLayout *L)
     L->plane_stride[o] = (uint64_t)L->pitch[o] * L->h[o];
     L->gauss_off[o] = off;
     off += L->plane_stride[o] * (inst->S + 3);
-    L->dog_off[o] = off;
-    off += L->plane_stride[o] * (inst->S + 2);
   }
   L->img_floats = off;
   uint64_t so = 0, co = 0;
@@ -29,9 +27,9 @@ void compute_layout(vksift_Instance inst, uint32_t w, uint32_t h, PyrLayout *L)
     L->seg_off[o] = so;
     so += (uint64_t)inst->S * L->h[o] * ((L->w[o] + 63) / 64);
     L->cand_off[o] = co;
-    /* strict 3x3x3 extrema cannot be denser than 1/4 of the texels; 1/8 (after the contrast pre-filter) is reserved,
-     * excess candidates of a pathological image are dropped in raster order */
-    L->cand_cap[o] = (uint64_t)inst->S * L->w[o] * L->h[o] / 8u + 64u;
+    /* strict 3x3x3 maxima cannot be denser than 1/8 of the texels (no two are adjacent), nor can minima: 1/4 together is a
+     * bound no image exceeds, so candidates are only ever lost through the section capacity, like in the reference */
+    L->cand_cap[o] = (uint64_t)inst->S * L->w[o] * L->h[o] / 4u + 64u;
     co += L->cand_cap[o];
   }
   L->seg_total = so;
@@ -176,7 +174,8 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   ALLOC_H(inst->h_match_n, sizeof(uint32_t) * 4 * batch_cap);
   inst->h_matches = NULL;
   inst->bufs = (BufferInfo *)calloc(config->sift_buffer_count, sizeof(BufferInfo));
-  ok = ok && inst->bufs != NULL;
+  inst->match_busy = (bool *)calloc(config->sift_buffer_count, sizeof(bool));
+  ok = ok && inst->bufs != NULL && inst->match_busy != NULL;
   /* All streams at the default priority: a high-priority instance stream with low-priority octave streams was measured
    * 20 % slower on MI355X (11.3k vs 14.1k frames/s). */
   inst->stream = vksift_hip_stream_create();
@@ -197,24 +196,12 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     inst->ev_pyr_done[o] = vksift_hip_event_create();
   }
   inst->ev_desc_start = vksift_hip_event_create();
-  {
-    const char *e = getenv("VKSIFT_OVERLAP_GATE");
-    inst->overlap_gate = e ? atoi(e) : 1;
-  }
+  inst->ev_input_free = vksift_hip_event_create();
   for (int i = 0; i < 2; i++)
-  {
     inst->ev_pyr_free[i] = vksift_hip_event_create();
-  }
   {
-    const char *e = getenv("VKSIFT_SERIAL_OCTAVES"); /* debug: everything on the main stream */
+    const char *e = getenv("VKSIFT_SERIAL_OCTAVES"); /* debug: everything on the instance stream */
     inst->serial_octaves = e && e[0] == '1';
-    e = getenv("VKSIFT_LAZY_TOP"); /* 0: always store the last Gaussian scale of every octave */
-    inst->lazy_top_scale = !(e && e[0] == '0');
-    /* Octave 1 starts after octave 0's last blur instead of right after its scale S: the two bandwidth-bound pyramids no
-     * longer compete (octave 0 runs 5-8 % faster alone; frames/s unchanged within noise), and the coarse octaves then
-     * overlap octave 0's extraction and descriptor stages. VKSIFT_COARSE_AFTER=0 restores the earliest possible start. */
-    e = getenv("VKSIFT_COARSE_AFTER");
-    inst->coarse_after = !(e && e[0] == '0');
     /* hipGraph capture + replay of the detection launch sequence. Measured on MI355X / ROCm 7.2: 10 % faster for one
      * 640x480 image (0.58 vs 0.65 ms), 12 % slower from 1536x1024 up (the graph runs the per-octave branches less
      * concurrently than the streams do) -> by default only small workloads are replayed (graph_max_pixels).
@@ -222,14 +209,6 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     e = getenv("VKSIFT_GRAPH");
     inst->use_graphs = !(e && e[0] == '0');
     inst->graph_max_pixels = (e && e[0] == '1') ? ~(uint64_t)0 : (uint64_t)640 * 480;
-    e = getenv("VKSIFT_STAGE_SYNC");
-    inst->stage_sync = e && e[0] == '1';
-    /* 1 selects the experimental fused scale-chain kernel (pyramid_fused.hip): bit-identical, but measured slower than the
-     * per-scale kernels on MI355X (VALU-issue bound) -> off by default */
-    e = getenv("VKSIFT_CHAIN");
-    inst->use_chain = (e && e[0] == '1') && vksift_hip_octave_chain_supported(inst->ntaps, inst->S);
-    e = getenv("VKSIFT_CHAIN_MIN_ROWS");
-    inst->chain_min_rows = e ? (uint32_t)atoi(e) : 200u;
   }
   inst->ev_detect = vksift_hip_event_create();
   inst->ev_match = vksift_hip_event_create();
@@ -244,6 +223,8 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     inst->prof[0].ev_pt[i] = vksift_hip_event_create();
     inst->prof[1].ev_pt[i] = vksift_hip_event_create();
   }
+  inst->prof[0].ev_scan = vksift_hip_event_create();
+  inst->prof[1].ev_scan = vksift_hip_event_create();
   inst->ev_m[0] = vksift_hip_event_create();
   inst->ev_m[1] = vksift_hip_event_create();
   ok = ok && inst->stream && inst->ev_detect && inst->ev_match;
@@ -334,6 +315,7 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_host_free(inst->h_match_n);
   vksift_hip_host_free(inst->h_matches);
   free(inst->bufs);
+  free(inst->match_busy);
   vksift_hip_event_destroy(inst->ev_detect);
   vksift_hip_event_destroy(inst->ev_match);
   vksift_hip_event_destroy(inst->ev_staging);
@@ -352,6 +334,9 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
     vksift_hip_event_destroy(inst->ev_pyr_done[o]);
   }
   vksift_hip_event_destroy(inst->ev_desc_start);
+  vksift_hip_event_destroy(inst->ev_input_free);
+  vksift_hip_event_destroy(inst->prof[0].ev_scan);
+  vksift_hip_event_destroy(inst->prof[1].ev_scan);
   for (int i = 0; i < 2; i++)
   {
     vksift_hip_event_destroy(inst->ev_pyr_free[i]);
@@ -398,6 +383,7 @@ bool match_running(vksift_Instance inst)
   if (vksift_hip_event_busy(inst->ev_match) == 1)
     return true;
   inst->match_pending = false;
+  memset(inst->match_busy, 0, sizeof(bool) * inst->cfg.sift_buffer_count);
   return false;
 }
 /* The reservation made at creation covers a square image of input_image_max_size pixels plus 25 %. A narrow image of the
@@ -439,12 +425,27 @@ int grow_image_scratch(vksift_Instance inst, const PyrLayout *L)
   inst->d_seg_off = vksift_hip_malloc(sizeof(uint32_t) * new_seg * n);
   inst->d_cand_xy = vksift_hip_malloc(sizeof(uint32_t) * new_cand * n);
   inst->d_cand_flag = vksift_hip_malloc(sizeof(uint32_t) * new_cand * n);
-  inst->pyr_img_stride = new_pyr, inst->seg_cap = new_seg, inst->cand_cap = new_cand;
-  inst->d_pyr = inst->d_pyr_buf[inst->pyr_pingpong ? inst->pyr_cur : 0];
   inst->pyr_free_valid[0] = inst->pyr_free_valid[1] = false;
   inst->cur_w = inst->cur_h = 0; /* no scale-space to download until the next detection */
   const bool ok = inst->d_pyr_buf[0] && (!inst->pyr_pingpong || inst->d_pyr_buf[1]) && inst->d_seg_mask && inst->d_seg_off && inst->d_cand_xy && inst->d_cand_flag;
-  return ok ? 0 : -1;
+  if (!ok)
+  {
+    /* out of device memory: leave NO scratch behind (capacities 0), so that the next detection retries the allocation or
+     * fails cleanly with VKSIFT_VULKAN_ERROR instead of launching kernels on freed pointers */
+    vksift_hip_free(inst->d_pyr_buf[0]);
+    vksift_hip_free(inst->d_pyr_buf[1]);
+    vksift_hip_free(inst->d_seg_mask);
+    vksift_hip_free(inst->d_seg_off);
+    vksift_hip_free(inst->d_cand_xy);
+    vksift_hip_free(inst->d_cand_flag);
+    inst->d_pyr_buf[0] = inst->d_pyr_buf[1] = inst->d_pyr = NULL;
+    inst->d_seg_mask = NULL, inst->d_seg_off = NULL, inst->d_cand_xy = NULL, inst->d_cand_flag = NULL;
+    inst->pyr_img_stride = 0, inst->seg_cap = 0, inst->cand_cap = 0;
+    return -1;
+  }
+  inst->pyr_img_stride = new_pyr, inst->seg_cap = new_seg, inst->cand_cap = new_cand;
+  inst->d_pyr = inst->d_pyr_buf[inst->pyr_pingpong ? inst->pyr_cur : 0];
+  return 0;
 }
 
 int wait_all(vksift_Instance inst)
@@ -453,6 +454,7 @@ int wait_all(vksift_Instance inst)
   int e = vksift_hip_stream_sync(inst->stream);
   mark_detect_done(inst);
   inst->match_pending = false;
+  memset(inst->match_busy, 0, sizeof(bool) * inst->cfg.sift_buffer_count);
   return e;
 }
 
@@ -463,7 +465,7 @@ bool vksift_isBufferAvailable(vksift_Instance instance, const uint32_t gpu_buffe
     return true;
   if (detect_running(instance) && !instance->bufs[gpu_buffer_id].counts_valid)
     return false;
-  if (match_running(instance) && (gpu_buffer_id == instance->match_a || gpu_buffer_id == instance->match_b))
+  if (match_running(instance) && instance->match_busy[gpu_buffer_id])
     return false;
   return true;
 }

@@ -43,8 +43,7 @@ typedef struct
   uint32_t n_oct;
   uint32_t w[VKSIFT_MAX_OCTAVES], h[VKSIFT_MAX_OCTAVES], pitch[VKSIFT_MAX_OCTAVES];
   uint64_t plane_stride[VKSIFT_MAX_OCTAVES]; /* floats */
-  uint64_t gauss_off[VKSIFT_MAX_OCTAVES];    /* floats from the image's pyramid base */
-  uint64_t dog_off[VKSIFT_MAX_OCTAVES];
+  uint64_t gauss_off[VKSIFT_MAX_OCTAVES];    /* floats from the image's pyramid base: S+3 Gaussian planes per octave (no DoG planes) */
   uint64_t img_floats; /* floats used by one image */
   uint64_t seg_off[VKSIFT_MAX_OCTAVES], seg_total;   /* per-octave slices of the segment scratch (elements) */
   uint64_t cand_off[VKSIFT_MAX_OCTAVES], cand_cap[VKSIFT_MAX_OCTAVES], cand_total;
@@ -58,7 +57,6 @@ typedef struct
   vksift_hip_graph exec;
   uint32_t w, h, count, first_buf;
   const uint8_t *d_src;
-  bool top_scale_stale[VKSIFT_MAX_OCTAVES];
   uint64_t stamp;
 } DetectGraph;
 
@@ -73,6 +71,7 @@ typedef struct
 {
   vksift_hip_event ev_t[8];  /* instance stream: start, upload end, pyramid end, extrema end, orientation end, descriptor end, call end */
   vksift_hip_event ev_pt[2]; /* start / end of octave 0's scale-space construction on its own stream (overlapping detections) */
+  vksift_hip_event ev_scan;  /* octave 0's streaming extrema scan (the kernel that forms the DoG values) has run */
   bool valid, accounted, overlap;
   uint32_t blur_launches;
   uint64_t alg_bytes;
@@ -149,19 +148,14 @@ struct vksift_Instance_T
   vksift_hip_event ev_pyr_free[2]; /* last reader of pyramid buffer i has finished */
   vksift_hip_event ev_desc_start;  /* octave 0 of the previous detection has reached its (compute-bound) descriptor stage */
   bool desc_start_valid;
-  int overlap_gate;                /* 0: next pyramid starts as early as possible, 1: not before the previous descriptor stage */
+  vksift_hip_event ev_input_free;  /* the last reader of d_input (seed pass of the most recent detection) has run */
+  bool input_free_valid;
   vksift_hip_event ev_fork[4], ev_join[4][VKSIFT_MAX_OCTAVES], ev_oct_ready[VKSIFT_MAX_OCTAVES];
   bool serial_octaves;
-  bool lazy_top_scale;    /* do not store Gaussian scale S+2 (only its DoG layer is consumed); re-created on download */
-  bool top_scale_stale[VKSIFT_MAX_OCTAVES];
-  bool coarse_after;      /* coarse octaves start after octave 0's pyramid instead of after its scale S */
-  bool stage_sync;        /* debug: join all octaves at every stage boundary instead of per-octave pipelines */
-  bool use_chain;         /* fused per-octave scale chain (pyramid_fused.hip) available for this tap set */
-  uint32_t chain_min_rows; /* octaves shorter than this keep the per-scale kernels (pipeline ramp dominates) */
   vksift_hip_event ev_detect, ev_match;
   bool detect_pending, match_pending;
   uint32_t detect_first_buf, detect_count;
-  uint32_t match_a, match_b;
+  bool *match_busy; /* per SIFT buffer: read by the matching pipeline in flight (all pairs of a batched call) */
   uint32_t curr_nb_matches;
 
   /* profiling */
@@ -170,7 +164,7 @@ struct vksift_Instance_T
   int prof_cur;
   vksift_hip_event ev_m[2];
   bool match_timing_valid;
-  double acc_ms[6];
+  double acc_ms[7]; /* upload, pyramid, extrema stage, orientation, descriptor, total, extrema scan kernel alone */
   uint32_t acc_calls;
   uint64_t acc_blur_launches, acc_alg_bytes;
   uint32_t last_blur_launches;

@@ -99,25 +99,27 @@ static int match_slots(vksift_Instance inst, const MatchScratch *ms, const uint3
 /* reverse-matching scratch + survivor lists of vksift_ext_matchFeaturesFiltered, allocated on first use */
 static bool ensure_filter_scratch(vksift_Instance inst)
 {
-  if (inst->d_filtered)
-    return true;
   const uint32_t bc = inst->batch_cap;
   inst->filtered_slot_stride = (((uint64_t)inst->cfg.max_nb_sift_per_buffer * 16u) + 255u) & ~(uint64_t)255u;
+  /* each block only if it does not exist yet: a call that ran out of memory half-way is retried without leaking */
   bool ok = true;
-  ok = ok && (inst->rev.desc_a = vksift_hip_malloc(inst->desc_slot_stride * bc)) != NULL;
-  ok = ok && (inst->rev.desc_b = vksift_hip_malloc(inst->desc_slot_stride * bc)) != NULL;
-  ok = ok && (inst->rev.matches = vksift_hip_malloc(inst->match_slot_stride * bc)) != NULL;
-  ok = ok && (inst->rev.norms = vksift_hip_malloc(sizeof(uint32_t) * inst->norm_slot_stride * bc)) != NULL;
-  ok = ok && (inst->rev.match_n = vksift_hip_malloc(sizeof(uint32_t) * 4 * bc)) != NULL;
-  ok = ok && (inst->d_filtered_n = vksift_hip_malloc(sizeof(uint32_t) * bc)) != NULL;
-  ok = ok && (inst->h_filtered_n = vksift_hip_host_malloc(sizeof(uint32_t) * bc)) != NULL;
-  ok = ok && (inst->d_filtered = vksift_hip_malloc(inst->filtered_slot_stride * bc)) != NULL;
+#define ENSURE_D(ptr, bytes) ok = ok && ((ptr) != NULL || ((ptr) = vksift_hip_malloc(bytes)) != NULL)
+  ENSURE_D(inst->rev.desc_a, inst->desc_slot_stride * bc);
+  ENSURE_D(inst->rev.desc_b, inst->desc_slot_stride * bc);
+  ENSURE_D(inst->rev.matches, inst->match_slot_stride * bc);
+  ENSURE_D(inst->rev.norms, sizeof(uint32_t) * inst->norm_slot_stride * bc);
+  ENSURE_D(inst->rev.match_n, sizeof(uint32_t) * 4 * bc);
+  ENSURE_D(inst->d_filtered_n, sizeof(uint32_t) * bc);
+  ENSURE_D(inst->d_filtered, inst->filtered_slot_stride * bc);
+#undef ENSURE_D
+  ok = ok && (inst->h_filtered_n != NULL || (inst->h_filtered_n = vksift_hip_host_malloc(sizeof(uint32_t) * bc)) != NULL);
   return ok;
 }
 
 static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32_t *ids_b, uint32_t count, const char *fn, bool filter, float ratio,
                        bool cross_check)
 {
+  bool range_open = false;
   bool valid = count >= 1 && count <= inst->batch_cap && count <= 64;
   for (uint32_t i = 0; valid && i < count; i++)
     valid = buffer_idx_valid(inst, ids_a[i]) && buffer_idx_valid(inst, ids_b[i]);
@@ -131,6 +133,7 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
   if (inst->profiling)
     vksift_hip_event_record(inst->ev_m[0], inst->stream);
   vksift_hip_range_push("Matching");
+  range_open = true;
   /* one batched launch sequence when every A buffer and every B buffer share a section layout (always the case
    * after a batched detection), otherwise pair by pair */
   bool uniform = true;
@@ -167,18 +170,22 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
     inst->filtered_slots_used = count;
   }
   vksift_hip_range_pop();
+  range_open = false;
   if (inst->profiling)
   {
     vksift_hip_event_record(inst->ev_m[1], inst->stream);
     inst->match_timing_valid = true;
   }
+  (void)match_running(inst); /* an earlier matching that has completed releases its buffers; one still in flight keeps them */
   HIP_CHECK(vksift_hip_event_record(inst->ev_match, inst->stream), "event record");
   inst->match_pending = true;
   inst->match_slots_used = count;
-  inst->match_a = ids_a[0];
-  inst->match_b = ids_b[0];
+  for (uint32_t i = 0; i < count; i++)
+    inst->match_busy[ids_a[i]] = inst->match_busy[ids_b[i]] = true; /* every pair of a batched call (vksift_isBufferAvailable) */
   return;
 gpu_error:
+  if (range_open)
+    vksift_hip_range_pop();
   logError(LOG_TAG, "%s error: Failed to start the matching pipeline.", fn);
   inst->error_cb(VKSIFT_VULKAN_ERROR);
 }
