@@ -6,30 +6,47 @@
         bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): SIFT detect+match frames/s on 640x480 frames with ~2k keypoints.
-One "step" = one pass of the hot path over one batch of `--batch` (default 128) synthetic 640x480 frames that are
-already resident in HBM: batched detection (default vksift_Config: 2x up-sampling, automatic octave
-count = 5, 3 scales/octave) followed by the 2-NN self-match of every frame (matchFeatures(i, i) of BASELINE
-config 2, issued through the batched extension vksift_ext_matchFeaturesBatch). Every step recomputes everything; nothing is cached between steps.
 
-Multi-GPU: one process per GPU; each rank owns its own batch (weak scaling, detection is per image and
-needs no collective); the timed region is bracketed by a barrier + device synchronize and the maximum
-over ranks is reported. PyTorch is used for torch.distributed (RCCL) and device buffers only.
+One "step" = one pass of the hot path over one batch of `--sub-batches` x `--batch` (default 8 x 128 = 1024) synthetic
+640x480 frames that are already resident in HBM: per 128 frames one batched detection (default vksift_Config: 2x
+up-sampling, automatic octave count = 5, 3 scales/octave) followed by the 2-NN self-match of every frame
+(matchFeatures(i, i) of BASELINE config 2, issued through the batched extension). Every step recomputes everything;
+nothing is cached between steps. 20 steps are ~1.1 s of timed GPU work.
 
-Extra objects on the JSON line:
-  roofline     pyramid+DoG pass of octave 0 (k_input_blit_2x + 6 k_blur_lean launches per step, 77 % of the pyramid's
-               bytes): algorithmic bytes per launch / average launch duration, measured with HIP
-               events recorded on the stream those kernels are launched on (the library's instance stream), inside
-               the timed region; the coarser octaves run concurrently on their own streams and share the HBM
-               bandwidth, so the figure is conservative. "traffic" is the PMC-measured HBM traffic per launch from a
-               separate rocprofv3 --pmc run (profiles/*pmc*.json), if present
-  cpu_baseline the CPU oracle (a scalar C port of the same algorithm) timed on a bounded sample (32 frames on 16 host
-               threads, ~25 core-seconds), rank 0, N=1
+Multi-GPU: one process per GPU; each rank owns its own frames (weak scaling: detection is per image and needs no
+collective); the timed region is bracketed by a barrier + device synchronize and the maximum over ranks is reported.
+After the timed region every rank also runs its shard of BASELINE config 4 (50k x 50k 2-NN, query rows sharded, ONE
+RCCL all-gather of the reference descriptors) and rank 0 prints the CRC-32 of the concatenated records: it must be the
+same number at N = 1, 2, 4, 8. PyTorch is used for torch.distributed (RCCL) and device buffers only.
+
+Objects on the JSON line besides the contract fields:
+  roofline          octave 0's scale-space construction (k_blur_lean x 6: fused up-sampling+seed blur, 5 scale blurs) plus
+                    the streaming extrema scan (k_extrema_lean) — the launches that produce the Gaussian planes and form the
+                    DoG values. Algorithmic bytes: 72.25 B per octave-0 pixel for pyramid + DoG, + 20 B for the
+                    scan = 92.25 B, divided by the summed duration of those 7 launches, measured with HIP events recorded on
+                    the streams the kernels run on, inside the timed region. `pyramid_only` is the same over the 6 blur launches
+                    and 72.25 B (this build never writes the DoG planes, so that figure flatters the blur kernels: the DoG
+                    values are formed in the scan). `traffic` / `physical_frac`: HBM bytes from rocprofv3 --pmc passes
+                    (profiles/*pmc_traffic*.json), accepted only if the kernel sources are the ones the file was measured on.
+  roofline_c3       the same for BASELINE config 3 (64 x 1920x1080, detect only), 5 steps
+  value_host_input  the reference's own measurement protocol on the same frames (src/perf/wrappers/vulkansift_wrapper.cpp:
+                    30-33): host images in, vksift_getFeaturesNumber + vksift_downloadFeatures (+ matches) out
+  single_image_ms   BASELINE config 2 literally: ONE 640x480 image through plain vksift_detectFeatures (+ matchFeatures),
+                    10 warm-up + 100 timed runs as src/perf/perf_runtime.cpp:63-81
+  cpu_baseline      the CPU oracle (scalar C port of the same algorithm) rebuilt -O3 -march=native on the box, one frame per
+                    host core on all host cores, rank 0, N=1
 """
 import argparse
+import ctypes as C
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
+import zlib
 
 import numpy as np
 
@@ -37,7 +54,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+INT8_PEAK_TOPS = 3944.0  # dense int8 MFMA peak used for the matcher
 
 
 def parse_args():
@@ -45,24 +63,90 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="frames per step and per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="frames per batched detection call")
+    ap.add_argument("--sub-batches", type=int, default=8, help="batched detection calls per step (frames per step = batch x sub-batches)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--no-match", action="store_true", help="detect only (BASELINE config 3 style runs)")
+    ap.add_argument("--no-match", action="store_true", help="detect only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-input", action="store_true", help="hand over host images (vksift_ext_detectFeaturesBatch): PCIe-inclusive rate, not the headline value")
-    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the workload given to the CPU oracle")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="worker threads of the CPU baseline (one frame per thread at a time)")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_host_input / single_image_ms / roofline_c3 / sharded match")
+    ap.add_argument("--host-input", action="store_true", help="time the PCIe-inclusive protocol as the main loop (not the headline value)")
+    ap.add_argument("--match-rows", type=int, default=50000, help="rows of A and of B in the sharded 2-NN leg (BASELINE config 4)")
     return ap.parse_args()
 
 
-def cpu_baseline(frames, do_match, threads):
-    """Time the oracle (scalar C port of the same algorithm) on a bounded sample of the same workload: one frame per
-    worker thread at a time (the ctypes calls release the GIL, so the threads run on separate host cores). The first
-    frame is also timed alone for the single-thread rate."""
+# ---------------------------------------------------------------------------------------------------------------------
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "vulkansift_amd", "csrc", "hip", "*.hip"))):
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(w, h, batch):
+    """HBM bytes per step of the octave-0 blur + scan launches from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+    gfx950 FETCH_SIZE correction applied, see profiles/README.md). A file measured on other kernel sources is refused."""
+    sha = kernel_source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if (d.get("width"), d.get("height"), d.get("batch")) == (w, h, batch) and d.get("kernel_source_sha") == sha:
+            return d
+    return None
+
+
+def roofline_from(acc, pmc, label):
+    calls = max(acc["nb_calls"], 1)
+    launches = max(acc["nb_blur_launches"], 1)
+    pyr_s = acc["pyramid_ms"] * 1e-3
+    scan_s = acc["scan_ms"] * 1e-3
+    alg_pyr = float(acc["pyramid_algorithmic_bytes"])                   # 72.25 B per octave-0 pixel (SURVEY.md 8d), whole run
+    alg_scan = float(acc["scan_algorithmic_bytes"])                    # + 20 B per octave-0 pixel for the extrema scan
+    n_launch = launches + calls                                        # blur launches + one scan per detection call
+    achieved = (alg_pyr + alg_scan) / (pyr_s + scan_s) / 1e9 if pyr_s + scan_s > 0 else 0.0
+    pyr_only = alg_pyr / pyr_s / 1e9 if pyr_s > 0 else 0.0
+    out = {
+        "bound": "hbm",
+        "kernel": label,
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": None,
+        "algorithmic_bytes_per_launch": (alg_pyr + alg_scan) / n_launch,
+        "avg_launch_us": (pyr_s + scan_s) / n_launch * 1e6,
+        "launches_per_call": n_launch / calls,
+        "pyramid_only": {"achieved": pyr_only, "frac": pyr_only / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg_pyr / launches,
+                         "avg_launch_us": pyr_s / launches * 1e6, "launches_per_call": launches / calls,
+                         "note": "SURVEY.md 8(d) counts 20 B/px of DoG writes that this build never performs (DoG values are formed in the scan)"},
+        "scan_only": {"achieved": alg_scan / scan_s / 1e9 if scan_s > 0 else 0.0, "avg_launch_us": scan_s / calls * 1e6},
+    }
+    if pmc is not None:
+        per_call = pmc["hbm_bytes_per_call"]
+        out["traffic"] = per_call / (n_launch / calls)                 # HBM bytes per launch, like algorithmic_bytes_per_launch
+        out["physical_frac"] = per_call * calls / (pyr_s + scan_s) / 1e9 / HBM_PEAK_GBPS
+        out["traffic_source"] = os.path.basename(pmc["_path"]) if "_path" in pmc else "profiles/"
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(frames, do_match):
+    """The oracle rebuilt on this box with -O3 -march=native (its fp32 operation order stays pinned: -ffp-contract=off),
+    one frame per worker thread, one worker per logical host core (the ctypes calls release the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
 
+    tmp = tempfile.mkdtemp(prefix="vksift_oracle_")
+    so = os.path.join(tmp, "liboracle_native.so")
+    flags = ["-O3", "-march=native", "-std=c99", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
+    try:
+        subprocess.run(["gcc"] + flags + ["-shared", "-o", so, os.path.join(ROOT, "oracle", "sift_oracle.c"), "-lm"], check=True, capture_output=True)
+        O.use_library(so)
+        build = "gcc " + " ".join(flags)
+    except Exception:
+        build = "committed oracle/Makefile flags (-O2 -mavx2 -mfma): the -march=native rebuild failed on this box"
     cfg = O.default_config(math_mode=0)
 
     def one(img):
@@ -72,41 +156,130 @@ def cpu_baseline(frames, do_match, threads):
         return len(feats)
 
     t0 = time.perf_counter()
-    n0 = one(frames[0])
+    one(frames[0])
     t_single = time.perf_counter() - t0
-    threads = max(1, min(threads, len(frames)))
+    threads = max(1, os.cpu_count() or 1)
+    work = [frames[i % len(frames)] for i in range(threads)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=threads) as ex:
-        nfeat = list(ex.map(one, frames))
+        nfeat = list(ex.map(one, work))
     dt = time.perf_counter() - t0
     return {
-        "value": len(frames) / dt,
+        "value": len(work) / dt,
         "unit": "frames/s",
         "cores": threads,
         "kind": "port",
         "single_thread_value": 1.0 / t_single,
-        "sample": f"{len(frames)} of the benchmark's {frames[0].shape[1]}x{frames[0].shape[0]} frames, detect"
-                  + ("+self-match" if do_match else "") + f", {int(np.mean(nfeat))} features/frame, {threads} worker threads x "
-                  + f"{len(frames) // threads} frame(s) each, {dt:.1f} s wall ({dt * threads:.0f} core-seconds); one frame alone {t_single:.2f} s; "
-                  + f"host has {os.cpu_count()} logical cores",
+        "build": build,
+        "sample": f"{len(work)} frames of the benchmark's {frames[0].shape[1]}x{frames[0].shape[0]} workload (one per logical host core), detect"
+                  + ("+self-match" if do_match else "") + f", {int(np.mean(nfeat))} features/frame, {dt:.1f} s wall ({dt * threads:.0f} core-seconds); "
+                  + f"one frame alone on one core {t_single:.2f} s",
     }
 
 
-def pmc_traffic(w, h, batch):
-    """HBM bytes per k_blur_stream launch measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE in separate passes,
-    gfx950 FETCH_SIZE correction applied: see profiles/README.md). Only valid for the workload it was measured on."""
-    import glob
+# ---------------------------------------------------------------------------------------------------------------------
+def reference_protocol(api, inst, frames, W, H, B, do_match, steps):
+    """src/perf/wrappers/vulkansift_wrapper.cpp:30-33 per frame = detect(host image) + getFeaturesNumber + downloadFeatures; here
+    per batch of B frames, followed by the self-match and the download of its records. Returns frames/s."""
+    lib = api.lib()
+    cap = inst.cfg.max_nb_sift_per_buffer
+    feat_buf = np.zeros(cap, api.FEATURE_DTYPE)
+    match_buf = np.zeros(cap, api.MATCH_DTYPE)
 
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
-        try:
-            d = json.load(open(path))
-            if (d.get("width"), d.get("height"), d.get("batch")) == (w, h, batch):
-                return d["hbm_bytes_per_blur_launch"]
-        except Exception:
-            pass
-    return None
+    def step():
+        inst.detectFeaturesBatch(frames, 0)
+        for i in range(B):
+            n = lib.vksift_getFeaturesNumber(inst._h, i)
+            if n:
+                lib.vksift_downloadFeatures(inst._h, feat_buf.ctypes.data, i)
+        if do_match:
+            for i0 in range(0, B, 64):
+                ids = list(range(i0, min(B, i0 + 64)))
+                inst.matchFeaturesBatch(ids, ids)
+                for k in range(len(ids)):
+                    if lib.vksift_ext_getMatchesNumberBatch(inst._h, k):
+                        lib.vksift_ext_downloadMatchesBatch(inst._h, k, match_buf.ctypes.data)
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return B * steps / dt
 
 
+def single_image_latency(api, dev_index, img, runs=100, warm=10):
+    """perf_runtime.cpp:63-81: warm-up, then the mean over `runs` of detect + count + download of ONE host image (and of the
+    same followed by matchFeatures(0, 0) + downloadMatches = BASELINE config 2)."""
+    lib = api.lib()
+    h, w = img.shape
+    cfg = api.default_config(gpu_device_index=dev_index, input_image_max_size=max(w * h, 1024))
+    out = {}
+    with api.Instance(cfg) as inst:
+        feat_buf = np.zeros(cfg.max_nb_sift_per_buffer, api.FEATURE_DTYPE)
+        match_buf = np.zeros(cfg.max_nb_sift_per_buffer, api.MATCH_DTYPE)
+        for with_match in (False, True):
+            ts = []
+            for i in range(warm + runs):
+                t0 = time.perf_counter()
+                inst.detectFeatures(img, 0)
+                n = lib.vksift_getFeaturesNumber(inst._h, 0)
+                lib.vksift_downloadFeatures(inst._h, feat_buf.ctypes.data, 0)
+                if with_match:
+                    lib.vksift_matchFeatures(inst._h, 0, 0)
+                    lib.vksift_downloadMatches(inst._h, match_buf.ctypes.data)
+                if i >= warm:
+                    ts.append(time.perf_counter() - t0)
+            out["detect_match_ms" if with_match else "detect_ms"] = float(np.mean(ts) * 1e3)
+            out["features"] = int(n)
+    out["protocol"] = f"{warm} warm-up + {runs} timed runs, host image in, count + features (+ matches) downloaded, plain vksift_detectFeatures/matchFeatures"
+    return out
+
+
+def c3_roofline(api, torch, dev, steps=5):
+    """BASELINE config 3: 64 x 1920x1080, detect only, inputs resident in HBM."""
+    W, H, B = 1920, 1080, 64
+    frames = np.stack([api.gen_synthetic_image(0x5EED0000 + i, W, H) for i in range(8)])
+    d_frames = torch.from_numpy(np.concatenate([frames] * (B // 8))).to(dev)      # 8 distinct frames, repeated: generation is host time
+    cfg = api.default_config(sift_buffer_count=B, gpu_device_index=dev.index, input_image_max_size=W * H)
+    inst = api.Instance(cfg, batch_capacity=B)
+    inst.detectFeaturesBatchDevice(d_frames.data_ptr(), B, W, H, 0)
+    torch.cuda.synchronize()
+    nfeat = float(np.mean([inst.getFeaturesNumber(i) for i in range(0, B, 8)]))
+    inst.setProfiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        inst.detectFeaturesBatchDevice(d_frames.data_ptr(), B, W, H, 0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    acc = inst.getAccumulatedDetectTimings()
+    inst.close()
+    r = roofline_from(acc, None, "k_blur_lean x6 + k_extrema_lean, octave 0 (3840x2160 planes) of 64 x 1920x1080 frames")
+    r.update({"workload": "BASELINE config 3: 64 x 1920x1080 uint8 frames, detect only, default vksift_Config, inputs resident in HBM",
+              "steps": steps, "frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "mean_features_per_frame": nfeat,
+              "stage_ms_per_step": {k: acc[k] / max(acc["nb_calls"], 1) for k in ("pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")}})
+    return r
+
+
+def sharded_match(api, torch, dist, dev, rank, world, rows):
+    """BASELINE config 4 through the C entry vksift_ext_matchSharded: query rows of A sharded over the ranks, the reference set B
+    all-gathered once (RCCL, uint8 rows) inside the library, every rank scans all of B. Returns (ms, CRC-32 of all records)."""
+    from vulkansift_amd import multigpu
+
+    a = api.gen_synthetic_descriptors(1, rows)
+    b = api.gen_synthetic_descriptors(2, rows)
+    lo, hi = multigpu.shard_bounds(rows, world, rank)
+    blo, bhi = multigpu.shard_bounds(rows, world, rank)
+    d_a = torch.from_numpy(a[lo:hi]).to(dev)
+    d_b_shard = torch.from_numpy(b[blo:bhi]).to(dev)
+    ms, rec = multigpu.sharded_match_timed(d_a, lo, d_b_shard, rows, world, rank, repeats=5)
+    rec_all = multigpu.gather_records(rec, rows, world, rank)
+    crc = zlib.crc32(rec_all.cpu().numpy().tobytes()) & 0xFFFFFFFF if rank == 0 else None
+    return ms, crc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     import torch
@@ -125,26 +298,32 @@ def main():
     from vulkansift_amd import api
 
     api.lib().vksift_setLogLevel(api.VKSIFT_LOG_ERROR)
-    W, H, B = args.width, args.height, args.batch
+    W, H, B, NSUB = args.width, args.height, args.batch, max(1, args.sub_batches)
     do_match = not args.no_match
 
-    # synthetic frames (seeded per global frame index), uploaded once: inputs are HBM-resident when timing starts
+    # synthetic frames (seeded per global frame index), uploaded once: inputs are HBM-resident when timing starts.
+    # 128 distinct frames per rank; the sub-batches of a step rotate through them with a different first frame.
     frames = [api.gen_synthetic_image(0x5EED0000 + rank * B + i, W, H) for i in range(B)]
-    d_frames = torch.from_numpy(np.stack(frames)).to(dev)
+    host = np.stack(frames)
+    d_sub = [torch.from_numpy(np.roll(host, -k, axis=0).copy()).to(dev) for k in range(NSUB)]
     torch.cuda.synchronize()
 
     cfg = api.default_config(sift_buffer_count=B, gpu_device_index=dev.index, input_image_max_size=max(W * H, 1024))
     inst = api.Instance(cfg, batch_capacity=B)
 
+    def match_all():
+        for i0 in range(0, B, 64):      # 2-NN self-match of every frame, batched launches of <= 64 pairs
+            ids = list(range(i0, min(B, i0 + 64)))
+            inst.matchFeaturesBatch(ids, ids)
+
     def step():
-        if args.host_input:
-            inst.detectFeaturesBatch(frames, 0)   # host memcpy into pinned staging + H2D inside the timed region
-        else:
-            inst.detectFeaturesBatchDevice(d_frames.data_ptr(), B, W, H, 0)
-        if do_match:
-            for i0 in range(0, B, 64):      # 2-NN self-match of every frame, batched launches of <= 64 pairs
-                ids = list(range(i0, min(B, i0 + 64)))
-                inst.matchFeaturesBatch(ids, ids)
+        for k in range(NSUB):
+            if args.host_input:
+                inst.detectFeaturesBatch(frames, 0)   # host memcpy into pinned staging + H2D inside the timed region
+            else:
+                inst.detectFeaturesBatchDevice(d_sub[k].data_ptr(), B, W, H, 0)
+            if do_match:
+                match_all()
 
     for _ in range(args.warmup):
         step()
@@ -170,14 +349,29 @@ def main():
 
     acc = inst.getAccumulatedDetectTimings()
     match_ms = inst.getMatchTime() if do_match else None
+    inst.setProfiling(False)
+
+    extras = {}
+    if not args.no_extras:
+        ms, crc = sharded_match(api, torch, dist, dev, rank, world, args.match_rows)
+        if world > 1:
+            t = torch.tensor([ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+        ops = 2.0 * args.match_rows * args.match_rows * 128
+        extras["sharded_match"] = {"workload": f"BASELINE config 4: 2-NN {args.match_rows} x {args.match_rows} x 128-D, query rows sharded x{world}, one RCCL all-gather of B",
+                                   "ms": ms, "tops_int8": ops / (ms * 1e-3) / 1e12, "frac_of_int8_peak": ops / (ms * 1e-3) / 1e12 / INT8_PEAK_TOPS / world,
+                                   "records_crc32": crc}
+        if world == 1:
+            extras["value_host_input"] = reference_protocol(api, inst, frames, W, H, B, do_match, 3)
     inst.close()
+    if not args.no_extras and world == 1:
+        extras["single_image_ms"] = single_image_latency(api, dev.index, frames[0])
+        extras["roofline_c3"] = c3_roofline(api, torch, dev)
 
     if rank == 0:
-        frames_total = B * world * args.steps
-        launches = max(acc["nb_blur_launches"], 1)
-        alg_per_launch = acc["pyramid_algorithmic_bytes"] / launches
-        avg_launch_s = (acc["pyramid_ms"] * 1e-3) / launches
-        achieved = alg_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        frames_total = B * NSUB * world * args.steps
+        pmc = pmc_traffic(W, H, B)
         out = {
             "metric": "SIFT detect+match frames/sec (640x480, ~2k kp)" if do_match else "SIFT detect frames/sec",
             "value": frames_total / elapsed,
@@ -194,30 +388,21 @@ def main():
             "config": {
                 "workload": f"BASELINE config 2: {W}x{H} uint8 frames, detect" + (" + 2-NN self-match" if do_match else "")
                             + ", default vksift_Config (2x up-sampling, auto octaves, 3 scales/octave), inputs resident in HBM",
-                "frames_per_step_per_gpu": B,
+                "frames_per_step_per_gpu": B * NSUB,
+                "frames_per_detection_call": B,
                 "octaves": 5 if (W, H) == (640, 480) else None,
                 "mean_features_per_frame": float(np.mean(nfeat)),
                 "parallelism": f"batch split x{world}, no collectives",
                 "input": "host images, upload inside the timed region" if args.host_input else "resident in HBM",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_blur_lean (pyramid + DoG pass, octave 0: 1280x960 planes)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(W, H, B),
-                "algorithmic_bytes_per_launch": alg_per_launch,
-                "avg_launch_us": avg_launch_s * 1e6,
-                "launches_per_step": launches / max(acc["nb_calls"], 1),
-            },
-            "stage_ms_per_step": {k: acc[k] / max(acc["nb_calls"], 1) for k in
+            "roofline": roofline_from(acc, pmc, "k_blur_lean x6 + k_extrema_lean, octave 0 (1280x960 planes): scale-space construction + the scan that forms the DoG values"),
+            "stage_ms_per_call": {k: acc[k] / max(acc["nb_calls"], 1) for k in
                                   ("upload_ms", "pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")},
             "last_match_ms": match_ms,
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames[: max(1, min(args.cpu_frames, B))], do_match, args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(frames, do_match)
         print(json.dumps(out), flush=True)
 
     if world > 1:

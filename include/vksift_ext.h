@@ -67,6 +67,7 @@ extern "C"
     uint32_t nb_blur_launches;
     uint64_t pyramid_algorithmic_bytes; /* SURVEY.md §8(d) definition, whole batch */
     float scan_ms;                      /* the streaming extrema scan of octave 0 alone (mask clear + the kernel that reads the S+3 planes) */
+    uint64_t scan_algorithmic_bytes;    /* 4*(S+2) B per octave-0 pixel, whole batch */
   } vksift_ext_DetectTimings;
   VKSIFT_EXPORT void vksift_ext_setProfiling(vksift_Instance instance, bool enabled);
   VKSIFT_EXPORT void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *out);
@@ -80,6 +81,29 @@ extern "C"
    * provided DEVICE memory (>= vksift_getFeaturesNumber()*128 bytes, 16-byte aligned). Blocking.
    * Returns the number of rows written. Used to feed the RCCL all-gather of the sharded matcher. */
   VKSIFT_EXPORT uint32_t vksift_ext_exportDescriptorsDevice(vksift_Instance instance, uint32_t gpu_buffer_id, uint8_t *d_descriptors);
+
+  /* ---------------------------------------------------------------------------------------------------------------
+   * Sharded 2-NN matching over the GPUs of one node. One process per GPU. The query rows of A are sharded
+   * by the caller (any split); the reference set B is sharded in equal blocks of nb_shard = ceil(nb_total / world) rows
+   * (rank r holds rows [r*nb_shard, ...); rows past nb_total are padding) and all-gathered ONCE inside the call: an RCCL
+   * all-gather of uint8 rows over xGMI, issued first and overlapped with the norm pre-pass of the local A rows. Every
+   * rank then scans all of B in index order, so the records are bit-identical to a single-GPU vksift_matchFeatures for
+   * every world size. RCCL is loaded on first use (dlopen).
+   *   rank 0: vksift_ext_shardGetUniqueId(id), then send the 128 bytes to the other ranks by any host channel
+   *   all   : vksift_ext_shardGroupCreate(&group, device, world, rank, id)      (collective: ncclCommInitRank)
+   *   all   : vksift_ext_matchSharded(...)                                       (collective, asynchronous on the group's stream)
+   *   all   : vksift_ext_shardGroupSynchronize(group, &ms)
+   * d_a_rows / d_b_shard / d_matches are DEVICE pointers (dense 128-byte rows; na records of 20 bytes = vksift_Match_2NN with
+   * idx_a = a_index_base + row). vksift_ext_exportDescriptorsDevice() produces such rows from a SIFT buffer. */
+#define VKSIFT_EXT_SHARD_ID_BYTES 128
+  typedef struct vksift_ext_ShardGroup_T *vksift_ext_ShardGroup;
+  VKSIFT_EXPORT vksift_Result vksift_ext_shardGetUniqueId(uint8_t id[VKSIFT_EXT_SHARD_ID_BYTES]);
+  VKSIFT_EXPORT vksift_Result vksift_ext_shardGroupCreate(vksift_ext_ShardGroup *group_ptr, int gpu_device_index, uint32_t world, uint32_t rank,
+                                                          const uint8_t id[VKSIFT_EXT_SHARD_ID_BYTES]);
+  VKSIFT_EXPORT void vksift_ext_shardGroupDestroy(vksift_ext_ShardGroup *group_ptr);
+  VKSIFT_EXPORT vksift_Result vksift_ext_matchSharded(vksift_ext_ShardGroup group, const uint8_t *d_a_rows, uint32_t na, uint32_t a_index_base,
+                                                      const uint8_t *d_b_shard, uint32_t nb_shard, uint32_t nb_total, uint8_t *d_matches);
+  VKSIFT_EXPORT vksift_Result vksift_ext_shardGroupSynchronize(vksift_ext_ShardGroup group, float *last_match_ms);
 
   /* Deterministic synthetic test image: 128 + sum of Gaussian blobs + uniform noise,
    * splitmix64-seeded, clamped to [0,255]. nb_blobs == 0 picks the density used by the benchmarks. */

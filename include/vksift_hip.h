@@ -170,6 +170,12 @@ extern "C"
    * shard offset) gives bit-identical results to a single call. */
   int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
                                 uint8_t *matches, vksift_hip_stream s);
+  /* The two halves of vksift_hip_match_2nn_desc, for callers that overlap the pre-pass of A with the arrival of B (the sharded
+   * matcher: RCCL all-gather of B): norms[i] = sum over the 128 bytes of (byte - 128)^2; scratch: na u32 (+ 5*na*VKSIFT_HIP_MATCH_CHUNKS
+   * when na > 32768). */
+  int vksift_hip_shifted_norms(const uint8_t *desc, uint32_t n, uint32_t *norms, vksift_hip_stream s);
+  int vksift_hip_match_2nn_prenormed(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b,
+                                     const uint32_t *norm_b, uint32_t nb, uint32_t *scratch, uint8_t *matches, vksift_hip_stream s);
 
   /* Cross-check + Lowe ratio over forward (A->B) and optional reverse (B->A, rev != NULL) 2-NN records, the CPU loop of
    * src/examples/test_sift_match.cpp:90-107 / src/perf/perf_common.cpp:123-169: keep record i iff d1/d2 < ratio and (with

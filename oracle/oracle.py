@@ -59,6 +59,14 @@ def build(force=False):
 _lib = None
 
 
+def use_library(path):
+    """Bind another build of sift_oracle.c (bench.py's cpu_baseline: -O3 -march=native, compiled on the box it runs on)."""
+    global _lib, _LIB_PATH
+    _LIB_PATH = path
+    _lib = None
+    return lib()
+
+
 def lib():
     global _lib
     if _lib is None:

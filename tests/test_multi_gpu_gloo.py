@@ -1,6 +1,7 @@
-"""world_size-2 run of the multi-GPU layer on CPU (gloo): batch splitting needs no collective, the
-query-sharded matcher needs exactly one all-gather of B and gives the single-process result bit for bit.
-The HIP matcher is replaced by the oracle here (compute stand-in); the collective logic is the real one."""
+"""world_size-2 run of the multi-GPU data flow on CPU (gloo): batch splitting needs no collective, the query-sharded
+matcher needs exactly one all-gather of equal (padded) blocks of B and gives the single-process result bit for bit.
+There is no GPU here, so the compute step is the oracle; the product path — the C entry vksift_ext_matchSharded with its
+own RCCL all-gather — is exercised on the GPU box by tests/test_gpu_sharded.py (world size 1) and by bench.py --gpus N."""
 import os
 import socket
 import sys
@@ -41,8 +42,8 @@ def _worker(rank, world, port, na, nb, q):
     b = api.gen_synthetic_descriptors(32, nb)
     b[1] = b[0]
     a0, a1 = multigpu.shard_range(na, world, rank)
-    b0, b1 = multigpu.shard_range(nb, world, rank)
-    rec = multigpu.sharded_match(torch.from_numpy(a[a0:a1]), a0, torch.from_numpy(b[b0:b1]), match_fn=_oracle_match_fn)
+    b0, b1 = multigpu.shard_bounds(nb, world, rank)
+    rec = multigpu.sharded_match_reference(torch.from_numpy(a[a0:a1]), a0, torch.from_numpy(b[b0:b1]), nb, match_fn=_oracle_match_fn)
     # detection-side splitting: no collective, just a partition
     imgs = list(range(13))
     mine = multigpu.split_batch(imgs, world, rank)
@@ -51,7 +52,7 @@ def _worker(rank, world, port, na, nb, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("na,nb", [(101, 77), (8, 3)])
+@pytest.mark.parametrize("na,nb", [(101, 77), (8, 3), (5, 2)])
 def test_sharded_match_equals_single_process(oracle, vk, na, nb):
     world = 2
     ctx = mp.get_context("spawn")
@@ -86,3 +87,15 @@ def test_shard_range_partitions():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             sizes = [e - s for s, e in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_bounds_are_equal_blocks():
+    from vulkansift_amd import multigpu
+
+    for n in (2, 3, 7, 64, 50000, 50001):
+        for world in (1, 2, 3, 8):
+            blk = (n + world - 1) // world
+            parts = [multigpu.shard_bounds(n, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and max(e for _, e in parts) == n
+            assert all(e - s <= blk for s, e in parts)
+            assert all(s == min(n, r * blk) for r, (s, _) in enumerate(parts))

@@ -57,7 +57,7 @@ class vksift_ext_DetectTimings(C.Structure):
     _fields_ = [
         ("upload_ms", C.c_float), ("pyramid_ms", C.c_float), ("extrema_ms", C.c_float), ("orientation_ms", C.c_float),
         ("descriptor_ms", C.c_float), ("total_ms", C.c_float), ("nb_blur_launches", C.c_uint32), ("pyramid_algorithmic_bytes", C.c_uint64),
-        ("scan_ms", C.c_float),
+        ("scan_ms", C.c_float), ("scan_algorithmic_bytes", C.c_uint64),
     ]
 
 
@@ -132,6 +132,15 @@ def lib():
     L.vksift_ext_exportDescriptorsDevice.restype = u32
     L.vksift_ext_genSyntheticImage.argtypes = [C.c_uint64, u32, u32, u32, C.c_void_p]
     L.vksift_ext_genSyntheticDescriptors.argtypes = [C.c_uint64, u32, C.c_void_p]
+    L.vksift_ext_shardGetUniqueId.argtypes = [C.c_void_p]
+    L.vksift_ext_shardGetUniqueId.restype = C.c_int
+    L.vksift_ext_shardGroupCreate.argtypes = [C.POINTER(C.c_void_p), C.c_int, u32, u32, C.c_void_p]
+    L.vksift_ext_shardGroupCreate.restype = C.c_int
+    L.vksift_ext_shardGroupDestroy.argtypes = [C.POINTER(C.c_void_p)]
+    L.vksift_ext_matchSharded.argtypes = [C.c_void_p, C.c_void_p, u32, u32, C.c_void_p, u32, u32, C.c_void_p]
+    L.vksift_ext_matchSharded.restype = C.c_int
+    L.vksift_ext_shardGroupSynchronize.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.vksift_ext_shardGroupSynchronize.restype = C.c_int
     # kernel-layer C-ABI (include/vksift_hip.h) entry points used directly by bench.py / tests
     L.vksift_hip_match_2nn_desc.argtypes = [C.c_void_p, u32, u32, C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.vksift_hip_match_2nn_desc.restype = C.c_int

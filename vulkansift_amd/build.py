@@ -16,7 +16,7 @@ OUT_DIR = os.path.join(PKG, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB_PATH = os.path.join(OUT_DIR, "libvulkansift.so")
 
-HOST_SRCS = ["host/vksift_api.c", "host/vksift_instance.c", "host/vksift_detect.c", "host/vksift_buffers.c", "host/vksift_match.c", "host/vksift_ext.c",
+HOST_SRCS = ["host/vksift_api.c", "host/vksift_instance.c", "host/vksift_detect.c", "host/vksift_buffers.c", "host/vksift_match.c", "host/vksift_ext.c", "host/vksift_sharded.c",
              "host/vksift_hostmath.c", "host/vksift_log.c", "host/vksift_synth.c"]
 HIP_SRCS = ["hip/runtime.hip", "hip/pyramid.hip", "hip/extrema.hip", "hip/features.hip", "hip/match.hip"]
 
@@ -102,7 +102,7 @@ def build(force=False, verbose=False):
         if verbose:
             print("[ld ]", os.path.relpath(LIB_PATH, ROOT))
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs +
-             ["-L" + os.path.join(ROCM, "lib"), "-lroctx64", "-lm", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+             ["-L" + os.path.join(ROCM, "lib"), "-lroctx64", "-lm", "-ldl", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
     return LIB_PATH
 
 

@@ -832,19 +832,25 @@ extern "C"
     return (int)hipGetLastError();
   }
 
-  int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
-                                uint8_t *matches, vksift_hip_stream s)
+  int vksift_hip_shifted_norms(const uint8_t *desc, uint32_t n, uint32_t *norms, vksift_hip_stream s)
+  {
+    if (n == 0)
+      return 0;
+    hipLaunchKernelGGL(k_shifted_norms, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)s, (const uint32_t *)desc, n, norms);
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_match_2nn_prenormed(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b,
+                                     const uint32_t *norm_b, uint32_t nb, uint32_t *scratch, uint8_t *matches, vksift_hip_stream s)
   {
     if (na == 0)
       return 0;
     if (nb < 2)
       return (int)hipErrorInvalidValue; /* callers pad B to two rows (quirk Q6) */
     hipStream_t hs = (hipStream_t)s;
-    uint32_t *norm_a = norm_scratch, *norm_b = norm_scratch + na, *redo = norm_scratch + na + nb;
+    uint32_t *redo = scratch;
     const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
     const SlotStrides z{0, 0, 0, 0, 0, 0, 0, 0};
-    hipLaunchKernelGGL(k_shifted_norms, dim3((na + 255u) / 256u), dim3(256), 0, hs, da, na, norm_a);
-    hipLaunchKernelGGL(k_shifted_norms, dim3((nb + 255u) / 256u), dim3(256), 0, hs, db, nb, norm_b);
     /* Small problems: 16 A rows per workgroup with B split over its waves; medium: 16 rows per wave; large: 32 rows per
      * wave (B-tile reuse) with B split into VKSIFT_HIP_MATCH_CHUNKS chunks across grid.z + exact merge. */
     if (na <= 8192u)
@@ -865,6 +871,22 @@ extern "C"
     hipLaunchKernelGGL(k_match_redo, dim3(rblocks > 1024u ? 1024u : rblocks), dim3(64), 0, hs, da, na, a_index_base, db, nb, (uint32_t *)matches,
                        (const uint32_t *)redo, (const uint32_t *)nullptr, z);
     return (int)hipGetLastError();
+  }
+
+  int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
+                                uint8_t *matches, vksift_hip_stream s)
+  {
+    if (na == 0)
+      return 0;
+    if (nb < 2)
+      return (int)hipErrorInvalidValue; /* callers pad B to two rows (quirk Q6) */
+    uint32_t *norm_a = norm_scratch, *norm_b = norm_scratch + na;
+    int e = vksift_hip_shifted_norms(desc_a, na, norm_a, s);
+    if (e == 0)
+      e = vksift_hip_shifted_norms(desc_b, nb, norm_b, s);
+    if (e == 0)
+      e = vksift_hip_match_2nn_prenormed(desc_a, norm_a, na, a_index_base, desc_b, norm_b, nb, norm_scratch + na + nb, matches, s);
+    return e;
   }
 
   int vksift_hip_gather_sections(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, uint32_t nslots, uint32_t nsec,

@@ -45,6 +45,7 @@ void account_set(vksift_Instance inst, ProfSet *ps)
   inst->acc_calls++;
   inst->acc_blur_launches += ps->blur_launches;
   inst->acc_alg_bytes += ps->alg_bytes;
+  inst->acc_scan_bytes += ps->scan_bytes;
   ps->accounted = true;
 }
 
@@ -340,6 +341,8 @@ static int enqueue_detection(DetectCtx *c)
   inst->last_blur_launches = c->nblur;
   /* profiling: the pyramid interval is octave 0's when pipelined, the whole pyramid's otherwise */
   inst->last_alg_bytes = algorithmic_pyramid_bytes(inst, c->w, c->h, c->pipelined ? 1u : L->n_oct) * c->count;
+  /* "the extrema scan adds 20 B/px.octave" = one read of the S+2 DoG layers (octave 0: the timed scan) */
+  inst->last_scan_bytes = L->n_oct ? (uint64_t)L->w[0] * L->h[0] * 4u * (inst->S + 2) * c->count : 0;
 
   if (!c->pipelined)
   {
@@ -541,6 +544,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     PS->accounted = false;
     PS->blur_launches = inst->last_blur_launches;
     PS->alg_bytes = inst->last_alg_bytes;
+    PS->scan_bytes = inst->last_scan_bytes;
   }
   HIP_CHECK(vksift_hip_event_record(inst->ev_detect, st), "event record");
   inst->detect_pending = true;

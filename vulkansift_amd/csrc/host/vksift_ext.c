@@ -34,6 +34,7 @@ void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext
   sum->descriptor_ms = (float)instance->acc_ms[4];
   sum->total_ms = (float)instance->acc_ms[5];
   sum->scan_ms = (float)instance->acc_ms[6];
+  sum->scan_algorithmic_bytes = instance->acc_scan_bytes;
   sum->nb_blur_launches = (uint32_t)instance->acc_blur_launches;
   sum->pyramid_algorithmic_bytes = instance->acc_alg_bytes;
   *nb_calls = instance->acc_calls;
@@ -43,6 +44,7 @@ void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext
     instance->acc_calls = 0;
     instance->acc_blur_launches = 0;
     instance->acc_alg_bytes = 0;
+    instance->acc_scan_bytes = 0;
   }
 }
 
@@ -62,6 +64,7 @@ void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimi
   out->descriptor_ms = vksift_hip_event_elapsed_ms(e[4], e[5]);
   out->total_ms = vksift_hip_event_elapsed_ms(e[0], e[6]);
   out->scan_ms = vksift_hip_event_elapsed_ms(e[2], ps->ev_scan);
+  out->scan_algorithmic_bytes = instance->last_scan_bytes;
   out->nb_blur_launches = instance->last_blur_launches;
   out->pyramid_algorithmic_bytes = instance->last_alg_bytes;
 }

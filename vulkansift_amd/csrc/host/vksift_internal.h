@@ -74,7 +74,7 @@ typedef struct
   vksift_hip_event ev_scan;  /* octave 0's streaming extrema scan (the kernel that forms the DoG values) has run */
   bool valid, accounted, overlap;
   uint32_t blur_launches;
-  uint64_t alg_bytes;
+  uint64_t alg_bytes, scan_bytes;
 } ProfSet;
 
 struct vksift_Instance_T
@@ -166,9 +166,9 @@ struct vksift_Instance_T
   bool match_timing_valid;
   double acc_ms[7]; /* upload, pyramid, extrema stage, orientation, descriptor, total, extrema scan kernel alone */
   uint32_t acc_calls;
-  uint64_t acc_blur_launches, acc_alg_bytes;
+  uint64_t acc_blur_launches, acc_alg_bytes, acc_scan_bytes;
   uint32_t last_blur_launches;
-  uint64_t last_alg_bytes;
+  uint64_t last_alg_bytes, last_scan_bytes;
   bool device_input_last;
 };
 

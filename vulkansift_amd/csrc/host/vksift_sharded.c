@@ -1,0 +1,231 @@
+/*
+ * vksift_sharded.c — the multi-GPU matcher behind a C entry point (BASELINE.json north_star: "the matcher shards
+ * the query set across the GPUs of one node with an RCCL all-gather of the reference descriptors over xGMI").
+ *
+ * The reference is single-GPU (vulkansift.h:32-34): Get2NearestNeighbors.comp (sift_matcher.c:246-279) scans ALL of B in index
+ * order for every row of A. Sharding the ROWS OF A keeps that scan — and with it the tie rules (quirk Q7, strict '<') — intact,
+ * so the records are bit-identical for every world size. The only exchange is one all-gather of B's descriptor rows (uint8,
+ * 128 B each; 6.4 MB for 50 k rows): issued first, on its own stream, while the instance stream runs the norm pre-pass of the
+ * local A rows; the B norms and the MFMA matcher follow once the gather has landed.
+ *
+ * RCCL is loaded lazily (dlopen of librccl.so) so that single-GPU users of libvulkansift.so do not depend on it. One process per
+ * GPU; the 128-byte unique id travels from rank 0 to the other ranks by whatever host channel the application has
+ * (torch.distributed / MPI / a socket).
+ */
+#include "vksift_internal.h"
+
+#include <dlfcn.h>
+
+typedef struct
+{
+  char internal[128];
+} rccl_UniqueId; /* == ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128) */
+typedef void *rccl_Comm;
+enum
+{
+  RCCL_UINT8 = 1 /* ncclUint8 */
+};
+
+static struct
+{
+  void *so;
+  int (*GetUniqueId)(rccl_UniqueId *);
+  int (*CommInitRank)(rccl_Comm *, int, rccl_UniqueId, int);
+  int (*CommDestroy)(rccl_Comm);
+  int (*AllGather)(const void *, void *, size_t, int, rccl_Comm, void *);
+  const char *(*GetErrorString)(int);
+} g_rccl;
+
+static bool rccl_load(void)
+{
+  if (g_rccl.so)
+    return true;
+  const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void *so = NULL;
+  for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]) && !so; i++)
+    so = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!so)
+  {
+    logError(LOG_TAG, "RCCL not found (librccl.so): %s", dlerror());
+    return false;
+  }
+  *(void **)&g_rccl.GetUniqueId = dlsym(so, "ncclGetUniqueId");
+  *(void **)&g_rccl.CommInitRank = dlsym(so, "ncclCommInitRank");
+  *(void **)&g_rccl.CommDestroy = dlsym(so, "ncclCommDestroy");
+  *(void **)&g_rccl.AllGather = dlsym(so, "ncclAllGather");
+  *(void **)&g_rccl.GetErrorString = dlsym(so, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather)
+  {
+    logError(LOG_TAG, "librccl.so lacks a required entry point");
+    dlclose(so);
+    return false;
+  }
+  g_rccl.so = so;
+  return true;
+}
+
+struct vksift_ext_ShardGroup_T
+{
+  int device;
+  uint32_t world, rank;
+  rccl_Comm comm;
+  vksift_hip_stream stream, comm_stream;
+  vksift_hip_event ev_fork, ev_gathered, ev_t0, ev_t1;
+  uint8_t *d_b_full;
+  uint32_t *d_scratch;
+  size_t b_cap, scratch_cap; /* bytes / u32 elements */
+  bool timed;
+};
+
+vksift_Result vksift_ext_shardGetUniqueId(uint8_t id[VKSIFT_EXT_SHARD_ID_BYTES])
+{
+  if (!id || !rccl_load())
+    return VKSIFT_VULKAN_ERROR;
+  rccl_UniqueId u;
+  const int e = g_rccl.GetUniqueId(&u);
+  if (e != 0)
+  {
+    logError(LOG_TAG, "ncclGetUniqueId failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return VKSIFT_VULKAN_ERROR;
+  }
+  memcpy(id, u.internal, VKSIFT_EXT_SHARD_ID_BYTES);
+  return VKSIFT_SUCCESS;
+}
+
+vksift_Result vksift_ext_shardGroupCreate(vksift_ext_ShardGroup *out, int gpu_device_index, uint32_t world, uint32_t rank,
+                                          const uint8_t id[VKSIFT_EXT_SHARD_ID_BYTES])
+{
+  if (!out || *out != NULL || world == 0 || rank >= world || !id)
+    return VKSIFT_INVALID_INPUT_ERROR;
+  if (!vksift_g_loaded || !rccl_load())
+    return VKSIFT_VULKAN_ERROR;
+  if (gpu_device_index < 0 || gpu_device_index >= vksift_hip_device_count() || vksift_hip_set_device(gpu_device_index) != 0)
+    return VKSIFT_VULKAN_ERROR;
+  vksift_ext_ShardGroup g = (vksift_ext_ShardGroup)calloc(1, sizeof(*g));
+  if (!g)
+    return VKSIFT_VULKAN_ERROR;
+  g->device = gpu_device_index, g->world = world, g->rank = rank;
+  rccl_UniqueId u;
+  memcpy(u.internal, id, VKSIFT_EXT_SHARD_ID_BYTES);
+  const int e = g_rccl.CommInitRank(&g->comm, (int)world, u, (int)rank);
+  if (e != 0)
+  {
+    logError(LOG_TAG, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    free(g);
+    return VKSIFT_VULKAN_ERROR;
+  }
+  g->stream = vksift_hip_stream_create();
+  g->comm_stream = vksift_hip_stream_create();
+  g->ev_fork = vksift_hip_event_create();
+  g->ev_gathered = vksift_hip_event_create();
+  g->ev_t0 = vksift_hip_event_create();
+  g->ev_t1 = vksift_hip_event_create();
+  *out = g;
+  return VKSIFT_SUCCESS;
+}
+
+void vksift_ext_shardGroupDestroy(vksift_ext_ShardGroup *gp)
+{
+  if (!gp || !*gp)
+    return;
+  vksift_ext_ShardGroup g = *gp;
+  vksift_hip_set_device(g->device);
+  vksift_hip_stream_sync(g->comm_stream);
+  vksift_hip_stream_sync(g->stream);
+  if (g->comm)
+    g_rccl.CommDestroy(g->comm);
+  vksift_hip_free(g->d_b_full);
+  vksift_hip_free(g->d_scratch);
+  vksift_hip_event_destroy(g->ev_fork);
+  vksift_hip_event_destroy(g->ev_gathered);
+  vksift_hip_event_destroy(g->ev_t0);
+  vksift_hip_event_destroy(g->ev_t1);
+  vksift_hip_stream_destroy(g->comm_stream);
+  vksift_hip_stream_destroy(g->stream);
+  free(g);
+  *gp = NULL;
+}
+
+vksift_Result vksift_ext_matchSharded(vksift_ext_ShardGroup g, const uint8_t *d_a_rows, uint32_t na, uint32_t a_index_base, const uint8_t *d_b_shard,
+                                      uint32_t nb_shard, uint32_t nb_total, uint8_t *d_matches)
+{
+  if (!g || (na > 0 && (!d_a_rows || !d_matches)) || !d_b_shard || nb_shard == 0 || nb_total < 2 || (uint64_t)nb_shard * g->world < nb_total)
+    return VKSIFT_INVALID_INPUT_ERROR;
+  vksift_hip_set_device(g->device);
+  const size_t b_bytes = (size_t)nb_shard * g->world * 128u;
+  /* norms of A, norms of B (padded rows included), redo flags, partial lists of the B-chunked kernel */
+  const size_t scratch = (size_t)2 * na + (size_t)nb_shard * g->world + 64 + (na > 32768u ? (size_t)na * 5u * VKSIFT_HIP_MATCH_CHUNKS : 0);
+  if (b_bytes > g->b_cap || scratch > g->scratch_cap)
+  {
+    vksift_hip_stream_sync(g->comm_stream);
+    vksift_hip_stream_sync(g->stream);
+    if (b_bytes > g->b_cap)
+    {
+      vksift_hip_free(g->d_b_full);
+      g->d_b_full = (uint8_t *)vksift_hip_malloc(b_bytes);
+      g->b_cap = g->d_b_full ? b_bytes : 0;
+    }
+    if (scratch > g->scratch_cap)
+    {
+      vksift_hip_free(g->d_scratch);
+      g->d_scratch = (uint32_t *)vksift_hip_malloc(scratch * sizeof(uint32_t));
+      g->scratch_cap = g->d_scratch ? scratch : 0;
+    }
+    if (!g->d_b_full || !g->d_scratch)
+    {
+      logError(LOG_TAG, "vksift_ext_matchSharded() error: out of device memory");
+      return VKSIFT_VULKAN_ERROR;
+    }
+  }
+  uint32_t *norm_a = g->d_scratch, *norm_b = norm_a + na, *rest = norm_b + (size_t)nb_shard * g->world;
+  vksift_hip_range_push("Sharded matching");
+  int e = vksift_hip_event_record(g->ev_t0, g->stream);
+  /* 1. the exchange first, on its own stream (behind everything already queued on the group's stream) */
+  if (e == 0)
+    e = vksift_hip_event_record(g->ev_fork, g->stream);
+  if (e == 0)
+    e = vksift_hip_stream_wait_event(g->comm_stream, g->ev_fork);
+  if (e == 0)
+  {
+    const int ne = g_rccl.AllGather(d_b_shard, g->d_b_full, (size_t)nb_shard * 128u, RCCL_UINT8, g->comm, g->comm_stream);
+    if (ne != 0)
+    {
+      logError(LOG_TAG, "ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(ne) : "?");
+      e = -1;
+    }
+  }
+  if (e == 0)
+    e = vksift_hip_event_record(g->ev_gathered, g->comm_stream);
+  /* 2. meanwhile: the pre-pass of the local query rows */
+  if (e == 0)
+    e = vksift_hip_shifted_norms(d_a_rows, na, norm_a, g->stream);
+  /* 3. B has landed: its norms, then every local row of A against ALL of B in index order */
+  if (e == 0)
+    e = vksift_hip_stream_wait_event(g->stream, g->ev_gathered);
+  if (e == 0)
+    e = vksift_hip_shifted_norms(g->d_b_full, nb_total, norm_b, g->stream);
+  if (e == 0)
+    e = vksift_hip_match_2nn_prenormed(d_a_rows, norm_a, na, a_index_base, g->d_b_full, norm_b, nb_total, rest, d_matches, g->stream);
+  if (e == 0)
+    e = vksift_hip_event_record(g->ev_t1, g->stream);
+  vksift_hip_range_pop();
+  if (e != 0)
+  {
+    logError(LOG_TAG, "vksift_ext_matchSharded() error: %s", e > 0 ? vksift_hip_error_string(e) : "collective failed");
+    return VKSIFT_VULKAN_ERROR;
+  }
+  g->timed = true;
+  return VKSIFT_SUCCESS;
+}
+
+vksift_Result vksift_ext_shardGroupSynchronize(vksift_ext_ShardGroup g, float *last_match_ms)
+{
+  if (!g)
+    return VKSIFT_INVALID_INPUT_ERROR;
+  vksift_hip_set_device(g->device);
+  if (vksift_hip_stream_sync(g->stream) != 0)
+    return VKSIFT_VULKAN_ERROR;
+  if (last_match_ms)
+    *last_match_ms = g->timed ? vksift_hip_event_elapsed_ms(g->ev_t0, g->ev_t1) : -1.f;
+  return VKSIFT_SUCCESS;
+}

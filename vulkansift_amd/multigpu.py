@@ -1,26 +1,36 @@
-"""Multi-GPU layer above the single-instance vksift API: one process per GPU, torch.distributed
-(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+"""Multi-GPU layer above the single-instance vksift API: one process per GPU.
 
-The reference is single-GPU (vulkansift.h:32-34). Two things shard naturally (SURVEY.md §8e):
+The reference is single-GPU (vulkansift.h:32-34). Two things shard naturally:
 
   * detection — images are independent: rank r takes images [r*B/G, (r+1)*B/G); no collective
-  * matching  — the QUERY set A is sharded by rows; every rank needs all of B, which arrives through
-    ONE all-gather of the uint8 descriptor matrix (M x 128 bytes). Each query row still scans the
-    whole of B in index order, so the 2-NN result (including the reference's tie rules) is
-    bit-identical for every world size; results are concatenated in rank order.
+  * matching  — the QUERY set A is sharded by rows; every rank needs all of B, which arrives through ONE all-gather of
+    the uint8 descriptor matrix (M x 128 bytes). Each query row still scans the whole of B in index order, so the 2-NN
+    result (including the reference's tie rules) is bit-identical for every world size.
 
-torch is used for device memory, the all-gather and nothing else; the distances/top-2 are computed
-by the HIP matcher behind the C-ABI (vksift_hip_match_2nn_desc). The compute step is injectable so
-that the collective logic can be exercised on CPU (gloo) with the oracle standing in for the kernel.
+The product path is the C entry vksift_ext_matchSharded (csrc/host/vksift_sharded.c): RCCL all-gather issued inside the
+library, overlapped with the norm pre-pass of the local rows, then the MFMA matcher. `ShardGroup` below is its ctypes
+handle; torch.distributed is used only to carry the 128-byte RCCL id from rank 0 to the other ranks and to collect
+results. `sharded_match_reference` is the same data flow over any torch.distributed backend with an injectable compute
+step — the form the CPU tests run (gloo, world size 2, the oracle standing in for the kernel).
 """
+import ctypes as C
+
 import numpy as np
 
 
 def shard_range(n, world, rank):
-    """Contiguous, balanced split of n items: the first n % world ranks get one extra item."""
+    """Contiguous, balanced split of n items: the first n % world ranks get one extra item (query rows, images)."""
     base, rem = divmod(n, world)
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_bounds(n, world, rank):
+    """Equal blocks of ceil(n / world) rows — the layout of the reference set B that vksift_ext_matchSharded all-gathers
+    (the last blocks may be short or empty; the caller pads them to the block size)."""
+    blk = (n + world - 1) // world
+    lo = min(n, rank * blk)
+    return lo, min(n, lo + blk)
 
 
 def split_batch(items, world, rank):
@@ -29,7 +39,7 @@ def split_batch(items, world, rank):
 
 
 def hip_match_fn(desc_a, a_index_base, desc_b):
-    """2-NN of the dense uint8 descriptor tensors (torch, on the current GPU) through the C-ABI."""
+    """2-NN of the dense uint8 descriptor tensors (torch, on the current GPU) through the kernel C-ABI (single GPU)."""
     import torch
 
     from . import api
@@ -47,36 +57,120 @@ def hip_match_fn(desc_a, a_index_base, desc_b):
     return out
 
 
-def all_gather_rows(local_rows, group=None):
-    """All-gather of row-sharded 2-D tensors with (possibly) different row counts; returns the
-    concatenation in rank order. One size exchange + one padded all_gather (a single collective on
-    the data path: RCCL all-gather over xGMI)."""
+class ShardGroup:
+    """vksift_ext_ShardGroup: the library's own RCCL communicator. `dist` (torch.distributed, initialised) only broadcasts the id."""
+
+    def __init__(self, device_index, world, rank, dist=None):
+        import torch
+
+        from . import api
+
+        self._api = api
+        api.load()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            if api.lib().vksift_ext_shardGetUniqueId(buf) != 0:
+                raise RuntimeError("vksift_ext_shardGetUniqueId failed (RCCL missing?)")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if world > 1:
+            ident = ident.to(torch.device("cuda", device_index)) if dist.get_backend() == "nccl" else ident
+            dist.broadcast(ident, src=0)
+            ident = ident.cpu()
+        raw = (C.c_uint8 * 128)(*ident.tolist())
+        self._h = C.c_void_p(None)
+        r = api.lib().vksift_ext_shardGroupCreate(C.byref(self._h), device_index, world, rank, raw)
+        if r != 0:
+            raise RuntimeError(f"vksift_ext_shardGroupCreate failed ({r})")
+        self.world, self.rank = world, rank
+
+    def match(self, d_a, a_index_base, d_b_shard, nb_total):
+        """d_a: this rank's query rows (n x 128 uint8, cuda); d_b_shard: its block of B padded to ceil(nb_total / world) rows.
+        Returns (records (n x 5 int32, cuda), milliseconds of the whole pipeline on this rank)."""
+        import torch
+
+        assert d_a.is_cuda and d_a.dtype == torch.uint8 and d_a.is_contiguous() and d_b_shard.is_contiguous()
+        out = torch.empty((d_a.shape[0], 5), dtype=torch.int32, device=d_a.device)
+        torch.cuda.synchronize(d_a.device)      # the group's stream is the library's own: inputs must be complete
+        r = self._api.lib().vksift_ext_matchSharded(self._h, d_a.data_ptr(), d_a.shape[0], a_index_base, d_b_shard.data_ptr(), d_b_shard.shape[0], nb_total,
+                                                    out.data_ptr())
+        if r != 0:
+            raise RuntimeError(f"vksift_ext_matchSharded failed ({r})")
+        ms = C.c_float(0)
+        if self._api.lib().vksift_ext_shardGroupSynchronize(self._h, C.byref(ms)) != 0:
+            raise RuntimeError("vksift_ext_shardGroupSynchronize failed")
+        return out, float(ms.value)
+
+    def close(self):
+        if self._h:
+            self._api.lib().vksift_ext_shardGroupDestroy(C.byref(self._h))
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pad_rows(rows, n):
+    """zero-pad a (k x 128) tensor to n rows (padding rows are never addressed: nb_total bounds the scan)"""
+    import torch
+
+    if rows.shape[0] == n:
+        return rows.contiguous()
+    out = torch.zeros((n,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    out[: rows.shape[0]] = rows
+    return out
+
+
+def sharded_match_timed(d_a, a_index_base, d_b_block, nb_total, world, rank, repeats=3):
+    """bench.py helper: best-of-`repeats` time of vksift_ext_matchSharded on this rank + its records."""
+    import torch
+    import torch.distributed as dist
+
+    blk = (nb_total + world - 1) // world
+    grp = ShardGroup(d_a.device.index, world, rank, dist if world > 1 else None)
+    try:
+        d_b = pad_rows(d_b_block, blk)
+        best, rec = None, None
+        for _ in range(repeats):
+            if world > 1:
+                dist.barrier()
+            rec, ms = grp.match(d_a, a_index_base, d_b, nb_total)
+            best = ms if best is None else min(best, ms)
+        return best, rec
+    finally:
+        grp.close()
+
+
+def gather_records(rec_local, n_total, world, rank):
+    """all ranks' (n_local x 5) int32 records -> rank order concatenation (on every rank); A was split with shard_bounds"""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return rec_local
+    blk = (n_total + world - 1) // world
+    pad = torch.zeros((blk, 5), dtype=rec_local.dtype, device=rec_local.device)
+    pad[: rec_local.shape[0]] = rec_local
+    full = torch.empty((world * blk, 5), dtype=rec_local.dtype, device=rec_local.device)
+    dist.all_gather_into_tensor(full, pad)
+    return full[:n_total]
+
+
+def sharded_match_reference(desc_a_local, a_index_base, desc_b_block, nb_total, match_fn, group=None):
+    """The data flow of vksift_ext_matchSharded over torch.distributed (any backend) with an injectable compute step:
+    equal B blocks (padded once), ONE all_gather_into_tensor, no host round trip, then match_fn(local A rows, base, all of B)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    n_local = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=local_rows.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes + [1])
-    pad = torch.zeros((mx,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
-    pad[: local_rows.shape[0]] = local_rows
-    gathered = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(gathered, pad, group=group)
-    return torch.cat([g[:n] for g, n in zip(gathered, sizes)], dim=0), sizes
-
-
-def sharded_match(desc_a_local, a_index_base, desc_b_local, match_fn=hip_match_fn, group=None):
-    """Query-sharded 2-NN.
-
-    desc_a_local : this rank's rows of A (n_a_local x 128, uint8), global row index of its first row = a_index_base
-    desc_b_local : this rank's shard of B (rows in global order by rank)
-    returns      : (n_a_local x 5) int32 match records {idx_a, idx_b1, idx_b2, dist1 bits, dist2 bits} for the
-                   local A rows against the FULL B.
-    """
-    b_full, _ = all_gather_rows(desc_b_local, group=group)
-    return match_fn(desc_a_local, a_index_base, b_full)
+    blk = (nb_total + world - 1) // world
+    b_pad = pad_rows(desc_b_block, blk)
+    b_full = torch.empty((world * blk,) + tuple(b_pad.shape[1:]), dtype=b_pad.dtype, device=b_pad.device)
+    dist.all_gather_into_tensor(b_full, b_pad, group=group)
+    return match_fn(desc_a_local, a_index_base, b_full[:nb_total])
 
 
 def records_to_struct(rec_int32):
