@@ -186,22 +186,24 @@ extern "C"
                                 uint32_t n_stride, float ratio, uint32_t nslots, uint8_t *out, uint64_t out_slot_stride, uint32_t *out_n, vksift_hip_stream s);
 
   /* Asynchronous (and batched) matching pipeline used by vksift_matchFeatures / vksift_ext_matchFeaturesBatch — no
-   * host round trip for the feature counts. Slot i of a batch handles SIFT buffer buf_ids[i] (feats_base +
-   * buf_ids[i]*buf_stride, counters found_base + buf_ids[i]*found_buf_stride); all buffers of one call share the
-   * section table. gather_sections walks up to 16 sections whose stored counts are min(found[o], sec_cap[o]) (or
-   * fixed_counts[o] when found_base is NULL), writes the dense descriptor rows in download order, their shifted norms
-   * and the row total (n_out_dev[slot*n_slot_stride]); rows below pad_rows_to are zero-filled (quirk Q6). max_rows
-   * bounds the launch. match_2nn_async reads {N_A, N_B} of slot i from n_dev[i*n_slot_stride + 0..1].
-   * Slot strides are in bytes for desc/matches and in u32 elements for norms/n. partial_scratch (may be NULL):
-   * 5*max_na*VKSIFT_HIP_MATCH_CHUNKS u32 used by the B-chunked large-N kernel when nslots == 1. redo: max_na u32 per slot
-   * (same slot stride as the norms) of row flags for the exact scalar replay k_match_redo. */
+   * host round trip for the feature counts.
+   * gather_sections: fills the matcher's per-buffer cache entries of the SIFT buffers buf_ids[0..nslots) (feats_base +
+   * id*buf_stride, counters found_base + id*found_buf_stride; all buffers of one call share the section table): walks up
+   * to 16 sections whose stored counts are min(found[o], sec_cap[o]) (or fixed_counts[o] when found_base is NULL), writes
+   * the dense descriptor rows in download order to desc + id*desc_stride, their shifted norms to norms + id*norm_stride and
+   * the row total to n_out_dev[id*n_stride]; rows below pad_rows_to are zero-filled (quirk Q6). max_rows bounds the launch.
+   * match_2nn_async: slot i matches cache entry ids_a[i] against ids_b[i]; it first writes {N_A, N_B} of every slot to
+   * n_dev[i*n_slot_stride + 0..1] (read by the kernels, the filter and the host). Strides in bytes for desc/matches and in
+   * u32 elements for norms/redo/n. partial_scratch (may be NULL): 5*max_na*VKSIFT_HIP_MATCH_CHUNKS u32 used by the
+   * B-chunked large-N kernel when nslots == 1. redo: max_na u32 per slot of row flags for the exact scalar replay. */
   int vksift_hip_gather_sections(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, uint32_t nslots, uint32_t nsec,
                                  const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *fixed_counts, const uint32_t *found_base,
-                                 uint32_t found_buf_stride, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint64_t desc_slot_stride,
-                                 uint32_t *norms, uint64_t norm_slot_stride, uint32_t *n_out_dev, uint32_t n_slot_stride, vksift_hip_stream s);
-  int vksift_hip_match_2nn_async(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t max_na, const uint8_t *desc_b, const uint32_t *norm_b,
-                                 uint32_t *redo, const uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t desc_slot_stride, uint64_t norm_slot_stride,
-                                 uint64_t match_slot_stride, uint32_t n_slot_stride, uint32_t *partial_scratch, vksift_hip_stream s);
+                                 uint32_t found_buf_stride, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint64_t desc_stride,
+                                 uint32_t *norms, uint64_t norm_stride, uint32_t *n_out_dev, uint32_t n_stride, vksift_hip_stream s);
+  int vksift_hip_match_2nn_async(const uint8_t *cache_desc, const uint32_t *cache_norm, const uint32_t *cache_n, const uint32_t *ids_a, const uint32_t *ids_b,
+                                 uint32_t max_na, uint32_t *redo, uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t cache_desc_stride,
+                                 uint64_t cache_norm_stride, uint64_t redo_slot_stride, uint64_t match_slot_stride, uint32_t n_slot_stride,
+                                 uint32_t *partial_scratch, vksift_hip_stream s);
 
 #ifdef __cplusplus
 }

@@ -97,9 +97,10 @@ __global__ void __launch_bounds__(256) k_gather_sections(const uint8_t *__restri
   const uint32_t bufi = map.buf[slot];
   const uint8_t *feats = feats_base + (size_t)bufi * buf_stride;
   const uint32_t *found = found_base ? found_base + (size_t)bufi * found_buf_stride : nullptr;
-  desc += (size_t)slot * desc_slot_stride;
-  norms += (size_t)slot * norm_slot_stride;
-  n_out += (size_t)slot * n_slot_stride;
+  // the dense rows, their norms and the row count land in the per-BUFFER cache entry (reused by every later match of the buffer)
+  desc += (size_t)bufi * desc_slot_stride;
+  norms += (size_t)bufi * norm_slot_stride;
+  n_out += (size_t)bufi * n_slot_stride;
 
   const uint32_t j = threadIdx.x & 31u;
   // stored count of every section (uniform), then a grid-stride walk over the rows that exist
@@ -158,7 +159,25 @@ struct SlotStrides
   uint32_t n;              // u32 between the {N_A, N_B} pairs
   uint64_t redo;           // u32
   uint32_t slot_fast;      // k_match_mfma: blockIdx.x is the slot, blockIdx.y the row block
+  uint32_t use_ids;        // descriptor / norm strides address the per-buffer cache: entry = SlotIds::a/b[slot] instead of the slot
 };
+
+// SIFT buffer (= cache entry) matched by each slot of a batched launch
+struct SlotIds
+{
+  uint32_t a[64], b[64];
+};
+
+// {N_A, N_B} of every slot, from the per-buffer row counts of the cache (the matcher kernels and the host read them per slot)
+__global__ void k_slot_counts(const uint32_t *__restrict__ cache_n, uint32_t cache_n_stride, SlotIds ids, uint32_t nslots, uint32_t *__restrict__ n_out,
+                              uint32_t n_slot_stride)
+{
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nslots)
+    return;
+  n_out[(size_t)slot * n_slot_stride + 0] = cache_n[(size_t)ids.a[slot] * cache_n_stride];
+  n_out[(size_t)slot * n_slot_stride + 1] = cache_n[(size_t)ids.b[slot] * cache_n_stride];
+}
 
 struct Top2
 {
@@ -227,14 +246,15 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
                                                     uint32_t a_index_base, const uint32_t *__restrict__ desc_b, const uint32_t *__restrict__ norm_b,
                                                     uint32_t nb, uint32_t *__restrict__ matches, uint32_t *__restrict__ redo,
                                                     const uint32_t *__restrict__ n_dev, uint32_t na_lo, uint32_t na_hi, SlotStrides ss,
-                                                    uint32_t *__restrict__ partial)
+                                                    uint32_t *__restrict__ partial, SlotIds ids)
 {
   const uint32_t nchunks = gridDim.z, chunk = blockIdx.z;
   // ss.slot_fast: grid = (slots, row blocks) — see the batched launch
   const uint32_t slot = ss.slot_fast ? blockIdx.x : blockIdx.y;
   const uint32_t rb0 = ss.slot_fast ? blockIdx.y : blockIdx.x, rb_step = ss.slot_fast ? gridDim.y : gridDim.x;
-  desc_a += (size_t)slot * ss.desc_a, desc_b += (size_t)slot * ss.desc_b;
-  norm_a += (size_t)slot * ss.norm_a, norm_b += (size_t)slot * ss.norm_b;
+  const uint32_t ea = ss.use_ids ? ids.a[slot] : slot, eb = ss.use_ids ? ids.b[slot] : slot;
+  desc_a += (size_t)ea * ss.desc_a, desc_b += (size_t)eb * ss.desc_b;
+  norm_a += (size_t)ea * ss.norm_a, norm_b += (size_t)eb * ss.norm_b;
   matches += (size_t)slot * ss.matches;
   redo += (size_t)slot * ss.redo;
   if (n_dev)
@@ -506,10 +526,11 @@ __global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__rest
                                                           uint32_t a_index_base, const uint32_t *__restrict__ desc_b,
                                                           const uint32_t *__restrict__ norm_b, uint32_t nb, uint32_t *__restrict__ matches,
                                                           uint32_t *__restrict__ redo, const uint32_t *__restrict__ n_dev, uint32_t na_lo, uint32_t na_hi,
-                                                          SlotStrides ss)
+                                                          SlotStrides ss, SlotIds ids)
 {
-  desc_a += (size_t)blockIdx.y * ss.desc_a, desc_b += (size_t)blockIdx.y * ss.desc_b;
-  norm_a += (size_t)blockIdx.y * ss.norm_a, norm_b += (size_t)blockIdx.y * ss.norm_b;
+  const uint32_t ea = ss.use_ids ? ids.a[blockIdx.y] : blockIdx.y, eb = ss.use_ids ? ids.b[blockIdx.y] : blockIdx.y;
+  desc_a += (size_t)ea * ss.desc_a, desc_b += (size_t)eb * ss.desc_b;
+  norm_a += (size_t)ea * ss.norm_a, norm_b += (size_t)eb * ss.norm_b;
   matches += (size_t)blockIdx.y * ss.matches;
   redo += (size_t)blockIdx.y * ss.redo;
   if (n_dev)
@@ -690,9 +711,10 @@ __global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__rest
 // Never taken for real SIFT descriptors; adversarial inputs just run at scalar speed.
 __global__ void __launch_bounds__(64) k_match_redo(const uint32_t *__restrict__ desc_a, uint32_t na, uint32_t a_index_base,
                                                    const uint32_t *__restrict__ desc_b, uint32_t nb, uint32_t *__restrict__ matches,
-                                                   const uint32_t *__restrict__ redo, const uint32_t *__restrict__ n_dev, SlotStrides ss)
+                                                   const uint32_t *__restrict__ redo, const uint32_t *__restrict__ n_dev, SlotStrides ss, SlotIds ids)
 {
-  desc_a += (size_t)blockIdx.y * ss.desc_a, desc_b += (size_t)blockIdx.y * ss.desc_b;
+  const uint32_t ea = ss.use_ids ? ids.a[blockIdx.y] : blockIdx.y, eb = ss.use_ids ? ids.b[blockIdx.y] : blockIdx.y;
+  desc_a += (size_t)ea * ss.desc_a, desc_b += (size_t)eb * ss.desc_b;
   matches += (size_t)blockIdx.y * ss.matches;
   redo += (size_t)blockIdx.y * ss.redo;
   if (n_dev)
@@ -850,26 +872,27 @@ extern "C"
     hipStream_t hs = (hipStream_t)s;
     uint32_t *redo = scratch;
     const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
-    const SlotStrides z{0, 0, 0, 0, 0, 0, 0, 0};
+    const SlotStrides z{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const SlotIds noids{};
     /* Small problems: 16 A rows per workgroup with B split over its waves; medium: 16 rows per wave; large: 32 rows per
      * wave (B-tile reuse) with B split into VKSIFT_HIP_MATCH_CHUNKS chunks across grid.z + exact merge. */
     if (na <= 8192u)
       hipLaunchKernelGGL(k_match_mfma_split, dim3((na + 15u) / 16u), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
-                         (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z);
+                         (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, noids);
     else if (na <= 32768u)
       hipLaunchKernelGGL(k_match_mfma<1>, dim3((na + 63u) / 64u), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
-                         (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, (uint32_t *)nullptr);
+                         (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, (uint32_t *)nullptr, noids);
     else
     {
       uint32_t *partial = redo + na;
       hipLaunchKernelGGL(k_match_mfma<2>, dim3((na + 127u) / 128u, 1, VKSIFT_HIP_MATCH_CHUNKS), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb,
-                         (uint32_t *)matches, redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial);
+                         (uint32_t *)matches, redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids);
       hipLaunchKernelGGL(k_match_merge, dim3((na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial, na, (uint32_t)VKSIFT_HIP_MATCH_CHUNKS,
                          a_index_base, (uint32_t *)matches, redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
     }
     uint32_t rblocks = (na + 63u) / 64u;
     hipLaunchKernelGGL(k_match_redo, dim3(rblocks > 1024u ? 1024u : rblocks), dim3(64), 0, hs, da, na, a_index_base, db, nb, (uint32_t *)matches,
-                       (const uint32_t *)redo, (const uint32_t *)nullptr, z);
+                       (const uint32_t *)redo, (const uint32_t *)nullptr, z, noids);
     return (int)hipGetLastError();
   }
 
@@ -919,22 +942,29 @@ extern "C"
     return (int)hipGetLastError();
   }
 
-  int vksift_hip_match_2nn_async(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t max_na, const uint8_t *desc_b, const uint32_t *norm_b,
-                                 uint32_t *redo, const uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t desc_slot_stride,
-                                 uint64_t norm_slot_stride, uint64_t match_slot_stride, uint32_t n_slot_stride, uint32_t *partial_scratch,
-                                 vksift_hip_stream s)
+  int vksift_hip_match_2nn_async(const uint8_t *cache_desc, const uint32_t *cache_norm, const uint32_t *cache_n, const uint32_t *ids_a, const uint32_t *ids_b,
+                                 uint32_t max_na, uint32_t *redo, uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t cache_desc_stride,
+                                 uint64_t cache_norm_stride, uint64_t redo_slot_stride, uint64_t match_slot_stride, uint32_t n_slot_stride,
+                                 uint32_t *partial_scratch, vksift_hip_stream s)
   {
-    if (max_na == 0)
-      return 0;
-    if (nslots < 1)
+    if (nslots < 1 || nslots > 64)
       return (int)hipErrorInvalidValue;
+    SlotIds ids;
+    for (uint32_t i = 0; i < 64; i++)
+      ids.a[i] = i < nslots ? ids_a[i] : 0u, ids.b[i] = i < nslots ? ids_b[i] : 0u;
+    hipLaunchKernelGGL(k_slot_counts, dim3(1), dim3(64), 0, (hipStream_t)s, cache_n, 1u, ids, nslots, n_dev, n_slot_stride);
+    if (max_na == 0)
+      return (int)hipGetLastError();
+    const uint8_t *desc_a = cache_desc, *desc_b = cache_desc;
+    const uint32_t *norm_a = cache_norm, *norm_b = cache_norm;
     SlotStrides ss;
-    ss.desc_a = ss.desc_b = desc_slot_stride / 4;
-    ss.norm_a = ss.norm_b = norm_slot_stride;
+    ss.desc_a = ss.desc_b = cache_desc_stride / 4;
+    ss.norm_a = ss.norm_b = cache_norm_stride;
     ss.matches = match_slot_stride / 4;
     ss.n = n_slot_stride;
-    ss.redo = norm_slot_stride; /* the redo flags live in the same per-slot scratch block as the norms */
+    ss.redo = redo_slot_stride;
     ss.slot_fast = 0;
+    ss.use_ids = 1;
     /* The row count is only known on the device: launch for the capacity (surplus workgroups exit at once), one
      * kernel per size regime, each of which returns immediately unless N_A falls in its range:
      *   N_A <= S1          B-split kernel, 16 A rows per workgroup (keeps a few thousand rows busy on every CU)
@@ -952,7 +982,7 @@ extern "C"
     auto bounded = [](uint32_t blocks, uint32_t slots) { uint32_t lim = slots >= 8 ? 64u : 1024u; return blocks < lim ? blocks : lim; };
     const uint32_t n1 = max_na < S1 ? max_na : S1;
     hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev,
-                       0u, S1, ss);
+                       0u, S1, ss, ids);
     if (max_na > S1)
     {
       const uint32_t n2 = max_na < S2 ? max_na : S2;
@@ -968,25 +998,25 @@ extern "C"
       s2.slot_fast = (slot_fast && nslots > 1) ? 1u : 0u;
       const uint32_t gb = bounded((n2 + 63u) / 64u, nslots);
       hipLaunchKernelGGL(k_match_mfma<1>, s2.slot_fast ? dim3(nslots, gb) : dim3(gb, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
-                         (uint32_t *)matches, redo, n_dev, S1, S2, s2, (uint32_t *)nullptr);
+                         (uint32_t *)matches, redo, n_dev, S1, S2, s2, (uint32_t *)nullptr, ids);
     }
     if (max_na > S2)
     {
       if (nslots == 1 && partial_scratch)
       {
         hipLaunchKernelGGL(k_match_mfma<2>, dim3(bounded((max_na + 127u) / 128u, 1), 1, VKSIFT_HIP_MATCH_CHUNKS), dim3(256), 0, hs, da, norm_a, 0u, 0u, db,
-                           norm_b, 0u, (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, partial_scratch);
+                           norm_b, 0u, (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, partial_scratch, ids);
         hipLaunchKernelGGL(k_match_merge, dim3((max_na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial_scratch, 0u,
                            (uint32_t)VKSIFT_HIP_MATCH_CHUNKS, 0u, (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu);
       }
       else
         hipLaunchKernelGGL(k_match_mfma<2>, dim3(bounded((max_na + 127u) / 128u, nslots), nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
-                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, (uint32_t *)nullptr);
+                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, (uint32_t *)nullptr, ids);
     }
     uint32_t rblocks = (max_na + 63u) / 64u;
     if (rblocks > 64u)
       rblocks = 64u;
-    hipLaunchKernelGGL(k_match_redo, dim3(rblocks, nslots), dim3(64), 0, hs, da, 0u, 0u, db, 0u, (uint32_t *)matches, (const uint32_t *)redo, n_dev, ss);
+    hipLaunchKernelGGL(k_match_redo, dim3(rblocks, nslots), dim3(64), 0, hs, da, 0u, 0u, db, 0u, (uint32_t *)matches, (const uint32_t *)redo, n_dev, ss, ids);
     return (int)hipGetLastError();
   }
 

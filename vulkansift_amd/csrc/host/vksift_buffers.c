@@ -118,6 +118,7 @@ void vksift_uploadFeatures(vksift_Instance instance, const vksift_Feature *feats
   /* the buffer becomes one packed section (sift_memory.c:1262-1266) */
   b->is_packed = true;
   b->nb_stored = nb_feats;
+  inst->cache_valid[gpu_buffer_id] = false;
   b->nb_sections = 0;
   b->counts_valid = true;
   return;

@@ -450,7 +450,10 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   }
   inst->cur_batch = count;
   for (uint32_t i = 0; i < count; i++)
+  {
     set_buffer_sections(inst, first_buf + i, inst->lay.n_oct, w, h);
+    inst->cache_valid[first_buf + i] = false; /* the matcher's view of the buffer is rebuilt on its next matching */
+  }
 
   DetectCtx c;
   c.inst = inst, c.L = &inst->lay, c.PS = PS;

@@ -88,16 +88,16 @@ uint32_t vksift_ext_exportDescriptorsDevice(vksift_Instance instance, uint32_t g
   }
   vksift_Instance inst = instance;
   vksift_hip_set_device(inst->device);
-  uint32_t n = 0, max_rows = 0;
+  uint32_t n = 0;
   HIP_CHECK(wait_all(inst), "stream synchronisation");
   {
-    /* gather into slot 0's A scratch (norms are a by-product), then copy the rows out */
-    const MatchScratch fwd = fwd_scratch(inst);
-    HIP_CHECK(gather_buffers(inst, &fwd, &gpu_buffer_id, 1, 0, false, inst->d_desc_a, 2, 0u, &max_rows), "descriptor gather");
-    HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n + 2, inst->d_match_n + 2, sizeof(uint32_t), inst->stream), "descriptor gather");
+    /* the matcher's cache entry of the buffer holds exactly these rows (filled now if the buffer changed since its last matching) */
+    HIP_CHECK(refresh_match_cache(inst, &gpu_buffer_id, 1), "descriptor gather");
+    HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n + 2, inst->d_cache_n + gpu_buffer_id, sizeof(uint32_t), inst->stream), "descriptor gather");
     HIP_CHECK(vksift_hip_stream_sync(inst->stream), "descriptor gather");
     n = inst->h_match_n[2];
-    HIP_CHECK(vksift_hip_memcpy_d2d(d_descriptors, inst->d_desc_a, (size_t)n * 128u, inst->stream), "descriptor gather");
+    HIP_CHECK(vksift_hip_memcpy_d2d(d_descriptors, inst->d_cache_desc + (uint64_t)gpu_buffer_id * inst->desc_slot_stride, (size_t)n * 128u, inst->stream),
+              "descriptor gather");
     HIP_CHECK(vksift_hip_stream_sync(inst->stream), "descriptor gather");
   }
   return n;

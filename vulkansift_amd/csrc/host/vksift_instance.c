@@ -163,11 +163,15 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   /* matching scratch: one slot per batch entry (slot 0 serves vksift_matchFeatures) */
   inst->desc_slot_stride = (((uint64_t)config->max_nb_sift_per_buffer * 128u + 256u) + 255u) & ~(uint64_t)255u;
   inst->match_slot_stride = (((uint64_t)config->max_nb_sift_per_buffer * MATCH_BYTES) + 255u) & ~(uint64_t)255u;
-  inst->norm_slot_stride = 3u * (uint64_t)config->max_nb_sift_per_buffer + 96u; /* norms of A, norms of B, redo flags */
-  ALLOC_D(inst->d_desc_a, inst->desc_slot_stride * batch_cap);
-  ALLOC_D(inst->d_desc_b, inst->desc_slot_stride * batch_cap);
+  inst->redo_slot_stride = (uint64_t)config->max_nb_sift_per_buffer + 32u;
+  inst->cache_norm_stride = (uint64_t)config->max_nb_sift_per_buffer + 32u;
+  ALLOC_D(inst->d_cache_desc, inst->desc_slot_stride * config->sift_buffer_count);
+  ALLOC_D(inst->d_cache_norm, sizeof(uint32_t) * inst->cache_norm_stride * config->sift_buffer_count);
+  ALLOC_D(inst->d_cache_n, sizeof(uint32_t) * config->sift_buffer_count);
+  inst->cache_valid = (bool *)calloc(config->sift_buffer_count, sizeof(bool));
+  ok = ok && inst->cache_valid != NULL;
   ALLOC_D(inst->d_matches, inst->match_slot_stride * batch_cap);
-  ALLOC_D(inst->d_norms, sizeof(uint32_t) * inst->norm_slot_stride * batch_cap);
+  ALLOC_D(inst->d_redo, sizeof(uint32_t) * inst->redo_slot_stride * batch_cap);
   ALLOC_D(inst->d_match_n, sizeof(uint32_t) * 4 * batch_cap);
   if (config->max_nb_sift_per_buffer > 32768u)
     ALLOC_D(inst->d_match_partial, sizeof(uint32_t) * (size_t)config->max_nb_sift_per_buffer * 5u * VKSIFT_HIP_MATCH_CHUNKS);
@@ -296,18 +300,18 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_free(inst->d_ori_ang);
   vksift_hip_free(inst->d_ori_cnt);
   vksift_hip_free(inst->d_desc_fp);
-  vksift_hip_free(inst->d_desc_a);
-  vksift_hip_free(inst->d_desc_b);
+  vksift_hip_free(inst->d_cache_desc);
+  vksift_hip_free(inst->d_cache_norm);
+  vksift_hip_free(inst->d_cache_n);
+  free(inst->cache_valid);
   vksift_hip_free(inst->d_matches);
-  vksift_hip_free(inst->d_norms);
+  vksift_hip_free(inst->d_redo);
   vksift_hip_free(inst->d_match_n);
   vksift_hip_free(inst->d_match_partial);
   for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
     vksift_hip_graph_destroy(inst->graphs[i].exec);
-  vksift_hip_free(inst->rev.desc_a);
-  vksift_hip_free(inst->rev.desc_b);
   vksift_hip_free(inst->rev.matches);
-  vksift_hip_free(inst->rev.norms);
+  vksift_hip_free(inst->rev.redo);
   vksift_hip_free(inst->rev.match_n);
   vksift_hip_free(inst->d_filtered);
   vksift_hip_free(inst->d_filtered_n);

@@ -63,8 +63,8 @@ typedef struct
 /* device scratch of one set of matching slots (slot i serves pair i of a batched call) */
 typedef struct
 {
-  uint8_t *desc_a, *desc_b, *matches;
-  uint32_t *norms, *match_n;
+  uint8_t *matches;
+  uint32_t *redo, *match_n;
 } MatchScratch;
 
 typedef struct
@@ -116,8 +116,14 @@ struct vksift_Instance_T
   uint64_t ori_cap; /* keypoints reserved per image */
   float *d_desc_fp;
   uint32_t desc_fp_len;
-  uint8_t *d_desc_a, *d_desc_b, *d_matches, *h_matches;
-  uint32_t *d_norms;
+  uint8_t *d_matches, *h_matches;
+  uint32_t *d_redo;        /* per match slot: row flags for the exact scalar replay (k_match_redo) */
+  /* per SIFT buffer: the matcher's view of it (dense descriptor rows in download order, shifted norms, row count), filled by a
+   * device-side gather when the buffer is first matched after a detection / upload */
+  uint8_t *d_cache_desc;
+  uint32_t *d_cache_norm, *d_cache_n;
+  uint64_t cache_norm_stride; /* u32 elements */
+  bool *cache_valid;
   uint32_t *d_match_partial; /* partial top-2 lists of the B-chunked large-N matcher (NULL when max_nb <= 32768) */
   uint32_t *d_match_n, *h_match_n; /* per match slot: {N_A, N_B, spare, spare} of the last matching pipeline */
   /* filtered matching (vksift_ext_matchFeaturesFiltered): scratch of the reverse (B->A) matching and the survivors; allocated on first use */
@@ -133,7 +139,7 @@ struct vksift_Instance_T
   uint64_t filtered_slot_stride;
   uint32_t filtered_slots_used;
   uint64_t desc_slot_stride, match_slot_stride; /* bytes */
-  uint64_t norm_slot_stride;                    /* u32 elements */
+  uint64_t redo_slot_stride;                    /* u32 elements */
   uint32_t match_slots_used;
   vksift_hip_event ev_staging;      /* host image staging buffer consumed by the H2D copy */
   bool staging_pending;
@@ -211,7 +217,6 @@ VKSIFT_INTERNAL uint32_t buffer_counts(vksift_Instance inst, uint32_t buf, uint3
 
 /* vksift_match.c */
 VKSIFT_INTERNAL MatchScratch fwd_scratch(vksift_Instance inst);
-VKSIFT_INTERNAL int gather_buffers(vksift_Instance inst, const MatchScratch *ms, const uint32_t *ids, uint32_t count, uint32_t first_slot, bool side_b,
-                                   uint8_t *d_desc_base, uint32_t n_index, uint32_t pad_rows_to, uint32_t *max_rows_out);
+VKSIFT_INTERNAL int refresh_match_cache(vksift_Instance inst, const uint32_t *ids, uint32_t count);
 
 #endif

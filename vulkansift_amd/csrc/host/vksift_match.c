@@ -19,81 +19,99 @@ static bool same_layout(const BufferInfo *x, const BufferInfo *y)
   return true;
 }
 
-/* Device-side gather of `count` buffers (all with the layout of bufs[ids[0]]) into match slots first_slot.. .
- * The reference physically packs the octave sections (pack_BufferMemory, sift_memory.c:957-1047) after reading the
- * counts on the host; here the gather kernel reads the counters in HBM and walks the sections in the same order, so
- * nothing waits on the host. Returns the launch bound on the row count through *max_rows_out. */
-int gather_buffers(vksift_Instance inst, const MatchScratch *ms, const uint32_t *ids, uint32_t count, uint32_t first_slot, bool side_b, uint8_t *d_desc_base,
-                          uint32_t n_index, uint32_t pad_rows_to, uint32_t *max_rows_out)
+/* Launch bound on the number of stored rows of a buffer: the real total if its counters have reached the host, else the
+ * sum of its section capacities. */
+static uint32_t rows_bound(vksift_Instance inst, uint32_t id)
 {
-  const BufferInfo *b = &inst->bufs[ids[0]];
-  const uint32_t cap = inst->cfg.max_nb_sift_per_buffer;
-  uint8_t *d_desc = d_desc_base + (uint64_t)first_slot * inst->desc_slot_stride;
-  uint32_t *d_norm = ms->norms + (uint64_t)first_slot * inst->norm_slot_stride + (side_b ? cap + 32u : 0u);
-  uint32_t *d_n = ms->match_n + (size_t)first_slot * 4 + n_index;
-  uint32_t max_rows = 0;
-  int e;
+  const BufferInfo *b = &inst->bufs[id];
   if (b->nb_sections == 0)
+    return b->nb_stored;
+  uint32_t known = 0, cap_sum = 0;
+  const uint32_t *found = inst->h_found + (size_t)id * VKSIFT_MAX_OCTAVES;
+  for (uint32_t o = 0; o < b->nb_sections; o++)
   {
-    uint32_t zero_off = 0, cap1 = b->nb_stored, fixed1 = b->nb_stored;
-    max_rows = b->nb_stored;
-    e = vksift_hip_gather_sections(inst->d_feats, inst->buf_stride, ids, count, 1, &zero_off, &cap1, &fixed1, NULL, 0, max_rows, pad_rows_to, d_desc,
-                                   inst->desc_slot_stride, d_norm, inst->norm_slot_stride, d_n, 4, inst->stream);
+    known += found[o] < b->sec_cap[o] ? found[o] : b->sec_cap[o];
+    cap_sum += b->sec_cap[o];
   }
-  else
+  return b->counts_valid ? known : cap_sum;
+}
+
+/* The matcher's input of a SIFT buffer — dense 128-byte descriptor rows in download order, their shifted norms and the row
+ * count — lives in a per-buffer cache entry, filled by ONE device-side gather the first time the buffer is matched after it
+ * changed (detection, upload) and reused by every later matching: a self-match gathers once instead of twice, the two
+ * directions of a pair matching gather nothing the second time. The reference physically packs the octave sections
+ * (pack_BufferMemory, sift_memory.c:957-1047) after reading the counts on the host; here the gather kernel reads the
+ * counters in HBM and walks the sections in the same order, so nothing waits on the host. Rows below 2 are zero-filled:
+ * Get2NearestNeighbors.comp:66-67 reads b[0] and b[1] unconditionally (stale memory in the reference when B holds fewer
+ * than two features); here the missing rows are defined as all-zero descriptors. */
+int refresh_match_cache(vksift_Instance inst, const uint32_t *ids, uint32_t count)
+{
+  detect_running(inst); /* refreshes counts_valid if the last detection has finished */
+  uint32_t todo[128];
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < count && n < 128; i++)
   {
-    detect_running(inst); /* refreshes counts_valid if the last detection has finished */
-    bool all_known = true;
-    uint32_t known_max = 0, cap_sum = 0;
-    for (uint32_t o = 0; o < b->nb_sections; o++)
-      cap_sum += b->sec_cap[o];
-    for (uint32_t i = 0; i < count; i++)
+    bool seen = inst->cache_valid[ids[i]];
+    for (uint32_t k = 0; k < n && !seen; k++)
+      seen = todo[k] == ids[i];
+    if (!seen)
+      todo[n++] = ids[i];
+  }
+  uint32_t i0 = 0;
+  while (i0 < n)
+  {
+    /* one launch per run of buffers that share a section layout (always all of them after a batched detection) */
+    const BufferInfo *b = &inst->bufs[todo[i0]];
+    uint32_t i1 = i0 + 1, max_rows = rows_bound(inst, todo[i0]);
+    while (i1 < n && i1 - i0 < 64 && same_layout(b, &inst->bufs[todo[i1]]))
     {
-      const BufferInfo *bi = &inst->bufs[ids[i]];
-      if (!bi->counts_valid)
-      {
-        all_known = false;
-        break;
-      }
-      uint32_t known = 0;
-      const uint32_t *found = inst->h_found + (size_t)ids[i] * VKSIFT_MAX_OCTAVES;
-      for (uint32_t o = 0; o < bi->nb_sections; o++)
-        known += found[o] < bi->sec_cap[o] ? found[o] : bi->sec_cap[o];
-      if (known > known_max)
-        known_max = known;
+      const uint32_t r = rows_bound(inst, todo[i1]);
+      max_rows = r > max_rows ? r : max_rows;
+      i1++;
     }
-    max_rows = all_known ? known_max : cap_sum; /* counts already on the host? then bound the launch by the real total */
-    e = vksift_hip_gather_sections(inst->d_feats, inst->buf_stride, ids, count, b->nb_sections, b->sec_off, b->sec_cap, NULL, inst->d_found,
-                                   VKSIFT_MAX_OCTAVES, max_rows, pad_rows_to, d_desc, inst->desc_slot_stride, d_norm, inst->norm_slot_stride, d_n, 4,
-                                   inst->stream);
+    int e;
+    if (b->nb_sections == 0)
+    {
+      uint32_t zero_off = 0, cap1 = b->nb_stored, fixed1 = b->nb_stored;
+      e = vksift_hip_gather_sections(inst->d_feats, inst->buf_stride, todo + i0, i1 - i0, 1, &zero_off, &cap1, &fixed1, NULL, 0, max_rows, 2u, inst->d_cache_desc,
+                                     inst->desc_slot_stride, inst->d_cache_norm, inst->cache_norm_stride, inst->d_cache_n, 1, inst->stream);
+    }
+    else
+      e = vksift_hip_gather_sections(inst->d_feats, inst->buf_stride, todo + i0, i1 - i0, b->nb_sections, b->sec_off, b->sec_cap, NULL, inst->d_found,
+                                     VKSIFT_MAX_OCTAVES, max_rows, 2u, inst->d_cache_desc, inst->desc_slot_stride, inst->d_cache_norm, inst->cache_norm_stride,
+                                     inst->d_cache_n, 1, inst->stream);
+    if (e)
+      return e;
+    for (uint32_t k = i0; k < i1; k++)
+      inst->cache_valid[todo[k]] = true;
+    i0 = i1;
   }
-  *max_rows_out = max_rows;
-  return e;
+  return 0;
 }
 
 MatchScratch fwd_scratch(vksift_Instance inst)
 {
-  MatchScratch ms = {inst->d_desc_a, inst->d_desc_b, inst->d_matches, inst->d_norms, inst->d_match_n};
+  MatchScratch ms = {inst->d_matches, inst->d_redo, inst->d_match_n};
   return ms;
 }
 
 static int match_slots(vksift_Instance inst, const MatchScratch *ms, const uint32_t *ids_a, const uint32_t *ids_b, uint32_t count, uint32_t first_slot)
 {
-  const uint32_t cap = inst->cfg.max_nb_sift_per_buffer;
-  uint32_t max_na = 0, max_nb = 0;
-  int e = gather_buffers(inst, ms, ids_a, count, first_slot, false, ms->desc_a, 0, 0u, &max_na);
+  int e = refresh_match_cache(inst, ids_a, count);
+  if (e == 0)
+    e = refresh_match_cache(inst, ids_b, count);
   if (e)
     return e;
-  /* Get2NearestNeighbors.comp:66-67 reads b[0] and b[1] unconditionally (stale memory in the reference when B holds
-   * fewer than two features); here the missing rows are defined as all-zero descriptors. */
-  e = gather_buffers(inst, ms, ids_b, count, first_slot, true, ms->desc_b, 1, 2u, &max_nb);
-  if (e)
-    return e;
-  const uint32_t *norm_a = ms->norms + (uint64_t)first_slot * inst->norm_slot_stride;
-  return vksift_hip_match_2nn_async(ms->desc_a + (uint64_t)first_slot * inst->desc_slot_stride, norm_a, max_na,
-                                    ms->desc_b + (uint64_t)first_slot * inst->desc_slot_stride, norm_a + cap + 32u, (uint32_t *)norm_a + 2u * cap + 64u,
-                                    ms->match_n + (size_t)first_slot * 4, ms->matches + (uint64_t)first_slot * inst->match_slot_stride, count,
-                                    inst->desc_slot_stride, inst->norm_slot_stride, inst->match_slot_stride, 4, inst->d_match_partial, inst->stream);
+  uint32_t max_na = 0;
+  for (uint32_t i = 0; i < count; i++)
+  {
+    const uint32_t r = rows_bound(inst, ids_a[i]);
+    max_na = r > max_na ? r : max_na;
+  }
+  return vksift_hip_match_2nn_async(inst->d_cache_desc, inst->d_cache_norm, inst->d_cache_n, ids_a, ids_b, max_na,
+                                    ms->redo + (uint64_t)first_slot * inst->redo_slot_stride, ms->match_n + (size_t)first_slot * 4,
+                                    ms->matches + (uint64_t)first_slot * inst->match_slot_stride, count, inst->desc_slot_stride, inst->cache_norm_stride,
+                                    inst->redo_slot_stride, inst->match_slot_stride, 4, inst->d_match_partial, inst->stream);
 }
 
 /* reverse-matching scratch + survivor lists of vksift_ext_matchFeaturesFiltered, allocated on first use */
@@ -104,10 +122,8 @@ static bool ensure_filter_scratch(vksift_Instance inst)
   /* each block only if it does not exist yet: a call that ran out of memory half-way is retried without leaking */
   bool ok = true;
 #define ENSURE_D(ptr, bytes) ok = ok && ((ptr) != NULL || ((ptr) = vksift_hip_malloc(bytes)) != NULL)
-  ENSURE_D(inst->rev.desc_a, inst->desc_slot_stride * bc);
-  ENSURE_D(inst->rev.desc_b, inst->desc_slot_stride * bc);
   ENSURE_D(inst->rev.matches, inst->match_slot_stride * bc);
-  ENSURE_D(inst->rev.norms, sizeof(uint32_t) * inst->norm_slot_stride * bc);
+  ENSURE_D(inst->rev.redo, sizeof(uint32_t) * inst->redo_slot_stride * bc);
   ENSURE_D(inst->rev.match_n, sizeof(uint32_t) * 4 * bc);
   ENSURE_D(inst->d_filtered_n, sizeof(uint32_t) * bc);
   ENSURE_D(inst->d_filtered, inst->filtered_slot_stride * bc);
@@ -134,17 +150,8 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
     vksift_hip_event_record(inst->ev_m[0], inst->stream);
   vksift_hip_range_push("Matching");
   range_open = true;
-  /* one batched launch sequence when every A buffer and every B buffer share a section layout (always the case
-   * after a batched detection), otherwise pair by pair */
-  bool uniform = true;
-  for (uint32_t i = 1; i < count && uniform; i++)
-    uniform = same_layout(&inst->bufs[ids_a[0]], &inst->bufs[ids_a[i]]) && same_layout(&inst->bufs[ids_b[0]], &inst->bufs[ids_b[i]]);
   const MatchScratch fwd = fwd_scratch(inst);
-  if (uniform)
-    HIP_CHECK(match_slots(inst, &fwd, ids_a, ids_b, count, 0), "2-NN matching");
-  else
-    for (uint32_t i = 0; i < count; i++)
-      HIP_CHECK(match_slots(inst, &fwd, ids_a + i, ids_b + i, 1, i), "2-NN matching");
+  HIP_CHECK(match_slots(inst, &fwd, ids_a, ids_b, count, 0), "2-NN matching");
   HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n, inst->d_match_n, sizeof(uint32_t) * 4 * count, inst->stream), "match count read-back");
   inst->filtered_slots_used = 0;
   if (filter)
@@ -156,13 +163,7 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
       goto gpu_error;
     }
     if (cross_check)
-    {
-      if (uniform)
-        HIP_CHECK(match_slots(inst, &inst->rev, ids_b, ids_a, count, 0), "reverse 2-NN matching");
-      else
-        for (uint32_t i = 0; i < count; i++)
-          HIP_CHECK(match_slots(inst, &inst->rev, ids_b + i, ids_a + i, 1, i), "reverse 2-NN matching");
-    }
+      HIP_CHECK(match_slots(inst, &inst->rev, ids_b, ids_a, count, 0), "reverse 2-NN matching");
     HIP_CHECK(vksift_hip_filter_matches(inst->d_matches, inst->match_slot_stride, cross_check ? inst->rev.matches : NULL, inst->match_slot_stride,
                                         inst->d_match_n, 4, ratio, count, inst->d_filtered, inst->filtered_slot_stride, inst->d_filtered_n, inst->stream),
               "match filtering");
