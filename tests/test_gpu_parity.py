@@ -146,6 +146,32 @@ def test_match_float_collisions(vk, oracle):
     _assert_matches_equal(_match_via_api(vk, a, b), oracle.match_2nn(a, b))
 
 
+@pytest.mark.parametrize("na,nb,via_ptr", [(9000, 700, False), (20000, 2100, True), (33000, 5000, True), (40000, 300, False)])
+def test_match_ties_in_every_kernel_regime(vk, oracle, na, nb, via_ptr):
+    """quirk Q7 (d(b0) == d(b1): index 1 first), duplicate B rows (earlier index first) and exact zero distances in the 16-rows-per-wave
+    kernel, the 64-rows-per-wave kernel with B chunks, through the instance and through the device-pointer entry"""
+    rng = np.random.default_rng(na + nb)
+    a = vk.gen_synthetic_descriptors(na, na)
+    b = vk.gen_synthetic_descriptors(nb, nb)
+    b[1] = b[0]                                   # Q7 for every row of A
+    dup = rng.permutation(np.arange(2, nb))[: nb // 4]
+    b[dup] = b[rng.integers(2, nb, len(dup))]     # many duplicate rows anywhere in B (also across chunk borders)
+    hit = rng.permutation(na)[: na // 10]
+    a[hit] = b[rng.integers(0, nb, len(hit))]     # zero distances, some of them to b0 / b1 and to duplicated rows
+    a[::97] = b[0]
+    ref = oracle.match_2nn(a, b)
+    if via_ptr:
+        import torch
+        from vulkansift_amd import multigpu
+        rec = multigpu.hip_match_fn(torch.from_numpy(a).cuda(), 0, torch.from_numpy(b).cuda())
+        torch.cuda.synchronize()
+        got = multigpu.records_to_struct(rec.cpu().numpy())
+    else:
+        got = _match_via_api(vk, a, b)
+    _assert_matches_equal(got, ref)
+    assert (ref["idx_b1"][::97] == 1).all() and (ref["idx_b2"][::97] == 0).all()
+
+
 def test_match_fewer_than_two_b_rows(vk, oracle):
     """nb < 2: this build defines the rows the shader would read as stale memory as zero descriptors"""
     a = vk.gen_synthetic_descriptors(21, 40)

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Where the time of the reference's measurement protocol goes (host image in, features + matches out), 128 x 640x480."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vulkansift_amd import api
+import torch
+
+api.lib().vksift_setLogLevel(api.VKSIFT_LOG_ERROR)
+B, W, H = 128, 640, 480
+frames = [api.gen_synthetic_image(0x5EED0000 + i, W, H) for i in range(B)]
+cfg = api.default_config(sift_buffer_count=B, input_image_max_size=W * H)
+inst = api.Instance(cfg, batch_capacity=B)
+lib = api.lib()
+feat = np.zeros(cfg.max_nb_sift_per_buffer, api.FEATURE_DTYPE)
+mt = np.zeros(cfg.max_nb_sift_per_buffer, api.MATCH_DTYPE)
+def T(f, n=5):
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+def det(): inst.detectFeaturesBatch(frames, 0)
+def det_sync():
+    inst.detectFeaturesBatch(frames, 0); lib.vksift_getFeaturesNumber(inst._h, 0)
+def dl():
+    for i in range(B):
+        lib.vksift_getFeaturesNumber(inst._h, i); lib.vksift_downloadFeatures(inst._h, feat.ctypes.data, i)
+def match():
+    for i0 in range(0, B, 64):
+        ids = list(range(i0, i0 + 64)); inst.matchFeaturesBatch(ids, ids)
+        for k in range(64):
+            lib.vksift_ext_getMatchesNumberBatch(inst._h, k); lib.vksift_ext_downloadMatchesBatch(inst._h, k, mt.ctypes.data)
+t0 = time.perf_counter(); inst.detectFeaturesBatch(frames, 0); t_enq = (time.perf_counter() - t0) * 1e3
+print("enqueue detectFeaturesBatch(host) returns after %.2f ms" % t_enq)
+print("detect (host images) + wait: %.2f ms" % T(det_sync))
+print("128 x (count + downloadFeatures): %.2f ms" % T(dl))
+print("2 x matchFeaturesBatch(64) + 128 x downloadMatches: %.2f ms" % T(match))
+inst.close()

@@ -185,7 +185,7 @@ struct Top2
 };
 
 constexpr uint32_t Q_EXACT = 1u << 22;
-constexpr uint32_t SYNC_TILES = 4; // tiles between two exchanges of the row-wide pruning bound (power of two)
+constexpr uint32_t SYNC_TILES = 8;  // tiles between two exchanges of the row-wide pruning bound in the steady state (power of two)
 
 // Accumulator-space form of the pruning test (see k_match_mfma): D > acc_threshold(an, eff) is implied by an + par - 2 D < eff.
 // Real accumulators stay above -2^22 (|a'.b'| <= 2^21, bn/2 <= 2^20): ACC_PASS lets all of them through, ACC_DEAD none.
@@ -267,8 +267,18 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
     if (na <= na_lo || na > na_hi)
       return;
   }
+  // Operand roles are swapped with respect to the textbook A x B^T: the B descriptors are the MFMA's A operand and the query
+  // rows its B operand, so the 16x16 result block is indexed [B column][A row] and lane (col = lane & 15, grp = lane >> 4)
+  // holds, for ITS A row `col` of the tile, the four B columns grp*4 + j of the block. Consequences:
+  //   * one top-2 state per (lane, row tile) instead of four: the candidates of an A row live in 4 lanes (grp 0..3), each
+  //     seeing a quarter of the columns in increasing order — its own second best is already a fair bound
+  //   * the row-wide bound is a 2-step butterfly over grp (2 values, lanes ^16 and ^32): cheap enough for every tile
+  //   * the pruning test needs no per-column work: the accumulator starts at C = -(bn >> 1), read as one 16-byte LDS vector,
+  //     and "can any of these four candidates beat eff?" is max(acc) > thr with thr = floor((an - eff) / 2) per lane
+  //     (an + (bn & 1) - 2 acc < eff  =>  acc > thr; conservative by the parity bit, the exact d2 is formed behind it)
   __shared__ __attribute__((aligned(16))) uint8_t s_b[BT * B_STRIDE];
-  __shared__ uint32_t s_nb[BT];
+  __shared__ __attribute__((aligned(16))) int s_nbh[BT];  // -(bn >> 1), ACC_DEAD for rows beyond B: the MFMA's C operand
+  __shared__ __attribute__((aligned(16))) uint32_t s_nb[BT];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, grp = lane >> 4;
@@ -281,9 +291,9 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
   {
     const uint32_t row_base = (rb * 4 + wave) * (16 * AT);
 
-    // A fragments (XOR 0x80 -> int8) and norms of the rows this lane accumulates
+    // query fragments (XOR 0x80 -> int8) and the norm of the row this lane accumulates
     v4i afrag[AT][2];
-    uint32_t an[AT][4];
+    uint32_t an[AT];
 #pragma unroll
     for (int t = 0; t < AT; t++)
     {
@@ -294,40 +304,24 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
       uint4 v0 = p[grp], v1 = p[4 + grp];
       afrag[t][0] = v4i{(int)(v0.x ^ 0x80808080u), (int)(v0.y ^ 0x80808080u), (int)(v0.z ^ 0x80808080u), (int)(v0.w ^ 0x80808080u)};
       afrag[t][1] = v4i{(int)(v1.x ^ 0x80808080u), (int)(v1.y ^ 0x80808080u), (int)(v1.z ^ 0x80808080u), (int)(v1.w ^ 0x80808080u)};
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-      {
-        uint32_t rr = row_base + t * 16 + grp * 4 + j;
-        an[t][j] = norm_a[rr < na ? rr : na - 1];
-      }
+      an[t] = norm_a[r];
     }
 
-    Top2 st[AT][4];
+    Top2 st[AT];
+    uint32_t eff[AT]; // min(own second best, row-wide bound): what a candidate has to beat
+    int thr[AT];      // eff in accumulator space
 #pragma unroll
     for (int t = 0; t < AT; t++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        st[t][j] = Top2{QMAX, QMAX, QMAX, QMAX};
-    // Row-wide pruning bound. The 16 lanes of a row group each keep the top-2 of their own column subset, and a lane's own
-    // second best is a loose filter (a stream of L columns updates it ~2 ln L times: with 256 results per MFMA pair some
-    // lane passes it almost every time). Every SYNC_TILES tiles the lanes exchange their lists (DPP row rotations) and
-    // take the second smallest d2 of the whole row so far as a common bound: a later candidate that does not beat it
-    // cannot be in the final top-2 (two candidates with smaller-or-equal d2 and smaller index already exist in the
-    // lanes' lists, which all take part in the final merge), so it is dropped before the insertion logic — exact.
-    uint32_t eff[AT][4]; // min(own second best, row-wide bound): what a candidate has to beat
-#pragma unroll
-    for (int t = 0; t < AT; t++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        eff[t][j] = QMAX;
-    int thr[AT][4]; // eff translated into accumulator space, see the column-block loop
-#pragma unroll
-    for (int t = 0; t < AT; t++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        thr[t][j] = ACC_PASS;
-    uint32_t swap_bits = 0;  // bit (t*4+j): d2(b0) == d2(b1) for that A row (quirk Q7)
-    uint32_t risky_bits = 0; // bit (t*4+j): a candidate >= 2^22 was inserted -> the row goes to k_match_redo
+    {
+      st[t] = Top2{QMAX, QMAX, QMAX, QMAX};
+      eff[t] = QMAX;
+      thr[t] = ACC_PASS;
+    }
+    // Row-wide pruning bound: the second smallest d2 of the whole row so far. A later candidate that does not beat it cannot
+    // be in the final top-2 (two candidates with smaller-or-equal d2 and smaller index already sit in the four lanes' lists,
+    // which all take part in the final merge), so it is dropped before the insertion logic — exact.
+    uint32_t swap_bits = 0;  // bit t: d2(b0) == d2(b1) for that A row (quirk Q7)
+    uint32_t risky_bits = 0; // bit t: a candidate >= 2^22 was inserted -> the row goes to k_match_redo
 
     // B tiles are prefetched one tile ahead into registers (2 x 16 B per thread) so that the global-load latency of
     // tile t+1 hides behind the MFMA + epilogue work of tile t.
@@ -362,7 +356,10 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
         *(uint4 *)(s_b + r * B_STRIDE + c * 16) = v;
       }
       if (threadIdx.x < BT)
+      {
         s_nb[threadIdx.x] = pfn;
+        s_nbh[threadIdx.x] = t0 + threadIdx.x < nb ? -(int)(pfn >> 1) : ACC_DEAD; // te is nb or a tile boundary: < te inside a tile == < nb
+      }
       __syncthreads();
       if (t0 + BT < te)
         fetch_tile(t0 + BT);
@@ -370,117 +367,122 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
 #pragma unroll
       for (int sub = 0; sub < BT / 16; sub++)
       {
-        const uint32_t bcol = t0 + sub * 16 + col; // B index this lane's outputs belong to
-        if (t0 + sub * 16 >= te)
-          break;
+        // the 16 B rows of the sub-block as the MFMA's A operand (lane: row col, 16 bytes of K from grp), C = -(bn >> 1) of
+        // the lane's four columns
         const uint8_t *pb = s_b + (sub * 16 + col) * B_STRIDE + grp * 16;
         const v4i b0 = *(const v4i *)pb;
         const v4i b1 = *(const v4i *)(pb + 64);
-        const uint32_t bn = s_nb[sub * 16 + col];
-        const bool first = (t0 == 0 && sub == 0);
-        // The accumulator starts at -(bn >> 1), so a result is D = a'.b' - (bn >> 1) and d2 = an + (bn & 1) - 2 D. The
-        // common-path test "can this beat eff?" is one signed compare D > thr with thr = floor((an - eff) / 2) kept per state
-        // (conservative by the parity bit; the exact d2 is formed only behind it). Columns >= nb start so low that no
-        // threshold lets them through.
-        const int cinit = bcol < nb ? -(int)(bn >> 1) : ACC_DEAD;
-        const uint32_t par = bn & 1u;
+        const v4i cinit = *(const v4i *)(s_nbh + sub * 16 + grp * 4);
+        const bool first = (sub == 0 && t0 == 0);
+        v4i acc[AT];
 #pragma unroll
         for (int t = 0; t < AT; t++)
         {
-          v4i acc = v4i{cinit, cinit, cinit, cinit};
-          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[t][0], b0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[t][1], b1, acc, 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b0, afrag[t][0], cinit, 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, afrag[t][1], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < AT; t++)
+        {
+          const int m = max(max(acc[t][0], acc[t][1]), max(acc[t][2], acc[t][3]));
+          if (!first && !(m > thr[t]))
+            continue;
+          const uint32_t bc0 = t0 + sub * 16 + grp * 4; // first of this lane's four B columns
+          const v4i bn4 = *(const v4i *)(s_nb + sub * 16 + grp * 4); // parity bits of the four column norms
+          uint32_t q4[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            q4[j] = bc0 + j < nb ? an[t] + ((uint32_t)bn4[j] & 1u) - 2u * (uint32_t)acc[t][j] : QMAX;
+          if (first)
+          {
+            // quirk Q7: d2(b0) == d2(b1) (both in the grp-0 lane of the row): index 1 becomes the best
+            if (grp == 0 && q4[0] == q4[1])
+              swap_bits |= 1u << t;
+            if (grp == 0 && (q4[0] >= Q_EXACT || q4[1] >= Q_EXACT))
+              risky_bits |= 1u << t; // the tie test itself needs the float comparison
+          }
 #pragma unroll
           for (int j = 0; j < 4; j++)
           {
-            if (!first && !(acc[j] > thr[t][j]))
+            if (!first && !(acc[t][j] > thr[t]))
               continue;
-            const uint32_t q = bcol < nb ? an[t][j] + par - 2u * (uint32_t)acc[j] : QMAX;
-            uint32_t key = bcol;
-            if (first)
-            {
-              // quirk Q7: exchange d2(b0) / d2(b1) between the col-0 and col-1 lanes of each row group
-              const uint32_t other = __shfl_xor(q, 1, 64);
-              const bool sw = col < 2 && q == other;
-              if (sw)
-                swap_bits |= 1u << (t * 4 + j);
-              if (col < 2 && (q >= Q_EXACT || other >= Q_EXACT))
-                risky_bits |= 1u << (t * 4 + j); // the tie test itself needs the float comparison
-              key = sw ? (uint32_t)(col ^ 1) : bcol;
-            }
-            if (q < eff[t][j])
+            const uint32_t q = q4[j];
+            // (with sw the two tied columns keep their arrival keys 0, 1 — equal d2, so "key 0 first" already is the order
+            // index 1, index 0 once the final k ^ 1 of the swapped rows is applied)
+            const uint32_t key = bc0 + (uint32_t)j;
+            if (q < eff[t])
             {
               if (q >= Q_EXACT)
-                risky_bits |= 1u << (t * 4 + j);
-              insert_seq(st[t][j], q, key);
-              eff[t][j] = min(eff[t][j], st[t][j].q2);
-              thr[t][j] = acc_threshold(an[t][j], eff[t][j]);
+                risky_bits |= 1u << t;
+              insert_seq(st[t], q, key);
+              eff[t] = min(eff[t], st[t].q2);
+              thr[t] = acc_threshold(an[t], eff[t]);
             }
           }
         }
       }
-      // ---- every SYNC_TILES tiles: tighten the row-wide bound
-      if ((((t0 - tb) / BT) & (SYNC_TILES - 1)) == SYNC_TILES - 1)
+      // ---- tighten the row-wide bound: the four lanes of a row exchange their two smallest d2 (after every tile at the
+      // start, where the bound moves fast, then every SYNC_TILES tiles)
+      const uint32_t tile_no = (t0 - tb) / BT + 1u;
+      if (tile_no <= SYNC_TILES || (tile_no & (SYNC_TILES - 1u)) == 0u)
       {
 #pragma unroll
         for (int t = 0; t < AT; t++)
+        {
+          uint32_t m1 = st[t].q1, m2 = st[t].q2;
 #pragma unroll
-          for (int j = 0; j < 4; j++)
+          for (int x = 16; x <= 32; x <<= 1)
           {
-            uint32_t m1 = st[t][j].q1, m2 = st[t][j].q2; // two smallest d2 seen by this lane
-            merge_ror<8>(m1, m2);
-            merge_ror<4>(m1, m2);
-            merge_ror<2>(m1, m2);
-            merge_ror<1>(m1, m2);
-            eff[t][j] = min(eff[t][j], m2);
-            thr[t][j] = acc_threshold(an[t][j], eff[t][j]);
+            const uint32_t r1 = __shfl_xor(m1, x, 64), r2 = __shfl_xor(m2, x, 64);
+            const uint32_t hi = max(m1, r1);
+            m1 = min(m1, r1);
+            m2 = min(hi, min(m2, r2));
           }
+          eff[t] = min(eff[t], m2);
+          thr[t] = acc_threshold(an[t], eff[t]);
+        }
       }
     }
 
-    // merge the 16 lanes that share A rows (butterfly over the column bits), then lane col==0 writes
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1)
-    {
-      risky_bits |= __shfl_xor(risky_bits, m, 64);
-      swap_bits |= __shfl_xor(swap_bits, m, 64);
-    }
+    // merge the 4 lanes that share an A row (butterfly over grp), then the grp-0 lane writes
+    risky_bits |= __shfl_xor(risky_bits, 16, 64);
+    risky_bits |= __shfl_xor(risky_bits, 32, 64);
+    swap_bits |= __shfl_xor(swap_bits, 16, 64);
+    swap_bits |= __shfl_xor(swap_bits, 32, 64);
 #pragma unroll
     for (int t = 0; t < AT; t++)
+    {
+      Top2 s = st[t];
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int x = 16; x <= 32; x <<= 1)
       {
-        Top2 s = st[t][j];
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1)
+        Top2 o;
+        o.q1 = __shfl_xor(s.q1, x, 64), o.k1 = __shfl_xor(s.k1, x, 64);
+        o.q2 = __shfl_xor(s.q2, x, 64), o.k2 = __shfl_xor(s.k2, x, 64);
+        s = merge2(s, o);
+      }
+      const uint32_t r = row_base + t * 16 + col;
+      const uint32_t sw = (swap_bits >> t) & 1u, rk = (risky_bits >> t) & 1u;
+      if (grp == 0 && r < na)
+      {
+        if (nchunks > 1)
         {
-          Top2 o;
-          o.q1 = __shfl_xor(s.q1, m, 64), o.k1 = __shfl_xor(s.k1, m, 64);
-          o.q2 = __shfl_xor(s.q2, m, 64), o.k2 = __shfl_xor(s.k2, m, 64);
-          s = merge2(s, o);
+          uint32_t *pp = partial + ((size_t)r * nchunks + chunk) * 4;
+          pp[0] = s.q1, pp[1] = s.k1, pp[2] = s.q2, pp[3] = s.k2;
+          partial[(size_t)na * nchunks * 4 + (size_t)r * nchunks + chunk] = sw | (rk << 1);
         }
-        const uint32_t r = row_base + t * 16 + grp * 4 + j;
-        const uint32_t sw = (swap_bits >> (t * 4 + j)) & 1u, rk = (risky_bits >> (t * 4 + j)) & 1u;
-        if (col == 0 && r < na)
+        else
         {
-          if (nchunks > 1)
-          {
-            uint32_t *pp = partial + ((size_t)r * nchunks + chunk) * 4;
-            pp[0] = s.q1, pp[1] = s.k1, pp[2] = s.q2, pp[3] = s.k2;
-            partial[(size_t)na * nchunks * 4 + (size_t)r * nchunks + chunk] = sw | (rk << 1);
-          }
-          else
-          {
-            uint32_t *m = matches + (size_t)r * 5;
-            m[0] = a_index_base + r;
-            m[1] = (sw && s.k1 < 2) ? (s.k1 ^ 1u) : s.k1;
-            m[2] = (sw && s.k2 < 2) ? (s.k2 ^ 1u) : s.k2;
-            m[3] = __float_as_uint(sqrtf((float)s.q1));
-            m[4] = __float_as_uint(sqrtf((float)s.q2));
-            redo[r] = rk;
-          }
+          uint32_t *m = matches + (size_t)r * 5;
+          m[0] = a_index_base + r;
+          m[1] = (sw && s.k1 < 2) ? (s.k1 ^ 1u) : s.k1;
+          m[2] = (sw && s.k2 < 2) ? (s.k2 ^ 1u) : s.k2;
+          m[3] = __float_as_uint(sqrtf((float)s.q1));
+          m[4] = __float_as_uint(sqrtf((float)s.q2));
+          redo[r] = rk;
         }
       }
+    }
   } // row-block loop
 }
 
@@ -884,11 +886,18 @@ extern "C"
                          (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, (uint32_t *)nullptr, noids);
     else
     {
+      /* 64 A rows per wave, 256 per workgroup: every staged B tile serves 4x the MFMAs of the 16-row form (the B traffic out of
+       * L2 / infinity cache is N_A / 256 x the size of B: 1.25 TB at 50k x 50k). B is split into just enough chunks to give
+       * every CU two workgroups: every (row tile, chunk) pair starts with loose bounds, so chunks are not free. */
       uint32_t *partial = redo + na;
-      hipLaunchKernelGGL(k_match_mfma<2>, dim3((na + 127u) / 128u, 1, VKSIFT_HIP_MATCH_CHUNKS), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb,
-                         (uint32_t *)matches, redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids);
-      hipLaunchKernelGGL(k_match_merge, dim3((na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial, na, (uint32_t)VKSIFT_HIP_MATCH_CHUNKS,
-                         a_index_base, (uint32_t *)matches, redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
+      const uint32_t blocks = (na + 255u) / 256u;
+      uint32_t nchunks = (512u + blocks - 1u) / blocks;
+      nchunks = nchunks < 1u ? 1u : (nchunks > VKSIFT_HIP_MATCH_CHUNKS ? VKSIFT_HIP_MATCH_CHUNKS : nchunks);
+      hipLaunchKernelGGL(k_match_mfma<4>, dim3(blocks, 1, nchunks), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
+                         (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids);
+      if (nchunks > 1)
+        hipLaunchKernelGGL(k_match_merge, dim3((na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial, na, nchunks, a_index_base, (uint32_t *)matches,
+                           redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
     }
     uint32_t rblocks = (na + 63u) / 64u;
     hipLaunchKernelGGL(k_match_redo, dim3(rblocks > 1024u ? 1024u : rblocks), dim3(64), 0, hs, da, na, a_index_base, db, nb, (uint32_t *)matches,
@@ -1004,10 +1013,12 @@ extern "C"
     {
       if (nslots == 1 && partial_scratch)
       {
-        hipLaunchKernelGGL(k_match_mfma<2>, dim3(bounded((max_na + 127u) / 128u, 1), 1, VKSIFT_HIP_MATCH_CHUNKS), dim3(256), 0, hs, da, norm_a, 0u, 0u, db,
-                           norm_b, 0u, (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, partial_scratch, ids);
-        hipLaunchKernelGGL(k_match_merge, dim3((max_na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial_scratch, 0u,
-                           (uint32_t)VKSIFT_HIP_MATCH_CHUNKS, 0u, (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu);
+        /* N_A is only known on the device: four chunks whatever it is (see vksift_hip_match_2nn_prenormed) */
+        const uint32_t nchunks = 4u;
+        hipLaunchKernelGGL(k_match_mfma<4>, dim3(bounded((max_na + 255u) / 256u, 1), 1, nchunks), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, partial_scratch, ids);
+        hipLaunchKernelGGL(k_match_merge, dim3((max_na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial_scratch, 0u, nchunks, 0u,
+                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu);
       }
       else
         hipLaunchKernelGGL(k_match_mfma<2>, dim3(bounded((max_na + 127u) / 128u, nslots), nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
