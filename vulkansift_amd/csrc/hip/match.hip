@@ -241,8 +241,8 @@ __device__ __forceinline__ Top2 merge2(const Top2 &a, const Top2 &b)
 // AT = 16-row A tiles per wave. Block = 4 waves = 64*AT A rows; B streams through LDS.
 // gridDim.z > 1: B is split into gridDim.z chunks of whole 64-row tiles; every chunk writes its partial top-2 per A row to
 // `partial` ([row][chunk][4], then one flag word per (row, chunk): bit0 = Q7 swap, bit1 = redo) and k_match_merge combines them.
-template <int AT>
-__global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
+template <int AT, int NW = 4, int BTT = BT>
+__global__ void __launch_bounds__(64 * NW) k_match_mfma(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
                                                     uint32_t a_index_base, const uint32_t *__restrict__ desc_b, const uint32_t *__restrict__ norm_b,
                                                     uint32_t nb, uint32_t *__restrict__ matches, uint32_t *__restrict__ redo,
                                                     const uint32_t *__restrict__ n_dev, uint32_t na_lo, uint32_t na_hi, SlotStrides ss,
@@ -276,20 +276,21 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
   //   * the pruning test needs no per-column work: the accumulator starts at C = -(bn >> 1), read as one 16-byte LDS vector,
   //     and "can any of these four candidates beat eff?" is max(acc) > thr with thr = floor((an - eff) / 2) per lane
   //     (an + (bn & 1) - 2 acc < eff  =>  acc > thr; conservative by the parity bit, the exact d2 is formed behind it)
-  __shared__ __attribute__((aligned(16))) uint8_t s_b[BT * B_STRIDE];
-  __shared__ __attribute__((aligned(16))) int s_nbh[BT];  // -(bn >> 1), ACC_DEAD for rows beyond B: the MFMA's C operand
-  __shared__ __attribute__((aligned(16))) uint32_t s_nb[BT];
+  // two staging buffers: tile k+1 is written while tile k is consumed -> one barrier per tile
+  __shared__ __attribute__((aligned(16))) uint8_t s_b2[2][BTT * B_STRIDE];
+  __shared__ __attribute__((aligned(16))) int s_nbh2[2][BTT]; // -(bn >> 1), ACC_DEAD for rows beyond B: the MFMA's C operand
+  __shared__ __attribute__((aligned(16))) uint32_t s_nb2[2][BTT];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, grp = lane >> 4;
-  const uint32_t tiles = (nb + BT - 1) / BT, tiles_per_chunk = (tiles + nchunks - 1) / nchunks;
-  const uint32_t tb = chunk * tiles_per_chunk * BT;
-  const uint32_t te = min(nb, tb + tiles_per_chunk * BT);
+  const uint32_t tiles = (nb + BTT - 1) / BTT, tiles_per_chunk = (tiles + nchunks - 1) / nchunks;
+  const uint32_t tb = chunk * tiles_per_chunk * BTT;
+  const uint32_t te = min(nb, tb + tiles_per_chunk * BTT);
 
   // the grid may be smaller than the number of 64*AT-row blocks (bounded launch): loop over row blocks
-  for (uint32_t rb = rb0; rb * (64u * AT) < na; rb += rb_step)
+  for (uint32_t rb = rb0; rb * (16u * NW * AT) < na; rb += rb_step)
   {
-    const uint32_t row_base = (rb * 4 + wave) * (16 * AT);
+    const uint32_t row_base = (rb * NW + wave) * (16 * AT);
 
     // query fragments (XOR 0x80 -> int8) and the norm of the row this lane accumulates
     v4i afrag[AT][2];
@@ -325,62 +326,85 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
 
     // B tiles are prefetched one tile ahead into registers (2 x 16 B per thread) so that the global-load latency of
     // tile t+1 hides behind the MFMA + epilogue work of tile t.
-    constexpr int NLD = BT * 8 / 256;
-    uint4 pfb[NLD];
-    uint32_t pfn = 0;
-    auto fetch_tile = [&](uint32_t t0) {
-#pragma unroll
-      for (int q = 0; q < NLD; q++)
-      {
-        int i = threadIdx.x + q * 256;
-        int r = i >> 3, c = i & 7;
-        pfb[q] = make_uint4(0, 0, 0, 0);
-        if (t0 + r < nb)
-          pfb[q] = ((const uint4 *)(desc_b + (size_t)(t0 + r) * 32))[c];
-      }
-      pfn = (threadIdx.x < BT && t0 + threadIdx.x < nb) ? norm_b[t0 + threadIdx.x] : 0u;
-    };
-    fetch_tile(tb);
-
-    for (uint32_t t0 = tb; t0 < te; t0 += BT)
+    // B tiles travel global -> registers -> LDS one tile ahead of the MFMAs (a second register set for two tiles ahead costs
+    // the 64-row form an occupancy step and gains the others nothing: measured)
+    constexpr int NTH = 64 * NW, NLD = (BTT * 8 + NTH - 1) / NTH;
+    struct TileRegs
     {
-      __syncthreads();
-      // stage the prefetched BT rows (zero beyond nb), converting to int8
+      uint4 d[NLD];
+      uint32_t n;
+    };
+    TileRegs pf0;
+    auto fetch_tile = [&](uint32_t t0, TileRegs &pf) {
 #pragma unroll
       for (int q = 0; q < NLD; q++)
       {
-        int i = threadIdx.x + q * 256;
+        int i = threadIdx.x + q * NTH;
         int r = i >> 3, c = i & 7;
-        uint4 v = pfb[q];
-        v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
-        *(uint4 *)(s_b + r * B_STRIDE + c * 16) = v;
+        pf.d[q] = make_uint4(0, 0, 0, 0);
+        if (i < BTT * 8 && t0 + r < nb)
+          pf.d[q] = ((const uint4 *)(desc_b + (size_t)(t0 + r) * 32))[c];
       }
-      if (threadIdx.x < BT)
-      {
-        s_nb[threadIdx.x] = pfn;
-        s_nbh[threadIdx.x] = t0 + threadIdx.x < nb ? -(int)(pfn >> 1) : ACC_DEAD; // te is nb or a tile boundary: < te inside a tile == < nb
-      }
-      __syncthreads();
-      if (t0 + BT < te)
-        fetch_tile(t0 + BT);
-
+      pf.n = (threadIdx.x < BTT && t0 + threadIdx.x < nb) ? norm_b[t0 + threadIdx.x] : 0u;
+    };
+    // stage a fetched tile (zero beyond nb) into buffer `bufi`, converting to int8
+    auto stage_tile = [&](uint32_t t0, int bufi, const TileRegs &pf) {
 #pragma unroll
-      for (int sub = 0; sub < BT / 16; sub++)
+      for (int q = 0; q < NLD; q++)
       {
+        int i = threadIdx.x + q * NTH;
+        int r = i >> 3, c = i & 7;
+        uint4 v = pf.d[q];
+        v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
+        if (i < BTT * 8)
+          *(uint4 *)(s_b2[bufi] + r * B_STRIDE + c * 16) = v;
+      }
+      if (threadIdx.x < BTT)
+      {
+        s_nb2[bufi][threadIdx.x] = pf.n;
+        s_nbh2[bufi][threadIdx.x] = t0 + threadIdx.x < nb ? -(int)(pf.n >> 1) : ACC_DEAD; // te is nb or a tile boundary: < te inside a tile == < nb
+      }
+    };
+    __syncthreads(); // the previous row block has finished reading both buffers
+    fetch_tile(tb, pf0);
+    stage_tile(tb, 0, pf0);
+    __syncthreads();
+
+    int buf = 0;
+    for (uint32_t t0 = tb; t0 < te; t0 += BTT, buf ^= 1)
+    {
+      const bool more = t0 + BTT < te;
+      if (more)
+        fetch_tile(t0 + BTT, pf0); // in flight during this tile's MFMAs
+      const uint8_t *s_b = s_b2[buf];
+      const int *s_nbh = s_nbh2[buf];
+      const uint32_t *s_nb = s_nb2[buf];
+
+      // The MFMAs of a sub-block depend on nothing the tests produce (their C operand is a property of the B columns), so the
+      // MFMAs of sub-block s+1 are issued before the tests of sub-block s: the matrix pipe works while the VALU tests.
+      auto issue = [&](int sub, v4i *acc) {
         // the 16 B rows of the sub-block as the MFMA's A operand (lane: row col, 16 bytes of K from grp), C = -(bn >> 1) of
         // the lane's four columns
         const uint8_t *pb = s_b + (sub * 16 + col) * B_STRIDE + grp * 16;
         const v4i b0 = *(const v4i *)pb;
         const v4i b1 = *(const v4i *)(pb + 64);
         const v4i cinit = *(const v4i *)(s_nbh + sub * 16 + grp * 4);
-        const bool first = (sub == 0 && t0 == 0);
-        v4i acc[AT];
 #pragma unroll
         for (int t = 0; t < AT; t++)
         {
           acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b0, afrag[t][0], cinit, 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, afrag[t][1], acc[t], 0, 0, 0);
         }
+      };
+      v4i accp[2][AT];
+      issue(0, accp[0]);
+#pragma unroll
+      for (int sub = 0; sub < BTT / 16; sub++)
+      {
+        if (sub + 1 < BTT / 16)
+          issue(sub + 1, accp[(sub + 1) & 1]);
+        const v4i *acc = accp[sub & 1];
+        const bool first = (sub == 0 && t0 == 0);
 #pragma unroll
         for (int t = 0; t < AT; t++)
         {
@@ -389,32 +413,30 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
             continue;
           const uint32_t bc0 = t0 + sub * 16 + grp * 4; // first of this lane's four B columns
           const v4i bn4 = *(const v4i *)(s_nb + sub * 16 + grp * 4); // parity bits of the four column norms
-          uint32_t q4[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            q4[j] = bc0 + j < nb ? an[t] + ((uint32_t)bn4[j] & 1u) - 2u * (uint32_t)acc[t][j] : QMAX;
           if (first)
           {
             // quirk Q7: d2(b0) == d2(b1) (both in the grp-0 lane of the row): index 1 becomes the best
-            if (grp == 0 && q4[0] == q4[1])
+            const uint32_t q0 = an[t] + ((uint32_t)bn4[0] & 1u) - 2u * (uint32_t)acc[t][0], q1 = an[t] + ((uint32_t)bn4[1] & 1u) - 2u * (uint32_t)acc[t][1];
+            if (grp == 0 && q0 == q1)
               swap_bits |= 1u << t;
-            if (grp == 0 && (q4[0] >= Q_EXACT || q4[1] >= Q_EXACT))
+            if (grp == 0 && (q0 >= Q_EXACT || q1 >= Q_EXACT))
               risky_bits |= 1u << t; // the tie test itself needs the float comparison
           }
 #pragma unroll
           for (int j = 0; j < 4; j++)
           {
-            if (!first && !(acc[t][j] > thr[t]))
+            // columns beyond B carry ACC_DEAD accumulators: they only get here in the first block (B is padded to >= 2 rows,
+            // so columns 0 and 1 are always real)
+            if (!(acc[t][j] > thr[t]) || bc0 + j >= nb)
               continue;
-            const uint32_t q = q4[j];
-            // (with sw the two tied columns keep their arrival keys 0, 1 — equal d2, so "key 0 first" already is the order
+            // (with a Q7 tie the two columns keep their arrival keys 0, 1 — equal d2, so "key 0 first" already is the order
             // index 1, index 0 once the final k ^ 1 of the swapped rows is applied)
-            const uint32_t key = bc0 + (uint32_t)j;
+            const uint32_t q = an[t] + ((uint32_t)bn4[j] & 1u) - 2u * (uint32_t)acc[t][j];
             if (q < eff[t])
             {
               if (q >= Q_EXACT)
                 risky_bits |= 1u << t;
-              insert_seq(st[t], q, key);
+              insert_seq(st[t], q, bc0 + (uint32_t)j);
               eff[t] = min(eff[t], st[t].q2);
               thr[t] = acc_threshold(an[t], eff[t]);
             }
@@ -423,7 +445,7 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
       }
       // ---- tighten the row-wide bound: the four lanes of a row exchange their two smallest d2 (after every tile at the
       // start, where the bound moves fast, then every SYNC_TILES tiles)
-      const uint32_t tile_no = (t0 - tb) / BT + 1u;
+      const uint32_t tile_no = (t0 - tb) / BTT + 1u;
       if (tile_no <= SYNC_TILES || (tile_no & (SYNC_TILES - 1u)) == 0u)
       {
 #pragma unroll
@@ -442,6 +464,9 @@ __global__ void __launch_bounds__(256) k_match_mfma(const uint32_t *__restrict__
           thr[t] = acc_threshold(an[t], eff[t]);
         }
       }
+      if (more)
+        stage_tile(t0 + BTT, buf ^ 1, pf0); // nobody reads that buffer any more (barrier at the end of the previous tile)
+      __syncthreads();
     }
 
     // merge the 4 lanes that share an A row (butterfly over grp), then the grp-0 lane writes
@@ -893,8 +918,15 @@ extern "C"
       const uint32_t blocks = (na + 255u) / 256u;
       uint32_t nchunks = (512u + blocks - 1u) / blocks;
       nchunks = nchunks < 1u ? 1u : (nchunks > VKSIFT_HIP_MATCH_CHUNKS ? VKSIFT_HIP_MATCH_CHUNKS : nchunks);
-      hipLaunchKernelGGL(k_match_mfma<4>, dim3(blocks, 1, nchunks), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
-                         (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids);
+      /* measured on MI355X: up to ~80k rows 4 waves x 64 rows with 64-row B tiles (0.59 ms at 50k x 50k, 27 % of the int8 peak),
+       * above that 8 waves x 32 rows with 128-row tiles (1.78 ms at 100k x 100k, 36 %): the larger grid fills the second
+       * block slot of every CU and the longer tiles cover the L2 / infinity-cache latency of the B stream */
+      if (na >= 80000u)
+        hipLaunchKernelGGL((k_match_mfma<2, 8, 128>), dim3(blocks, 1, nchunks), dim3(512), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
+                           (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids);
+      else
+        hipLaunchKernelGGL((k_match_mfma<4, 4, 64>), dim3(blocks, 1, nchunks), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
+                           (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids);
       if (nchunks > 1)
         hipLaunchKernelGGL(k_match_merge, dim3((na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial, na, nchunks, a_index_base, (uint32_t *)matches,
                            redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
@@ -1015,7 +1047,7 @@ extern "C"
       {
         /* N_A is only known on the device: four chunks whatever it is (see vksift_hip_match_2nn_prenormed) */
         const uint32_t nchunks = 4u;
-        hipLaunchKernelGGL(k_match_mfma<4>, dim3(bounded((max_na + 255u) / 256u, 1), 1, nchunks), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+        hipLaunchKernelGGL((k_match_mfma<4, 4, 64>), dim3(bounded((max_na + 255u) / 256u, 1), 1, nchunks), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
                            (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, partial_scratch, ids);
         hipLaunchKernelGGL(k_match_merge, dim3((max_na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial_scratch, 0u, nchunks, 0u,
                            (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu);
