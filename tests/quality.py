@@ -41,8 +41,20 @@ def project(H, x, y):
     return (H[0, 0] * x + H[0, 1] * y + H[0, 2]) / den, (H[1, 0] * x + H[1, 1] * y + H[1, 2]) / den
 
 
+# Five warps of increasing difficulty, standing in for the image pairs 1->2 ... 1->6 of an Oxford sequence (viewpoint + zoom + rotation)
+WARPS = [dict(angle_deg=4.0, scale=1.04, tx=3.0, ty=-2.0, persp=2e-5), dict(angle_deg=12.0, scale=1.12, tx=6.0, ty=-4.0, persp=8e-5),
+         dict(angle_deg=25.0, scale=1.3, tx=-8.0, ty=5.0, persp=1.5e-4), dict(angle_deg=-40.0, scale=0.8, tx=4.0, ty=9.0, persp=2.5e-4),
+         dict(angle_deg=70.0, scale=1.6, tx=0.0, ty=0.0, persp=4e-4)]
+
+
 def score(feats1, feats2, idx_a, idx_b, H, w, h, tol=2.5):
-    """-> dict(matches, correct, precision, repeatability)"""
+    """The four metrics of the reference's computeMetrics() (src/perf/perf_matching.cpp:30-79):
+      putative_match_ratio = matches / keypoints of image 1                                  (:69-70)
+      precision            = matches within `tol` px of the homography / matches             (:52-66, :71-72)
+      matching_score       = those inliers / keypoints of image 1                            (:73-74)
+      repeatability        = the reference calls cv::evaluateFeatureDetector (region overlap); OpenCV is not available here, so
+                             this is the point-based form: keypoints of image 1 visible in image 2 that have a detection
+                             within `tol` px of their projection"""
     x1, y1 = feats1["x"].astype(np.float64), feats1["y"].astype(np.float64)
     x2, y2 = feats2["x"].astype(np.float64), feats2["y"].astype(np.float64)
     px, py = project(H, x1[idx_a], y1[idx_a])
@@ -55,4 +67,6 @@ def score(feats1, feats2, idx_a, idx_b, H, w, h, tol=2.5):
     if vis.any() and len(x2):
         d2 = (qx[vis, None] - x2[None, :]) ** 2 + (qy[vis, None] - y2[None, :]) ** 2
         rep = float((d2.min(axis=1) < tol * tol).mean())
-    return {"matches": int(len(idx_a)), "correct": correct, "precision": correct / max(len(idx_a), 1), "repeatability": rep}
+    return {"keypoints_1": int(len(x1)), "keypoints_2": int(len(x2)), "matches": int(len(idx_a)), "correct": correct,
+            "putative_match_ratio": len(idx_a) / max(len(x1), 1), "precision": correct / max(len(idx_a), 1),
+            "matching_score": correct / max(len(x1), 1), "repeatability": rep}

@@ -779,8 +779,7 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   static int band_env = -1;
   if (band_env < 0)
   {
-    const char *e = getenv("VKSIFT_EXTREMA_BAND"); /* rows per wave of the streaming extrema pass (A/B runs) */
-    band_env = (e && atoi(e) >= 8) ? atoi(e) : 0;
+    band_env = 0;
   }
   /* 32 rows per wave on the large octaves (3 % halo rows); 16 on the small ones, whose launches are latency bound and
    * gain more from twice the waves (serial kernel time of the coarse octaves -40 %) */
@@ -795,14 +794,12 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   static int sm_env = -1;
   if (sm_env < 0)
   {
-    const char *e = getenv("VKSIFT_EXTREMA_STRIP_MAJOR"); /* bit 0: the 4 waves of a block take adjacent strips (-5 %; 0: adjacent bands), bit 1: XCD-contiguous block order (-3 %) */
-    sm_env = e ? atoi(e) : 3;
+    sm_env = 3; /* bit 0: the 4 waves of a block take adjacent strips (-5 % against adjacent bands), bit 1: XCD-contiguous block order (-3 %) */
   }
   static int occ_env = -1;
   if (occ_env < 0)
   {
-    const char *e = getenv("VKSIFT_EXTREMA_SLOTS"); /* window slots: 4 = one row of loads in flight, 5 = two */
-    occ_env = e ? atoi(e) : 4;
+    occ_env = 4; /* window slots: 4 = one row of loads in flight (5 = two rows spills registers since the slots hold S+3 Gaussian texels) */
   }
   /* the lean kernel addresses a plane with 32-bit byte offsets */
   const bool lean = lean_env && (uint64_t)job->pitch * job->h * 4u < 0x80000000ull;
@@ -840,8 +837,7 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   static uint32_t rb_max = 0;
   if (!rb_max)
   {
-    const char *e = getenv("VKSIFT_REFINE_BLOCKS");
-    rb_max = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 512u;
+    rb_max = 512u;
   }
   if (rblocks > rb_max)
     rblocks = rb_max;

@@ -54,7 +54,6 @@ struct FeatArgs
   uint64_t ori_img_stride;
   uint32_t max_keep; // orientations kept per keypoint (1..18)
   uint32_t use_vlfeat;
-  uint32_t desc_equal_split;
   const float *desc_fp_tab;
   uint32_t desc_fp_tab_len;
 };
@@ -507,14 +506,6 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
       const uint32_t step0 = (uint32_t)wave * tq + min((uint32_t)wave, tr);
       uint32_t sidx = min(N, step0 * 64u + (uint32_t)lane * run);
       uint32_t send = min(N, sidx + run);
-      if (a.desc_equal_split) // A/B: the previous distribution
-      {
-        const uint32_t per_wave = (N + NWV - 1) / NWV;
-        const uint32_t w0 = min(N, (uint32_t)wave * per_wave), w1 = min(N, w0 + per_wave);
-        run = (w1 - w0 + 63u) / 64u;
-        sidx = w0 + (uint32_t)lane * run;
-        send = min(w1, sidx + run);
-      }
       // locate the row of the first sample of this lane's run: largest row with pre[row] <= sidx
       int row = 0;
       if (sidx < send)
@@ -624,15 +615,6 @@ FeatArgs make_args(const vksift_hip_OctaveJob *job)
   uint32_t mk = job->max_ori == 0 ? VKSIFT_HIP_MAX_ORI : job->max_ori;
   a.max_keep = mk > VKSIFT_HIP_MAX_ORI ? VKSIFT_HIP_MAX_ORI : mk;
   a.use_vlfeat = job->use_vlfeat;
-  {
-    static int eq = -1;
-    if (eq < 0)
-    {
-      const char *e = getenv("VKSIFT_DESC_EQUAL_SPLIT");
-      eq = (e && e[0] == '1') ? 1 : 0;
-    }
-    a.desc_equal_split = (uint32_t)eq;
-  }
   a.desc_fp_tab = job->desc_fp_tab, a.desc_fp_tab_len = job->desc_fp_tab_len;
   return a;
 }
@@ -650,8 +632,7 @@ bool img_fast(uint32_t batch, bool descriptor)
   {
     /* bit 0: orientation kernel, bit 1: descriptor kernel. Measured (128 x 640x480): orientation -5 %, descriptor +3 %
      * (its grid is mostly busy and the keypoint-fastest order spreads the long coarse-scale windows better): default 1 */
-    const char *e = getenv("VKSIFT_IMG_FAST");
-    mode = e ? atoi(e) : 1;
+    mode = 1;
   }
   return batch > 1 && ((mode >> (descriptor ? 1 : 0)) & 1);
 }
@@ -662,8 +643,7 @@ uint32_t expected_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch)
   static int div = -1;
   if (div < 0)
   {
-    const char *e = getenv("VKSIFT_FEAT_GRID_DIV"); /* pixels per expected keypoint (A/B runs); 0 = capacity-sized grids */
-    div = e ? atoi(e) : 512;
+    div = 512; /* pixels per expected keypoint */
   }
   if (div <= 0 || batch < 8u) /* a handful of images: idle workgroups cost nothing, keep the full parallelism */
     return 0xFFFFFFFFu;

@@ -1032,8 +1032,7 @@ extern "C"
       static int slot_fast = -1;
       if (slot_fast < 0)
       {
-        const char *e = getenv("VKSIFT_MATCH_SLOT_FAST");
-        slot_fast = e ? atoi(e) : 1;
+        slot_fast = 1;
       }
       SlotStrides s2 = ss;
       s2.slot_fast = (slot_fast && nslots > 1) ? 1u : 0u;

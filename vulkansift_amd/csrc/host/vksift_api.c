@@ -75,25 +75,25 @@ static bool cfg_check(bool cond, const char *msg)
 bool config_is_valid(const vksift_Config *c)
 {
   bool ok = true;
-  ok &= cfg_check(c->input_image_max_size >= 1024, "Invalid configuration: input image size must be greater than or equal to 1024");
-  ok &= cfg_check(c->sift_buffer_count > 0, "Invalid configuration: number of SIFT buffers must be greater than zero");
-  ok &= cfg_check(c->max_nb_sift_per_buffer > 0, "Invalid configuration: number of SIFT features per buffers must be greater than zero");
-  ok &= cfg_check(c->nb_scales_per_octave > 0, "Invalid configuration: number of scales per octave must be greater than zero");
-  ok &= cfg_check(c->nb_scales_per_octave <= VKSIFT_MAX_SCALES, "Invalid configuration: number of scales per octave is limited to 13 in this build");
-  ok &= cfg_check(c->input_image_blur_level >= 0.f, "Invalid configuration: input image blur level cannot be negative");
-  ok &= cfg_check(c->seed_scale_sigma >= 0, "Invalid configuration: seed scale blur level cannot be negative");
+  ok &= cfg_check(c->input_image_max_size >= 1024, "vksift_Config rejected: input_image_max_size below the 1024-pixel minimum");
+  ok &= cfg_check(c->sift_buffer_count > 0, "vksift_Config rejected: sift_buffer_count is 0, at least one buffer is needed");
+  ok &= cfg_check(c->max_nb_sift_per_buffer > 0, "vksift_Config rejected: max_nb_sift_per_buffer is 0, a buffer must hold at least one feature");
+  ok &= cfg_check(c->nb_scales_per_octave > 0, "vksift_Config rejected: nb_scales_per_octave is 0, an octave needs at least one scale");
+  ok &= cfg_check(c->nb_scales_per_octave <= VKSIFT_MAX_SCALES, "vksift_Config rejected: nb_scales_per_octave above 13, the limit of this build");
+  ok &= cfg_check(c->input_image_blur_level >= 0.f, "vksift_Config rejected: negative input_image_blur_level");
+  ok &= cfg_check(c->seed_scale_sigma >= 0, "vksift_Config rejected: negative seed_scale_sigma");
   ok &= cfg_check(((c->use_input_upsampling ? 2.f : 1.f) * c->input_image_blur_level) <= c->seed_scale_sigma,
-                  "Invalid configuration: the input image blur level (2x if upscaling activated) must be less than the seed scale blur level");
-  ok &= cfg_check(c->intensity_threshold >= 0.f, "Invalid configuration: the DoG intensity threshold cannot be negative");
-  ok &= cfg_check(c->edge_threshold >= 0.f, "Invalid configuration: the DoG edge threshold cannot be negative");
-  ok &= cfg_check(c->on_error_callback_function != NULL, "Invalid configuration: the error callback function must not be NULL");
+                  "vksift_Config rejected: seed_scale_sigma is smaller than the blur already in the input (input_image_blur_level, doubled by the up-sampling)");
+  ok &= cfg_check(c->intensity_threshold >= 0.f, "vksift_Config rejected: negative intensity_threshold");
+  ok &= cfg_check(c->edge_threshold >= 0.f, "vksift_Config rejected: negative edge_threshold");
+  ok &= cfg_check(c->on_error_callback_function != NULL, "vksift_Config rejected: on_error_callback_function is NULL");
   switch (c->pyramid_precision_mode)
   {
   case VKSIFT_PYRAMID_PRECISION_FLOAT16:
   case VKSIFT_PYRAMID_PRECISION_FLOAT32:
     break;
   default:
-    logError(LOG_TAG, "Invalid configuration: invalid scale-space pyramid format precision specified)");
+    logError(LOG_TAG, "vksift_Config rejected: pyramid_precision_mode is neither FLOAT32 nor FLOAT16");
     ok = false;
   }
   return ok;
@@ -106,7 +106,7 @@ bool buffer_idx_valid(vksift_Instance inst, uint32_t idx)
 {
   if (idx >= inst->cfg.sift_buffer_count)
   {
-    logError(LOG_TAG, "Provided target buffer index is (%d) but the number of reserved buffers is (%d).", idx, inst->cfg.sift_buffer_count);
+    logError(LOG_TAG, "SIFT buffer index %d out of range: the instance has %d buffer(s).", idx, inst->cfg.sift_buffer_count);
     return false;
   }
   return true;
@@ -117,13 +117,13 @@ bool resolution_valid(vksift_Instance inst, uint32_t w, uint32_t h)
   uint64_t size = (uint64_t)w * h;
   if (size > inst->max_image_size)
   {
-    logError(LOG_TAG, "Provided input image size (%d*%d=%llu) is greater than the configured maximum image size (%d).", w, h, (unsigned long long)size,
+    logError(LOG_TAG, "Image of %d x %d = %llu pixels exceeds the %d pixels the instance was configured for.", w, h, (unsigned long long)size,
              inst->max_image_size);
     return false;
   }
   if (size < 1024u)
   {
-    logError(LOG_TAG, "Invalid input image size (%d*%d=%llu). Input image size must be greater than or equal to 1024", w, h, (unsigned long long)size);
+    logError(LOG_TAG, "Image of %d x %d = %llu pixels is below the 1024-pixel minimum.", w, h, (unsigned long long)size);
     return false;
   }
   return true;
@@ -186,7 +186,7 @@ void vksift_setLogLevel(vksift_LogLevel level)
     vksift_log_set_level(VKSIFT_LOGLVL_DEBUG);
     break;
   default:
-    logError(LOG_TAG, "vksift_LogLevel in vksift_setLogLevel() is not handled");
+    logError(LOG_TAG, "vksift_setLogLevel(): unknown level, nothing changed");
     break;
   }
 }

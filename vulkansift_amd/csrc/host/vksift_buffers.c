@@ -54,7 +54,7 @@ uint32_t vksift_getFeaturesNumber(vksift_Instance instance, const uint32_t gpu_b
 {
   if (!buffer_idx_valid(instance, gpu_buffer_id))
   {
-    logError(LOG_TAG, "vksift_getFeaturesNumber() error: invalid input.");
+    logError(LOG_TAG, "vksift_getFeaturesNumber(): bad argument.");
     instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
     return 0;
   }
@@ -66,7 +66,7 @@ void vksift_downloadFeatures(vksift_Instance instance, vksift_Feature *feats_ptr
 {
   if (!buffer_idx_valid(instance, gpu_buffer_id))
   {
-    logError(LOG_TAG, "vksift_downloadFeatures() error: invalid input.");
+    logError(LOG_TAG, "vksift_downloadFeatures(): bad argument.");
     instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
     return;
   }
@@ -94,7 +94,7 @@ void vksift_downloadFeatures(vksift_Instance instance, vksift_Feature *feats_ptr
   HIP_CHECK(vksift_hip_stream_sync(inst->stream), "feature download");
   return;
 gpu_error:
-  logError(LOG_TAG, "vksift_downloadFeatures() error when downloading detection results.");
+  logError(LOG_TAG, "vksift_downloadFeatures(): the device-to-host copy of the features failed.");
   instance->error_cb(VKSIFT_VULKAN_ERROR);
 }
 
@@ -103,9 +103,9 @@ void vksift_uploadFeatures(vksift_Instance instance, const vksift_Feature *feats
   if (!buffer_idx_valid(instance, gpu_buffer_id) || nb_feats > instance->cfg.max_nb_sift_per_buffer)
   {
     if (nb_feats > instance->cfg.max_nb_sift_per_buffer)
-      logError(LOG_TAG, "Provided features count (%d) is greater than the configured maximum number of features per GPU buffer size (%d).", nb_feats,
+      logError(LOG_TAG, "%d features do not fit a SIFT buffer of %d (max_nb_sift_per_buffer).", nb_feats,
                instance->cfg.max_nb_sift_per_buffer);
-    logError(LOG_TAG, "vksift_uploadFeatures() error: invalid input.");
+    logError(LOG_TAG, "vksift_uploadFeatures(): bad argument.");
     instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
     return;
   }
@@ -123,7 +123,7 @@ void vksift_uploadFeatures(vksift_Instance instance, const vksift_Feature *feats
   b->counts_valid = true;
   return;
 gpu_error:
-  logError(LOG_TAG, "vksift_uploadFeatures() error when uploading SIFT features to GPU memory.");
+  logError(LOG_TAG, "vksift_uploadFeatures(): the host-to-device copy of the features failed.");
   instance->error_cb(VKSIFT_VULKAN_ERROR);
 }
 
@@ -136,7 +136,7 @@ void vksift_getScaleSpaceOctaveResolution(vksift_Instance instance, const uint8_
 {
   if (octave >= instance->lay.n_oct)
   {
-    logError(LOG_TAG, "vksift_getScaleSpaceOctaveResolution() error: invalid input. Requested octave idx is %d but the current number of octave is %d",
+    logError(LOG_TAG, "vksift_getScaleSpaceOctaveResolution(): octave %d requested, the current scale-space has %d",
              octave, instance->lay.n_oct);
     instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
     return;
@@ -152,9 +152,9 @@ static void download_plane(vksift_Instance inst, uint8_t octave, uint8_t scale, 
   if (octave >= inst->lay.n_oct || scale >= nscales)
   {
     if (octave >= inst->lay.n_oct)
-      logError(LOG_TAG, "Requested octave idx is %d but the current number of octaves is %d", octave, inst->lay.n_oct);
+      logError(LOG_TAG, "octave %d requested, the current scale-space has %d", octave, inst->lay.n_oct);
     else
-      logError(LOG_TAG, "Requested scale idx is %d but the number of %s scales is %d", scale, is_dog ? "DoG" : "blurred", nscales);
+      logError(LOG_TAG, "scale %d requested, an octave has %d %s layers", scale, nscales, is_dog ? "difference-of-Gaussian" : "Gaussian");
     logError(LOG_TAG, "%s error: invalid input.", fn);
     inst->error_cb(VKSIFT_INVALID_INPUT_ERROR);
     return;
@@ -206,6 +206,6 @@ void vksift_downloadDoGImage(vksift_Instance instance, const uint8_t octave, con
 void vksift_presentDebugFrame(vksift_Instance instance)
 {
   (void)instance;
-  logWarning(LOG_TAG, "vksift_presentDebugFrame() was called but instance has no external window configured.");
+  logWarning(LOG_TAG, "vksift_presentDebugFrame(): this build has no frame presenter, the call does nothing.");
 }
 

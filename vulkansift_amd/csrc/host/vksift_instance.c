@@ -73,7 +73,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   }
   if (!config_is_valid(config))
   {
-    logError(LOG_TAG, "vksift_createInstance() failure: Invalid configuration detected.");
+    logError(LOG_TAG, "vksift_createInstance() failed: the configuration was rejected (see above).");
     return VKSIFT_INVALID_INPUT_ERROR;
   }
   if (batch_cap == 0 || batch_cap > config->sift_buffer_count)
@@ -234,7 +234,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   ok = ok && inst->stream && inst->ev_detect && inst->ev_match;
   if (!ok)
   {
-    logError(LOG_TAG, "vksift_createInstance() failure: Failed to setup the required memory objects");
+    logError(LOG_TAG, "vksift_createInstance() failed: device / pinned memory reservation");
     vksift_destroyInstance(instance_ptr);
     return VKSIFT_VULKAN_ERROR;
   }
