@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip value_host_input / single_image_ms / roofline_c3 / sharded match")
     ap.add_argument("--host-input", action="store_true", help="time the PCIe-inclusive protocol as the main loop (not the headline value)")
+    ap.add_argument("--fp16", action="store_true", help="VKSIFT_PYRAMID_PRECISION_FLOAT16: binary16 scale-space storage (not the headline configuration)")
     ap.add_argument("--match-rows", type=int, default=50000, help="rows of A and of B in the sharded 2-NN leg (BASELINE config 4)")
     return ap.parse_args()
 
@@ -308,7 +309,8 @@ def main():
     d_sub = [torch.from_numpy(np.roll(host, -k, axis=0).copy()).to(dev) for k in range(NSUB)]
     torch.cuda.synchronize()
 
-    cfg = api.default_config(sift_buffer_count=B, gpu_device_index=dev.index, input_image_max_size=max(W * H, 1024))
+    cfg = api.default_config(sift_buffer_count=B, gpu_device_index=dev.index, input_image_max_size=max(W * H, 1024),
+                             pyramid_precision_mode=1 if args.fp16 else 0)
     inst = api.Instance(cfg, batch_capacity=B)
 
     def match_all():
@@ -383,7 +385,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 arithmetic, binary16 scale-space storage" if args.fp16 else "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE config 2: {W}x{H} uint8 frames, detect" + (" + 2-NN self-match" if do_match else "")

@@ -78,7 +78,9 @@ extern "C"
     float *base;         /* plane of image 0 */
     uint32_t w, h;       /* valid extent */
     uint32_t pitch;      /* floats per row */
-    uint64_t img_stride; /* floats between consecutive images of the batch */
+    uint64_t img_stride; /* texels between consecutive images of the batch */
+    uint32_t fp16;       /* 0: fp32 texels; 1: IEEE binary16 texels (VKSIFT_PYRAMID_PRECISION_FLOAT16: stored round-to-nearest-even,
+                          * widened exactly on every read, all arithmetic fp32); base then points at 2-byte texels */
   } vksift_hip_Plane;
 
   /* vkCmdCopyBufferToImage + vkCmdBlitImage(LINEAR) of sift_detector.c:881,909-916:
@@ -108,14 +110,16 @@ extern "C"
   /* vkCmdBlitImage(NEAREST) of sift_detector.c:1003-1034: dst(x,y) = src(floor((x+.5)*sw/dw), ...). */
   int vksift_hip_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, uint32_t batch, vksift_hip_stream s);
 
-  /* DifferenceOfGaussian.comp:13-17 for one layer of one image: out (dense w x h) = hi - lo. Only vksift_downloadDoGImage uses
-   * it — the detection path never materialises a DoG plane. */
-  int vksift_hip_dog_plane(const float *lo, const float *hi, uint32_t w, uint32_t h, uint32_t pitch, float *out_dense, vksift_hip_stream s);
+  /* DifferenceOfGaussian.comp:13-17 for one layer of one image: out (dense w x h, fp32) = hi - lo (rounded to binary16 for an
+   * fp16 pyramid); hi == NULL: the layer lo itself, widened. Only the debug downloads use it — the detection path never
+   * materialises a DoG plane. */
+  int vksift_hip_dog_plane(const float *lo, const float *hi, uint32_t w, uint32_t h, uint32_t pitch, uint32_t fp16, float *out_dense, vksift_hip_stream s);
 
   /* ------------------------------------------------------------------ keypoints */
   typedef struct
   {
     float *gauss;        /* Gaussian layer 0 of image 0 of this octave (S+3 layers; DoG layer s = layer s+1 - layer s) */
+    uint32_t fp16;       /* the layers hold binary16 texels (see vksift_hip_Plane); strides stay in texels */
     uint32_t w, h, pitch;
     uint64_t plane_stride; /* floats between layers */
     uint64_t img_stride;   /* floats between images */

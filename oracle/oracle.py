@@ -31,6 +31,7 @@ class Config(C.Structure):
         ("use_vlfeat_format", C.c_int32),
         ("use_hardware_interpolated_blur", C.c_int32),
         ("math_mode", C.c_int32),
+        ("pyramid_fp16", C.c_int32),
     ]
 
 

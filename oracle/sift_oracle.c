@@ -85,6 +85,7 @@ void orc_default_config(orc_Config *cfg)
   cfg->use_vlfeat_format = 0;
   cfg->use_hardware_interpolated_blur = 1;
   cfg->math_mode = 0;
+  cfg->pyramid_fp16 = 0;
 }
 
 /* sift_memory.c:644-660 */
@@ -250,7 +251,71 @@ static inline int mirror_idx(int i, int n)
 
 /* One separable blur: H pass src -> tmp, V pass tmp -> dst (sift_detector.c:918-1001).
  * Per pass (GaussianBlur*.comp:32-44): acc = c*k0; acc += (t(+i) + t(-i)) * k[i], i ascending. */
-static void blur_plane(const float *src, float *dst, float *tmp, int w, int h, const float *taps, int n)
+/* fp32 -> IEEE binary16 (round to nearest even, subnormals kept) -> fp32: what storing a texel in an R16_SFLOAT image and
+ * loading it back does. Plain integer code: no dependence on F16C or on the compiler's _Float16 support. */
+static float round_trip_f16(float x)
+{
+  uint32_t f;
+  memcpy(&f, &x, 4);
+  const uint32_t sign = f & 0x80000000u, e = (f >> 23) & 0xffu;
+  uint32_t m = f & 0x7fffffu, h;
+  if (e == 255u)
+    return x; /* inf / nan */
+  const int E = (int)e - 127 + 15;
+  if (E >= 31)
+    h = 0x7c00u; /* overflow -> inf */
+  else if (E <= 0)
+  {
+    if (E < -10)
+      h = 0; /* below half of the smallest subnormal */
+    else
+    {
+      m |= 0x800000u;
+      const uint32_t shift = (uint32_t)(14 - E), rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+      h = m >> shift;
+      if (rem > half || (rem == half && (h & 1u)))
+        h++;
+    }
+  }
+  else
+  {
+    h = ((uint32_t)E << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u)))
+      h++; /* a mantissa carry moves into the exponent field: still the right encoding */
+  }
+  /* widen */
+  const uint32_t he = (h >> 10) & 0x1fu, hm = h & 0x3ffu;
+  uint32_t o;
+  if (he == 0)
+  {
+    if (hm == 0)
+      o = sign;
+    else
+    {
+      int sh = 0;
+      uint32_t mm = hm;
+      while (!(mm & 0x400u))
+        mm <<= 1, sh++;
+      o = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((mm & 0x3ffu) << 13);
+    }
+  }
+  else if (he == 31u)
+    o = sign | 0x7f800000u | (hm << 13);
+  else
+    o = sign | ((he + 127u - 15u) << 23) | (hm << 13);
+  float r;
+  memcpy(&r, &o, 4);
+  return r;
+}
+
+static void store_as_f16(float *plane, size_t n)
+{
+  for (size_t i = 0; i < n; i++)
+    plane[i] = round_trip_f16(plane[i]);
+}
+
+static void blur_plane(const float *src, float *dst, float *tmp, int w, int h, const float *taps, int n, int fp16)
 {
   for (int y = 0; y < h; y++)
   {
@@ -261,7 +326,7 @@ static void blur_plane(const float *src, float *dst, float *tmp, int w, int h, c
       float acc = row[x] * taps[0];
       for (int i = 1; i < n; i++)
         acc = fmaf(row[mirror_idx(x + i, w)] + row[mirror_idx(x - i, w)], taps[i], acc);
-      out[x] = acc;
+      out[x] = fp16 ? round_trip_f16(acc) : acc; /* the horizontal pass writes the octave's temporary image: R16 in the fp16 mode */
     }
   }
   for (int y = 0; y < h; y++)
@@ -272,7 +337,7 @@ static void blur_plane(const float *src, float *dst, float *tmp, int w, int h, c
       float acc = tmp[(size_t)y * w + x] * taps[0];
       for (int i = 1; i < n; i++)
         acc = fmaf(tmp[(size_t)mirror_idx(y + i, h) * w + x] + tmp[(size_t)mirror_idx(y - i, h) * w + x], taps[i], acc);
-      out[x] = acc;
+      out[x] = fp16 ? round_trip_f16(acc) : acc;
     }
   }
 }
@@ -346,19 +411,25 @@ orc_Pyramid *orc_pyramid_build(const orc_Config *cfg, const uint8_t *img, uint32
     if (o == 0)
     {
       blit_input(img, (int)w, (int)h, g, (int)p->w[0], (int)p->h[0]);
+      /* fp16 mode: every image the reference allocates in the pyramid format holds binary16 texels (sift_memory.c:139,185-186:
+       * the octave images AND the blur temporaries): the blit target, the horizontal pass's output, every layer, every DoG layer */
+      if (cfg->pyramid_fp16)
+        store_as_f16(g, px);
       /* seed blur in place on layer 0: H layer0 -> tmp, V tmp -> layer0 (sift_detector.c:927-952) */
-      blur_plane(g, g, tmp, (int)p->w[0], (int)p->h[0], &taps[0], (int)ntaps[0]);
+      blur_plane(g, g, tmp, (int)p->w[0], (int)p->h[0], &taps[0], (int)ntaps[0], cfg->pyramid_fp16);
     }
     else
     {
       blit_nearest(p->gauss[o - 1] + (size_t)S * p->w[o - 1] * p->h[o - 1], (int)p->w[o - 1], (int)p->h[o - 1], g, (int)p->w[o], (int)p->h[o]);
     }
     for (uint32_t s = 1; s < S + 3; s++)
-      blur_plane(g + (s - 1) * px, g + s * px, tmp, (int)p->w[o], (int)p->h[o], &taps[s * ORC_MAX_KERNEL], (int)ntaps[s]);
+      blur_plane(g + (s - 1) * px, g + s * px, tmp, (int)p->w[o], (int)p->h[o], &taps[s * ORC_MAX_KERNEL], (int)ntaps[s], cfg->pyramid_fp16);
     /* DifferenceOfGaussian.comp:13-17 */
     for (uint32_t s = 0; s < S + 2; s++)
       for (size_t i = 0; i < px; i++)
         p->dog[o][s * px + i] = g[(s + 1) * px + i] - g[s * px + i];
+    if (cfg->pyramid_fp16)
+      store_as_f16(p->dog[o], px * (S + 2));
   }
   free(tmp);
   return p;

@@ -42,6 +42,12 @@ extern "C"
     /* 0: libm expf/atan2f/... (independent of the product code)
      * 1: vulkansift_amd/csrc/detmath.h (bit-exact against the HIP kernels) */
     int32_t math_mode;
+    /* VKSIFT_PYRAMID_PRECISION_FLOAT16 as this build defines it (the reference's own FLOAT16 mode binds R16 images to r32f
+     * shader declarations, vulkansift_types.h:57-61 / sift_memory.c:139 vs GaussianBlur.comp:5 — undefined in Vulkan): every
+     * image the reference allocates in the pyramid format — the blit target, the blur temporaries (horizontal-pass output), the
+     * scale-space layers and the DoG layers — holds IEEE binary16 texels (round-to-nearest-even of the fp32 result), every
+     * read widens exactly, all arithmetic stays fp32. */
+    int32_t pyramid_fp16;
   } orc_Config;
 
   /* 164-byte feature record == vksift_Feature. */

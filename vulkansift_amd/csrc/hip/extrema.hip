@@ -30,17 +30,24 @@ struct DogView
 {
   const float *base; // GAUSSIAN layer 0 of the octave: DoG layer s = Gaussian layer s+1 - Gaussian layer s
   int w, h, pitch;
-  size_t plane; // floats between layers
+  size_t plane; // texels between layers
   int S;
+  int fp16;     // binary16 texels (VKSIFT_PYRAMID_PRECISION_FLOAT16): widened exactly; the DoG image of such a pyramid is binary16 too
 };
+
+__device__ __forceinline__ float gauss_texel(const DogView &d, size_t idx)
+{
+  return d.fp16 ? (float)((const _Float16 *)d.base)[idx] : d.base[idx];
+}
 
 // imageLoad of the DoG image with robust out-of-bounds behaviour on the layer axis (quirk Q1): layer S+2 reads 0.
 __device__ __forceinline__ float ld(const DogView &d, int s, int x, int y)
 {
   if (s < 0 || s > d.S + 1)
     return 0.f;
-  const float *p = d.base + (size_t)s * d.plane + (size_t)y * d.pitch + x;
-  return p[d.plane] - p[0];
+  const size_t idx = (size_t)s * d.plane + (size_t)y * d.pitch + x;
+  const float v = gauss_texel(d, idx + d.plane) - gauss_texel(d, idx);
+  return d.fp16 ? (float)(_Float16)v : v;
 }
 
 struct KpRecord
@@ -124,6 +131,7 @@ __device__ bool refine_texel(const DogView &d, int x, int y, int s, float dog_th
 struct ExtremaArgs
 {
   const float *gauss; // Gaussian layer 0 of image 0 of the octave (S+3 layers, plane_stride apart)
+  int fp16;           // binary16 texels (strides stay in texels)
   int w, h, pitch;
   uint64_t plane_stride, img_stride;
   int S, octave_idx;
@@ -213,7 +221,7 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
     return;
   const int y1 = min(y0 + band, a.h);
   const int x0 = blockIdx.x * 128, x = x0 + 2 * lane;
-  DogView d{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
+  DogView d{a.fp16 ? (const float *)((const _Float16 *)a.gauss + (size_t)b * a.img_stride) : a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
   const bool in0 = x < a.w, in1 = x + 1 < a.w;
   const int hx = lane == 0 ? x0 - 1 : x0 + 128;
   const bool hok = (lane == 0 || lane == 63) && hx >= 0 && hx < a.w;
@@ -248,18 +256,17 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
       p.va[l] = p.vb[l] = p.hv[l] = 0.f;
       if (r >= 0 && r < a.h && r <= y1)
       {
-        const float *row = d.base + (size_t)l * d.plane + (size_t)r * d.pitch; // Gaussian layer l; layer l+1 one plane further
-        const float *rowu = row + d.plane;
+        const size_t row = (size_t)l * d.plane + (size_t)r * d.pitch; // Gaussian layer l; layer l+1 one plane further
+        auto dog = [&](int xx) {
+          const float v = gauss_texel(d, row + d.plane + xx) - gauss_texel(d, row + xx);
+          return d.fp16 ? (float)(_Float16)v : v;
+        };
         if (in1)
-        {
-          const float2 t = *(const float2 *)(row + x); // x is even and the pitch a multiple of 64: 8-byte aligned
-          const float2 u = *(const float2 *)(rowu + x);
-          p.va[l] = u.x - t.x, p.vb[l] = u.y - t.y;
-        }
+          p.va[l] = dog(x), p.vb[l] = dog(x + 1);
         else if (in0)
-          p.va[l] = rowu[x] - row[x];
+          p.va[l] = dog(x);
         if (hok)
-          p.hv[l] = rowu[hx] - row[hx];
+          p.hv[l] = dog(hx);
       }
     }
   };
@@ -368,10 +375,11 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 constexpr unsigned EXT_OOB = 0x80000000u;
 
-template <int S, int NSLOT>
+template <int S, int NSLOT, bool F16>
 __global__ void __launch_bounds__(256, 4) k_extrema_lean(ExtremaArgs a, int band, int strip_major)
 {
   constexpr int NL = S + 2;
+  constexpr int EB = F16 ? 2 : 4; // bytes per texel
   constexpr int AHEAD = NSLOT - 3; // rows of loads in flight behind the 3-row window
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 4 independent waves per block, one row band each
@@ -402,16 +410,16 @@ __global__ void __launch_bounds__(256, 4) k_extrema_lean(ExtremaArgs a, int band
     return;
   const int y1 = min(y0 + band, a.h);
   const int x0 = bx * 128, x = x0 + 2 * lane;
-  const float *img = a.gauss + (size_t)b * a.img_stride;
-  const int pitch4 = a.pitch * 4;
+  const uint8_t *img = (const uint8_t *)a.gauss + (size_t)b * a.img_stride * EB;
+  const int pitch4 = a.pitch * EB; // row pitch in bytes
   __amdgpu_buffer_rsrc_t rs[NL + 1]; // one resource per GAUSSIAN layer
 #pragma unroll
   for (int l = 0; l <= NL; l++)
-    rs[l] = __builtin_amdgcn_make_buffer_rsrc((void *)(img + (size_t)l * a.plane_stride), 0, a.pitch * a.h * 4, 0x00020000);
-  // the pitch is a multiple of 64 floats, x is even: the pair (x, x+1) is inside the row or entirely outside
-  const unsigned off2 = x < a.pitch ? (unsigned)x * 4u : EXT_OOB;
+    rs[l] = __builtin_amdgcn_make_buffer_rsrc((void *)(img + (size_t)l * a.plane_stride * EB), 0, a.pitch * a.h * EB, 0x00020000);
+  // the pitch is a multiple of 64 texels, x is even: the pair (x, x+1) is inside the row or entirely outside
+  const unsigned off2 = x < a.pitch ? (unsigned)x * (unsigned)EB : EXT_OOB;
   const int hx = lane == 0 ? x0 - 1 : x0 + 128;
-  const unsigned offh = ((lane == 0 || lane == 63) && hx >= 0 && hx < a.pitch) ? (unsigned)hx * 4u : EXT_OOB;
+  const unsigned offh = ((lane == 0 || lane == 63) && hx >= 0 && hx < a.pitch) ? (unsigned)hx * (unsigned)EB : EXT_OOB;
   const unsigned long long colA = __ballot(x >= 1 && x < a.w - 1), colB = __ballot(x + 1 < a.w - 1);
   const float pre = a.dog_threshold * 0.8f;
   const int seg0 = bx * 2;
@@ -431,12 +439,43 @@ __global__ void __launch_bounds__(256, 4) k_extrema_lean(ExtremaArgs a, int band
 #pragma unroll
     for (int l = 0; l <= NL; l++)
     {
-      wv2[slot][l] = __builtin_amdgcn_raw_buffer_load_b64(rs[l], off2, so, 0);
-      wh[slot][l] = __builtin_amdgcn_raw_buffer_load_b32(rs[l], offh, so, 0);
+      if (F16)
+      {
+        // two binary16 texels in one dword, the halo texel in the low half of another: half the registers of the fp32 form in flight
+        wv2[slot][l].x = __builtin_amdgcn_raw_buffer_load_b32(rs[l], off2, so, 0);
+        wh[slot][l] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs[l], offh, so, 0);
+      }
+      else
+      {
+        wv2[slot][l] = __builtin_amdgcn_raw_buffer_load_b64(rs[l], off2, so, 0);
+        wh[slot][l] = __builtin_amdgcn_raw_buffer_load_b32(rs[l], offh, so, 0);
+      }
     }
   };
+  typedef _Float16 h2x __attribute__((ext_vector_type(2)));
   auto to_dog = [&](auto SLOT) {
     constexpr int slot = decltype(SLOT)::value;
+    if (F16)
+    {
+      float lo0, lo1, loh;
+      {
+        const h2x t = __builtin_bit_cast(h2x, wv2[slot][0].x);
+        lo0 = (float)t.x, lo1 = (float)t.y;
+        loh = (float)__builtin_bit_cast(h2x, wh[slot][0]).x;
+      }
+#pragma unroll
+      for (int l = 0; l < NL; l++)
+      {
+        const h2x t = __builtin_bit_cast(h2x, wv2[slot][l + 1].x);
+        const float hi0 = (float)t.x, hi1 = (float)t.y, hih = (float)__builtin_bit_cast(h2x, wh[slot][l + 1]).x;
+        // the DoG image of a binary16 pyramid is a binary16 image: round the difference, keep it widened
+        wv2[slot][l].x = __float_as_uint((float)(_Float16)(hi0 - lo0));
+        wv2[slot][l].y = __float_as_uint((float)(_Float16)(hi1 - lo1));
+        wh[slot][l] = __float_as_uint((float)(_Float16)(hih - loh));
+        lo0 = hi0, lo1 = hi1, loh = hih;
+      }
+      return;
+    }
 #pragma unroll
     for (int l = 0; l < NL; l++)
     {
@@ -668,7 +707,7 @@ __global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
   uint32_t n = a.cand_n[b];
   n = n < a.cand_cap ? n : a.cand_cap;
   const uint32_t nch = (n + 255u) / 256u;
-  DogView d{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
+  DogView d{a.fp16 ? (const float *)((const _Float16 *)a.gauss + (size_t)b * a.img_stride) : a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
   const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
   uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
   uint32_t *chunk_sum = a.seg_off + (size_t)b * a.seg_img_stride;
@@ -705,7 +744,7 @@ __global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
   uint32_t n = a.cand_n[b];
   n = n < a.cand_cap ? n : a.cand_cap;
   const uint32_t nch = (n + 255u) / 256u;
-  DogView d{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S};
+  DogView d{a.fp16 ? (const float *)((const _Float16 *)a.gauss + (size_t)b * a.img_stride) : a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
   const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
   const uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
   const uint32_t *chunk_base = a.seg_off + (size_t)b * a.seg_img_stride;
@@ -753,6 +792,7 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
     return (int)hipErrorInvalidValue; /* candidate coordinates are packed 14 + 14 + 4 bits */
   ExtremaArgs a;
   a.gauss = job->gauss;
+  a.fp16 = (int)job->fp16;
   a.w = (int)job->w, a.h = (int)job->h, a.pitch = (int)job->pitch;
   a.plane_stride = job->plane_stride, a.img_stride = job->img_stride;
   a.S = (int)job->S, a.octave_idx = job->octave_idx;
@@ -796,21 +836,18 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   {
     sm_env = 3; /* bit 0: the 4 waves of a block take adjacent strips (-5 % against adjacent bands), bit 1: XCD-contiguous block order (-3 %) */
   }
-  static int occ_env = -1;
-  if (occ_env < 0)
-  {
-    occ_env = 4; /* window slots: 4 = one row of loads in flight (5 = two rows spills registers since the slots hold S+3 Gaussian texels) */
-  }
+  /* window slots: fp32 texels 4 (one row of loads in flight; two rows spill registers since the slots receive S+3 Gaussian
+   * texels), binary16 texels 5 (a row in flight costs half the registers) */
   /* the lean kernel addresses a plane with 32-bit byte offsets */
-  const bool lean = lean_env && (uint64_t)job->pitch * job->h * 4u < 0x80000000ull;
+  const bool lean = lean_env && (uint64_t)job->pitch * job->h * (job->fp16 ? 2u : 4u) < 0x80000000ull;
   switch (job->S)
   {
 #define VKSIFT_CASE(N)                                                         \
   case N:                                                                      \
-    if (lean && occ_env == 4)                                                  \
-      hipLaunchKernelGGL((k_extrema_lean<N, 4>), sgrid, dim3(256), 0, hs, a, band, sm_env); \
-    else if (lean)                                                  \
-      hipLaunchKernelGGL((k_extrema_lean<N, 5>), sgrid, dim3(256), 0, hs, a, band, sm_env); \
+    if (lean && a.fp16)                                                        \
+      hipLaunchKernelGGL((k_extrema_lean<N, 5, true>), sgrid, dim3(256), 0, hs, a, band, sm_env); \
+    else if (lean)                                                             \
+      hipLaunchKernelGGL((k_extrema_lean<N, 4, false>), sgrid, dim3(256), 0, hs, a, band, sm_env); \
     else                                                                       \
       hipLaunchKernelGGL(k_extrema_stream<N>, sgrid, dim3(256), 0, hs, a, band); \
     break;

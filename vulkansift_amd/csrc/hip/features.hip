@@ -31,6 +31,21 @@ struct GaussView
   size_t plane;
 };
 
+// One texel of the keypoint's Gaussian layer through its buffer resource. voff / soff are the byte offsets of the fp32 layout;
+// a binary16 pyramid (VKSIFT_PYRAMID_PRECISION_FLOAT16, f16 = wave-uniform) halves them and widens the texel exactly.
+__device__ __forceinline__ float tap_ld(const __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff, bool f16)
+{
+  if (f16)
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff >> 1, soff >> 1, 0));
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+// layer `layer` of image `img` (strides in texels)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t layer_rsrc(const float *gauss, size_t texel_off, int pitch, int h, bool f16)
+{
+  const void *p = f16 ? (const void *)((const _Float16 *)gauss + texel_off) : (const void *)(gauss + texel_off);
+  return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, pitch * h * (f16 ? 2 : 4), 0x00020000);
+}
+
 // imageLoad with robust out-of-bounds behaviour (returns 0) — quirk Q2 relies on it.
 __device__ __forceinline__ float ldg(const GaussView &g, const float *layer, int x, int y)
 {
@@ -42,6 +57,7 @@ __device__ __forceinline__ float ldg(const GaussView &g, const float *layer, int
 struct FeatArgs
 {
   const float *gauss;
+  uint32_t fp16; // binary16 texels
   int w, h, pitch;
   uint64_t plane_stride, img_stride;
   uint8_t *feats;
@@ -100,7 +116,8 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
       const int octave_idx = ((const int *)rec)[5];
       const float sigma = rec[6];
       // planes stay below 2 GiB (vksift_hip_extract_keypoints refuses sides of 16384 and more)
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(g.base + (size_t)scale_idx * g.plane), 0, g.pitch * g.h * 4, 0x00020000);
+      const bool f16 = a.fp16 != 0;
+      const __amdgpu_buffer_rsrc_t rs = layer_rsrc(a.gauss, (size_t)b * a.img_stride + (size_t)scale_idx * g.plane, g.pitch, g.h, f16);
 
       float scale_factor = dm_pow2i(octave_idx);
       float lambda = 1.5f * (sigma / scale_factor);
@@ -151,8 +168,8 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
         const unsigned o_l = (yin && (unsigned)(gx - 1) < (unsigned)g.w) ? o0 - 4u : 0x80000000u;
         const unsigned o_d = (xin && (unsigned)(gy + 1) < (unsigned)g.h) ? (__umul24((unsigned)(gy + 1), (unsigned)g.pitch) + (unsigned)gx) * 4u : 0x80000000u;
         const unsigned o_u = (xin && (unsigned)(gy - 1) < (unsigned)g.h) ? (__umul24((unsigned)(gy - 1), (unsigned)g.pitch) + (unsigned)gx) * 4u : 0x80000000u;
-        float gradX = 0.5f * (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_r, 0, 0)) - __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_l, 0, 0)));
-        float gradY = 0.5f * (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_d, 0, 0)) - __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o_u, 0, 0)));
+        float gradX = 0.5f * (tap_ld(rs, o_r, 0, f16) - tap_ld(rs, o_l, 0, f16));
+        float gradY = 0.5f * (tap_ld(rs, o_d, 0, f16) - tap_ld(rs, o_u, 0, f16));
         float mag = dm_expf_nb_nonpos(d2 * es) /* d2 >= 0 > es */ * sqrtf((gradX * gradX) + (gradY * gradY));
         float ori = wrap_2pi(dm_atan2f(gradY, gradX));
         int bin = (int)(dm_div_2pi(ori * 36.f)); // == ori * 36 / (2 pi)
@@ -280,6 +297,7 @@ __device__ __forceinline__ int smod8(int v) { return v & 7; } // floored modulo 
 struct DescCtx
 {
   __amdgpu_buffer_rsrc_t rs; // the keypoint's Gaussian layer
+  bool f16;                  // binary16 texels
   int pitch, pitch4;
   float scale_x, scale_y, rsx, rsy, kcos, ksin, kori, fp, bin_scale;
 };
@@ -304,10 +322,10 @@ __device__ __forceinline__ DescSample desc_sample(const DescCtx &c, int cdx, int
   // the four taps through the layer's buffer resource: one 32-bit offset (texel (ix-1, iy-1)), the rest is immediate /
   // scalar offsets (the window is clipped to the image interior, so every tap of a live sample is in range)
   const unsigned v0 = (__umul24((unsigned)(iy - 1), (unsigned)c.pitch) + (unsigned)(ix - 1)) * 4u; // sides < 16384: 24-bit factors
-  const float t_up = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c.rs, v0 + 4u, 0, 0));
-  const float t_lf = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c.rs, v0, c.pitch4, 0));
-  const float t_rt = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c.rs, v0 + 8u, c.pitch4, 0));
-  const float t_dn = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(c.rs, v0 + 4u, 2 * c.pitch4, 0));
+  const float t_up = tap_ld(c.rs, v0 + 4u, 0, c.f16);
+  const float t_lf = tap_ld(c.rs, v0, c.pitch4, c.f16);
+  const float t_rt = tap_ld(c.rs, v0 + 8u, c.pitch4, c.f16);
+  const float t_dn = tap_ld(c.rs, v0 + 4u, 2 * c.pitch4, c.f16);
   float gradX = 0.5f * (t_rt - t_lf);
   float gradY = 0.5f * (t_dn - t_up);
   float ori = wrap_2pi(dm_atan2f(gradY, gradX));
@@ -412,7 +430,8 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
     DescCtx c;
     c.scale_x = rec[2], c.scale_y = rec[3], c.kori = rec[7];
     // planes stay below 2 GiB (vksift_hip_extract_keypoints refuses sides of 16384 and more): 32-bit byte offsets
-    c.rs = __builtin_amdgcn_make_buffer_rsrc((void *)(g.base + (size_t)scale_idx * g.plane), 0, g.pitch * g.h * 4, 0x00020000);
+    c.f16 = a.fp16 != 0;
+    c.rs = layer_rsrc(a.gauss, (size_t)b * a.img_stride + (size_t)scale_idx * g.plane, g.pitch, g.h, c.f16);
     c.pitch = g.pitch, c.pitch4 = g.pitch * 4;
     c.bin_scale = a.use_vlfeat ? 8.f : -8.f;
     float scale_factor = dm_pow2i(octave_idx);
@@ -607,6 +626,7 @@ FeatArgs make_args(const vksift_hip_OctaveJob *job)
 {
   FeatArgs a;
   a.gauss = job->gauss;
+  a.fp16 = job->fp16;
   a.w = (int)job->w, a.h = (int)job->h, a.pitch = (int)job->pitch;
   a.plane_stride = job->plane_stride, a.img_stride = job->img_stride;
   a.feats = job->feats, a.feat_img_stride = job->feat_img_stride, a.cap = job->cap;

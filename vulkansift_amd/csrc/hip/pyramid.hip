@@ -30,6 +30,46 @@ struct Taps
   float k[VKSIFT_HIP_MAX_TAPS];
 };
 
+// Scale-space texels are fp32, or (VKSIFT_PYRAMID_PRECISION_FLOAT16, F16 = true) IEEE binary16: stored with round-to-nearest-even
+// from the fp32 result, widened exactly on every read; all arithmetic is fp32 either way (the oracle's pyramid_fp16 mode).
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+template <bool F16>
+__device__ __forceinline__ float ld_px(const float *base, size_t idx)
+{
+  if (F16)
+    return (float)((const _Float16 *)base)[idx];
+  return base[idx];
+}
+template <bool F16>
+__device__ __forceinline__ void st_px(float *base, size_t idx, float v)
+{
+  if (F16)
+    ((_Float16 *)base)[idx] = (_Float16)v;
+  else
+    base[idx] = v;
+}
+// image b of a batch: strides are in texels
+template <bool F16>
+__device__ __forceinline__ float *img_ptr(float *base, size_t texels)
+{
+  return F16 ? (float *)((_Float16 *)base + texels) : base + texels;
+}
+template <bool F16>
+__device__ __forceinline__ const float *img_ptr(const float *base, size_t texels)
+{
+  return F16 ? (const float *)((const _Float16 *)base + texels) : base + texels;
+}
+__device__ __forceinline__ unsigned pack_h2(float a, float b)
+{
+  const h2v h{(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ void unpack_h2(unsigned u, float &a, float &b)
+{
+  const h2v h = __builtin_bit_cast(h2v, u);
+  a = (float)h.x, b = (float)h.y;
+}
+
 // VK_SAMPLER_ADDRESS_MODE_MIRRORED_REPEAT (sift_detector.c:214-216)
 __device__ __forceinline__ int mirror_idx(int i, int n)
 {
@@ -48,6 +88,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // u8 -> fp32 with optional bilinear resize (Vulkan blit coordinate rules, clamp-to-edge).
 // One thread per destination pixel; destination rows are written fully coalesced.
 // ---------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ void __launch_bounds__(256) k_input_blit(const uint8_t *__restrict__ src, int sw, int sh, uint64_t src_img_stride, float *__restrict__ dst,
                                                     int dw, int dh, int dpitch, uint64_t dst_img_stride)
 {
@@ -56,10 +97,10 @@ __global__ void __launch_bounds__(256) k_input_blit(const uint8_t *__restrict__ 
   if (x >= dw || y >= dh)
     return;
   const uint8_t *img = src + (size_t)blockIdx.z * src_img_stride;
-  float *out = dst + (size_t)blockIdx.z * dst_img_stride;
+  float *out = img_ptr<F16>(dst, (size_t)blockIdx.z * dst_img_stride);
   if (dw == sw && dh == sh)
   {
-    out[(size_t)y * dpitch + x] = (float)img[(size_t)y * sw + x] / 255.f;
+    st_px<F16>(out, (size_t)y * dpitch + x, (float)img[(size_t)y * sw + x] / 255.f);
     return;
   }
   float sx = (float)sw / (float)dw, sy = (float)sh / (float)dh;
@@ -75,7 +116,7 @@ __global__ void __launch_bounds__(256) k_input_blit(const uint8_t *__restrict__ 
   float t01 = (float)img[(size_t)y1 * sw + x0] / 255.f, t11 = (float)img[(size_t)y1 * sw + x1] / 255.f;
   float r0 = fmaf(a, t10, (1.f - a) * t00);
   float r1 = fmaf(a, t11, (1.f - a) * t01);
-  out[(size_t)y * dpitch + x] = fmaf(b, r1, (1.f - b) * r0);
+  st_px<F16>(out, (size_t)y * dpitch + x, fmaf(b, r1, (1.f - b) * r0));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -85,6 +126,7 @@ __global__ void __launch_bounds__(256) k_input_blit(const uint8_t *__restrict__ 
 // so this evaluates the same fmaf expressions as k_input_blit (bit-identical) with 8 instead of 16
 // u8 -> float divisions per 4 texels.
 // ---------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ void __launch_bounds__(256) k_input_blit_2x(const uint8_t *__restrict__ src, int sw, int sh, uint64_t src_img_stride,
                                                        float *__restrict__ dst, int dw, int dh, int dpitch, uint64_t dst_img_stride)
 {
@@ -94,7 +136,7 @@ __global__ void __launch_bounds__(256) k_input_blit_2x(const uint8_t *__restrict
   if (x >= dw || y >= dh)
     return;
   const uint8_t *img = src + (size_t)blockIdx.z * src_img_stride;
-  float *out = dst + (size_t)blockIdx.z * dst_img_stride + (size_t)y * dpitch + x;
+  float *out = img_ptr<F16>(dst, (size_t)blockIdx.z * dst_img_stride + (size_t)y * dpitch + x);
   // rows: v = (y + 0.5)/2 - 0.5 -> fy = floor(v), b = v - fy
   const float v = ((float)y + 0.5f) * 0.5f - 0.5f;
   const float fy = floorf(v);
@@ -121,11 +163,13 @@ __global__ void __launch_bounds__(256) k_input_blit_2x(const uint8_t *__restrict
     const float r1 = fmaf(a, t1[i0 + 1], (1.f - a) * t1[i0]);
     res[k] = fmaf(b, r1, (1.f - b) * r0);
   }
-  if (x + 3 < dw)
+  if (x + 3 < dw && !F16)
     *(float4 *)out = make_float4(res[0], res[1], res[2], res[3]);
+  else if (x + 3 < dw)
+    *(uint2 *)out = make_uint2(pack_h2(res[0], res[1]), pack_h2(res[2], res[3])); // x is a multiple of 4: 8-byte aligned
   else
     for (int k = 0; k < 4 && x + k < dw; k++)
-      out[k] = res[k];
+      st_px<F16>(out, k, res[k]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -138,6 +182,7 @@ __global__ void __launch_bounds__(256) k_input_blit_2x(const uint8_t *__restrict
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE = 64;
 
+template <bool F16>
 __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src, uint64_t src_img_stride, int spitch, float *__restrict__ dst,
                                                    uint64_t dst_img_stride, int dpitch, int w, int h, Taps taps, int ntaps)
 {
@@ -152,14 +197,13 @@ __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
-  const float *in = src + (size_t)blockIdx.z * src_img_stride;
+  const float *in = img_ptr<F16>(src, (size_t)blockIdx.z * src_img_stride);
 
   for (int r = wave; r < SH; r += 4)
   {
     int gy = mirror_idx(y0 - R + r, h);
-    const float *row = in + (size_t)gy * spitch;
     for (int c = lane; c < SW; c += 64)
-      s_src[r * SS + c] = row[mirror_idx(x0 - R + c, w)];
+      s_src[r * SS + c] = ld_px<F16>(in, (size_t)gy * spitch + mirror_idx(x0 - R + c, w));
   }
   __syncthreads();
 
@@ -170,12 +214,12 @@ __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src
     float acc = p[0] * k0;
     for (int i = 1; i < ntaps; i++)
       acc = fmaf(p[i] + p[-i], taps.k[i], acc);
-    s_mid[r * TILE + lane] = acc;
+    s_mid[r * TILE + lane] = F16 ? (float)(_Float16)acc : acc; // the blur temporary is an image of the pyramid format
   }
   __syncthreads();
 
   const int gx = x0 + lane;
-  float *out = dst + (size_t)blockIdx.z * dst_img_stride;
+  float *out = img_ptr<F16>(dst, (size_t)blockIdx.z * dst_img_stride);
   for (int rr = wave * 16; rr < wave * 16 + 16; rr++)
   {
     int gy = y0 + rr;
@@ -186,7 +230,7 @@ __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src
     for (int i = 1; i < ntaps; i++)
       acc = fmaf(p[i * TILE] + p[-i * TILE], taps.k[i], acc);
     if (gx < w)
-      out[(size_t)gy * dpitch + gx] = acc;
+      st_px<F16>(out, (size_t)gy * dpitch + gx, acc);
   }
 }
 // ---------------------------------------------------------------------------------------------
@@ -232,19 +276,21 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned BUF_OOB = 0x80000000u; // byte offset beyond any plane: loads return 0, stores are dropped
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base, int pitch, int h)
+template <bool F16>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base, size_t texel_off, int pitch, int h)
 {
-  return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, pitch * h * 4, 0x00020000);
+  return __builtin_amdgcn_make_buffer_rsrc((void *)img_ptr<F16>(base, texel_off), 0, pitch * h * (F16 ? 2 : 4), 0x00020000);
 }
 
 // UPS: the source is the u8 input image at half the resolution; the staged rows are produced on the fly by the exact
 // 2:1 LINEAR blit of k_input_blit_2x (same expressions, value/255 through a 256-entry table of the same correctly
 // rounded quotients), i.e. vkCmdCopyBufferToImage + vkCmdBlitImage + the seed blur in one pass: the up-sampled plane
 // never exists in HBM. a.src then points at the u8 images (a.src_img_stride in bytes), a.spitch is the source width.
-template <int NT, bool UPS>
+template <int NT, bool UPS, bool F16>
 __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 {
   constexpr int NR = 8;
+  constexpr unsigned EB = F16 ? 2u : 4u; // bytes per texel
   constexpr int R = NT - 1;
   constexpr int RA = (R + 3) & ~3;
   constexpr int TW = 128;
@@ -279,10 +325,11 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   const int y1 = min(y0 + a.seg, H);
   const __amdgpu_buffer_rsrc_t rs =
       UPS ? __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)a.src + (size_t)bimg * a.src_img_stride), 0, a.spitch * (H / 2), 0x00020000)
-          : plane_rsrc(a.src + (size_t)bimg * a.src_img_stride, a.spitch, H);
-  const __amdgpu_buffer_rsrc_t rd = plane_rsrc(a.dst + (size_t)bimg * a.dst_img_stride, a.dpitch, H);
+          : plane_rsrc<F16>(a.src, (size_t)bimg * a.src_img_stride, a.spitch, H);
+  const __amdgpu_buffer_rsrc_t rd = plane_rsrc<F16>(a.dst, (size_t)bimg * a.dst_img_stride, a.dpitch, H);
   const bool has_ds = !UPS && a.ds != nullptr;
-  const __amdgpu_buffer_rsrc_t rds = plane_rsrc(has_ds ? a.ds + (size_t)bimg * a.ds_img_stride : a.dst, has_ds ? a.ds_pitch : a.dpitch, has_ds ? H / 2 : H);
+  const __amdgpu_buffer_rsrc_t rds =
+      plane_rsrc<F16>(has_ds ? a.ds : a.dst, has_ds ? (size_t)bimg * a.ds_img_stride : 0, has_ds ? a.ds_pitch : a.dpitch, has_ds ? H / 2 : H);
 
   // ---- lane constants
   const int gx4 = x0 - RA + 4 * lane;
@@ -291,10 +338,10 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   if (lane < NV4)
   {
     if (gx4 >= 0 && gx4 + 3 < W)
-      ld_off = (unsigned)gx4 * 4u;
+      ld_off = (unsigned)gx4 * EB;
     else
     {
-      ld_off = (unsigned)mirror_idx(gx4 + 3, W) * 4u; // the four virtual columns map to m3+3, m3+2, m3+1, m3
+      ld_off = (unsigned)mirror_idx(gx4 + 3, W) * EB; // the four virtual columns map to m3+3, m3+2, m3+1, m3
       rev = true;
     }
   }
@@ -308,7 +355,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
       s_lut[i] = (float)i / 255.f;
     if (lane < NV4)
     {
-      const int X = (int)(ld_off / 4u);
+      const int X = (int)(ld_off / EB);
       const int sw = a.spitch;
       int cb = X / 2 - 1;
       if (cb < 0)
@@ -319,14 +366,23 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
     }
   }
   const int px = x0 + 2 * lane;
-  const unsigned st_off = px + 1 < W ? (unsigned)px * 4u : BUF_OOB;
-  const int spitch4 = a.spitch * 4, dpitch4 = a.dpitch * 4;
-  const unsigned st_off_ds = px + 1 < W ? (unsigned)(px >> 1) * 4u : BUF_OOB; // column px+1 (odd) -> column px/2 of the half-size plane
-  const int dspitch4 = a.ds_pitch * 4;
+  const unsigned st_off = px + 1 < W ? (unsigned)px * EB : BUF_OOB;
+  const int spitch4 = a.spitch * (int)EB, dpitch4 = a.dpitch * (int)EB; // row pitches in bytes
+  const unsigned st_off_ds = px + 1 < W ? (unsigned)(px >> 1) * EB : BUF_OOB; // column px+1 (odd) -> column px/2 of the half-size plane
+  const int dspitch4 = a.ds_pitch * (int)EB;
   const float k0 = a.taps.k[0];
 
   u32x4 pf[NR];
   float vb[NR]; // UPS: vertical weight of the lower source row (wave-uniform)
+  // four texels of a source row: one 16-byte load (fp32) or one 8-byte load (fp16: .x, .y carry the four halves)
+  auto load4 = [&](int so) -> u32x4 {
+    if (F16)
+    {
+      const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, ld_off, so, 0);
+      return u32x4{t.x, t.y, 0u, 0u};
+    }
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, so, 0);
+  };
   auto prefetch = [&](int r0) {
     if (UPS)
     {
@@ -347,13 +403,13 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
       int so = r0 * spitch4;
 #pragma unroll
       for (int j = 0; j < NR; j++, so += spitch4)
-        pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, so, 0);
+        pf[j] = load4(so);
     }
     else
     {
 #pragma unroll
       for (int j = 0; j < NR; j++)
-        pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, mirror_idx(r0 + j, H) * spitch4, 0);
+        pf[j] = load4(mirror_idx(r0 + j, H) * spitch4);
     }
   };
 
@@ -394,8 +450,17 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
             const float r0 = fmaf(aw, t0[i0 + 1], (1.f - aw) * t0[i0]);
             const float r1 = fmaf(aw, t1[i0 + 1], (1.f - aw) * t1[i0]);
             res[k] = fmaf(b, r1, (1.f - b) * r0);
+            if (F16)
+              res[k] = (float)(_Float16)res[k]; // the blit target is an image of the pyramid format
           }
           v = u32x4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
+        }
+        else if (F16)
+        {
+          float f0, f1, f2, f3;
+          unpack_h2(v.x, f0, f1);
+          unpack_h2(v.y, f2, f3);
+          v = u32x4{__float_as_uint(f0), __float_as_uint(f1), __float_as_uint(f2), __float_as_uint(f3)};
         }
         if (rev)
           v = u32x4{v.w, v.z, v.y, v.x};
@@ -433,6 +498,8 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
           b0 = fmaf(vb2[C0 + i] + vb2[C0 - i], a.taps.k[i], b0);
           b1 = fmaf(vb2[C0 + 1 + i] + vb2[C0 + 1 - i], a.taps.k[i], b1);
         }
+        if (F16) // the horizontal pass's output is an image of the pyramid format too (the reference's blur temporary)
+          a0 = (float)(_Float16)a0, a1 = (float)(_Float16)a1, b0 = (float)(_Float16)b0, b1 = (float)(_Float16)b1;
         wv[2 * R + j] = make_float2(a0, a1);
         wv[2 * R + j + 1] = make_float2(b0, b1);
         __builtin_amdgcn_sched_barrier(0);
@@ -444,11 +511,19 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
     if (yb + NR > y0)
     {
       auto emit = [&](int j, int so_d, float acc0, float acc1) {
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0), __float_as_uint(acc1)}, rd, st_off, so_d, 0);
+        if (F16)
+          __builtin_amdgcn_raw_buffer_store_b32(pack_h2(acc0, acc1), rd, st_off, so_d, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0), __float_as_uint(acc1)}, rd, st_off, so_d, 0);
         // vkCmdBlitImage(NEAREST) into the next octave, exact 2:1: destination (x, y) takes source (2x+1, 2y+1). yb is even
         // (segments start on multiples of 8), so the odd rows are the odd j: a compile-time choice in the unrolled loops
         if (has_ds && (j & 1))
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1), rds, st_off_ds, ((yb + j) >> 1) * dspitch4, 0);
+        {
+          if (F16)
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack_h2(acc1, 0.f) & 0xffffu), rds, st_off_ds, ((yb + j) >> 1) * dspitch4, 0);
+          else
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1), rds, st_off_ds, ((yb + j) >> 1) * dspitch4, 0);
+        }
       };
       if (yb >= y0 && yb + NR <= y1)
       {
@@ -501,6 +576,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 // ---------------------------------------------------------------------------------------------
 // Nearest-neighbour resample (2:1 -> odd source texels), one thread per destination pixel.
 // ---------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ void __launch_bounds__(256) k_downsample(const float *__restrict__ src, uint64_t src_img_stride, int sw, int sh, int spitch,
                                                     float *__restrict__ dst, uint64_t dst_img_stride, int dw, int dh, int dpitch)
 {
@@ -511,20 +587,26 @@ __global__ void __launch_bounds__(256) k_downsample(const float *__restrict__ sr
   float sx = (float)sw / (float)dw, sy = (float)sh / (float)dh;
   int yy = clampi((int)floorf(((float)y + 0.5f) * sy), 0, sh - 1);
   int xx = clampi((int)floorf(((float)x + 0.5f) * sx), 0, sw - 1);
-  const float *in = src + (size_t)blockIdx.z * src_img_stride;
-  float *out = dst + (size_t)blockIdx.z * dst_img_stride;
-  out[(size_t)y * dpitch + x] = in[(size_t)yy * spitch + xx];
+  const float *in = img_ptr<F16>(src, (size_t)blockIdx.z * src_img_stride);
+  float *out = img_ptr<F16>(dst, (size_t)blockIdx.z * dst_img_stride);
+  st_px<F16>(out, (size_t)y * dpitch + x, ld_px<F16>(in, (size_t)yy * spitch + xx)); // widening + narrowing a binary16 value is the identity
 }
 
 // DifferenceOfGaussian.comp:13-17 for ONE layer of ONE image, dense w x h output: only vksift_downloadDoGImage needs a DoG plane
 // in memory (the detection path forms the differences in registers).
+// hi == nullptr: the Gaussian layer `lo` itself, widened to fp32 (vksift_downloadScaleSpaceImage of an fp16 pyramid).
+template <bool F16>
 __global__ void __launch_bounds__(256) k_dog_plane(const float *__restrict__ lo, const float *__restrict__ hi, int w, int h, int pitch, float *__restrict__ out)
 {
   int x = blockIdx.x * 64 + (threadIdx.x & 63);
   int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= w || y >= h)
     return;
-  out[(size_t)y * w + x] = hi[(size_t)y * pitch + x] - lo[(size_t)y * pitch + x];
+  const float l = ld_px<F16>(lo, (size_t)y * pitch + x);
+  float d = hi ? ld_px<F16>(hi, (size_t)y * pitch + x) - l : l;
+  if (F16 && hi)
+    d = (float)(_Float16)d; // the DoG image of an fp16 pyramid is a binary16 image too
+  out[(size_t)y * w + x] = d;
 }
 
 } // namespace
@@ -537,13 +619,21 @@ extern "C"
     if (dst.w == 2 * sw && dst.h == 2 * sh)
     {
       dim3 grid2(((dst.w + 3) / 4 + 63) / 64, (dst.h + 3) / 4, batch);
-      hipLaunchKernelGGL(k_input_blit_2x, grid2, dim3(256), 0, (hipStream_t)s, src, (int)sw, (int)sh, src_img_stride, dst.base, (int)dst.w, (int)dst.h,
-                         (int)dst.pitch, dst.img_stride);
+      if (dst.fp16)
+        hipLaunchKernelGGL(k_input_blit_2x<true>, grid2, dim3(256), 0, (hipStream_t)s, src, (int)sw, (int)sh, src_img_stride, dst.base, (int)dst.w, (int)dst.h,
+                           (int)dst.pitch, dst.img_stride);
+      else
+        hipLaunchKernelGGL(k_input_blit_2x<false>, grid2, dim3(256), 0, (hipStream_t)s, src, (int)sw, (int)sh, src_img_stride, dst.base, (int)dst.w, (int)dst.h,
+                           (int)dst.pitch, dst.img_stride);
       return (int)hipGetLastError();
     }
     dim3 grid((dst.w + 63) / 64, (dst.h + 3) / 4, batch);
-    hipLaunchKernelGGL(k_input_blit, grid, dim3(256), 0, (hipStream_t)s, src, (int)sw, (int)sh, src_img_stride, dst.base, (int)dst.w, (int)dst.h,
-                       (int)dst.pitch, dst.img_stride);
+    if (dst.fp16)
+      hipLaunchKernelGGL(k_input_blit<true>, grid, dim3(256), 0, (hipStream_t)s, src, (int)sw, (int)sh, src_img_stride, dst.base, (int)dst.w, (int)dst.h,
+                         (int)dst.pitch, dst.img_stride);
+    else
+      hipLaunchKernelGGL(k_input_blit<false>, grid, dim3(256), 0, (hipStream_t)s, src, (int)sw, (int)sh, src_img_stride, dst.base, (int)dst.w, (int)dst.h,
+                         (int)dst.pitch, dst.img_stride);
     return (int)hipGetLastError();
   }
 
@@ -558,14 +648,20 @@ extern "C"
       /* largest tile (R = 19) needs 68 KiB of the CU's 160 KiB LDS: above the 64 KiB default opt-in limit */
       const int Rm = VKSIFT_HIP_MAX_TAPS - 1;
       const int max_bytes = (int)(sizeof(float) * ((TILE + 2 * Rm) * (TILE + 2 * Rm + 1) + (TILE + 2 * Rm) * TILE));
-      hipError_t ae = hipFuncSetAttribute((const void *)k_blur_tile, hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
+      hipError_t ae = hipFuncSetAttribute((const void *)k_blur_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
+      if (ae == hipSuccess)
+        ae = hipFuncSetAttribute((const void *)k_blur_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
       if (ae != hipSuccess)
         return (int)ae;
       lds_attr_set = true;
     }
     dim3 grid((src.w + TILE - 1) / TILE, (src.h + TILE - 1) / TILE, batch);
-    hipLaunchKernelGGL(k_blur_tile, grid, dim3(256), lds_bytes, (hipStream_t)s, src.base, src.img_stride, (int)src.pitch, dst.base, dst.img_stride,
-                       (int)dst.pitch, (int)src.w, (int)src.h, t, (int)ntaps);
+    if (src.fp16)
+      hipLaunchKernelGGL(k_blur_tile<true>, grid, dim3(256), lds_bytes, (hipStream_t)s, src.base, src.img_stride, (int)src.pitch, dst.base, dst.img_stride,
+                         (int)dst.pitch, (int)src.w, (int)src.h, t, (int)ntaps);
+    else
+      hipLaunchKernelGGL(k_blur_tile<false>, grid, dim3(256), lds_bytes, (hipStream_t)s, src.base, src.img_stride, (int)src.pitch, dst.base, dst.img_stride,
+                         (int)dst.pitch, (int)src.w, (int)src.h, t, (int)ntaps);
     return (int)hipGetLastError();
   }
 
@@ -621,7 +717,10 @@ extern "C"
     {
 #define VKSIFT_CASE(N)                                                        \
   case N:                                                                     \
-    hipLaunchKernelGGL((k_blur_lean<N, false>), grid, dim3(64), 0, hs, a);    \
+    if (src.fp16)                                                             \
+      hipLaunchKernelGGL((k_blur_lean<N, false, true>), grid, dim3(64), 0, hs, a);  \
+    else                                                                      \
+      hipLaunchKernelGGL((k_blur_lean<N, false, false>), grid, dim3(64), 0, hs, a); \
     break;
       VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9) VKSIFT_CASE(10)
       VKSIFT_CASE(11) VKSIFT_CASE(12) VKSIFT_CASE(13) VKSIFT_CASE(14) VKSIFT_CASE(15) VKSIFT_CASE(16) VKSIFT_CASE(17) VKSIFT_CASE(18)
@@ -677,7 +776,10 @@ extern "C"
     {
 #define VKSIFT_CASE(N)                                                                        \
   case N:                                                                                     \
-    hipLaunchKernelGGL((k_blur_lean<N, true>), grid, dim3(64), 0, (hipStream_t)s, a);         \
+    if (dst.fp16)                                                                             \
+      hipLaunchKernelGGL((k_blur_lean<N, true, true>), grid, dim3(64), 0, (hipStream_t)s, a);   \
+    else                                                                                      \
+      hipLaunchKernelGGL((k_blur_lean<N, true, false>), grid, dim3(64), 0, (hipStream_t)s, a);  \
     break;
       VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9) VKSIFT_CASE(10)
       VKSIFT_CASE(11) VKSIFT_CASE(12)
@@ -691,15 +793,22 @@ extern "C"
   int vksift_hip_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, uint32_t batch, vksift_hip_stream s)
   {
     dim3 grid((dst.w + 63) / 64, (dst.h + 3) / 4, batch);
-    hipLaunchKernelGGL(k_downsample, grid, dim3(256), 0, (hipStream_t)s, src.base, src.img_stride, (int)src.w, (int)src.h, (int)src.pitch, dst.base,
-                       dst.img_stride, (int)dst.w, (int)dst.h, (int)dst.pitch);
+    if (src.fp16)
+      hipLaunchKernelGGL(k_downsample<true>, grid, dim3(256), 0, (hipStream_t)s, src.base, src.img_stride, (int)src.w, (int)src.h, (int)src.pitch, dst.base,
+                         dst.img_stride, (int)dst.w, (int)dst.h, (int)dst.pitch);
+    else
+      hipLaunchKernelGGL(k_downsample<false>, grid, dim3(256), 0, (hipStream_t)s, src.base, src.img_stride, (int)src.w, (int)src.h, (int)src.pitch, dst.base,
+                         dst.img_stride, (int)dst.w, (int)dst.h, (int)dst.pitch);
     return (int)hipGetLastError();
   }
 
-  int vksift_hip_dog_plane(const float *lo, const float *hi, uint32_t w, uint32_t h, uint32_t pitch, float *out_dense, vksift_hip_stream s)
+  int vksift_hip_dog_plane(const float *lo, const float *hi, uint32_t w, uint32_t h, uint32_t pitch, uint32_t fp16, float *out_dense, vksift_hip_stream s)
   {
     dim3 grid((w + 63) / 64, (h + 3) / 4, 1);
-    hipLaunchKernelGGL(k_dog_plane, grid, dim3(256), 0, (hipStream_t)s, lo, hi, (int)w, (int)h, (int)pitch, out_dense);
+    if (fp16)
+      hipLaunchKernelGGL(k_dog_plane<true>, grid, dim3(256), 0, (hipStream_t)s, lo, hi, (int)w, (int)h, (int)pitch, out_dense);
+    else
+      hipLaunchKernelGGL(k_dog_plane<false>, grid, dim3(256), 0, (hipStream_t)s, lo, hi, (int)w, (int)h, (int)pitch, out_dense);
     return (int)hipGetLastError();
   }
 }

@@ -169,15 +169,18 @@ static void download_plane(vksift_Instance inst, uint8_t octave, uint8_t scale, 
     inst->error_cb(VKSIFT_INVALID_INPUT_ERROR);
     return;
   }
-  const float *src = inst->d_pyr + L->gauss_off[octave] + (uint64_t)scale * L->plane_stride[octave];
-  if (is_dog)
+  const float *src = pyr_at(inst, L->gauss_off[octave] + (uint64_t)scale * L->plane_stride[octave]);
+  if (is_dog || inst->fp16)
   {
     /* DifferenceOfGaussian.comp layer z = G[z+1] - G[z]: the detection path forms these in registers and never stores them;
-     * this (debug) accessor materialises the requested layer of image 0 */
+     * this (debug) accessor materialises the requested layer of image 0. A binary16 pyramid is widened to fp32 the same way
+     * (the reference blits R16 -> R32 for the download, sift_memory.c:1313-1325). */
     tmp = (float *)vksift_hip_malloc(sizeof(float) * (size_t)L->w[octave] * L->h[octave]);
     if (!tmp)
       goto gpu_error;
-    HIP_CHECK(vksift_hip_dog_plane(src, src + L->plane_stride[octave], L->w[octave], L->h[octave], L->pitch[octave], tmp, inst->stream), "DoG layer");
+    HIP_CHECK(vksift_hip_dog_plane(src, is_dog ? pyr_at(inst, L->gauss_off[octave] + (uint64_t)(scale + 1) * L->plane_stride[octave]) : NULL, L->w[octave],
+                                   L->h[octave], L->pitch[octave], inst->fp16 ? 1u : 0u, tmp, inst->stream),
+              "layer conversion");
     HIP_CHECK(vksift_hip_memcpy_d2h(dst, tmp, sizeof(float) * (size_t)L->w[octave] * L->h[octave], inst->stream), "plane download");
   }
   else

@@ -9,7 +9,8 @@
 vksift_hip_Plane plane_at(vksift_Instance inst, uint32_t o, uint64_t base_off, uint32_t layer)
 {
   vksift_hip_Plane p;
-  p.base = inst->d_pyr + base_off + (uint64_t)layer * inst->lay.plane_stride[o];
+  p.base = pyr_at(inst, base_off + (uint64_t)layer * inst->lay.plane_stride[o]);
+  p.fp16 = inst->fp16 ? 1u : 0u;
   p.w = inst->lay.w[o];
   p.h = inst->lay.h[o];
   p.pitch = inst->lay.pitch[o];
@@ -24,8 +25,8 @@ static uint64_t algorithmic_pyramid_bytes(vksift_Instance inst, uint32_t w, uint
   const PyrLayout *L = &inst->lay;
   uint64_t bytes = 0;
   for (uint32_t o = 0; o < L->n_oct && o < nb_octaves; o++)
-    bytes += (uint64_t)L->w[o] * L->h[o] * 4u * ((inst->S + 3) + (inst->S + 2) + (inst->S + 2));
-  bytes += (uint64_t)w * h + (uint64_t)L->w[0] * L->h[0] * 8u;
+    bytes += (uint64_t)L->w[o] * L->h[o] * pyr_texel_bytes(inst) * ((inst->S + 3) + (inst->S + 2) + (inst->S + 2));
+  bytes += (uint64_t)w * h + (uint64_t)L->w[0] * L->h[0] * 2u * pyr_texel_bytes(inst);
   return bytes;
 }
 
@@ -97,7 +98,8 @@ static void build_jobs(DetectCtx *c)
   {
     vksift_hip_OctaveJob *j = &c->jobs[o];
     memset(j, 0, sizeof(*j));
-    j->gauss = inst->d_pyr + L->gauss_off[o];
+    j->gauss = pyr_at(inst, L->gauss_off[o]);
+    j->fp16 = inst->fp16 ? 1u : 0u;
     j->w = L->w[o], j->h = L->h[o], j->pitch = L->pitch[o];
     j->plane_stride = L->plane_stride[o];
     j->img_stride = inst->pyr_img_stride;
@@ -342,7 +344,7 @@ static int enqueue_detection(DetectCtx *c)
   /* profiling: the pyramid interval is octave 0's when pipelined, the whole pyramid's otherwise */
   inst->last_alg_bytes = algorithmic_pyramid_bytes(inst, c->w, c->h, c->pipelined ? 1u : L->n_oct) * c->count;
   /* "the extrema scan adds 20 B/px.octave" = one read of the S+2 DoG layers (octave 0: the timed scan) */
-  inst->last_scan_bytes = L->n_oct ? (uint64_t)L->w[0] * L->h[0] * 4u * (inst->S + 2) * c->count : 0;
+  inst->last_scan_bytes = L->n_oct ? (uint64_t)L->w[0] * L->h[0] * pyr_texel_bytes(inst) * (inst->S + 2) * c->count : 0;
 
   if (!c->pipelined)
   {

@@ -107,8 +107,9 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     vksift_destroyInstance(instance_ptr);
     return VKSIFT_VULKAN_ERROR;
   }
-  if (config->pyramid_precision_mode == VKSIFT_PYRAMID_PRECISION_FLOAT16)
-    logWarning(LOG_TAG, "VKSIFT_PYRAMID_PRECISION_FLOAT16 requested: this build keeps the scale-space in fp32 (superset precision).");
+  /* the reference's FLOAT16 mode binds R16_SFLOAT images to shaders that declare r32f (undefined in Vulkan); this build defines it:
+   * texels stored as IEEE binary16 (round to nearest even), widened exactly on every read, all arithmetic fp32 */
+  inst->fp16 = config->pyramid_precision_mode == VKSIFT_PYRAMID_PRECISION_FLOAT16;
   if (config->use_gpu_debug_functions)
     logWarning(LOG_TAG, "use_gpu_debug_functions requested: there is no frame presenter in the HIP build; use rocprofv3 / roctx ranges instead.");
 
@@ -143,9 +144,9 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     const char *e = getenv("VKSIFT_PYR_PINGPONG");
     inst->pyr_pingpong = e ? (e[0] == '1') : (batch_cap >= 8u);
   }
-  ALLOC_D(inst->d_pyr_buf[0], sizeof(float) * inst->pyr_img_stride * batch_cap);
+  ALLOC_D(inst->d_pyr_buf[0], pyr_texel_bytes(inst) * inst->pyr_img_stride * batch_cap);
   if (inst->pyr_pingpong)
-    ALLOC_D(inst->d_pyr_buf[1], sizeof(float) * inst->pyr_img_stride * batch_cap);
+    ALLOC_D(inst->d_pyr_buf[1], pyr_texel_bytes(inst) * inst->pyr_img_stride * batch_cap);
   inst->d_pyr = inst->d_pyr_buf[0];
   ALLOC_D(inst->d_input, (size_t)inst->max_image_size * batch_cap);
   ALLOC_H(inst->h_input, (size_t)inst->max_image_size * batch_cap);
@@ -422,9 +423,9 @@ int grow_image_scratch(vksift_Instance inst, const PyrLayout *L)
   vksift_hip_free(inst->d_cand_xy);
   vksift_hip_free(inst->d_cand_flag);
   inst->d_pyr_buf[1] = NULL;
-  inst->d_pyr_buf[0] = vksift_hip_malloc(sizeof(float) * new_pyr * n);
+  inst->d_pyr_buf[0] = vksift_hip_malloc(pyr_texel_bytes(inst) * new_pyr * n);
   if (inst->pyr_pingpong)
-    inst->d_pyr_buf[1] = vksift_hip_malloc(sizeof(float) * new_pyr * n);
+    inst->d_pyr_buf[1] = vksift_hip_malloc(pyr_texel_bytes(inst) * new_pyr * n);
   inst->d_seg_mask = vksift_hip_malloc(sizeof(uint64_t) * new_seg * n);
   inst->d_seg_off = vksift_hip_malloc(sizeof(uint32_t) * new_seg * n);
   inst->d_cand_xy = vksift_hip_malloc(sizeof(uint32_t) * new_cand * n);

@@ -83,6 +83,7 @@ struct vksift_Instance_T
   void (*error_cb)(vksift_Result);
   int device;
   uint32_t S;
+  bool fp16;               /* VKSIFT_PYRAMID_PRECISION_FLOAT16: the scale-space holds IEEE binary16 texels (2 bytes), arithmetic stays fp32 */
   uint32_t max_image_size; /* rounded up to a square, sift_memory.c:644-647 */
   uint32_t max_octaves;
   uint32_t batch_cap;
@@ -96,7 +97,7 @@ struct vksift_Instance_T
   PyrLayout lay;
 
   /* device memory */
-  float *d_pyr;            /* pyramid storage of the current detection (= d_pyr_buf[pyr_cur]) */
+  float *d_pyr;            /* pyramid storage of the current detection (= d_pyr_buf[pyr_cur]); texel offsets scale with pyr_texel_bytes() */
   float *d_pyr_buf[2];     /* ping-pong: detection N+1 builds its pyramid while detection N still reads its own */
   int pyr_cur;
   bool pyr_pingpong;
@@ -189,6 +190,10 @@ struct vksift_Instance_T
       goto gpu_error;                                                              \
     }                                                                              \
   } while (0)
+
+static inline size_t pyr_texel_bytes(const struct vksift_Instance_T *inst) { return inst->fp16 ? 2u : 4u; }
+/* address of texel `off` (texels from the start of the pyramid buffer) */
+static inline float *pyr_at(const struct vksift_Instance_T *inst, uint64_t off) { return (float *)((uint8_t *)inst->d_pyr + off * pyr_texel_bytes(inst)); }
 
 /* vksift_api.c */
 extern VKSIFT_INTERNAL bool vksift_g_loaded;
