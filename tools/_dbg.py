@@ -1,16 +1,15 @@
-import sys, numpy as np, torch
+import sys, numpy as np, os
 sys.path.insert(0,'/root/repo')
-from vulkansift_amd import api as vk, multigpu
-from oracle import oracle
-vk.load()
-a = vk.gen_synthetic_descriptors(51, 33000)
-b = vk.gen_synthetic_descriptors(52, 1000)
-b[1] = b[0]; b[700] = b[3]; b[999] = b[130]; a[7] = b[3]; a[8] = b[130]
-rec = multigpu.hip_match_fn(torch.from_numpy(a).cuda(), 100, torch.from_numpy(b).cuda())
-torch.cuda.synchronize()
-got = multigpu.records_to_struct(rec.cpu().numpy())
-ref = oracle.match_2nn(a, b)
-bad = np.flatnonzero((got["idx_b1"] != ref["idx_b1"]) | (got["idx_b2"] != ref["idx_b2"]))
-print(len(bad), bad[:20])
-for r in bad[:8]:
-    print(r, got[r], ref[r])
+from vulkansift_amd import api as vk
+if os.environ.get("VKLIB"): vk.LIB_PATH = os.environ["VKLIB"]
+from oracle import oracle as O
+vk.lib().vksift_setLogLevel(1)
+imgs = [vk.gen_synthetic_image(7000 + i, 256, 192) for i in range(3)]
+cfg = vk.default_config(sift_buffer_count=3, input_image_max_size=256*192)
+with vk.Instance(cfg, batch_capacity=3) as inst:
+    inst.detectFeaturesBatch(imgs, 0)
+    feats = [inst.downloadFeatures(i) for i in range(3)]
+for i in range(3):
+    ref,_ = O.detect(O.default_config(math_mode=1), imgs[i])
+    f = feats[i]
+    print(os.environ.get("TAG"), i, len(f), len(ref), [int((f["octave_idx"]==o).sum()) for o in range(-1,4)], [int((ref["octave_idx"]==o).sum()) for o in range(-1,4)])

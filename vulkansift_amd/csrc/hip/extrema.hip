@@ -35,19 +35,21 @@ struct DogView
   int fp16;     // binary16 texels (VKSIFT_PYRAMID_PRECISION_FLOAT16): widened exactly; the DoG image of such a pyramid is binary16 too
 };
 
-__device__ __forceinline__ float gauss_texel(const DogView &d, size_t idx)
-{
-  return d.fp16 ? (float)((const _Float16 *)d.base)[idx] : d.base[idx];
-}
-
 // imageLoad of the DoG image with robust out-of-bounds behaviour on the layer axis (quirk Q1): layer S+2 reads 0.
+// F16 (binary16 texels) is a template parameter of everything that refines: a run-time flag inside this function was
+// miscompiled (fp32 results of images >= 1 of a batch changed with unrelated edits of the callers).
+template <bool F16>
 __device__ __forceinline__ float ld(const DogView &d, int s, int x, int y)
 {
   if (s < 0 || s > d.S + 1)
     return 0.f;
-  const size_t idx = (size_t)s * d.plane + (size_t)y * d.pitch + x;
-  const float v = gauss_texel(d, idx + d.plane) - gauss_texel(d, idx);
-  return d.fp16 ? (float)(_Float16)v : v;
+  if (F16)
+  {
+    const _Float16 *p = (const _Float16 *)d.base + (size_t)s * d.plane + (size_t)y * d.pitch + x;
+    return (float)(_Float16)((float)p[d.plane] - (float)p[0]);
+  }
+  const float *p = d.base + (size_t)s * d.plane + (size_t)y * d.pitch + x;
+  return p[d.plane] - p[0];
 }
 
 struct KpRecord
@@ -59,6 +61,7 @@ struct KpRecord
 };
 
 // Refinement + acceptance tests (ExtractKeypoints.comp:121-224).
+template <bool F16>
 __device__ bool refine_texel(const DogView &d, int x, int y, int s, float dog_threshold, float edge_limit, float seed_sigma, int octave_idx, KpRecord *kp)
 {
   const int W = d.w, H = d.h, S = d.S;
@@ -66,19 +69,19 @@ __device__ bool refine_texel(const DogView &d, int x, int y, int s, float dog_th
   int rx = x, ry = y, rs = s;
   for (int step = 0; step < 5; step++)
   {
-    float vc = ld(d, rs, rx, ry);
-    float sp = ld(d, rs + 1, rx, ry), sm = ld(d, rs - 1, rx, ry);
-    float xp = ld(d, rs, rx + 1, ry), xm = ld(d, rs, rx - 1, ry);
-    float yp = ld(d, rs, rx, ry + 1), ym = ld(d, rs, rx, ry - 1);
+    float vc = ld<F16>(d, rs, rx, ry);
+    float sp = ld<F16>(d, rs + 1, rx, ry), sm = ld<F16>(d, rs - 1, rx, ry);
+    float xp = ld<F16>(d, rs, rx + 1, ry), xm = ld<F16>(d, rs, rx - 1, ry);
+    float yp = ld<F16>(d, rs, rx, ry + 1), ym = ld<F16>(d, rs, rx, ry - 1);
     gS = 0.5f * (sp - sm);
     gX = 0.5f * (xp - xm);
     gY = 0.5f * (yp - ym);
     float h11 = sp + sm - 2.f * vc;
     float h22 = xp + xm - 2.f * vc;
     float h33 = yp + ym - 2.f * vc;
-    float h12 = 0.25f * (ld(d, rs + 1, rx + 1, ry) - ld(d, rs + 1, rx - 1, ry) - ld(d, rs - 1, rx + 1, ry) + ld(d, rs - 1, rx - 1, ry));
-    float h13 = 0.25f * (ld(d, rs + 1, rx, ry + 1) - ld(d, rs + 1, rx, ry - 1) - ld(d, rs - 1, rx, ry + 1) + ld(d, rs - 1, rx, ry - 1));
-    float h23 = 0.25f * (ld(d, rs, rx + 1, ry + 1) - ld(d, rs, rx + 1, ry - 1) - ld(d, rs, rx - 1, ry + 1) + ld(d, rs, rx - 1, ry - 1));
+    float h12 = 0.25f * (ld<F16>(d, rs + 1, rx + 1, ry) - ld<F16>(d, rs + 1, rx - 1, ry) - ld<F16>(d, rs - 1, rx + 1, ry) + ld<F16>(d, rs - 1, rx - 1, ry));
+    float h13 = 0.25f * (ld<F16>(d, rs + 1, rx, ry + 1) - ld<F16>(d, rs + 1, rx, ry - 1) - ld<F16>(d, rs - 1, rx, ry + 1) + ld<F16>(d, rs - 1, rx, ry - 1));
+    float h23 = 0.25f * (ld<F16>(d, rs, rx + 1, ry + 1) - ld<F16>(d, rs, rx + 1, ry - 1) - ld<F16>(d, rs, rx - 1, ry + 1) + ld<F16>(d, rs, rx - 1, ry - 1));
 
     float det = h11 * ((h22 * h33) - (h23 * h23)) - h12 * ((h12 * h33) - (h13 * h23)) + h13 * ((h12 * h23) - (h13 * h22));
     if (det == 0.0f)
@@ -103,14 +106,14 @@ __device__ bool refine_texel(const DogView &d, int x, int y, int s, float dog_th
     }
   }
   float sx = (float)rx + oX, sy = (float)ry + oY, ss = (float)rs + oS;
-  float vc = ld(d, rs, rx, ry);
+  float vc = ld<F16>(d, rs, rx, ry);
   float nv = vc + 0.5f * (gX * oX + gY * oY + gS * oS);
   if (!(fabsf(nv) > dog_threshold && fabsf(oX) < 1.5f && fabsf(oY) < 1.5f && fabsf(oS) < 1.5f && sx >= 0 && sx < (float)W && sy >= 0 && sy < (float)H &&
         ss >= 0 && ss <= (float)(S + 1)))
     return false;
-  float e11 = ld(d, rs, rx + 1, ry) + ld(d, rs, rx - 1, ry) - 2.f * vc;
-  float e22 = ld(d, rs, rx, ry + 1) + ld(d, rs, rx, ry - 1) - 2.f * vc;
-  float e12 = 0.25f * (ld(d, rs, rx + 1, ry + 1) - ld(d, rs, rx + 1, ry - 1) - ld(d, rs, rx - 1, ry + 1) + ld(d, rs, rx - 1, ry - 1));
+  float e11 = ld<F16>(d, rs, rx + 1, ry) + ld<F16>(d, rs, rx - 1, ry) - 2.f * vc;
+  float e22 = ld<F16>(d, rs, rx, ry + 1) + ld<F16>(d, rs, rx, ry - 1) - 2.f * vc;
+  float e12 = 0.25f * (ld<F16>(d, rs, rx + 1, ry + 1) - ld<F16>(d, rs, rx + 1, ry - 1) - ld<F16>(d, rs, rx - 1, ry + 1) + ld<F16>(d, rs, rx - 1, ry - 1));
   float edgeness = ((e11 + e22) * (e11 + e22)) / ((e11 * e22) - (e12 * e12));
   if (!((edgeness < edge_limit) && (edgeness >= 0)))
     return false;
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
     return;
   const int y1 = min(y0 + band, a.h);
   const int x0 = blockIdx.x * 128, x = x0 + 2 * lane;
-  DogView d{a.fp16 ? (const float *)((const _Float16 *)a.gauss + (size_t)b * a.img_stride) : a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
+  DogView d{(const float *)((const uint8_t *)a.gauss + (size_t)b * a.img_stride * (a.fp16 ? 2u : 4u)), a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
   const bool in0 = x < a.w, in1 = x + 1 < a.w;
   const int hx = lane == 0 ? x0 - 1 : x0 + 128;
   const bool hok = (lane == 0 || lane == 63) && hx >= 0 && hx < a.w;
@@ -256,11 +259,8 @@ __global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
       p.va[l] = p.vb[l] = p.hv[l] = 0.f;
       if (r >= 0 && r < a.h && r <= y1)
       {
-        const size_t row = (size_t)l * d.plane + (size_t)r * d.pitch; // Gaussian layer l; layer l+1 one plane further
-        auto dog = [&](int xx) {
-          const float v = gauss_texel(d, row + d.plane + xx) - gauss_texel(d, row + xx);
-          return d.fp16 ? (float)(_Float16)v : v;
-        };
+        // Gaussian layer l; layer l+1 one plane further
+        auto dog = [&](int xx) { return d.fp16 ? ld<true>(d, l, xx, r) : ld<false>(d, l, xx, r); };
         if (in1)
           p.va[l] = dog(x), p.vb[l] = dog(x + 1);
         else if (in0)
@@ -700,6 +700,7 @@ __global__ void __launch_bounds__(256) k_cand_list(ExtremaArgs a, uint32_t nsegs
 // Dense refinement: thread t of a 256-candidate chunk refines candidate chunk*256 + t (count read from HBM, workgroups
 // stride over the chunks). Besides the accept flags every chunk publishes its number of accepted candidates (into the
 // segment-offset array, free again after k_cand_list) for the two-level scan of k_chunk_offsets / k_cand_emit.
+template <bool F16>
 __global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
 {
   __shared__ uint32_t s_cnt[4];
@@ -707,7 +708,7 @@ __global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
   uint32_t n = a.cand_n[b];
   n = n < a.cand_cap ? n : a.cand_cap;
   const uint32_t nch = (n + 255u) / 256u;
-  DogView d{a.fp16 ? (const float *)((const _Float16 *)a.gauss + (size_t)b * a.img_stride) : a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
+  DogView d{(const float *)((const uint8_t *)a.gauss + (size_t)b * a.img_stride * (a.fp16 ? 2u : 4u)), a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
   const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
   uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
   uint32_t *chunk_sum = a.seg_off + (size_t)b * a.seg_img_stride;
@@ -719,7 +720,7 @@ __global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
     {
       const uint32_t c = xy[i];
       KpRecord kp;
-      ok = refine_texel(d, (int)(c & 0x3fffu), (int)((c >> 14) & 0x3fffu), (int)(c >> 28), a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
+      ok = refine_texel<F16>(d, (int)(c & 0x3fffu), (int)((c >> 14) & 0x3fffu), (int)(c >> 28), a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
       flag[i] = ok ? 1u : 0u;
     }
     const unsigned long long bal = __ballot(ok);
@@ -735,6 +736,7 @@ __global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
 // Accepted candidates recompute their record (bit-identical) and store it at chunk base + rank inside the chunk (raster
 // order is preserved) if it fits the section. About one candidate in six is accepted: the accepted ones of a chunk are
 // first compacted through LDS, so the recomputation runs on dense lanes (one wave per chunk instead of four sparse ones).
+template <bool F16>
 __global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
 {
   __shared__ uint32_t s_cnt[4];
@@ -744,7 +746,7 @@ __global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
   uint32_t n = a.cand_n[b];
   n = n < a.cand_cap ? n : a.cand_cap;
   const uint32_t nch = (n + 255u) / 256u;
-  DogView d{a.fp16 ? (const float *)((const _Float16 *)a.gauss + (size_t)b * a.img_stride) : a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
+  DogView d{(const float *)((const uint8_t *)a.gauss + (size_t)b * a.img_stride * (a.fp16 ? 2u : 4u)), a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
   const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
   const uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
   const uint32_t *chunk_base = a.seg_off + (size_t)b * a.seg_img_stride;
@@ -768,7 +770,7 @@ __global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
     {
       const uint32_t c = s_list[threadIdx.x];
       KpRecord kp;
-      refine_texel(d, (int)(c & 0x3fffu), (int)((c >> 14) & 0x3fffu), (int)(c >> 28), a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
+      refine_texel<F16>(d, (int)(c & 0x3fffu), (int)((c >> 14) & 0x3fffu), (int)(c >> 28), a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
       uint32_t *rec = (uint32_t *)(a.feats + (size_t)b * a.feat_img_stride + (size_t)idx * 164);
       rec[0] = __float_as_uint(kp.x);
       rec[1] = __float_as_uint(kp.y);
@@ -882,9 +884,15 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
    * contiguous in dispatch order. With the chunk index fastest they formed a short run at the start of every image's row of
    * 512 workgroups, which the dispatcher's round-robin maps onto the same half of the shader engines of every XCD:
    * measured 221 us instead of 70 us for this launch (and 137 instead of 51 us for k_cand_emit). */
-  hipLaunchKernelGGL(k_refine_flags, dim3(batch, rblocks), dim3(256), 0, hs, a);
+  if (a.fp16)
+    hipLaunchKernelGGL(k_refine_flags<true>, dim3(batch, rblocks), dim3(256), 0, hs, a);
+  else
+    hipLaunchKernelGGL(k_refine_flags<false>, dim3(batch, rblocks), dim3(256), 0, hs, a);
   hipLaunchKernelGGL(k_chunk_offsets, dim3(batch), dim3(1024), 0, hs, a.seg_off, a.seg_img_stride, 0u, (const uint32_t *)a.cand_n, a.cand_cap, 256u, a.found,
                      a.found_img_stride);
-  hipLaunchKernelGGL(k_cand_emit, dim3(batch, rblocks), dim3(256), 0, hs, a);
+  if (a.fp16)
+    hipLaunchKernelGGL(k_cand_emit<true>, dim3(batch, rblocks), dim3(256), 0, hs, a);
+  else
+    hipLaunchKernelGGL(k_cand_emit<false>, dim3(batch, rblocks), dim3(256), 0, hs, a);
   return (int)hipGetLastError();
 }
