@@ -32,10 +32,12 @@ struct GaussView
 };
 
 // One texel of the keypoint's Gaussian layer through its buffer resource. voff / soff are the byte offsets of the fp32 layout;
-// a binary16 pyramid (VKSIFT_PYRAMID_PRECISION_FLOAT16, f16 = wave-uniform) halves them and widens the texel exactly.
-__device__ __forceinline__ float tap_ld(const __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff, bool f16)
+// a binary16 pyramid (VKSIFT_PYRAMID_PRECISION_FLOAT16) halves them and widens the texel exactly.
+// (F16 is a template parameter of the kernels: as a run-time flag it cost the VALU-bound descriptor kernel 60 %)
+template <bool F16>
+__device__ __forceinline__ float tap_ld(const __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff)
 {
-  if (f16)
+  if (F16)
     return (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff >> 1, soff >> 1, 0));
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 }
@@ -87,7 +89,7 @@ __device__ __forceinline__ float wrap_2pi(float t)
 // -------------------------------------------------------------------------------------------------
 // Orientation histogram (ComputeOrientation.comp:52-186). grid = (blocks, batch); 4 keypoints/block.
 // -------------------------------------------------------------------------------------------------
-template <bool IMG_FAST>
+template <bool IMG_FAST, bool F16>
 __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
 {
   // One wave per keypoint, four independent waves per block: every wave owns its histogram and LDS executes the DS
@@ -116,8 +118,7 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
       const int octave_idx = ((const int *)rec)[5];
       const float sigma = rec[6];
       // planes stay below 2 GiB (vksift_hip_extract_keypoints refuses sides of 16384 and more)
-      const bool f16 = a.fp16 != 0;
-      const __amdgpu_buffer_rsrc_t rs = layer_rsrc(a.gauss, (size_t)b * a.img_stride + (size_t)scale_idx * g.plane, g.pitch, g.h, f16);
+      const __amdgpu_buffer_rsrc_t rs = layer_rsrc(a.gauss, (size_t)b * a.img_stride + (size_t)scale_idx * g.plane, g.pitch, g.h, F16);
 
       float scale_factor = dm_pow2i(octave_idx);
       float lambda = 1.5f * (sigma / scale_factor);
@@ -168,8 +169,8 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
         const unsigned o_l = (yin && (unsigned)(gx - 1) < (unsigned)g.w) ? o0 - 4u : 0x80000000u;
         const unsigned o_d = (xin && (unsigned)(gy + 1) < (unsigned)g.h) ? (__umul24((unsigned)(gy + 1), (unsigned)g.pitch) + (unsigned)gx) * 4u : 0x80000000u;
         const unsigned o_u = (xin && (unsigned)(gy - 1) < (unsigned)g.h) ? (__umul24((unsigned)(gy - 1), (unsigned)g.pitch) + (unsigned)gx) * 4u : 0x80000000u;
-        float gradX = 0.5f * (tap_ld(rs, o_r, 0, f16) - tap_ld(rs, o_l, 0, f16));
-        float gradY = 0.5f * (tap_ld(rs, o_d, 0, f16) - tap_ld(rs, o_u, 0, f16));
+        float gradX = 0.5f * (tap_ld<F16>(rs, o_r, 0) - tap_ld<F16>(rs, o_l, 0));
+        float gradY = 0.5f * (tap_ld<F16>(rs, o_d, 0) - tap_ld<F16>(rs, o_u, 0));
         float mag = dm_expf_nb_nonpos(d2 * es) /* d2 >= 0 > es */ * sqrtf((gradX * gradX) + (gradY * gradY));
         float ori = wrap_2pi(dm_atan2f(gradY, gradX));
         int bin = (int)(dm_div_2pi(ori * 36.f)); // == ori * 36 / (2 pi)
@@ -297,7 +298,6 @@ __device__ __forceinline__ int smod8(int v) { return v & 7; } // floored modulo 
 struct DescCtx
 {
   __amdgpu_buffer_rsrc_t rs; // the keypoint's Gaussian layer
-  bool f16;                  // binary16 texels
   int pitch, pitch4;
   float scale_x, scale_y, rsx, rsy, kcos, ksin, kori, fp, bin_scale;
 };
@@ -310,6 +310,7 @@ struct DescSample
   float xb; // 8 * relative orientation, before the division by 2*pi
 };
 
+template <bool F16>
 __device__ __forceinline__ DescSample desc_sample(const DescCtx &c, int cdx, int cdy)
 {
   const float es = -1.f / (2.f * 2 * 2);
@@ -322,10 +323,10 @@ __device__ __forceinline__ DescSample desc_sample(const DescCtx &c, int cdx, int
   // the four taps through the layer's buffer resource: one 32-bit offset (texel (ix-1, iy-1)), the rest is immediate /
   // scalar offsets (the window is clipped to the image interior, so every tap of a live sample is in range)
   const unsigned v0 = (__umul24((unsigned)(iy - 1), (unsigned)c.pitch) + (unsigned)(ix - 1)) * 4u; // sides < 16384: 24-bit factors
-  const float t_up = tap_ld(c.rs, v0 + 4u, 0, c.f16);
-  const float t_lf = tap_ld(c.rs, v0, c.pitch4, c.f16);
-  const float t_rt = tap_ld(c.rs, v0 + 8u, c.pitch4, c.f16);
-  const float t_dn = tap_ld(c.rs, v0 + 4u, 2 * c.pitch4, c.f16);
+  const float t_up = tap_ld<F16>(c.rs, v0 + 4u, 0);
+  const float t_lf = tap_ld<F16>(c.rs, v0, c.pitch4);
+  const float t_rt = tap_ld<F16>(c.rs, v0 + 8u, c.pitch4);
+  const float t_dn = tap_ld<F16>(c.rs, v0 + 4u, 2 * c.pitch4);
   float gradX = 0.5f * (t_rt - t_lf);
   float gradY = 0.5f * (t_dn - t_up);
   float ori = wrap_2pi(dm_atan2f(gradY, gradX));
@@ -402,7 +403,7 @@ __device__ __forceinline__ void desc_fbin2(float xa, float xb, float *fa, float 
 // atan2, exp, 8 fixed-point atomics) runs on full 64-lane batches.
 constexpr int DESC_MAX_ROWS = 256; // window rows handled per pass (R <= 127: every stock configuration); taller windows take several passes
 
-template <int NWV, bool IMG_FAST>
+template <int NWV, bool IMG_FAST, bool F16>
 __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
 {
   constexpr int NT_ = 64 * NWV;
@@ -430,8 +431,7 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
     DescCtx c;
     c.scale_x = rec[2], c.scale_y = rec[3], c.kori = rec[7];
     // planes stay below 2 GiB (vksift_hip_extract_keypoints refuses sides of 16384 and more): 32-bit byte offsets
-    c.f16 = a.fp16 != 0;
-    c.rs = layer_rsrc(a.gauss, (size_t)b * a.img_stride + (size_t)scale_idx * g.plane, g.pitch, g.h, c.f16);
+    c.rs = layer_rsrc(a.gauss, (size_t)b * a.img_stride + (size_t)scale_idx * g.plane, g.pitch, g.h, F16);
     c.pitch = g.pitch, c.pitch4 = g.pitch * 4;
     c.bin_scale = a.use_vlfeat ? 8.f : -8.f;
     float scale_factor = dm_pow2i(octave_idx);
@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
         bool live[2];
         next_sample(sx[0], sy[0], live[0]);
         next_sample(sx[1], sy[1], live[1]);
-        const DescSample s0 = desc_sample(c, sx[0], sy[0]), s1 = desc_sample(c, sx[1], sy[1]);
+        const DescSample s0 = desc_sample<F16>(c, sx[0], sy[0]), s1 = desc_sample<F16>(c, sx[1], sy[1]);
         float f0, f1;
         desc_fbin2(s0.xb, s1.xb, &f0, &f1);
         desc_scatter(c, s0, f0, live[0], s_work);
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
         int sx, sy;
         bool live;
         next_sample(sx, sy, live);
-        const DescSample s0 = desc_sample(c, sx, sy);
+        const DescSample s0 = desc_sample<F16>(c, sx, sy);
         desc_scatter(c, s0, dm_div_2pi(s0.xb), live, s_work);
       }
     }
@@ -688,9 +688,19 @@ extern "C"
     if (blocks == 0)
       blocks = 1;
     if (img_fast(batch, false))
-      hipLaunchKernelGGL(k_orientation<true>, dim3(batch, blocks), dim3(256), 0, (hipStream_t)s, a);
+    {
+      if (a.fp16)
+        hipLaunchKernelGGL((k_orientation<true, true>), dim3(batch, blocks), dim3(256), 0, (hipStream_t)s, a);
+      else
+        hipLaunchKernelGGL((k_orientation<true, false>), dim3(batch, blocks), dim3(256), 0, (hipStream_t)s, a);
+    }
     else
-      hipLaunchKernelGGL(k_orientation<false>, dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
+    {
+      if (a.fp16)
+        hipLaunchKernelGGL((k_orientation<false, true>), dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
+      else
+        hipLaunchKernelGGL((k_orientation<false, false>), dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
+    }
     hipLaunchKernelGGL(k_orientation_finalize, dim3(batch), dim3(1024), 0, (hipStream_t)s, a);
     return (int)hipGetLastError();
   }
@@ -719,9 +729,19 @@ extern "C"
   do                                                                                            \
   {                                                                                             \
     if (f)                                                                                      \
-      hipLaunchKernelGGL((k_descriptor<N, true>), dim3(batch, blocks), dim3(64 * N), 0, hs, a);  \
+    {                                                                                           \
+      if (a.fp16)                                                                               \
+        hipLaunchKernelGGL((k_descriptor<N, true, true>), dim3(batch, blocks), dim3(64 * N), 0, hs, a);  \
+      else                                                                                      \
+        hipLaunchKernelGGL((k_descriptor<N, true, false>), dim3(batch, blocks), dim3(64 * N), 0, hs, a); \
+    }                                                                                           \
     else                                                                                        \
-      hipLaunchKernelGGL((k_descriptor<N, false>), dim3(blocks, batch), dim3(64 * N), 0, hs, a); \
+    {                                                                                           \
+      if (a.fp16)                                                                               \
+        hipLaunchKernelGGL((k_descriptor<N, false, true>), dim3(blocks, batch), dim3(64 * N), 0, hs, a); \
+      else                                                                                      \
+        hipLaunchKernelGGL((k_descriptor<N, false, false>), dim3(blocks, batch), dim3(64 * N), 0, hs, a); \
+    }                                                                                           \
   } while (0)
     if (nwv == 1)
       VKSIFT_DESC(1);
