@@ -14,11 +14,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 KERNEL = "k_blur_lean"
+SCAN = "k_extrema_lean"
 
 
-def pmc(dirpath, counter, gridx):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), dirpath, counter, KERNEL, str(gridx)], capture_output=True, text=True)
+def pmc(dirpath, counter, gridx, kernel=KERNEL):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), dirpath, counter, kernel, str(gridx)], capture_output=True, text=True)
     return json.loads(out.stdout)
+
+
+def kernel_source_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "vulkansift_amd", "csrc", "hip", "*.hip"))):
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -52,19 +61,29 @@ def main():
         gridx = ((2 * w + 127) // 128) * 64
         f = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", gridx)
         wr = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", gridx)
+        # the streaming extrema scan of octave 0: grid.x = ceil(nseg / 2) workgroups of 256 work-items, nseg = ceil(2w / 64)
+        sgridx = ((((2 * w + 63) // 64) + 1) // 2) * 256
+        sf = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", sgridx, SCAN)
+        sw_ = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", sgridx, SCAN)
         calls = sum(v["calls"] for v in f.values())
         fetch_kb = sum(v["sum"] for v in f.values())
         write_kb = sum(v["sum"] for v in wr.values())
         wcalls = sum(v["calls"] for v in wr.values())
+        scalls = sum(v["calls"] for v in sf.values()) or 1
+        swcalls = sum(v["calls"] for v in sw_.values()) or 1
         # FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
         # stream (MI355X_MICROARCH.md §HBM): doubled before use. WRITE_SIZE is taken as is (uncalibrated).
         per_launch = (2.0 * fetch_kb / max(calls, 1) + write_kb / max(wcalls, 1)) * 1024.0
-        rec = {"width": w, "height": h, "batch": batch, "kernel": KERNEL + " (octave-0 launches)", "launches_fetch_pass": calls, "launches_write_pass": wcalls,
+        scan_launch = (2.0 * sum(v["sum"] for v in sf.values()) / scalls + sum(v["sum"] for v in sw_.values()) / swcalls) * 1024.0
+        blur_per_call = calls / scalls          # blur launches of octave 0 per detection call (= per scan launch)
+        rec = {"width": w, "height": h, "batch": batch, "kernel": KERNEL + " + " + SCAN + " (octave-0 launches)", "kernel_source_sha": kernel_source_sha(),
+               "launches_fetch_pass": calls, "launches_write_pass": wcalls, "scan_launches": scalls,
                "FETCH_SIZE_KiB_sum": fetch_kb, "WRITE_SIZE_KiB_sum": write_kb, "fetch_correction": 2.0,
-               "hbm_bytes_per_blur_launch": per_launch,
-               "per_kernel_FETCH_SIZE": f, "per_kernel_WRITE_SIZE": wr}
+               "hbm_bytes_per_blur_launch": per_launch, "hbm_bytes_per_scan_launch": scan_launch,
+               "hbm_bytes_per_call": per_launch * blur_per_call + scan_launch,
+               "per_kernel_FETCH_SIZE": {**f, **sf}, "per_kernel_WRITE_SIZE": {**wr, **sw_}}
         json.dump(rec, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-        print("traffic per blur launch: %.1f MB" % (per_launch / 1e6))
+        print("traffic per blur launch: %.1f MB, per scan launch: %.1f MB, per detection call: %.1f MB" % (per_launch / 1e6, scan_launch / 1e6, rec["hbm_bytes_per_call"] / 1e6))
     print(summ[:3000])
 
 
