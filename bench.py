@@ -354,6 +354,22 @@ def main():
     inst.setProfiling(False)
 
     extras = {}
+    if not args.no_extras and world == 1:
+        # (before the sharded-match leg: once RCCL has created its streams, HIP maps this library's streams onto the hardware queues
+        # differently and the per-stage intervals of an overlapped detection get attributed differently — same step time)
+        extras["value_host_input"] = reference_protocol(api, inst, frames, W, H, B, do_match, 3)
+    inst.close()
+    if not args.no_extras and world == 1:
+        # in a fresh process: how HIP maps an instance's dozen streams onto the four hardware queues depends on the streams the
+        # process created before (the 640x480 instance above), and with it the attribution of an overlapped detection's time to
+        # its stages — same step time, stage intervals up to 2x apart. A fresh process is the reproducible case.
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "c3_leg.py")], capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("C3LEG ")][-1]
+            extras["roofline_c3"] = json.loads(line[6:])
+        except Exception as e:  # noqa: BLE001
+            extras["roofline_c3"] = {"error": repr(e)[:300]}
+        extras["single_image_ms"] = single_image_latency(api, dev.index, frames[0])
     if not args.no_extras:
         # every rank takes part (the all-gather is a collective); a failure of this leg must not cost the headline line
         try:
@@ -368,12 +384,6 @@ def main():
                                        "records_crc32": crc}
         except Exception as e:  # noqa: BLE001
             extras["sharded_match"] = {"error": repr(e)[:300]}
-        if world == 1:
-            extras["value_host_input"] = reference_protocol(api, inst, frames, W, H, B, do_match, 3)
-    inst.close()
-    if not args.no_extras and world == 1:
-        extras["single_image_ms"] = single_image_latency(api, dev.index, frames[0])
-        extras["roofline_c3"] = c3_roofline(api, torch, dev)
 
     if rank == 0:
         frames_total = B * NSUB * world * args.steps

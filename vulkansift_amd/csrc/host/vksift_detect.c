@@ -354,7 +354,10 @@ static int enqueue_detection(DetectCtx *c)
       vksift_hip_event_record(c->PS->ev_t[2], st);
     TRY(enqueue_stage(c, 1, "ExtractKeypoints", extract_untimed, "keypoint extraction"), "keypoint extraction");
     if (c->prof)
+    {
+      vksift_hip_event_record(c->PS->ev_scan, st); /* this schedule does not time the scan kernel alone: the whole stage stands in */
       vksift_hip_event_record(c->PS->ev_t[3], st);
+    }
     TRY(enqueue_stage(c, 2, "ComputeOrientation", vksift_hip_orientations, "orientation"), "orientation");
     if (c->prof)
       vksift_hip_event_record(c->PS->ev_t[4], st);
