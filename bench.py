@@ -283,6 +283,11 @@ def sharded_match(api, torch, dist, dev, rank, world, rows):
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    # The contract is ONE JSON line on stdout. Libraries loaded below write banners there through C stdio (RCCL prints its version
+    # block on communicator creation): everything written to fd 1 before the result line goes to stderr instead.
+    sys.stdout.flush()
+    fd_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -419,7 +424,11 @@ def main():
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, do_match)
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        os.dup2(fd_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
     if world > 1:
         dist.destroy_process_group()
