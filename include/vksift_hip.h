@@ -28,7 +28,9 @@ extern "C"
 #endif
 
 #define VKSIFT_HIP_MAX_TAPS 20 /* VKSIFT_DETECTOR_MAX_GAUSSIAN_KERNEL_SIZE, sift_detector.h:9 */
-#define VKSIFT_HIP_MATCH_CHUNKS 8 /* B chunks of the large-N matcher (partial top-2 lists merged exactly) */
+#define VKSIFT_HIP_MATCH_CHUNKS 32   /* partial top-2 lists per A row of the single-pair matcher (merged exactly) */
+#define VKSIFT_HIP_MATCH_SMALL_NA 1536u /* single pairs with N_A <= this (and, where the host knows it, N_B <= ..._SMALL_NB) */
+#define VKSIFT_HIP_MATCH_SMALL_NB 4096u /* take the one-launch small kernel and need no partial lists */
 #define VKSIFT_HIP_MAX_ORI 18  /* a 36-bin circular histogram has at most 18 strict local maxima */
 
   typedef void *vksift_hip_stream;
@@ -169,14 +171,15 @@ extern "C"
   int vksift_hip_gather_descriptors(const uint8_t *feats, uint32_t n, uint8_t *desc, vksift_hip_stream s);
   /* Get2NearestNeighbors.comp (sift_matcher.c:246-279) on dense descriptor matrices in HBM, as an exact int8
    * MFMA contraction with a fused top-2 epilogue. desc_a: na rows, desc_b: nb >= 2 rows (callers pad, quirk Q6).
-   * norm_scratch: 2*na + nb u32 of scratch, plus 5*na*VKSIFT_HIP_MATCH_CHUNKS u32 when na > 32768. matches: na records of 20 B {idx_a = a_index_base + row, idx_b1,
+   * norm_scratch: 2*na + nb + 5*na*VKSIFT_HIP_MATCH_CHUNKS u32 of scratch (the last term only when na > VKSIFT_HIP_MATCH_SMALL_NA or
+   * nb > VKSIFT_HIP_MATCH_SMALL_NB). matches: na records of 20 B {idx_a = a_index_base + row, idx_b1,
    * idx_b2, dist1, dist2}; B rows are scanned in index order, so sharding A rows over GPUs (a_index_base =
    * shard offset) gives bit-identical results to a single call. */
   int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
                                 uint8_t *matches, vksift_hip_stream s);
   /* The two halves of vksift_hip_match_2nn_desc, for callers that overlap the pre-pass of A with the arrival of B (the sharded
    * matcher: RCCL all-gather of B): norms[i] = sum over the 128 bytes of (byte - 128)^2; scratch: na u32 (+ 5*na*VKSIFT_HIP_MATCH_CHUNKS
-   * when na > 32768). */
+   * unless na <= VKSIFT_HIP_MATCH_SMALL_NA and nb <= VKSIFT_HIP_MATCH_SMALL_NB). */
   int vksift_hip_shifted_norms(const uint8_t *desc, uint32_t n, uint32_t *norms, vksift_hip_stream s);
   int vksift_hip_match_2nn_prenormed(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b,
                                      const uint32_t *norm_b, uint32_t nb, uint32_t *scratch, uint8_t *matches, vksift_hip_stream s);
@@ -199,7 +202,7 @@ extern "C"
    * match_2nn_async: slot i matches cache entry ids_a[i] against ids_b[i]; it first writes {N_A, N_B} of every slot to
    * n_dev[i*n_slot_stride + 0..1] (read by the kernels, the filter and the host). Strides in bytes for desc/matches and in
    * u32 elements for norms/redo/n. partial_scratch (may be NULL): 5*max_na*VKSIFT_HIP_MATCH_CHUNKS u32 used by the
-   * B-chunked large-N kernel when nslots == 1. redo: max_na u32 per slot of row flags for the exact scalar replay. */
+   * stream-decomposed single-pair kernel (nslots == 1; without it a single pair takes the batch kernels). redo: max_na u32 per slot of row flags for the exact scalar replay. */
   int vksift_hip_gather_sections(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, uint32_t nslots, uint32_t nsec,
                                  const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *fixed_counts, const uint32_t *found_base,
                                  uint32_t found_buf_stride, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint64_t desc_stride,

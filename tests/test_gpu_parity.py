@@ -146,10 +146,13 @@ def test_match_float_collisions(vk, oracle):
     _assert_matches_equal(_match_via_api(vk, a, b), oracle.match_2nn(a, b))
 
 
-@pytest.mark.parametrize("na,nb,via_ptr", [(9000, 700, False), (20000, 2100, True), (33000, 5000, True), (40000, 300, False)])
+@pytest.mark.parametrize("na,nb,via_ptr", [(1200, 900, False), (1200, 900, True), (1500, 5000, True), (300, 33000, True), (9000, 700, False), (20000, 2100, True),
+                                          (33000, 5000, True), (40000, 300, False), (70001, 130, True), (2600, 2500, False)])
 def test_match_ties_in_every_kernel_regime(vk, oracle, na, nb, via_ptr):
-    """quirk Q7 (d(b0) == d(b1): index 1 first), duplicate B rows (earlier index first) and exact zero distances in the 16-rows-per-wave
-    kernel, the 64-rows-per-wave kernel with B chunks, through the instance and through the device-pointer entry"""
+    """quirk Q7 (d(b0) == d(b1): index 1 first), duplicate B rows (earlier index first) and exact zero distances in the one-launch
+    small kernel and in the stream-decomposed kernel — few row blocks with the piece count at its cap (300 x 33000), runs that
+    end one row block and start the next, more workgroups than tiles (70001 x 130) — through the instance (device-side counts)
+    and through the device-pointer entry"""
     rng = np.random.default_rng(na + nb)
     a = vk.gen_synthetic_descriptors(na, na)
     b = vk.gen_synthetic_descriptors(nb, nb)
@@ -182,14 +185,14 @@ def test_match_fewer_than_two_b_rows(vk, oracle):
 
 
 def test_match_largest_regime(vk, oracle):
-    """na > 32768 selects the 64-rows-per-wave kernel"""
+    """many row blocks against a two-tile B: runs of one or two tiles"""
     a = vk.gen_synthetic_descriptors(41, 33001)
     b = vk.gen_synthetic_descriptors(42, 130)
     _assert_matches_equal(_match_via_api(vk, a, b), oracle.match_2nn(a, b))
 
 
 def test_match_device_pointer_api_chunked(vk, oracle):
-    """vksift_hip_match_2nn_desc on torch tensors: the B-chunked large-N path (na > 32768) with ties across chunk borders"""
+    """vksift_hip_match_2nn_desc on torch tensors: the stream-decomposed path with ties across piece borders"""
     import torch
     from vulkansift_amd import multigpu
     a = vk.gen_synthetic_descriptors(51, 33000)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extra randomised 2-NN / filtered-match parity against the oracle with fresh seeds: random sizes over all kernel regimes
-(split / 16 rows per wave / 32 rows per wave + chunks), low-entropy descriptors (ties), duplicates, batched pairs.
+(one-launch small kernel, stream-decomposed single pair, batched 16 / 32 rows per wave), low-entropy descriptors (ties), duplicates, batched pairs.
 usage (on the GPU box): python tools/fuzz_match.py <seed> <cases> [max_n]"""
 import os, sys
 import numpy as np

@@ -179,6 +179,33 @@ __global__ void k_slot_counts(const uint32_t *__restrict__ cache_n, uint32_t cac
   n_out[(size_t)slot * n_slot_stride + 1] = cache_n[(size_t)ids.b[slot] * cache_n_stride];
 }
 
+// Stream decomposition of the large single-pair matcher (k_match_mfma with `stream` set, k_match_merge): the list of
+// (row block, B tile) pairs, row block major, is cut into runs of `span` tiles, one per workgroup of a grid of G. A row block
+// is then covered by at most floor(tiles / span) + 2 runs, which must not exceed VKSIFT_HIP_MATCH_CHUNKS partial lists.
+__device__ __forceinline__ uint32_t stream_span(uint32_t nblocks, uint32_t tiles, uint32_t G)
+{
+  const uint32_t even = (nblocks * tiles + G - 1u) / G, floor_ = (tiles + (uint32_t)VKSIFT_HIP_MATCH_CHUNKS - 3u) / ((uint32_t)VKSIFT_HIP_MATCH_CHUNKS - 2u);
+  return max(max(even, floor_), 1u);
+}
+
+// compute units of the current device (workgroup slots of the stream decomposition)
+uint32_t device_cus()
+{
+  static int cached_dev = -1;
+  static uint32_t cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess)
+    return 256u;
+  if (dev != cached_dev)
+  {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cached = (uint32_t)n, cached_dev = dev;
+  }
+  return cached;
+}
+
 struct Top2
 {
   uint32_t q1, k1, q2, k2; // squared distances and index keys of best / second
@@ -246,9 +273,15 @@ __global__ void __launch_bounds__(64 * NW) k_match_mfma(const uint32_t *__restri
                                                     uint32_t a_index_base, const uint32_t *__restrict__ desc_b, const uint32_t *__restrict__ norm_b,
                                                     uint32_t nb, uint32_t *__restrict__ matches, uint32_t *__restrict__ redo,
                                                     const uint32_t *__restrict__ n_dev, uint32_t na_lo, uint32_t na_hi, SlotStrides ss,
-                                                    uint32_t *__restrict__ partial, SlotIds ids)
+                                                    uint32_t *__restrict__ partial, SlotIds ids, uint32_t stream)
 {
-  const uint32_t nchunks = gridDim.z, chunk = blockIdx.z;
+  // stream != 0 (single pair, grid = (G, 1, 1)): the (row block, B tile) pairs, row block major, are cut into G equal runs of
+  // `span` tiles (stream_span); a workgroup works through its run, which may end one row block and start the next. Every
+  // (row block, workgroup) piece writes a partial list (slot = workgroup - first workgroup of the block), k_match_merge
+  // combines them. All resident workgroups get the same number of tiles whatever N_A is; a grid of row blocks x chunks
+  // leaves up to a third of the CUs' workgroup slots idle (measured: 588 workgroups on 768 slots at 50k x 50k).
+  const uint32_t nchunks = stream ? (uint32_t)VKSIFT_HIP_MATCH_CHUNKS : gridDim.z;
+  uint32_t chunk = blockIdx.z;
   // ss.slot_fast: grid = (slots, row blocks) — see the batched launch
   const uint32_t slot = ss.slot_fast ? blockIdx.x : blockIdx.y;
   const uint32_t rb0 = ss.slot_fast ? blockIdx.y : blockIdx.x, rb_step = ss.slot_fast ? gridDim.y : gridDim.x;
@@ -283,13 +316,29 @@ __global__ void __launch_bounds__(64 * NW) k_match_mfma(const uint32_t *__restri
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, grp = lane >> 4;
-  const uint32_t tiles = (nb + BTT - 1) / BTT, tiles_per_chunk = (tiles + nchunks - 1) / nchunks;
-  const uint32_t tb = chunk * tiles_per_chunk * BTT;
-  const uint32_t te = min(nb, tb + tiles_per_chunk * BTT);
+  const uint32_t tiles = (nb + BTT - 1) / BTT, tiles_per_chunk = (tiles + gridDim.z - 1) / gridDim.z;
+  uint32_t tb = chunk * tiles_per_chunk * BTT;
+  uint32_t te = min(nb, tb + tiles_per_chunk * BTT);
+  const uint32_t nblocks = (na + 16u * NW * AT - 1u) / (16u * NW * AT);
+  const uint32_t span = stream ? stream_span(nblocks, tiles, gridDim.x) : 0u;
+  uint32_t pos = blockIdx.x * span;
+  const uint32_t pos_end = min(pos + span, nblocks * tiles);
 
   // the grid may be smaller than the number of 64*AT-row blocks (bounded launch): loop over row blocks
-  for (uint32_t rb = rb0; rb * (16u * NW * AT) < na; rb += rb_step)
+  for (uint32_t rb = rb0;; rb += rb_step)
   {
+    if (span)
+    {
+      if (pos >= pos_end)
+        break;
+      rb = pos / tiles;
+      const uint32_t t_first = pos - rb * tiles, t_cnt = min(tiles - t_first, pos_end - pos);
+      tb = t_first * BTT, te = min(nb, (t_first + t_cnt) * BTT);
+      chunk = blockIdx.x - (rb * tiles) / span;
+      pos += t_cnt;
+    }
+    else if (rb * (16u * NW * AT) >= na)
+      break;
     const uint32_t row_base = (rb * NW + wave) * (16 * AT);
 
     // query fragments (XOR 0x80 -> int8) and the norm of the row this lane accumulates
@@ -514,11 +563,13 @@ __global__ void __launch_bounds__(64 * NW) k_match_mfma(const uint32_t *__restri
 // Exact combination of the per-chunk partial top-2 lists of k_match_mfma (gridDim.z > 1): one thread per A row.
 __global__ void __launch_bounds__(256) k_match_merge(const uint32_t *__restrict__ partial, uint32_t na, uint32_t nchunks, uint32_t a_index_base,
                                                      uint32_t *__restrict__ matches, uint32_t *__restrict__ redo, const uint32_t *__restrict__ n_dev,
-                                                     uint32_t na_lo, uint32_t na_hi)
+                                                     uint32_t na_lo, uint32_t na_hi, uint32_t stream_grid, uint32_t nb, uint32_t tile_rows,
+                                                     uint32_t block_rows)
 {
   if (n_dev)
   {
     na = n_dev[0];
+    nb = n_dev[1] < 2u ? 2u : n_dev[1];
     if (na <= na_lo || na > na_hi)
       return;
   }
@@ -529,6 +580,13 @@ __global__ void __launch_bounds__(256) k_match_merge(const uint32_t *__restrict_
   const uint32_t *fl = partial + (size_t)na * nchunks * 4 + (size_t)r * nchunks;
   Top2 s{pp[0], pp[1], pp[2], pp[3]};
   uint32_t flags = fl[0];
+  if (stream_grid) // stream decomposition (k_match_mfma): the row block's pieces are the workgroups whose runs intersect its tiles
+  {
+    const uint32_t tiles = (nb + tile_rows - 1u) / tile_rows;
+    const uint32_t span = stream_span((na + block_rows - 1u) / block_rows, tiles, stream_grid);
+    const uint32_t rb = r / block_rows;
+    nchunks = ((rb + 1u) * tiles - 1u) / span - (rb * tiles) / span + 1u; // the stride stays VKSIFT_HIP_MATCH_CHUNKS
+  }
   for (uint32_t c = 1; c < nchunks; c++)
   {
     Top2 o{pp[c * 4 + 0], pp[c * 4 + 1], pp[c * 4 + 2], pp[c * 4 + 3]};
@@ -901,35 +959,22 @@ extern "C"
     const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
     const SlotStrides z{0, 0, 0, 0, 0, 0, 0, 0, 0};
     const SlotIds noids{};
-    /* Small problems: 16 A rows per workgroup with B split over its waves; medium: 16 rows per wave; large: 32 rows per
-     * wave (B-tile reuse) with B split into VKSIFT_HIP_MATCH_CHUNKS chunks across grid.z + exact merge. */
-    if (na <= 8192u)
+    /* A small problem (a few hundred thousand distances): 16 A rows per workgroup with B split over its waves, one launch.
+     * Everything else: the stream decomposition (see k_match_mfma) — 8 waves x 32 rows per workgroup, 128-row B tiles, two
+     * workgroups per CU, every workgroup the same number of tiles. Measured on MI355X against the three size regimes it
+     * replaced (rows x rows, whole call): 2k 0.033 -> 0.028 ms, 8k 0.099 -> 0.062, 16k 0.23 -> 0.126, 32k 0.50 -> 0.28,
+     * 50k 0.60 -> 0.51 (31.7 % of the dense int8 peak), 100k 1.78 -> 1.48 (44 %). */
+    if (na <= VKSIFT_HIP_MATCH_SMALL_NA && nb <= VKSIFT_HIP_MATCH_SMALL_NB)
       hipLaunchKernelGGL(k_match_mfma_split, dim3((na + 15u) / 16u), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
                          (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, noids);
-    else if (na <= 32768u)
-      hipLaunchKernelGGL(k_match_mfma<1>, dim3((na + 63u) / 64u), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
-                         (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, (uint32_t *)nullptr, noids);
     else
     {
-      /* 64 A rows per wave, 256 per workgroup: every staged B tile serves 4x the MFMAs of the 16-row form (the B traffic out of
-       * L2 / infinity cache is N_A / 256 x the size of B: 1.25 TB at 50k x 50k). B is split into just enough chunks to give
-       * every CU two workgroups: every (row tile, chunk) pair starts with loose bounds, so chunks are not free. */
       uint32_t *partial = redo + na;
-      const uint32_t blocks = (na + 255u) / 256u;
-      uint32_t nchunks = (512u + blocks - 1u) / blocks;
-      nchunks = nchunks < 1u ? 1u : (nchunks > VKSIFT_HIP_MATCH_CHUNKS ? VKSIFT_HIP_MATCH_CHUNKS : nchunks);
-      /* measured on MI355X: up to ~80k rows 4 waves x 64 rows with 64-row B tiles (0.59 ms at 50k x 50k, 27 % of the int8 peak),
-       * above that 8 waves x 32 rows with 128-row tiles (1.78 ms at 100k x 100k, 36 %): the larger grid fills the second
-       * block slot of every CU and the longer tiles cover the L2 / infinity-cache latency of the B stream */
-      if (na >= 80000u)
-        hipLaunchKernelGGL((k_match_mfma<2, 8, 128>), dim3(blocks, 1, nchunks), dim3(512), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
-                           (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids);
-      else
-        hipLaunchKernelGGL((k_match_mfma<4, 4, 64>), dim3(blocks, 1, nchunks), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
-                           (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids);
-      if (nchunks > 1)
-        hipLaunchKernelGGL(k_match_merge, dim3((na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial, na, nchunks, a_index_base, (uint32_t *)matches,
-                           redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu);
+      const uint32_t G = 2u * device_cus();
+      hipLaunchKernelGGL((k_match_mfma<2, 8, 128>), dim3(G), dim3(512), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
+                         (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids, 1u);
+      hipLaunchKernelGGL(k_match_merge, dim3((na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial, na, (uint32_t)VKSIFT_HIP_MATCH_CHUNKS, a_index_base,
+                         (uint32_t *)matches, redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, G, nb, 128u, 256u);
     }
     uint32_t rblocks = (na + 63u) / 64u;
     hipLaunchKernelGGL(k_match_redo, dim3(rblocks > 1024u ? 1024u : rblocks), dim3(64), 0, hs, da, na, a_index_base, db, nb, (uint32_t *)matches,
@@ -1006,54 +1051,55 @@ extern "C"
     ss.redo = redo_slot_stride;
     ss.slot_fast = 0;
     ss.use_ids = 1;
-    /* The row count is only known on the device: launch for the capacity (surplus workgroups exit at once), one
-     * kernel per size regime, each of which returns immediately unless N_A falls in its range:
-     *   N_A <= S1          B-split kernel, 16 A rows per workgroup (keeps a few thousand rows busy on every CU)
-     *   S1 < N_A <= 32768   16 A rows per wave
-     *   N_A > 32768         32 A rows per wave (B fragment reuse; 64 rows per wave costs too many registers: 2 waves per
-     *                       SIMD cannot hide the LDS / MFMA latencies, measured 1.27 vs 1.05 ms at 50k x 50k), B-chunked +
-     *                       merged when a single pair is matched */
-    /* The B-split kernel (16 A rows per workgroup) exists to keep every CU busy when ONE pair of a few thousand rows is
-     * matched; a batch of pairs has enough workgroups anyway and runs 24 % faster with 64 rows per workgroup (measured:
-     * 64 pairs of 1.9k x 1.9k, 0.285 -> 0.217 ms). */
-    const uint32_t S1 = nslots >= 8 ? 1024u : 8192u, S2 = 32768u;
     hipStream_t hs = (hipStream_t)s;
     const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
-    /* regimes 2/3 loop over their row blocks, so their grids stay small even when only the capacity is known */
-    auto bounded = [](uint32_t blocks, uint32_t slots) { uint32_t lim = slots >= 8 ? 64u : 1024u; return blocks < lim ? blocks : lim; };
-    const uint32_t n1 = max_na < S1 ? max_na : S1;
-    hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev,
-                       0u, S1, ss, ids);
-    if (max_na > S1)
+    if (nslots == 1 && partial_scratch)
     {
-      const uint32_t n2 = max_na < S2 ? max_na : S2;
-      /* a batch: slot index fastest, so that the busy workgroups (row block < N_A / 64, unknown here) are contiguous in
-       * dispatch order instead of a short run at the start of every slot's row (see features.hip: img_fast) */
-      static int slot_fast = -1;
-      if (slot_fast < 0)
+      /* one pair: as vksift_hip_match_2nn_prenormed, but N_A is only known on the device — both kernels are launched, each
+       * returns at once unless N_A falls in its range; the stream decomposition sizes its runs from the device-side counts */
+      const uint32_t SS = VKSIFT_HIP_MATCH_SMALL_NA;
+      const uint32_t n1 = max_na < SS ? max_na : SS;
+      hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u, 1), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev, 0u,
+                         SS, ss, ids);
+      if (max_na > SS)
       {
-        slot_fast = 1;
+        const uint32_t G = 2u * device_cus();
+        hipLaunchKernelGGL((k_match_mfma<2, 8, 128>), dim3(G), dim3(512), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev, SS,
+                           0xFFFFFFFFu, ss, partial_scratch, ids, 1u);
+        hipLaunchKernelGGL(k_match_merge, dim3((max_na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial_scratch, 0u,
+                           (uint32_t)VKSIFT_HIP_MATCH_CHUNKS, 0u, (uint32_t *)matches, redo, n_dev, SS, 0xFFFFFFFFu, G, 0u, 128u, 256u);
       }
-      SlotStrides s2 = ss;
-      s2.slot_fast = (slot_fast && nslots > 1) ? 1u : 0u;
-      const uint32_t gb = bounded((n2 + 63u) / 64u, nslots);
-      hipLaunchKernelGGL(k_match_mfma<1>, s2.slot_fast ? dim3(nslots, gb) : dim3(gb, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
-                         (uint32_t *)matches, redo, n_dev, S1, S2, s2, (uint32_t *)nullptr, ids);
     }
-    if (max_na > S2)
+    else
     {
-      if (nslots == 1 && partial_scratch)
+      /* A batch of pairs. The row counts are only known on the device: launch for the capacity (surplus workgroups exit at
+       * once), one kernel per size regime, each of which returns immediately unless N_A falls in its range:
+       *   N_A <= S1          B-split kernel, 16 A rows per workgroup
+       *   S1 < N_A <= 32768   16 A rows per wave
+       *   N_A > 32768         32 A rows per wave (B fragment reuse)
+       * The B-split kernel exists to keep every CU busy when few pairs of a few thousand rows are matched; a batch of 8 and
+       * more pairs has enough workgroups anyway and runs 24 % faster with 64 rows per workgroup (measured: 64 pairs of
+       * 1.9k x 1.9k, 0.285 -> 0.217 ms). */
+      const uint32_t S1 = nslots >= 8 ? 1024u : 8192u, S2 = 32768u;
+      /* regimes 2/3 loop over their row blocks, so their grids stay small even when only the capacity is known */
+      auto bounded = [](uint32_t blocks, uint32_t slots) { uint32_t lim = slots >= 8 ? 64u : 1024u; return blocks < lim ? blocks : lim; };
+      const uint32_t n1 = max_na < S1 ? max_na : S1;
+      hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev,
+                         0u, S1, ss, ids);
+      if (max_na > S1)
       {
-        /* N_A is only known on the device: four chunks whatever it is (see vksift_hip_match_2nn_prenormed) */
-        const uint32_t nchunks = 4u;
-        hipLaunchKernelGGL((k_match_mfma<4, 4, 64>), dim3(bounded((max_na + 255u) / 256u, 1), 1, nchunks), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
-                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, partial_scratch, ids);
-        hipLaunchKernelGGL(k_match_merge, dim3((max_na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial_scratch, 0u, nchunks, 0u,
-                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu);
+        const uint32_t n2 = max_na < S2 ? max_na : S2;
+        /* slot index fastest, so that the busy workgroups (row block < N_A / 64, unknown here) are contiguous in dispatch
+         * order instead of a short run at the start of every slot's row (see features.hip: img_fast) */
+        SlotStrides s2 = ss;
+        s2.slot_fast = nslots > 1 ? 1u : 0u;
+        const uint32_t gb = bounded((n2 + 63u) / 64u, nslots);
+        hipLaunchKernelGGL(k_match_mfma<1>, s2.slot_fast ? dim3(nslots, gb) : dim3(gb, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+                           (uint32_t *)matches, redo, n_dev, S1, S2, s2, (uint32_t *)nullptr, ids, 0u);
       }
-      else
+      if (max_na > S2)
         hipLaunchKernelGGL(k_match_mfma<2>, dim3(bounded((max_na + 127u) / 128u, nslots), nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
-                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, (uint32_t *)nullptr, ids);
+                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, (uint32_t *)nullptr, ids, 0u);
     }
     uint32_t rblocks = (max_na + 63u) / 64u;
     if (rblocks > 64u)

@@ -174,7 +174,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   ALLOC_D(inst->d_matches, inst->match_slot_stride * batch_cap);
   ALLOC_D(inst->d_redo, sizeof(uint32_t) * inst->redo_slot_stride * batch_cap);
   ALLOC_D(inst->d_match_n, sizeof(uint32_t) * 4 * batch_cap);
-  if (config->max_nb_sift_per_buffer > 32768u)
+  if (config->max_nb_sift_per_buffer > VKSIFT_HIP_MATCH_SMALL_NA)
     ALLOC_D(inst->d_match_partial, sizeof(uint32_t) * (size_t)config->max_nb_sift_per_buffer * 5u * VKSIFT_HIP_MATCH_CHUNKS);
   ALLOC_H(inst->h_match_n, sizeof(uint32_t) * 4 * batch_cap);
   inst->h_matches = NULL;

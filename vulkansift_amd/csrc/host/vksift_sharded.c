@@ -153,8 +153,8 @@ vksift_Result vksift_ext_matchSharded(vksift_ext_ShardGroup g, const uint8_t *d_
     return VKSIFT_INVALID_INPUT_ERROR;
   vksift_hip_set_device(g->device);
   const size_t b_bytes = (size_t)nb_shard * g->world * 128u;
-  /* norms of A, norms of B (padded rows included), redo flags, partial lists of the B-chunked kernel */
-  const size_t scratch = (size_t)2 * na + (size_t)nb_shard * g->world + 64 + (na > 32768u ? (size_t)na * 5u * VKSIFT_HIP_MATCH_CHUNKS : 0);
+  /* norms of A, norms of B (padded rows included), redo flags, partial lists of the stream-decomposed kernel */
+  const size_t scratch = (size_t)2 * na + (size_t)nb_shard * g->world + 64 + (size_t)na * 5u * VKSIFT_HIP_MATCH_CHUNKS;
   if (b_bytes > g->b_cap || scratch > g->scratch_cap)
   {
     vksift_hip_stream_sync(g->comm_stream);
