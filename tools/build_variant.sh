@@ -1,6 +1,7 @@
 #!/bin/bash
 # Build an A/B variant of libvulkansift.so: one .hip file recompiled with extra -D flags, everything else taken from the
 # regular object directory. Usage: tools/build_variant.sh <name> <hip file basename, e.g. features> [-DFLAG ...]
+# SRC=<path> compiles another source file in its place (e.g. a previous revision: git show HEAD:... > /tmp/x.hip).
 # Result: vulkansift_amd/lib/variants/lib_<name>.so (git-ignored; select it with VKSIFT_LIB=<path>).
 set -e
 cd "$(dirname "$0")/.."
@@ -16,7 +17,7 @@ mkdir -p vulkansift_amd/lib/variants
 extra=""
 [ "$file" = match ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-gpu-rdc $extra \
-  -Iinclude -Ivulkansift_amd/csrc/host -Ivulkansift_amd/csrc "$@" -c vulkansift_amd/csrc/hip/$file.hip -o /tmp/variant_${name}_$file.o
+  -Iinclude -Ivulkansift_amd/csrc/host -Ivulkansift_amd/csrc "$@" -c ${SRC:-vulkansift_amd/csrc/hip/$file.hip} -o /tmp/variant_${name}_$file.o
 objs=$(ls $OBJ/*.o | grep -v "/$file.hip.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o vulkansift_amd/lib/variants/lib_$name.so $objs /tmp/variant_${name}_$file.o \
   -L/opt/rocm/lib -lroctx64 -lm -ldl -Wl,-rpath,/opt/rocm/lib

@@ -362,6 +362,10 @@ __device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample 
   // per-lane dummy slot behind the histogram instead of being branched around: no exec-mask juggling in the hot loop.
   // (Packed v_pk_mul_f32 for the weight products was measured 9 % slower despite 6 % fewer instructions.)
   const unsigned dummy = (unsigned)DESC_HIST_WORDS * 4u + (threadIdx.x & 63u) * 8u;
+  // ((w * wb) * mag) * fp == (w * wb) * (mag * fp) bit for bit: fp is a power of two (2^0 .. 2^31), so mag * fp is exact and
+  // scaling by it commutes with the rounding of the product — except where (w * wb) * mag is subnormal, and there both
+  // forms are far below 1 and convert to 0. One multiply per sample instead of one per bin value (8).
+  const float magfp = r.mag * c.fp;
   const unsigned b0 = (unsigned)smod8(hb);
   const unsigned pair = ((b0 & 1u) ? 32u : 0u) + (b0 >> 1) * 8u; // byte offset of the (hb, hb+1) pair inside a cell
   char *base = (char *)s_work;
@@ -373,8 +377,8 @@ __device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample 
       const bool in_grid = live && (unsigned)(i + hx) < 4u && (unsigned)(j + hy) < 4u;
       const unsigned cell = (unsigned)((j + hy) * 256 + (i + hx) * 64);
       const float w = fabsf(1.f - (float)i - rhx) * fabsf(1.f - (float)j - rhy);
-      const uint32_t v0 = (uint32_t)((w * fabsf(1.f - 0.f - rb) * r.mag) * c.fp);
-      const uint32_t v1 = (uint32_t)((w * fabsf(1.f - 1.f - rb) * r.mag) * c.fp);
+      const uint32_t v0 = (uint32_t)((w * fabsf(1.f - 0.f - rb)) * magfp);
+      const uint32_t v1 = (uint32_t)((w * fabsf(1.f - 1.f - rb)) * magfp);
       atomicAdd((unsigned long long *)(base + (in_grid ? (cell | pair) : dummy)), ((unsigned long long)v1 << 32) | v0);
     }
 }
