@@ -45,6 +45,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 import zlib
 
@@ -72,6 +73,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip value_host_input / single_image_ms / roofline_c3 / sharded match")
     ap.add_argument("--host-input", action="store_true", help="time the PCIe-inclusive protocol as the main loop (not the headline value)")
     ap.add_argument("--fp16", action="store_true", help="VKSIFT_PYRAMID_PRECISION_FLOAT16: binary16 scale-space storage (not the headline configuration)")
+    ap.add_argument("--extras-timeout", type=float, default=420.0, help="seconds the legs after the timed region may take before the headline line is printed without them")
     ap.add_argument("--match-rows", type=int, default=50000, help="rows of A and of B in the sharded 2-NN leg (BASELINE config 4)")
     return ap.parse_args()
 
@@ -358,38 +360,9 @@ def main():
     match_ms = inst.getMatchTime() if do_match else None
     inst.setProfiling(False)
 
-    extras = {}
-    if not args.no_extras and world == 1:
-        # (before the sharded-match leg: once RCCL has created its streams, HIP maps this library's streams onto the hardware queues
-        # differently and the per-stage intervals of an overlapped detection get attributed differently — same step time)
-        extras["value_host_input"] = reference_protocol(api, inst, frames, W, H, B, do_match, 3)
-    inst.close()
-    if not args.no_extras and world == 1:
-        # in a fresh process: how HIP maps an instance's dozen streams onto the four hardware queues depends on the streams the
-        # process created before (the 640x480 instance above), and with it the attribution of an overlapped detection's time to
-        # its stages — same step time, stage intervals up to 2x apart. A fresh process is the reproducible case.
-        try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "c3_leg.py")], capture_output=True, text=True, timeout=600)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith("C3LEG ")][-1]
-            extras["roofline_c3"] = json.loads(line[6:])
-        except Exception as e:  # noqa: BLE001
-            extras["roofline_c3"] = {"error": repr(e)[:300]}
-        extras["single_image_ms"] = single_image_latency(api, dev.index, frames[0])
-    if not args.no_extras:
-        # every rank takes part (the all-gather is a collective); a failure of this leg must not cost the headline line
-        try:
-            ms, crc = sharded_match(api, torch, dist, dev, rank, world, args.match_rows)
-            if world > 1:
-                t = torch.tensor([ms], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                ms = float(t.item())
-            ops = 2.0 * args.match_rows * args.match_rows * 128
-            extras["sharded_match"] = {"workload": f"BASELINE config 4: 2-NN {args.match_rows} x {args.match_rows} x 128-D, query rows sharded x{world}, one RCCL all-gather of B",
-                                       "ms": ms, "tops_int8": ops / (ms * 1e-3) / 1e12, "frac_of_int8_peak": ops / (ms * 1e-3) / 1e12 / INT8_PEAK_TOPS / world,
-                                       "records_crc32": crc}
-        except Exception as e:  # noqa: BLE001
-            extras["sharded_match"] = {"error": repr(e)[:300]}
-
+    # The headline object first: the extra legs below run under a watchdog that prints it if one of them stalls (a collective
+    # that one rank never enters would otherwise cost the whole line).
+    out = None
     if rank == 0:
         frames_total = B * NSUB * world * args.steps
         pmc = pmc_traffic(W, H, B)
@@ -421,14 +394,66 @@ def main():
                                   ("upload_ms", "pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")},
             "last_match_ms": match_ms,
         }
-        out.update(extras)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, do_match)
+
+    emitted = threading.Lock()
+
+    def emit(obj):
+        if rank != 0 or not emitted.acquire(blocking=False):
+            return
         sys.stdout.flush()
         C.CDLL(None).fflush(None)
         os.dup2(fd_stdout, 1)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(obj), flush=True)
         os.dup2(2, 1)
+
+    def bail():
+        if out is not None:
+            emit(dict(out, extras_error=f"an extra leg did not finish within {args.extras_timeout} s; headline only"))
+        os._exit(0)
+
+    watchdog = threading.Timer(args.extras_timeout, bail)
+    watchdog.daemon = True
+    watchdog.start()
+
+    extras = {}
+    if not args.no_extras and world == 1:
+        # (before the sharded-match leg: once RCCL has created its streams, HIP maps this library's streams onto the hardware queues
+        # differently and the per-stage intervals of an overlapped detection get attributed differently — same step time)
+        extras["value_host_input"] = reference_protocol(api, inst, frames, W, H, B, do_match, 3)
+    inst.close()
+    if not args.no_extras and world == 1:
+        # in a fresh process: how HIP maps an instance's dozen streams onto the four hardware queues depends on the streams the
+        # process created before (the 640x480 instance above), and with it the attribution of an overlapped detection's time to
+        # its stages — same step time, stage intervals up to 2x apart. A fresh process is the reproducible case.
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "c3_leg.py")], capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("C3LEG ")][-1]
+            extras["roofline_c3"] = json.loads(line[6:])
+        except Exception as e:  # noqa: BLE001
+            extras["roofline_c3"] = {"error": repr(e)[:300]}
+        extras["single_image_ms"] = single_image_latency(api, dev.index, frames[0])
+    if not args.no_extras:
+        # every rank takes part (the all-gather is a collective); a failure of this leg must not cost the headline line
+        try:
+            ms, crc = sharded_match(api, torch, dist, dev, rank, world, args.match_rows)
+            if world > 1:
+                t = torch.tensor([ms], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms = float(t.item())
+            ops = 2.0 * args.match_rows * args.match_rows * 128
+            extras["sharded_match"] = {"workload": f"BASELINE config 4: 2-NN {args.match_rows} x {args.match_rows} x 128-D, query rows sharded x{world}, one RCCL all-gather of B",
+                                       "ms": ms, "tops_int8": ops / (ms * 1e-3) / 1e12, "frac_of_int8_peak": ops / (ms * 1e-3) / 1e12 / INT8_PEAK_TOPS / world,
+                                       "records_crc32": crc}
+        except Exception as e:  # noqa: BLE001
+            extras["sharded_match"] = {"error": repr(e)[:300]}
+
+    if rank == 0:
+        out.update(extras)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames, do_match)
+    watchdog.cancel()
+    if rank == 0:
+        emit(out)
 
     if world > 1:
         dist.destroy_process_group()
