@@ -203,6 +203,13 @@ extern "C"
    * n_dev[i*n_slot_stride + 0..1] (read by the kernels, the filter and the host). Strides in bytes for desc/matches and in
    * u32 elements for norms/redo/n. partial_scratch (may be NULL): 5*max_na*VKSIFT_HIP_MATCH_CHUNKS u32 used by the
    * stream-decomposed single-pair kernel (nslots == 1; without it a single pair takes the batch kernels). redo: max_na u32 per slot of row flags for the exact scalar replay. */
+  /* Download packing for a batch of up to 64 SIFT buffers that share one section table (the buffers of one batched detection):
+   * slot i copies the stored records of buffer buf_ids[i] — sections in order, min(found, capacity) each, the order
+   * vksift_downloadFeatures returns (sift_memory.c:957-1047, 1160-1196) — as dense 164-byte records to out + out_rows[i] * 164.
+   * The host then reads every buffer of the detection with one device-to-host copy instead of one per section and buffer. */
+  int vksift_hip_pack_features(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, const uint32_t *out_rows, uint32_t nslots, uint32_t nsec,
+                               const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *found_base, uint32_t found_buf_stride, uint8_t *out,
+                               uint32_t max_rows, vksift_hip_stream s);
   int vksift_hip_gather_sections(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, uint32_t nslots, uint32_t nsec,
                                  const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *fixed_counts, const uint32_t *found_base,
                                  uint32_t found_buf_stride, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint64_t desc_stride,

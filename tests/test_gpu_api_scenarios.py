@@ -174,6 +174,36 @@ def test_batch_detect_equals_single(vk):
         _eq_feats(b, s)
 
 
+def test_batched_download_equals_per_buffer_download(vk, oracle):
+    """detections of 8 images and more are downloaded through one packed copy of all their buffers (vksift_hip_pack_features): same
+    records as the per-section copies, also with clamped sections, after an upload into one buffer of the range, after a
+    single-image detection into another, and in any download order"""
+    imgs = [vk.gen_synthetic_image(900 + i, 224 + 16 * (i % 2), 160) for i in range(11)]
+    imgs = [im[:, :224].copy() for im in imgs]                     # one resolution per batched call
+    ocfg = oracle.default_config(math_mode=1, max_nb_sift_per_buffer=260)
+    refs = [oracle.detect(ocfg, im)[0] for im in imgs]
+    assert max(len(r) for r in refs) <= 260 and any(sum(oracle.detect(ocfg, im)[1]) > len(r) for im, r in zip(imgs, refs))   # some sections clamp
+    vk.lib().vksift_setLogLevel(vk.VKSIFT_NO_LOG)
+    try:
+        with vk.Instance(vk.default_config(max_nb_sift_per_buffer=260, sift_buffer_count=13), batch_capacity=11) as inst:
+            inst.detectFeaturesBatch(imgs, 2)
+            for i in (10, 0, 5, 3, 9, 1, 2, 4, 6, 7, 8):              # served from the packed copy
+                _eq_feats(inst.downloadFeatures(2 + i), refs[i])
+            up = refs[4][:17].copy()
+            inst.uploadFeatures(up, 2 + 6)                           # buffer 8 now holds uploaded features
+            _eq_feats(inst.downloadFeatures(8), up)
+            _eq_feats(inst.downloadFeatures(7), refs[5])             # its neighbours still the detection's
+            inst.detectFeatures(imgs[0], 4)                          # a single detection into the range
+            _eq_feats(inst.downloadFeatures(4), refs[0])
+            _eq_feats(inst.downloadFeatures(5), refs[3])
+            inst.detectFeaturesBatch(imgs[:8], 0)                    # a new batch over part of the range
+            for i in range(8):
+                _eq_feats(inst.downloadFeatures(i), refs[i])
+            _eq_feats(inst.downloadFeatures(12), refs[10])
+    finally:
+        vk.lib().vksift_setLogLevel(vk.VKSIFT_LOG_INFO)
+
+
 def test_section_overflow_counts_and_clamps(vk, oracle):
     """max_nb_sift_per_buffer too small: counters keep counting, stores are dropped (ExtractKeypoints.comp:208-212)"""
     img = vk.gen_synthetic_image(106, 320, 240)

@@ -102,7 +102,7 @@ def build(force=False, verbose=False):
         if verbose:
             print("[ld ]", os.path.relpath(LIB_PATH, ROOT))
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs +
-             ["-L" + os.path.join(ROCM, "lib"), "-lroctx64", "-lm", "-ldl", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+             ["-L" + os.path.join(ROCM, "lib"), "-lroctx64", "-lm", "-ldl", "-lpthread", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
     return LIB_PATH
 
 

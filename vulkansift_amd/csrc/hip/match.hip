@@ -150,6 +150,52 @@ __global__ void __launch_bounds__(256) k_gather_sections(const uint8_t *__restri
   }
 }
 
+// Download packing (sift_memory.c:957-1047 pack_BufferMemory, here for a whole batch of buffers at once): the stored features of
+// slot blockIdx.y's buffer — its sections in order, min(found, capacity) records each — as dense 164-byte records at
+// out + out_row[slot] * 164. One dword per thread step; the host then fetches all buffers of a detection with ONE copy.
+struct PackOffsets
+{
+  uint32_t row[64];
+};
+__global__ void __launch_bounds__(256) k_pack_features(const uint8_t *__restrict__ feats_base, uint64_t buf_stride, SlotMap map, SectionTable tab,
+                                                       const uint32_t *__restrict__ found_base, uint32_t found_buf_stride, uint32_t *__restrict__ out,
+                                                       PackOffsets offs)
+{
+  const uint32_t slot = blockIdx.y;
+  const uint32_t bufi = map.buf[slot];
+  const uint32_t *feats = (const uint32_t *)(feats_base + (size_t)bufi * buf_stride);
+  const uint32_t *found = found_base + (size_t)bufi * found_buf_stride;
+  uint32_t cnt[16];
+  uint32_t total = 0;
+#pragma unroll
+  for (uint32_t o = 0; o < 16; o++)
+  {
+    uint32_t n = 0;
+    if (o < tab.nsec)
+    {
+      n = found[o];
+      n = n < tab.cap[o] ? n : tab.cap[o];
+    }
+    cnt[o] = n;
+    total += n;
+  }
+  uint32_t *dst = out + (size_t)offs.row[slot] * 41u;
+  const uint32_t ndw = total * 41u; // 164-byte records = 41 dwords
+  for (uint32_t d = blockIdx.x * 256u + threadIdx.x; d < ndw; d += gridDim.x * 256u)
+  {
+    const uint32_t row = d / 41u, w = d - row * 41u;
+    uint32_t base = 0, src_row = 0;
+#pragma unroll
+    for (uint32_t o = 0; o < 16; o++)
+    {
+      if (row >= base && row < base + cnt[o])
+        src_row = tab.off[o] + (row - base);
+      base += cnt[o];
+    }
+    dst[d] = feats[(size_t)src_row * 41u + w];
+  }
+}
+
 // Per-slot strides of a batched matching launch (blockIdx.y = slot); all zero for a single pair.
 struct SlotStrides
 {
@@ -1025,6 +1071,31 @@ extern "C"
       blocks = 1;
     hipLaunchKernelGGL(k_gather_sections, dim3(blocks, nslots), dim3(256), 0, (hipStream_t)s, feats_base, buf_stride, m, t, found_base, found_buf_stride,
                        (uint32_t *)desc, desc_slot_stride / 4, norms, norm_slot_stride, n_out_dev, n_slot_stride, pad_rows_to);
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_pack_features(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, const uint32_t *out_rows, uint32_t nslots, uint32_t nsec,
+                               const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *found_base, uint32_t found_buf_stride, uint8_t *out,
+                               uint32_t max_rows, vksift_hip_stream s)
+  {
+    if (nslots < 1 || nslots > 64 || nsec > 16)
+      return (int)hipErrorInvalidValue;
+    SectionTable t;
+    t.nsec = nsec;
+    for (uint32_t o = 0; o < 16; o++)
+    {
+      t.off[o] = o < nsec ? sec_off[o] : 0u;
+      t.cap[o] = o < nsec ? sec_cap[o] : 0u;
+      t.fixed[o] = 0u;
+    }
+    SlotMap m;
+    PackOffsets po;
+    for (uint32_t i = 0; i < 64; i++)
+      m.buf[i] = i < nslots ? buf_ids[i] : 0u, po.row[i] = i < nslots ? out_rows[i] : 0u;
+    uint32_t blocks = (uint32_t)(((uint64_t)max_rows * 41u + 1023u) / 1024u); /* four dwords per thread */
+    blocks = blocks < 1u ? 1u : (blocks > 128u ? 128u : blocks);
+    hipLaunchKernelGGL(k_pack_features, dim3(blocks, nslots), dim3(256), 0, (hipStream_t)s, feats_base, buf_stride, m, t, found_base, found_buf_stride,
+                       (uint32_t *)out, po);
     return (int)hipGetLastError();
   }
 

@@ -62,6 +62,70 @@ uint32_t vksift_getFeaturesNumber(vksift_Instance instance, const uint32_t gpu_b
   return buffer_counts(instance, gpu_buffer_id, NULL, true);
 }
 
+/* Batched download (see vksift_internal.h: d_dl): true when feats_ptr was filled from the batch cache. Every failure falls
+ * back to the per-buffer copies below. The caller has waited for the detection that filled the buffer. */
+static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr, uint32_t buf)
+{
+  const BufferInfo *b = &inst->bufs[buf];
+  const uint32_t first = inst->detect_first_buf, count = inst->detect_count;
+  if (count < VKSIFT_DL_BATCH_MIN || buf < first || buf >= first + count || b->nb_sections == 0 || b->is_packed)
+    return false;
+  if (!(inst->dl_valid && inst->dl_first == first && inst->dl_count == count))
+  {
+    /* every buffer of the batch shares the section table of `b` (one resolution per batched detection) */
+    if (!inst->dl_row)
+      inst->dl_row = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)inst->cfg.sift_buffer_count + 1u));
+    if (!inst->dl_row)
+      return false;
+    uint32_t rows = 0, max_rows = 0;
+    for (uint32_t i = 0; i < count; i++)
+    {
+      const BufferInfo *bi = &inst->bufs[first + i];
+      if (bi->nb_sections != b->nb_sections || bi->is_packed || memcmp(bi->sec_off, b->sec_off, sizeof(uint32_t) * b->nb_sections) != 0 ||
+          memcmp(bi->sec_cap, b->sec_cap, sizeof(uint32_t) * b->nb_sections) != 0)
+        return false; /* a buffer of the range was refilled by something else since */
+      const uint32_t n = buffer_counts(inst, first + i, NULL, false);
+      inst->dl_row[i] = rows;
+      rows += n;
+      max_rows = n > max_rows ? n : max_rows;
+    }
+    inst->dl_row[count] = rows;
+    const size_t bytes = (size_t)rows * FEAT_BYTES;
+    if (bytes > inst->dl_cap)
+    {
+      vksift_hip_free(inst->d_dl);
+      vksift_hip_host_free(inst->h_dl);
+      const size_t cap = bytes + bytes / 4u + 4096u;
+      inst->d_dl = (uint8_t *)vksift_hip_malloc(cap);
+      inst->h_dl = (uint8_t *)vksift_hip_host_malloc(cap);
+      inst->dl_cap = (inst->d_dl && inst->h_dl) ? cap : 0;
+      if (!inst->dl_cap)
+      {
+        vksift_hip_free(inst->d_dl);
+        vksift_hip_host_free(inst->h_dl);
+        inst->d_dl = inst->h_dl = NULL;
+        return false;
+      }
+    }
+    uint32_t ids[64];
+    for (uint32_t i0 = 0; i0 < count; i0 += 64)
+    {
+      const uint32_t n = count - i0 < 64u ? count - i0 : 64u;
+      for (uint32_t k = 0; k < n; k++)
+        ids[k] = first + i0 + k;
+      if (vksift_hip_pack_features(inst->d_feats, inst->buf_stride, ids, inst->dl_row + i0, n, b->nb_sections, b->sec_off, b->sec_cap, inst->d_found,
+                                   VKSIFT_MAX_OCTAVES, inst->d_dl, max_rows, inst->stream) != 0)
+        return false;
+    }
+    if (vksift_hip_memcpy_d2h(inst->h_dl, inst->d_dl, bytes, inst->stream) != 0 || vksift_hip_stream_sync(inst->stream) != 0)
+      return false;
+    inst->dl_first = first, inst->dl_count = count, inst->dl_valid = true;
+  }
+  const uint32_t i = buf - first;
+  memcpy(feats_ptr, inst->h_dl + (size_t)inst->dl_row[i] * FEAT_BYTES, (size_t)(inst->dl_row[i + 1] - inst->dl_row[i]) * FEAT_BYTES);
+  return true;
+}
+
 void vksift_downloadFeatures(vksift_Instance instance, vksift_Feature *feats_ptr, uint32_t gpu_buffer_id)
 {
   if (!buffer_idx_valid(instance, gpu_buffer_id))
@@ -72,6 +136,8 @@ void vksift_downloadFeatures(vksift_Instance instance, vksift_Feature *feats_ptr
   }
   vksift_Instance inst = instance;
   wait_for_buffer(inst, gpu_buffer_id);
+  if (download_from_batch(inst, feats_ptr, gpu_buffer_id))
+    return;
   const BufferInfo *b = &inst->bufs[gpu_buffer_id];
   const uint8_t *base = inst->d_feats + (uint64_t)gpu_buffer_id * inst->buf_stride;
   if (b->nb_sections == 0)
@@ -119,6 +185,7 @@ void vksift_uploadFeatures(vksift_Instance instance, const vksift_Feature *feats
   b->is_packed = true;
   b->nb_stored = nb_feats;
   inst->cache_valid[gpu_buffer_id] = false;
+  inst->dl_valid = false;
   b->nb_sections = 0;
   b->counts_valid = true;
   return;

@@ -2,6 +2,52 @@
  * vksift_detect.c — the detection pipeline (vulkansift.c:315-344 + sift_memory.c:891-955 + sift_detector.c:1313-1410,1462-1542)
  */
 #include "vksift_internal.h"
+#include <pthread.h>
+
+/* Host copy of the caller's images into the pinned staging buffer. A batch is tens of megabytes: one thread moves ~10 GB/s,
+ * which made this copy as long as the detection itself (39 MB per 128 VGA frames: 4 ms); up to four threads share it. */
+typedef struct
+{
+  uint8_t *dst;
+  const uint8_t *const *images;
+  uint32_t i0, i1;
+  size_t img_bytes;
+} StageJob;
+
+static void *stage_worker(void *p)
+{
+  const StageJob *j = (const StageJob *)p;
+  for (uint32_t i = j->i0; i < j->i1; i++)
+    memcpy(j->dst + (size_t)i * j->img_bytes, j->images[i], j->img_bytes);
+  return NULL;
+}
+
+static void stage_images(uint8_t *dst, const uint8_t *const *images, uint32_t count, size_t img_bytes)
+{
+  enum { MAXT = 4 };
+  uint32_t nt = 1;
+  if ((size_t)count * img_bytes >= ((size_t)8 << 20) && count >= 2 * MAXT)
+    nt = MAXT;
+  StageJob job[MAXT];
+  pthread_t th[MAXT];
+  bool started[MAXT] = {false};
+  for (uint32_t t = 0; t < nt; t++)
+  {
+    job[t].dst = dst, job[t].images = images, job[t].img_bytes = img_bytes;
+    job[t].i0 = (uint32_t)((uint64_t)count * t / nt), job[t].i1 = (uint32_t)((uint64_t)count * (t + 1) / nt);
+  }
+  for (uint32_t t = 1; t < nt; t++)
+    started[t] = pthread_create(&th[t], NULL, stage_worker, &job[t]) == 0;
+  stage_worker(&job[0]);
+  for (uint32_t t = 1; t < nt; t++)
+  {
+    if (started[t])
+      pthread_join(th[t], NULL);
+    else
+      stage_worker(&job[t]); /* no thread: this one does the share */
+  }
+}
+
 
 /* ------------------------------------------------------------------------------------------------ */
 /* detection (vulkansift.c:315-344 + sift_memory.c:891-955 + sift_detector.c:1313-1410,1462-1542)   */
@@ -459,6 +505,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     set_buffer_sections(inst, first_buf + i, inst->lay.n_oct, w, h);
     inst->cache_valid[first_buf + i] = false; /* the matcher's view of the buffer is rebuilt on its next matching */
   }
+  inst->dl_valid = false; /* and so is the batched download */
 
   DetectCtx c;
   c.inst = inst, c.L = &inst->lay, c.PS = PS;
@@ -494,8 +541,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   c.d_src = d_images;
   if (images)
   {
-    for (uint32_t i = 0; i < count; i++)
-      memcpy(inst->h_input + i * c.img_bytes, images[i], c.img_bytes);
+    stage_images(inst->h_input, images, count, c.img_bytes);
     c.d_src = inst->d_input;
   }
   build_jobs(&c);

@@ -309,6 +309,9 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_free(inst->d_redo);
   vksift_hip_free(inst->d_match_n);
   vksift_hip_free(inst->d_match_partial);
+  vksift_hip_free(inst->d_dl);
+  vksift_hip_host_free(inst->h_dl);
+  free(inst->dl_row);
   for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
     vksift_hip_graph_destroy(inst->graphs[i].exec);
   vksift_hip_free(inst->rev.matches);

@@ -22,6 +22,7 @@
 
 #define LOG_TAG "VulkanSift"
 
+#define VKSIFT_DL_BATCH_MIN 8u
 #define FEAT_BYTES 164u
 #define MATCH_BYTES 20u
 #define PITCH_ALIGN 64u
@@ -162,6 +163,14 @@ struct vksift_Instance_T
   vksift_hip_event ev_detect, ev_match;
   bool detect_pending, match_pending;
   uint32_t detect_first_buf, detect_count;
+  /* batched download: the first vksift_downloadFeatures() after a detection of VKSIFT_DL_BATCH_MIN images and more packs the
+   * features of ALL its buffers on the device and fetches them with one copy into pinned memory; the downloads of the
+   * other buffers are host copies out of it (one copy per section and buffer costs 80 us per buffer otherwise) */
+  uint8_t *d_dl, *h_dl;
+  size_t dl_cap;       /* bytes of each */
+  uint32_t *dl_row;    /* sift_buffer_count + 1 row offsets of the cached buffers */
+  uint32_t dl_first, dl_count;
+  bool dl_valid;
   bool *match_busy; /* per SIFT buffer: read by the matching pipeline in flight (all pairs of a batched call) */
   uint32_t curr_nb_matches;
 
