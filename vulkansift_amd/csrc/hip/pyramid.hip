@@ -762,7 +762,7 @@ extern "C"
     a.w = (int)W, a.h = (int)H;
     for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
       a.taps.k[i] = i < ntaps ? taps[i] : 0.f;
-    uint32_t nseg = (1536u + strips * batch - 1u) / (strips * batch);
+    uint32_t nseg = (10240u + strips * batch - 1u) / (strips * batch); /* as the other launches (stream_grid): 2560 long-lived waves left the tail to a few CUs */
     uint32_t max_seg = (H + 63u) / 64u;
     if (nseg > max_seg)
       nseg = max_seg;
