@@ -432,6 +432,17 @@ def main():
         except Exception as e:  # noqa: BLE001
             extras["roofline_c3"] = {"error": repr(e)[:300]}
         extras["single_image_ms"] = single_image_latency(api, dev.index, frames[0])
+        # the same workload in the FP16 pyramid mode (binary16 scale-space storage, fp32 arithmetic: DESIGN.md 2.3), fresh process;
+        # its roofline is priced with the same per-pixel counts at 2 bytes per pyramid texel
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fp16", "--no-extras", "--no-cpu-baseline", "--steps", "5", "--warmup", "2",
+                                "--width", str(W), "--height", str(H), "--batch", str(B)], capture_output=True, text=True, timeout=300)
+            d16 = json.loads(r.stdout.strip().splitlines()[-1])
+            extras["fp16_mode"] = {"value": d16["value"], "unit": d16["unit"], "dtype": d16["dtype"], "mean_features_per_frame": d16["config"]["mean_features_per_frame"],
+                                   "roofline_frac": d16["roofline"]["frac"], "roofline_achieved": d16["roofline"]["achieved"],
+                                   "pyramid_only_frac": d16["roofline"]["pyramid_only"]["frac"], "stage_ms_per_call": d16["stage_ms_per_call"]}
+        except Exception as e:  # noqa: BLE001
+            extras["fp16_mode"] = {"error": repr(e)[:300]}
     if not args.no_extras:
         # every rank takes part (the all-gather is a collective); a failure of this leg must not cost the headline line
         try:
