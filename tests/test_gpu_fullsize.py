@@ -8,6 +8,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 
 def _reference_top2(a, b, chunk=2000, k=8):
     import torch
@@ -68,3 +72,25 @@ def test_c4_50k_by_50k_equals_gemm_reference(vk, via_instance):
     assert np.array_equal(got["dist_a_b1"].view(np.uint32), d1.view(np.uint32))
     assert np.array_equal(got["dist_a_b2"].view(np.uint32), d2.view(np.uint32))
     assert got["idx_b1"][123] == 77 and got["idx_b2"][123] == 40000 and got["dist_a_b1"][123] == 0
+
+
+@pytest.mark.parametrize("ups", [True, False])
+def test_c3_1080p_scale_space_equals_numpy_restatement(vk, ups):
+    """BASELINE config 3's image size: every Gaussian and DoG plane of every octave of a 1920x1080 frame against the numpy
+    restatement of the dense stages (tests/np_restatement.py: sampler-fetch formulation, closed-form up-sampling, odd-texel
+    down-sampling — written independently of the oracle and of the kernels), tolerance 3e-6 on texels in [0, 1]"""
+    import np_restatement as R
+    img = vk.gen_synthetic_image(4242, 1920, 1080)
+    ref = R.build_pyramid(img, ups=ups)
+    cfg = vk.default_config(use_input_upsampling=ups, input_image_max_size=1920 * 1080)
+    with vk.Instance(cfg) as inst:
+        inst.detectFeatures(img, 0)
+        assert inst.getScaleSpaceNbOctaves() == len(ref) == (7 if ups else 6)
+        worst_g = worst_d = 0.0
+        for o, (g, d) in enumerate(ref):
+            assert inst.getScaleSpaceOctaveResolution(o) == (g.shape[2], g.shape[1])
+            for s in range(g.shape[0]):
+                worst_g = max(worst_g, float(np.abs(inst.downloadScaleSpaceImage(o, s) - g[s]).max()))
+            for s in range(d.shape[0]):
+                worst_d = max(worst_d, float(np.abs(inst.downloadDoGImage(o, s) - d[s]).max()))
+    assert worst_g < 3e-6 and worst_d < 3e-6, (worst_g, worst_d)
