@@ -3,6 +3,7 @@
 (tests/np_restatement.py: pyramid; tests/np_features.py: K4/K5/K6), from the image up.
 
     python tests/golden/make_golden_np.py
+    python tests/golden/make_golden_np.py --bench-frame      (feats_c2_frame0_np.npy: frame 0 of the benchmark workload, 11 s)
 
 Writes img_192x144.npy and feats_192x144_<config>_np.npy. The oracle (libm math) and the HIP path are both
 compared against these files with the tolerances of tests/test_np_golden.py; a misreading of a shader would have
@@ -44,7 +45,20 @@ def detect(img, S=3, ups=True, interpolated=True, vlfeat=False, max_ori=4):
     return np.concatenate(secs), [len(s) for s in secs]
 
 
+def bench_frame():
+    """frame 0 of bench.py's workload (BASELINE config 2: 640x480, default configuration), from the numpy restatements alone. The
+    image comes from the library's deterministic generator (vksift_ext_genSyntheticImage, host code, no GPU)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from vulkansift_amd import api
+    img = api.gen_synthetic_image(0x5EED0000, 640, 480)
+    feats, counts = detect(img)
+    np.save(os.path.join(HERE, "feats_c2_frame0_np.npy"), feats)
+    print("c2 frame 0", counts)
+
+
 def main():
+    if "--bench-frame" in sys.argv:
+        return bench_frame()
     img = image()
     np.save(os.path.join(HERE, "img_192x144.npy"), img)
     for name, kw in CONFIGS.items():

@@ -67,3 +67,49 @@ def test_hip_matches_numpy_fixture(vk, case):
         inst.detectFeatures(img, 0)
         got = inst.downloadFeatures(0)
     _check(got, ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 2 at its own size: frame 0 of the benchmark workload (640x480, default configuration, ~1.9k features)
+# ---------------------------------------------------------------------------------------------------------------------
+def _match_sets(got, ref):
+    """one-to-one pairing of two feature lists by (octave, scale, position within 0.02 px, orientation within 1e-3); returns index arrays"""
+    used = np.zeros(len(ref), bool)
+    gi, ri = [], []
+    for i, f in enumerate(got):
+        c = np.flatnonzero((ref["octave_idx"] == f["octave_idx"]) & (ref["scale_idx"] == f["scale_idx"]) & ~used &
+                           (np.abs(ref["scale_x"] - f["scale_x"]) < 0.02) & (np.abs(ref["scale_y"] - f["scale_y"]) < 0.02) &
+                           (np.abs(ref["orientation"] - f["orientation"]) < 1e-3))
+        if len(c):
+            used[c[0]] = True
+            gi.append(i), ri.append(c[0])
+    return np.array(gi), np.array(ri)
+
+
+def _check_c2(got):
+    """A keypoint whose acceptance hangs on the last bit of an fp32 comparison (refinement offset at 0.5, contrast at the threshold)
+    may exist on one side only — the numpy restatement solves in float64: at most 0.3 % of the features may be unpaired; the paired
+    ones obey the tolerances of _check"""
+    ref = np.load(os.path.join(G, "feats_c2_frame0_np.npy"))
+    assert abs(len(got) - len(ref)) <= 3, (len(got), len(ref))
+    gi, ri = _match_sets(got, ref)
+    assert len(gi) >= 0.997 * max(len(got), len(ref)), (len(gi), len(got), len(ref))
+    _check(got[gi], ref[ri])
+
+
+def _bench_frame0():
+    from vulkansift_amd import api
+    return api.gen_synthetic_image(0x5EED0000, 640, 480)
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_oracle_matches_numpy_fixture_of_the_benchmark_frame(oracle, math_mode):
+    got, _ = oracle.detect(oracle.default_config(math_mode=math_mode), _bench_frame0())
+    _check_c2(got)
+
+
+@pytest.mark.gpu
+def test_hip_matches_numpy_fixture_of_the_benchmark_frame(vk):
+    with vk.Instance(vk.default_config()) as inst:
+        inst.detectFeatures(_bench_frame0(), 0)
+        _check_c2(inst.downloadFeatures(0))
