@@ -86,6 +86,8 @@ static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr,
         return false; /* a buffer of the range was refilled by something else since */
       const uint32_t n = buffer_counts(inst, first + i, NULL, false);
       inst->dl_row[i] = rows;
+      if (n > 0x7FFFFFFFu - rows)
+        return false; /* more records than the 32-bit row offsets of the packed copy address: per-buffer copies */
       rows += n;
       max_rows = n > max_rows ? n : max_rows;
     }
