@@ -96,6 +96,7 @@ def pmc_traffic(w, h, batch):
         except Exception:
             continue
         if (d.get("width"), d.get("height"), d.get("batch")) == (w, h, batch) and d.get("kernel_source_sha") == sha:
+            d["_path"] = os.path.join("profiles", os.path.basename(path))
             return d
     return None
 
@@ -130,7 +131,7 @@ def roofline_from(acc, pmc, label):
         per_call = pmc["hbm_bytes_per_call"]
         out["traffic"] = per_call / (n_launch / calls)                 # HBM bytes per launch, like algorithmic_bytes_per_launch
         out["physical_frac"] = per_call * calls / (pyr_s + scan_s) / 1e9 / HBM_PEAK_GBPS
-        out["traffic_source"] = os.path.basename(pmc["_path"]) if "_path" in pmc else "profiles/"
+        out["traffic_source"] = pmc.get("_path", "profiles/")
     return out
 
 
