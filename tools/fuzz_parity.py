@@ -31,6 +31,7 @@ for case in range(cases):
         kw["descriptor_format"] = vk.VKSIFT_DESCRIPTOR_FORMAT_VLFEAT
     if rng.random() < 0.2:
         kw["max_nb_sift_per_buffer"] = int(rng.integers(50, 2000))
+    fp16 = rng.random() < 0.25                    # the defined FP16 pyramid mode against the oracle's model of it
     nb = int(rng.choice([1, 2, 3, 8, 9, 13]))
     if w * h * nb > 3_000_000:
         nb = 1
@@ -42,6 +43,8 @@ for case in range(cases):
             okw["use_vlfeat_format"], vkw[k] = int(v), int(v)
         else:
             okw[k] = vkw[k] = v
+    if fp16:
+        vkw["pyramid_precision_mode"], okw["pyramid_fp16"] = 1, 1
     vcfg = vk.default_config(sift_buffer_count=nb, **vkw)
     ocfg = oracle.default_config(math_mode=1, **okw)
     imgs = [vk.gen_synthetic_image(seed * 1000 + 17 * case + i, w, h) for i in range(nb)]
@@ -59,6 +62,6 @@ for case in range(cases):
             ok = ok and len(ms[k]) == len(rm) and ms[k].tobytes() == rm.tobytes()
     if not ok:
         bad += 1
-        print("MISMATCH", case, w, h, nb, kw, [len(f) for f in feats], [len(r) for r in refs])
+        print("MISMATCH", case, w, h, nb, kw, "fp16" if fp16 else "fp32", [len(f) for f in feats], [len(r) for r in refs])
 print("cases", cases, "bad", bad, "features", sum(len(r) for r in refs))
 sys.exit(1 if bad else 0)
