@@ -73,7 +73,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip value_host_input / single_image_ms / roofline_c3 / sharded match")
     ap.add_argument("--host-input", action="store_true", help="time the PCIe-inclusive protocol as the main loop (not the headline value)")
     ap.add_argument("--fp16", action="store_true", help="VKSIFT_PYRAMID_PRECISION_FLOAT16: binary16 scale-space storage (not the headline configuration)")
-    ap.add_argument("--extras-timeout", type=float, default=420.0, help="seconds the legs after the timed region may take before the headline line is printed without them")
+    ap.add_argument("--extras-timeout", type=float, default=300.0, help="seconds the legs after the timed region may take before the headline line is printed without them")
     ap.add_argument("--match-rows", type=int, default=50000, help="rows of A and of B in the sharded 2-NN leg (BASELINE config 4)")
     return ap.parse_args()
 
