@@ -109,6 +109,11 @@ extern "C"
   int vksift_hip_seed_upsampled(const uint8_t *src, uint32_t sw, uint32_t sh, uint64_t src_img_stride, vksift_hip_Plane dst, const float *taps, uint32_t ntaps,
                                 uint32_t batch, vksift_hip_stream s);
 
+  /* The same without up-sampling (use_input_upsampling = false: the blit of sift_detector.c:909-916 is a 1:1 copy): dst = blur(src / 255)
+   * straight from the u8 images. Bit-identical to vksift_hip_input_blit + vksift_hip_blur; -1 when the shape is not covered. */
+  int vksift_hip_seed_direct(const uint8_t *src, uint32_t sw, uint32_t sh, uint64_t src_img_stride, vksift_hip_Plane dst, const float *taps, uint32_t ntaps,
+                             uint32_t batch, vksift_hip_stream s);
+
   /* vkCmdBlitImage(NEAREST) of sift_detector.c:1003-1034: dst(x,y) = src(floor((x+.5)*sw/dw), ...). */
   int vksift_hip_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, uint32_t batch, vksift_hip_stream s);
 

@@ -286,9 +286,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base, 
 // 2:1 LINEAR blit of k_input_blit_2x (same expressions, value/255 through a 256-entry table of the same correctly
 // rounded quotients), i.e. vkCmdCopyBufferToImage + vkCmdBlitImage + the seed blur in one pass: the up-sampled plane
 // never exists in HBM. a.src then points at the u8 images (a.src_img_stride in bytes), a.spitch is the source width.
-template <int NT, bool UPS, bool F16>
+// SRC: 0 = a plane of the pyramid; 1 = the u8 input at half the resolution (UPS above); 2 = the u8 input at the plane's own
+// resolution (use_input_upsampling = false: vkCmdCopyBufferToImage + the 1:1 blit + the seed blur in one pass, value / 255
+// through the same table). a.src then points at the u8 images (a.src_img_stride in bytes), a.spitch is the source width.
+template <int NT, int SRC, bool F16>
 __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 {
+  constexpr bool UPS = SRC == 1, U8 = SRC == 2;
   constexpr int NR = 8;
   constexpr unsigned EB = F16 ? 2u : 4u; // bytes per texel
   constexpr int R = NT - 1;
@@ -324,10 +328,10 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   const int y0 = bseg * a.seg;
   const int y1 = min(y0 + a.seg, H);
   const __amdgpu_buffer_rsrc_t rs =
-      UPS ? __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)a.src + (size_t)bimg * a.src_img_stride), 0, a.spitch * (H / 2), 0x00020000)
-          : plane_rsrc<F16>(a.src, (size_t)bimg * a.src_img_stride, a.spitch, H);
+      (UPS || U8) ? __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)a.src + (size_t)bimg * a.src_img_stride), 0, a.spitch * (UPS ? H / 2 : H), 0x00020000)
+                  : plane_rsrc<F16>(a.src, (size_t)bimg * a.src_img_stride, a.spitch, H);
   const __amdgpu_buffer_rsrc_t rd = plane_rsrc<F16>(a.dst, (size_t)bimg * a.dst_img_stride, a.dpitch, H);
-  const bool has_ds = !UPS && a.ds != nullptr;
+  const bool has_ds = SRC == 0 && a.ds != nullptr;
   const __amdgpu_buffer_rsrc_t rds =
       plane_rsrc<F16>(has_ds ? a.ds : a.dst, has_ds ? (size_t)bimg * a.ds_img_stride : 0, has_ds ? a.ds_pitch : a.dpitch, has_ds ? H / 2 : H);
 
@@ -348,12 +352,14 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   // UPS: the 4 output columns X..X+3 (X = real column of the float4 after mirroring) come from the source bytes
   // X/2-1 .. X/2+2, clamped to the row: one (byte-aligned) dword load + a lane-constant byte permutation
   unsigned perm_sel = 0x03020100u;
-  __shared__ float s_lut[UPS ? 256 : 1];
-  if (UPS)
+  __shared__ float s_lut[(UPS || U8) ? 256 : 1];
+  if (U8 && lane < NV4)
+    ld_off /= EB; // one byte per source texel: the (mirrored) column index itself, a multiple of 4
+  if (UPS || U8)
   {
     for (int i = lane; i < 256; i += 64)
       s_lut[i] = (float)i / 255.f;
-    if (lane < NV4)
+    if (UPS && lane < NV4)
     {
       const int X = (int)(ld_off / EB);
       const int sw = a.spitch;
@@ -397,6 +403,12 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
         pf[j].x = __builtin_amdgcn_raw_buffer_load_b32(rs, ld_off, ya * sw, 0);
         pf[j].y = __builtin_amdgcn_raw_buffer_load_b32(rs, ld_off, yb_ * sw, 0);
       }
+    }
+    else if (U8)
+    {
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+        pf[j].x = __builtin_amdgcn_raw_buffer_load_b32(rs, ld_off, mirror_idx(r0 + j, H) * a.spitch, 0);
     }
     else if (r0 >= 0 && r0 + NR <= H)
     {
@@ -450,6 +462,18 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
             const float r0 = fmaf(aw, t0[i0 + 1], (1.f - aw) * t0[i0]);
             const float r1 = fmaf(aw, t1[i0 + 1], (1.f - aw) * t1[i0]);
             res[k] = fmaf(b, r1, (1.f - b) * r0);
+            if (F16)
+              res[k] = (float)(_Float16)res[k]; // the blit target is an image of the pyramid format
+          }
+          v = u32x4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
+        }
+        else if (U8)
+        {
+          float res[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+          {
+            res[k] = s_lut[(v.x >> (8 * k)) & 0xffu];
             if (F16)
               res[k] = (float)(_Float16)res[k]; // the blit target is an image of the pyramid format
           }
@@ -718,9 +742,9 @@ extern "C"
 #define VKSIFT_CASE(N)                                                        \
   case N:                                                                     \
     if (src.fp16)                                                             \
-      hipLaunchKernelGGL((k_blur_lean<N, false, true>), grid, dim3(64), 0, hs, a);  \
+      hipLaunchKernelGGL((k_blur_lean<N, 0, true>), grid, dim3(64), 0, hs, a);  \
     else                                                                      \
-      hipLaunchKernelGGL((k_blur_lean<N, false, false>), grid, dim3(64), 0, hs, a); \
+      hipLaunchKernelGGL((k_blur_lean<N, 0, false>), grid, dim3(64), 0, hs, a); \
     break;
       VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9) VKSIFT_CASE(10)
       VKSIFT_CASE(11) VKSIFT_CASE(12) VKSIFT_CASE(13) VKSIFT_CASE(14) VKSIFT_CASE(15) VKSIFT_CASE(16) VKSIFT_CASE(17) VKSIFT_CASE(18)
@@ -777,9 +801,44 @@ extern "C"
 #define VKSIFT_CASE(N)                                                                        \
   case N:                                                                                     \
     if (dst.fp16)                                                                             \
-      hipLaunchKernelGGL((k_blur_lean<N, true, true>), grid, dim3(64), 0, (hipStream_t)s, a);   \
+      hipLaunchKernelGGL((k_blur_lean<N, 1, true>), grid, dim3(64), 0, (hipStream_t)s, a);   \
     else                                                                                      \
-      hipLaunchKernelGGL((k_blur_lean<N, true, false>), grid, dim3(64), 0, (hipStream_t)s, a);  \
+      hipLaunchKernelGGL((k_blur_lean<N, 1, false>), grid, dim3(64), 0, (hipStream_t)s, a);  \
+    break;
+      VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9) VKSIFT_CASE(10)
+      VKSIFT_CASE(11) VKSIFT_CASE(12)
+#undef VKSIFT_CASE
+    default:
+      return -1;
+    }
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_seed_direct(const uint8_t *src, uint32_t sw, uint32_t sh, uint64_t src_img_stride, vksift_hip_Plane dst, const float *taps, uint32_t ntaps,
+                             uint32_t batch, vksift_hip_stream s)
+  {
+    const uint32_t W = dst.w, H = dst.h;
+    const uint32_t ra = ((ntaps - 1u) + 3u) & ~3u;
+    const uint32_t strips = (W + 127u) / 128u;
+    if (ntaps < 2 || ntaps > VKSIFT_HIP_MAX_TAPS || W != sw || H != sh || (W % 4u) != 0 || ra > W || strips * 128u + ra > 2u * W)
+      return -1; /* not applicable: the caller runs vksift_hip_input_blit + vksift_hip_blur */
+    StreamArgs a;
+    a.ds = NULL, a.ds_img_stride = 0, a.ds_pitch = 0;
+    a.src = (const float *)src, a.dst = dst.base;
+    a.src_img_stride = src_img_stride, a.dst_img_stride = dst.img_stride;
+    a.spitch = (int)sw, a.dpitch = (int)dst.pitch;
+    a.w = (int)W, a.h = (int)H;
+    for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
+      a.taps.k[i] = i < ntaps ? taps[i] : 0.f;
+    const dim3 grid = stream_grid(W, H, batch, 10240u, &a.seg);
+    switch (ntaps)
+    {
+#define VKSIFT_CASE(N)                                                                        \
+  case N:                                                                                     \
+    if (dst.fp16)                                                                             \
+      hipLaunchKernelGGL((k_blur_lean<N, 2, true>), grid, dim3(64), 0, (hipStream_t)s, a);      \
+    else                                                                                      \
+      hipLaunchKernelGGL((k_blur_lean<N, 2, false>), grid, dim3(64), 0, (hipStream_t)s, a);     \
     break;
       VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9) VKSIFT_CASE(10)
       VKSIFT_CASE(11) VKSIFT_CASE(12)

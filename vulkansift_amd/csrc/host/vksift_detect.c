@@ -202,6 +202,12 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool 
       if (fused > 0)
         TRY(fused, "fused up-sampling + seed blur");
     }
+    else if (L->w[0] == c->w && L->h[0] == c->h)
+    {
+      fused = vksift_hip_seed_direct(c->d_src, c->w, c->h, c->img_bytes, plane_at(inst, 0, L->gauss_off[0], 0), &inst->taps[0], inst->ntaps[0], c->count, sp);
+      if (fused > 0)
+        TRY(fused, "fused input conversion + seed blur");
+    }
     if (fused < 0)
     {
       vksift_hip_Plane tmp = plane_at(inst, 0, L->gauss_off[0], 1);
