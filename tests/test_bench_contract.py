@@ -1,0 +1,44 @@
+"""bench.py pieces that can be checked without a GPU: the PMC traffic file is only used for the kernel sources it was measured on
+("make `traffic` refuse to load a PMC file whose kernel names/HEAD differ"), and the roofline object carries the fields
+the contract names."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_stale_pmc_capture_is_refused(monkeypatch):
+    b = _bench()
+    files = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")]
+    assert files, "no PMC capture committed"
+    newest = json.load(open(os.path.join(ROOT, "profiles", sorted(files)[-1])))
+    # a capture is accepted only for the sources it names ...
+    monkeypatch.setattr(b, "kernel_source_sha", lambda: newest["kernel_source_sha"])
+    got = b.pmc_traffic(newest["width"], newest["height"], newest["batch"])
+    assert got is not None and got["hbm_bytes_per_call"] == newest["hbm_bytes_per_call"]
+    # ... and for the workload it was taken on
+    assert b.pmc_traffic(newest["width"] + 2, newest["height"], newest["batch"]) is None
+    # any other kernel source hash: no traffic figure rather than a stale one
+    monkeypatch.setattr(b, "kernel_source_sha", lambda: "0" * 16)
+    assert b.pmc_traffic(newest["width"], newest["height"], newest["batch"]) is None
+
+
+def test_roofline_object_fields():
+    b = _bench()
+    acc = {"nb_calls": 8, "nb_blur_launches": 48, "pyramid_ms": 14.0, "scan_ms": 6.0, "pyramid_algorithmic_bytes": 8 * 11.36e9, "scan_algorithmic_bytes": 8 * 3.15e9}
+    r = b.roofline_from(acc, None, "label")
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] is None
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - (8 * 11.36e9 + 8 * 3.15e9) / 20.0e-3 / 1e9) < 1e-6
+    assert r["launches_per_call"] == 7.0 and abs(r["algorithmic_bytes_per_launch"] - (8 * 11.36e9 + 8 * 3.15e9) / 56) < 1.0
+    pmc = {"hbm_bytes_per_call": 12.0e9, "_path": "profiles/x.json"}
+    r2 = b.roofline_from(acc, pmc, "label")
+    assert abs(r2["traffic"] - 12.0e9 / 7.0) < 1.0 and abs(r2["physical_frac"] - 12.0e9 * 8 / 20.0e-3 / 1e9 / 8000.0) < 1e-9
