@@ -101,6 +101,13 @@ extern "C"
   VKSIFT_EXPORT vksift_Result vksift_ext_shardGroupCreate(vksift_ext_ShardGroup *group_ptr, int gpu_device_index, uint32_t world, uint32_t rank,
                                                           const uint8_t id[VKSIFT_EXT_SHARD_ID_BYTES]);
   VKSIFT_EXPORT void vksift_ext_shardGroupDestroy(vksift_ext_ShardGroup *group_ptr);
+  /* Local, not collective: reserves the device scratch for matchings of up to max_na local query rows against up to max_nb_total
+   * reference rows. A vksift_ext_matchSharded within the reservation allocates nothing, so it cannot fail for resources before its
+   * collective (a rank that cannot allocate the receive buffer inside matchSharded has to abort the communicator: see there). */
+  VKSIFT_EXPORT vksift_Result vksift_ext_shardGroupReserve(vksift_ext_ShardGroup group, uint32_t max_na, uint32_t max_nb_total);
+  /* Collective. Error discipline: nb_shard / nb_total (identical on every rank) are validated before anything is queued; a rank with
+   * a local failure (NULL local pointer, no scratch memory) still enters the all-gather and then returns its error, so its peers are
+   * not left blocked; only a missing receive buffer aborts the communicator (group unusable afterwards). */
   VKSIFT_EXPORT vksift_Result vksift_ext_matchSharded(vksift_ext_ShardGroup group, const uint8_t *d_a_rows, uint32_t na, uint32_t a_index_base,
                                                       const uint8_t *d_b_shard, uint32_t nb_shard, uint32_t nb_total, uint8_t *d_matches);
   VKSIFT_EXPORT vksift_Result vksift_ext_shardGroupSynchronize(vksift_ext_ShardGroup group, float *last_match_ms);

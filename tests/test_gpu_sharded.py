@@ -70,3 +70,34 @@ def test_invalid_arguments_are_rejected(vk):
     assert vk.lib().vksift_ext_shardGroupCreate(C.byref(h), 0, 2, 2, ident) == 1       # rank >= world: VKSIFT_INVALID_INPUT_ERROR
     assert vk.lib().vksift_ext_shardGroupCreate(C.byref(h), 99, 1, 0, ident) == 2      # no such device: VKSIFT_VULKAN_ERROR
     assert vk.lib().vksift_ext_matchSharded(None, None, 0, 0, None, 0, 0, None) == 1
+
+
+def test_local_failure_still_enters_the_collective(vk, oracle):
+    """a rank that returns before ncclAllGather strands its peers. Rank-local invalid input (a NULL query pointer) must
+    be reported AFTER the all-gather was entered, and must leave the group usable; reservations make later calls allocation-free"""
+    import ctypes as C
+    import torch
+    from vulkansift_amd import multigpu
+
+    na, nb = 3000, 2000
+    a = vk.gen_synthetic_descriptors(81, na)
+    b = vk.gen_synthetic_descriptors(82, nb)
+    d_a, d_b = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    out = torch.zeros((na, 5), dtype=torch.int32, device="cuda")
+    grp = multigpu.ShardGroup(0, 1, 0)
+    try:
+        assert grp.reserve(na, nb) == 0
+        L = vk.lib()
+        # arguments every rank shares: rejected before anything is queued
+        assert L.vksift_ext_matchSharded(grp._h, d_a.data_ptr(), na, 0, d_b.data_ptr(), 0, nb, out.data_ptr()) == 1
+        assert L.vksift_ext_matchSharded(grp._h, d_a.data_ptr(), na, 0, d_b.data_ptr(), nb - 1, nb, out.data_ptr()) == 1
+        # rank-local: NULL rows with na > 0 -> the collective runs (ev_gathered is recorded, synchronize returns), error code after
+        assert L.vksift_ext_matchSharded(grp._h, None, na, 0, d_b.data_ptr(), nb, nb, out.data_ptr()) == 1
+        ms = C.c_float(0)
+        assert L.vksift_ext_shardGroupSynchronize(grp._h, C.byref(ms)) == 0
+        assert int(out.abs().sum().item()) == 0          # no records were produced
+        rec, _ = grp.match(d_a, 0, d_b, nb)              # the group is still usable
+    finally:
+        grp.close()
+    got = multigpu.records_to_struct(rec.cpu().numpy())
+    assert got.tobytes() == oracle.match_2nn(a, b).tobytes()

@@ -1,0 +1,220 @@
+"""Parity of the path bench.py times — not of a path that resembles it.
+
+bench.py's step is: a batch_capacity = 128 instance (two pyramid buffers, overlapped detections),
+vksift_ext_detectFeaturesBatchDevice on 128 device-resident 640x480 frames, vksift_ext_matchFeaturesBatch(ids, ids) in two
+64-slot calls, the next step queued right behind it WITHOUT a host synchronisation. The reference makes a new detection wait
+for the running pipelines (src/vulkansift/vulkansift.c:326-327, include/vulkansift/vulkansift.h:43-47); here the ordering is done
+with events between streams (vksift_detect.c: ev_pyr_free, ev_desc_start, ev_input_free), which is exactly what these tests load:
+
+* three (or two) steps back to back, each on a DIFFERENT frame set, so a buffer recycled too early or a stale pyramid shows;
+* after the last step: every buffer byte-equal to the plain single-image vksift_detectFeatures on the same frame, sampled
+  frames byte-equal to the oracle, sampled self-match / pair-match records byte-equal to the oracle;
+* with and without profiling (the timed region of bench.py runs with it on: the event-set recycling is part of the path).
+
+The C5-share shape (64 x 1080p, up-sampling on, consecutive pairs in both directions, src/examples/test_sift_match.cpp:67-80)
+gets the same treatment.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+_FRAMES = {}
+
+
+def _frames(vk, n, w, h, seed0):
+    key = (n, w, h, seed0)
+    if key not in _FRAMES:                       # 85 ms per 640x480 frame on the host: generated once per module
+        _FRAMES[key] = np.stack([vk.gen_synthetic_image(seed0 + i, w, h) for i in range(n)])
+    return _FRAMES[key]
+
+
+def _feat_sets(vk, n, w, h, seed0):
+    """three frame sets for three steps: only the last one is a set of fresh synthetic frames; the earlier ones are flips of
+    it (different content in every buffer at no generation cost)"""
+    last = _frames(vk, n, w, h, seed0)
+    return [np.ascontiguousarray(last[::-1, ::-1, :]), np.ascontiguousarray(last[:, :, ::-1]), last]
+
+
+def _single_image_reference(vk, frames, **cfg_kw):
+    out = []
+    with vk.Instance(vk.default_config(**cfg_kw)) as inst:
+        for f in frames:
+            inst.detectFeatures(f, 0)
+            out.append(inst.downloadFeatures(0))
+    return out
+
+
+@pytest.mark.parametrize("profiling,last_half_first", [(True, False), (False, True)], ids=["profiled", "unprofiled_halves_swapped"])
+def test_bench_step_back_to_back_equals_single_image_and_oracle(vk, oracle, profiling, last_half_first):
+    import torch
+
+    B, W, H = 128, 640, 480
+    sets = _feat_sets(vk, B, W, H, 0x5EED0000)
+    d_sets = [torch.from_numpy(s).cuda() for s in sets]
+    torch.cuda.synchronize()
+    halves = [list(range(0, 64)), list(range(64, 128))]
+    if last_half_first:
+        halves.reverse()
+    cfg = vk.default_config(sift_buffer_count=B, input_image_max_size=W * H)
+    with vk.Instance(cfg, batch_capacity=B) as inst:
+        inst.setProfiling(profiling)
+        for k in range(3):                       # bench.py's step(), three times, nothing in between
+            inst.detectFeaturesBatchDevice(d_sets[k].data_ptr(), B, W, H, 0)
+            for ids in halves:
+                inst.matchFeaturesBatch(ids, ids)
+        # the matches of the last 64-slot call first (the accessors below synchronise)
+        ids = halves[-1]
+        matches = {ids[k]: inst.downloadMatchesBatch(k) for k in (0, 1, 31, 62, 63)}
+        counts = [inst.getFeaturesNumber(i) for i in range(B)]
+        feats = [inst.downloadFeatures(i) for i in range(B)]
+        if profiling:
+            acc = inst.getAccumulatedDetectTimings()
+            assert acc["nb_calls"] == 3 and acc["pyramid_ms"] > 0 and acc["scan_ms"] > 0 and acc["total_ms"] > 0
+    assert min(counts) > 1000
+    single = _single_image_reference(vk, sets[2], input_image_max_size=W * H)
+    for i in range(B):
+        assert counts[i] == len(single[i]), i
+        assert feats[i].tobytes() == single[i].tobytes(), i
+    ocfg = oracle.default_config(math_mode=1)
+    for i in (0, 17, 38, 63, 64, 90, 111, 127):
+        ref, _ = oracle.detect(ocfg, sets[2][i])
+        assert feats[i].tobytes() == ref.tobytes(), i
+    for b, m in matches.items():
+        assert m.tobytes() == oracle.match_2nn(feats[b], feats[b]).tobytes(), b
+
+
+def test_bench_step_host_protocol_back_to_back(vk):
+    """the same three steps through the host-image entry (vksift_ext_detectFeaturesBatch): the staging buffer and d_input are
+    recycled by the next call while the previous detection may still be running"""
+    B, W, H = 128, 640, 480
+    sets = _feat_sets(vk, B, W, H, 0x5EED0000)
+    cfg = vk.default_config(sift_buffer_count=B, input_image_max_size=W * H)
+    with vk.Instance(cfg, batch_capacity=B) as inst:
+        for k in range(3):
+            inst.detectFeaturesBatch(list(sets[k]), 0)
+            for ids in (list(range(0, 64)), list(range(64, 128))):
+                inst.matchFeaturesBatch(ids, ids)
+        feats = [inst.downloadFeatures(i) for i in range(B)]
+    single = _single_image_reference(vk, sets[2], input_image_max_size=W * H)
+    for i in range(B):
+        assert feats[i].tobytes() == single[i].tobytes(), i
+
+
+def test_c5_share_device_input_back_to_back(vk, oracle):
+    """one GPU's share of BASELINE config 5, as tools/bench_configs.py and bench.py's c5 leg run it: 64 x 1080p (up-sampling on)
+    from device memory + the 32 consecutive pairs matched in both directions, twice back to back on different frames"""
+    import torch
+
+    B, W, H = 64, 1920, 1080
+    last = _frames(vk, B, W, H, 0x5EED0000)
+    sets = [np.ascontiguousarray(last[:, ::-1, :]), last]
+    d_sets = [torch.from_numpy(s).cuda() for s in sets]
+    torch.cuda.synchronize()
+    even, odd = list(range(0, B, 2)), list(range(1, B, 2))
+    cfg = vk.default_config(sift_buffer_count=B, input_image_max_size=W * H)
+    with vk.Instance(cfg, batch_capacity=B) as inst:
+        for k in range(2):
+            inst.detectFeaturesBatchDevice(d_sets[k].data_ptr(), B, W, H, 0)
+            inst.matchFeaturesBatch(even, odd)
+            inst.matchFeaturesBatch(odd, even)
+        rev = {(odd[k], even[k]): inst.downloadMatchesBatch(k) for k in (0, 13, 31)}
+        feats = [inst.downloadFeatures(i) for i in range(B)]
+        inst.matchFeaturesBatch(even, odd)
+        fwd = {(even[k], odd[k]): inst.downloadMatchesBatch(k) for k in (0, 13, 31)}
+    assert min(len(f) for f in feats) > 5000
+    single = _single_image_reference(vk, last, input_image_max_size=W * H)
+    for i in range(B):
+        assert feats[i].tobytes() == single[i].tobytes(), i
+    ocfg = oracle.default_config(math_mode=1)
+    for i in (5, 58):
+        ref, _ = oracle.detect(ocfg, last[i])
+        assert feats[i].tobytes() == ref.tobytes(), i
+    for (a, b), m in {**rev, **fwd}.items():
+        assert m.tobytes() == oracle.match_2nn(feats[a], feats[b]).tobytes(), (a, b)
+
+
+@pytest.mark.parametrize("seed", [7, 8])
+def test_random_operation_sequences_on_a_pingpong_instance(vk, oracle, seed):
+    """250 random API calls on an instance with batch_capacity = 8 (two pyramid buffers, overlapped detections, batched
+    download): batched detections of 8 frames, single detections, uploads, single / batched / filtered matches whose records
+    are fetched only later, accessors in any order. Every observable result must equal a model built from the oracle.
+    Unlike tests/test_gpu_api_scenarios.py::test_random_operation_sequences_follow_the_model, most operations here do NOT
+    synchronise, so runs of detections and matches queue up behind each other."""
+    rng = np.random.default_rng(seed)
+    W, H = 320, 240
+    imgs = [vk.gen_synthetic_image(800 + i, W, H) for i in range(12)]
+    other = vk.gen_synthetic_image(820, 256, 192)
+    ocfg = oracle.default_config(math_mode=1)
+    ref = [oracle.detect(ocfg, im)[0] for im in imgs]
+    ref_other = oracle.detect(ocfg, other)[0]
+    nbuf = 12
+    model = {b: np.zeros(0, vk.FEATURE_DTYPE) for b in range(nbuf)}
+    pending = None            # (kind, expected records per pair) of the last matching call, not fetched yet
+    cfg = vk.default_config(sift_buffer_count=nbuf, input_image_max_size=W * H)
+    ops = ["batch", "detect", "detect_other", "match", "batchmatch", "fetch", "download", "count", "upload", "filtered"]
+    prob = [0.2, 0.1, 0.05, 0.15, 0.1, 0.12, 0.13, 0.05, 0.05, 0.05]
+    with vk.Instance(cfg, batch_capacity=8) as inst:
+        for step in range(250):
+            op = rng.choice(ops, p=prob)
+            if op == "batch":
+                b = int(rng.integers(nbuf - 7))
+                first = int(rng.integers(len(imgs) - 7))
+                inst.detectFeaturesBatch(imgs[first:first + 8], b)
+                for i in range(8):
+                    model[b + i] = ref[first + i]
+            elif op == "detect":
+                k, b = int(rng.integers(len(imgs))), int(rng.integers(nbuf))
+                inst.detectFeatures(imgs[k], b)
+                model[b] = ref[k]
+            elif op == "detect_other":            # a resolution change between overlapped detections
+                b = int(rng.integers(nbuf))
+                inst.detectFeatures(other, b)
+                model[b] = ref_other
+            elif op == "upload":
+                k, b = int(rng.integers(len(imgs))), int(rng.integers(nbuf))
+                n = int(rng.integers(2, len(ref[k]) + 1))
+                inst.uploadFeatures(ref[k][:n].copy(), b)
+                model[b] = ref[k][:n]
+            elif op == "count":
+                b = int(rng.integers(nbuf))
+                assert inst.getFeaturesNumber(b) == len(model[b]), (step, op, b)
+            elif op == "download":
+                b = int(rng.integers(nbuf))
+                assert inst.downloadFeatures(b).tobytes() == model[b].tobytes(), (step, op, b)
+            elif op == "match":
+                a, b = int(rng.integers(nbuf)), int(rng.integers(nbuf))
+                if len(model[a]) == 0 or len(model[b]) < 2:
+                    continue
+                inst.matchFeatures(a, b)
+                pending = ("single", [oracle.match_2nn(model[a], model[b])])
+            elif op == "batchmatch":
+                n = int(rng.integers(2, 9))
+                pa = [int(x) for x in rng.integers(nbuf, size=n)]
+                pb = [int(x) for x in rng.integers(nbuf, size=n)]
+                if any(len(model[a]) == 0 for a in pa) or any(len(model[b]) < 2 for b in pb):
+                    continue
+                inst.matchFeaturesBatch(pa, pb)
+                pending = ("batch", [oracle.match_2nn(model[a], model[b]) for a, b in zip(pa, pb)])
+            elif op == "fetch":
+                if pending is None:
+                    continue
+                kind, exp = pending
+                if kind == "single":
+                    assert inst.downloadMatches().tobytes() == exp[0].tobytes(), (step, op)
+                else:
+                    for k, e in enumerate(exp):
+                        assert inst.downloadMatchesBatch(k).tobytes() == e.tobytes(), (step, op, k)
+            else:
+                a, b = int(rng.integers(nbuf)), int(rng.integers(nbuf))
+                if len(model[a]) < 2 or len(model[b]) < 2:
+                    continue
+                inst.matchFeaturesFiltered([a], [b], 0.8, True)
+                got = inst.downloadFilteredMatches(0)
+                m12 = oracle.match_2nn(model[a], model[b])
+                ra, rb = oracle.filter_matches(m12, oracle.match_2nn(model[b], model[a]), 0.8, True)
+                assert np.array_equal(got["idx_a"], ra) and np.array_equal(got["idx_b"], rb), (step, op, a, b)
+                pending = ("single", [m12])       # the forward records stay available as pair 0
+        for b in range(nbuf):
+            assert inst.downloadFeatures(b).tobytes() == model[b].tobytes(), ("final", b)

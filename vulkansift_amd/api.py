@@ -139,6 +139,8 @@ def lib():
     L.vksift_ext_shardGroupDestroy.argtypes = [C.POINTER(C.c_void_p)]
     L.vksift_ext_matchSharded.argtypes = [C.c_void_p, C.c_void_p, u32, u32, C.c_void_p, u32, u32, C.c_void_p]
     L.vksift_ext_matchSharded.restype = C.c_int
+    L.vksift_ext_shardGroupReserve.argtypes = [C.c_void_p, u32, u32]
+    L.vksift_ext_shardGroupReserve.restype = C.c_int
     L.vksift_ext_shardGroupSynchronize.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.vksift_ext_shardGroupSynchronize.restype = C.c_int
     # kernel-layer C-ABI (include/vksift_hip.h) entry points used directly by bench.py / tests

@@ -70,6 +70,11 @@ static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr,
   const uint32_t first = inst->detect_first_buf, count = inst->detect_count;
   if (count < VKSIFT_DL_BATCH_MIN || buf < first || buf >= first + count || b->nb_sections == 0 || b->is_packed)
     return false;
+  /* The packed copy moves EVERY buffer of the detection: a caller that samples one frame of 128 must not pay for the other 127
+   * (nor for the staging memory). The first download after a detection therefore takes the per-section copies; a second one
+   * says the caller walks the batch, and the rest of it comes out of one packed copy. */
+  if (!inst->dl_valid && inst->dl_hits++ == 0 && !inst->dl_eager)
+    return false;
   if (!(inst->dl_valid && inst->dl_first == first && inst->dl_count == count))
   {
     /* every buffer of the batch shares the section table of `b` (one resolution per batched detection) */
@@ -93,7 +98,9 @@ static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr,
     }
     inst->dl_row[count] = rows;
     const size_t bytes = (size_t)rows * FEAT_BYTES;
-    if (bytes > inst->dl_cap)
+    /* the staging pair follows the workload down as well as up: a block more than four times what this detection needs (and
+     * beyond 64 MB) is released instead of being kept for the life of the instance */
+    if (bytes > inst->dl_cap || (inst->dl_cap > ((size_t)64 << 20) && inst->dl_cap / 4u > bytes + 4096u))
     {
       vksift_hip_free(inst->d_dl);
       vksift_hip_host_free(inst->h_dl);

@@ -512,6 +512,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     inst->cache_valid[first_buf + i] = false; /* the matcher's view of the buffer is rebuilt on its next matching */
   }
   inst->dl_valid = false; /* and so is the batched download */
+  inst->dl_hits = 0;
 
   DetectCtx c;
   c.inst = inst, c.L = &inst->lay, c.PS = PS;

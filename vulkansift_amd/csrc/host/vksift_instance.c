@@ -166,16 +166,15 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   inst->match_slot_stride = (((uint64_t)config->max_nb_sift_per_buffer * MATCH_BYTES) + 255u) & ~(uint64_t)255u;
   inst->redo_slot_stride = (uint64_t)config->max_nb_sift_per_buffer + 32u;
   inst->cache_norm_stride = (uint64_t)config->max_nb_sift_per_buffer + 32u;
-  ALLOC_D(inst->d_cache_desc, inst->desc_slot_stride * config->sift_buffer_count);
-  ALLOC_D(inst->d_cache_norm, sizeof(uint32_t) * inst->cache_norm_stride * config->sift_buffer_count);
+  /* the matcher's per-buffer cache (sift_buffer_count x max_nb_sift_per_buffer x 132 B: 1.7 GB for 128 buffers of 100 000) and the
+   * partial lists of the single-pair kernel are allocated by the first matching / export (ensure_match_cache): detect-only
+   * users never pay for them */
   ALLOC_D(inst->d_cache_n, sizeof(uint32_t) * config->sift_buffer_count);
   inst->cache_valid = (bool *)calloc(config->sift_buffer_count, sizeof(bool));
   ok = ok && inst->cache_valid != NULL;
   ALLOC_D(inst->d_matches, inst->match_slot_stride * batch_cap);
   ALLOC_D(inst->d_redo, sizeof(uint32_t) * inst->redo_slot_stride * batch_cap);
   ALLOC_D(inst->d_match_n, sizeof(uint32_t) * 4 * batch_cap);
-  if (config->max_nb_sift_per_buffer > VKSIFT_HIP_MATCH_SMALL_NA)
-    ALLOC_D(inst->d_match_partial, sizeof(uint32_t) * (size_t)config->max_nb_sift_per_buffer * 5u * VKSIFT_HIP_MATCH_CHUNKS);
   ALLOC_H(inst->h_match_n, sizeof(uint32_t) * 4 * batch_cap);
   inst->h_matches = NULL;
   inst->bufs = (BufferInfo *)calloc(config->sift_buffer_count, sizeof(BufferInfo));

@@ -171,6 +171,8 @@ struct vksift_Instance_T
   uint32_t *dl_row;    /* sift_buffer_count + 1 row offsets of the cached buffers */
   uint32_t dl_first, dl_count;
   bool dl_valid;
+  uint32_t dl_hits; /* vksift_downloadFeatures calls on buffers of the last batched detection, before its packed copy exists */
+  bool dl_eager;    /* vksift_ext_setBatchedDownload(true): the first download of a batched detection already packs */
   bool *match_busy; /* per SIFT buffer: read by the matching pipeline in flight (all pairs of a batched call) */
   uint32_t curr_nb_matches;
 

@@ -44,8 +44,28 @@ static uint32_t rows_bound(vksift_Instance inst, uint32_t id)
  * counters in HBM and walks the sections in the same order, so nothing waits on the host. Rows below 2 are zero-filled:
  * Get2NearestNeighbors.comp:66-67 reads b[0] and b[1] unconditionally (stale memory in the reference when B holds fewer
  * than two features); here the missing rows are defined as all-zero descriptors. */
+/* first matching / descriptor export of the instance: the cache blocks (see create_instance). A failed allocation is retried by
+ * the next call; nothing is leaked in between. */
+static int ensure_match_cache(vksift_Instance inst)
+{
+  if (!inst->d_cache_desc)
+    inst->d_cache_desc = (uint8_t *)vksift_hip_malloc(inst->desc_slot_stride * inst->cfg.sift_buffer_count);
+  if (!inst->d_cache_norm)
+    inst->d_cache_norm = (uint32_t *)vksift_hip_malloc(sizeof(uint32_t) * inst->cache_norm_stride * inst->cfg.sift_buffer_count);
+  if (!inst->d_match_partial && inst->cfg.max_nb_sift_per_buffer > VKSIFT_HIP_MATCH_SMALL_NA)
+  {
+    inst->d_match_partial = (uint32_t *)vksift_hip_malloc(sizeof(uint32_t) * (size_t)inst->cfg.max_nb_sift_per_buffer * 5u * VKSIFT_HIP_MATCH_CHUNKS);
+    if (!inst->d_match_partial)
+      return 2; /* hipErrorOutOfMemory */
+  }
+  return (inst->d_cache_desc && inst->d_cache_norm) ? 0 : 2;
+}
+
 int refresh_match_cache(vksift_Instance inst, const uint32_t *ids, uint32_t count)
 {
+  const int ce = ensure_match_cache(inst);
+  if (ce)
+    return ce;
   detect_running(inst); /* refreshes counts_valid if the last detection has finished */
   uint32_t todo[128];
   uint32_t n = 0;

@@ -32,32 +32,52 @@ static struct
   int (*GetUniqueId)(rccl_UniqueId *);
   int (*CommInitRank)(rccl_Comm *, int, rccl_UniqueId, int);
   int (*CommDestroy)(rccl_Comm);
+  int (*CommAbort)(rccl_Comm);
   int (*AllGather)(const void *, void *, size_t, int, rccl_Comm, void *);
   const char *(*GetErrorString)(int);
 } g_rccl;
+#define RTLD_DEFAULT_SENTINEL ((void *)&g_rccl) /* "bound through the global scope": nothing to dlclose */
 
+static bool rccl_bind(void *so)
+{
+  *(void **)&g_rccl.GetUniqueId = dlsym(so, "ncclGetUniqueId");
+  *(void **)&g_rccl.CommInitRank = dlsym(so, "ncclCommInitRank");
+  *(void **)&g_rccl.CommDestroy = dlsym(so, "ncclCommDestroy");
+  *(void **)&g_rccl.CommAbort = dlsym(so, "ncclCommAbort");
+  *(void **)&g_rccl.AllGather = dlsym(so, "ncclAllGather");
+  *(void **)&g_rccl.GetErrorString = dlsym(so, "ncclGetErrorString");
+  return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllGather;
+}
+
+/* Order of preference: (1) an RCCL the process has ALREADY loaded — in a torch.distributed process that is the copy torch bundles;
+ * a second copy would mean two communicator runtimes in one process — found through the global symbol scope or by asking the
+ * loader for the resident library without loading anything (RTLD_NOLOAD); (2) a private load (RTLD_LOCAL: our copy must not
+ * interpose nccl* symbols other libraries resolve later), versioned name first (runtime-only ROCm installs ship no librccl.so). */
 static bool rccl_load(void)
 {
   if (g_rccl.so)
     return true;
-  const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
   void *so = NULL;
+  if (dlsym(RTLD_DEFAULT, "ncclAllGather") != NULL && rccl_bind(RTLD_DEFAULT))
+  {
+    g_rccl.so = RTLD_DEFAULT_SENTINEL;
+    return true;
+  }
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
   for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]) && !so; i++)
-    so = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    so = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
+  for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]) && !so; i++)
+    so = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
   if (!so)
   {
-    logError(LOG_TAG, "RCCL not found (librccl.so): %s", dlerror());
+    logError(LOG_TAG, "RCCL not found (librccl.so.1): %s", dlerror());
     return false;
   }
-  *(void **)&g_rccl.GetUniqueId = dlsym(so, "ncclGetUniqueId");
-  *(void **)&g_rccl.CommInitRank = dlsym(so, "ncclCommInitRank");
-  *(void **)&g_rccl.CommDestroy = dlsym(so, "ncclCommDestroy");
-  *(void **)&g_rccl.AllGather = dlsym(so, "ncclAllGather");
-  *(void **)&g_rccl.GetErrorString = dlsym(so, "ncclGetErrorString");
-  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather)
+  if (!rccl_bind(so))
   {
     logError(LOG_TAG, "librccl.so lacks a required entry point");
     dlclose(so);
+    memset(&g_rccl, 0, sizeof(g_rccl));
     return false;
   }
   g_rccl.so = so;
@@ -75,6 +95,7 @@ struct vksift_ext_ShardGroup_T
   uint32_t *d_scratch;
   size_t b_cap, scratch_cap; /* bytes / u32 elements */
   bool timed;
+  bool broken; /* the communicator was aborted after a local failure: every later call fails */
 };
 
 vksift_Result vksift_ext_shardGetUniqueId(uint8_t id[VKSIFT_EXT_SHARD_ID_BYTES])
@@ -120,6 +141,14 @@ vksift_Result vksift_ext_shardGroupCreate(vksift_ext_ShardGroup *out, int gpu_de
   g->ev_gathered = vksift_hip_event_create();
   g->ev_t0 = vksift_hip_event_create();
   g->ev_t1 = vksift_hip_event_create();
+  if (!g->stream || !g->comm_stream || !g->ev_fork || !g->ev_gathered || !g->ev_t0 || !g->ev_t1)
+  {
+    /* a NULL stream would silently mean the default stream: fail the creation instead (the communicator exists on the peers too:
+     * abort ours, they notice at their first collective like for any rank that disappears) */
+    logError(LOG_TAG, "vksift_ext_shardGroupCreate() failure: stream / event creation");
+    vksift_ext_shardGroupDestroy(&g);
+    return VKSIFT_VULKAN_ERROR;
+  }
   *out = g;
   return VKSIFT_SUCCESS;
 }
@@ -130,8 +159,10 @@ void vksift_ext_shardGroupDestroy(vksift_ext_ShardGroup *gp)
     return;
   vksift_ext_ShardGroup g = *gp;
   vksift_hip_set_device(g->device);
-  vksift_hip_stream_sync(g->comm_stream);
-  vksift_hip_stream_sync(g->stream);
+  if (g->comm_stream)
+    vksift_hip_stream_sync(g->comm_stream);
+  if (g->stream)
+    vksift_hip_stream_sync(g->stream);
   if (g->comm)
     g_rccl.CommDestroy(g->comm);
   vksift_hip_free(g->d_b_full);
@@ -146,37 +177,75 @@ void vksift_ext_shardGroupDestroy(vksift_ext_ShardGroup *gp)
   *gp = NULL;
 }
 
+/* Device scratch for na query rows against nb_rows (padded) reference rows. Returns 0, or a bit mask: 1 = the all-gather's
+ * receive buffer is missing, 2 = the matcher's scratch is missing. */
+static int shard_reserve(vksift_ext_ShardGroup g, uint32_t na, size_t nb_rows)
+{
+  const size_t b_bytes = nb_rows * 128u;
+  /* norms of A, norms of B (padded rows included), redo flags, partial lists of the stream-decomposed kernel */
+  const size_t scratch = (size_t)2 * na + nb_rows + 64 + (size_t)na * 5u * VKSIFT_HIP_MATCH_CHUNKS;
+  if (b_bytes <= g->b_cap && scratch <= g->scratch_cap)
+    return 0;
+  vksift_hip_stream_sync(g->comm_stream);
+  vksift_hip_stream_sync(g->stream);
+  if (b_bytes > g->b_cap)
+  {
+    vksift_hip_free(g->d_b_full);
+    g->d_b_full = (uint8_t *)vksift_hip_malloc(b_bytes);
+    g->b_cap = g->d_b_full ? b_bytes : 0;
+  }
+  if (scratch > g->scratch_cap)
+  {
+    vksift_hip_free(g->d_scratch);
+    g->d_scratch = (uint32_t *)vksift_hip_malloc(scratch * sizeof(uint32_t));
+    g->scratch_cap = g->d_scratch ? scratch : 0;
+  }
+  return (g->d_b_full ? 0 : 1) | (g->d_scratch ? 0 : 2);
+}
+
+vksift_Result vksift_ext_shardGroupReserve(vksift_ext_ShardGroup g, uint32_t max_na, uint32_t max_nb_total)
+{
+  if (!g || g->broken)
+    return VKSIFT_INVALID_INPUT_ERROR;
+  vksift_hip_set_device(g->device);
+  const size_t shard = ((size_t)max_nb_total + g->world - 1) / g->world;
+  if (shard_reserve(g, max_na, shard * g->world) != 0)
+  {
+    logError(LOG_TAG, "vksift_ext_shardGroupReserve() error: out of device memory");
+    return VKSIFT_VULKAN_ERROR;
+  }
+  return VKSIFT_SUCCESS;
+}
+
+/* Failure discipline of a collective call: a rank that returns before ncclAllGather leaves every peer blocked inside it.
+ *   - arguments that every rank passes identically (nb_shard, nb_total) are checked first: a violation fails on EVERY rank, nobody
+ *     enters the collective;
+ *   - rank-local failures (a NULL local pointer, no memory for the matcher's scratch) are remembered, the rank STILL takes part in
+ *     the all-gather (sending its slot of the receive buffer in place of a missing shard), skips its own matching and returns the error;
+ *   - the one failure that makes taking part impossible — no memory for the receive buffer — aborts the communicator
+ *     (ncclCommAbort) and marks the group broken. vksift_ext_shardGroupReserve() on every rank, agreed over the host channel
+ *     before the first matching, removes that case: a call within the reservation allocates nothing. */
 vksift_Result vksift_ext_matchSharded(vksift_ext_ShardGroup g, const uint8_t *d_a_rows, uint32_t na, uint32_t a_index_base, const uint8_t *d_b_shard,
                                       uint32_t nb_shard, uint32_t nb_total, uint8_t *d_matches)
 {
-  if (!g || (na > 0 && (!d_a_rows || !d_matches)) || !d_b_shard || nb_shard == 0 || nb_total < 2 || (uint64_t)nb_shard * g->world < nb_total)
+  if (!g || g->broken)
     return VKSIFT_INVALID_INPUT_ERROR;
+  if (nb_shard == 0 || nb_total < 2 || (uint64_t)nb_shard * g->world < nb_total)
+    return VKSIFT_INVALID_INPUT_ERROR; /* the same on every rank */
   vksift_hip_set_device(g->device);
-  const size_t b_bytes = (size_t)nb_shard * g->world * 128u;
-  /* norms of A, norms of B (padded rows included), redo flags, partial lists of the stream-decomposed kernel */
-  const size_t scratch = (size_t)2 * na + (size_t)nb_shard * g->world + 64 + (size_t)na * 5u * VKSIFT_HIP_MATCH_CHUNKS;
-  if (b_bytes > g->b_cap || scratch > g->scratch_cap)
+  const bool local_args_ok = (na == 0 || (d_a_rows && d_matches)) && d_b_shard;
+  const int missing = shard_reserve(g, na, (size_t)nb_shard * g->world);
+  if (missing & 1)
   {
-    vksift_hip_stream_sync(g->comm_stream);
-    vksift_hip_stream_sync(g->stream);
-    if (b_bytes > g->b_cap)
-    {
-      vksift_hip_free(g->d_b_full);
-      g->d_b_full = (uint8_t *)vksift_hip_malloc(b_bytes);
-      g->b_cap = g->d_b_full ? b_bytes : 0;
-    }
-    if (scratch > g->scratch_cap)
-    {
-      vksift_hip_free(g->d_scratch);
-      g->d_scratch = (uint32_t *)vksift_hip_malloc(scratch * sizeof(uint32_t));
-      g->scratch_cap = g->d_scratch ? scratch : 0;
-    }
-    if (!g->d_b_full || !g->d_scratch)
-    {
-      logError(LOG_TAG, "vksift_ext_matchSharded() error: out of device memory");
-      return VKSIFT_VULKAN_ERROR;
-    }
+    logError(LOG_TAG, "vksift_ext_matchSharded() error: no device memory for the gathered reference set; aborting the communicator");
+    if (g->comm && g_rccl.CommAbort)
+      g_rccl.CommAbort(g->comm);
+    g->comm = NULL;
+    g->broken = true;
+    return VKSIFT_VULKAN_ERROR;
   }
+  const bool compute = local_args_ok && !(missing & 2);
+  const uint8_t *send = d_b_shard ? d_b_shard : g->d_b_full + (size_t)g->rank * nb_shard * 128u;
   uint32_t *norm_a = g->d_scratch, *norm_b = norm_a + na, *rest = norm_b + (size_t)nb_shard * g->world;
   vksift_hip_range_push("Sharded matching");
   int e = vksift_hip_event_record(g->ev_t0, g->stream);
@@ -185,9 +254,9 @@ vksift_Result vksift_ext_matchSharded(vksift_ext_ShardGroup g, const uint8_t *d_
     e = vksift_hip_event_record(g->ev_fork, g->stream);
   if (e == 0)
     e = vksift_hip_stream_wait_event(g->comm_stream, g->ev_fork);
-  if (e == 0)
   {
-    const int ne = g_rccl.AllGather(d_b_shard, g->d_b_full, (size_t)nb_shard * 128u, RCCL_UINT8, g->comm, g->comm_stream);
+    /* entered even when the event calls above failed: the peers are (or will be) inside it */
+    const int ne = g_rccl.AllGather(send, g->d_b_full, (size_t)nb_shard * 128u, RCCL_UINT8, g->comm, g->comm_stream);
     if (ne != 0)
     {
       logError(LOG_TAG, "ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(ne) : "?");
@@ -197,14 +266,14 @@ vksift_Result vksift_ext_matchSharded(vksift_ext_ShardGroup g, const uint8_t *d_
   if (e == 0)
     e = vksift_hip_event_record(g->ev_gathered, g->comm_stream);
   /* 2. meanwhile: the pre-pass of the local query rows */
-  if (e == 0)
+  if (e == 0 && compute)
     e = vksift_hip_shifted_norms(d_a_rows, na, norm_a, g->stream);
   /* 3. B has landed: its norms, then every local row of A against ALL of B in index order */
   if (e == 0)
     e = vksift_hip_stream_wait_event(g->stream, g->ev_gathered);
-  if (e == 0)
+  if (e == 0 && compute)
     e = vksift_hip_shifted_norms(g->d_b_full, nb_total, norm_b, g->stream);
-  if (e == 0)
+  if (e == 0 && compute)
     e = vksift_hip_match_2nn_prenormed(d_a_rows, norm_a, na, a_index_base, g->d_b_full, norm_b, nb_total, rest, d_matches, g->stream);
   if (e == 0)
     e = vksift_hip_event_record(g->ev_t1, g->stream);
@@ -214,13 +283,19 @@ vksift_Result vksift_ext_matchSharded(vksift_ext_ShardGroup g, const uint8_t *d_
     logError(LOG_TAG, "vksift_ext_matchSharded() error: %s", e > 0 ? vksift_hip_error_string(e) : "collective failed");
     return VKSIFT_VULKAN_ERROR;
   }
+  if (!compute)
+  {
+    logError(LOG_TAG, "vksift_ext_matchSharded() error: %s (the all-gather was entered, no records were produced on this rank)",
+             local_args_ok ? "out of device memory" : "invalid input");
+    return local_args_ok ? VKSIFT_VULKAN_ERROR : VKSIFT_INVALID_INPUT_ERROR;
+  }
   g->timed = true;
   return VKSIFT_SUCCESS;
 }
 
 vksift_Result vksift_ext_shardGroupSynchronize(vksift_ext_ShardGroup g, float *last_match_ms)
 {
-  if (!g)
+  if (!g || g->broken)
     return VKSIFT_INVALID_INPUT_ERROR;
   vksift_hip_set_device(g->device);
   if (vksift_hip_stream_sync(g->stream) != 0)

@@ -84,6 +84,12 @@ class ShardGroup:
             raise RuntimeError(f"vksift_ext_shardGroupCreate failed ({r})")
         self.world, self.rank = world, rank
 
+    def reserve(self, max_na, max_nb_total):
+        """vksift_ext_shardGroupReserve: device scratch up front, so that match() within these sizes allocates nothing (a rank that
+        runs out of memory inside a collective call cannot leave it without stranding its peers). Local; returns the result code —
+        agree on it across the ranks (e.g. an all-reduce) before the first match()."""
+        return self._api.lib().vksift_ext_shardGroupReserve(self._h, max_na, max_nb_total)
+
     def match(self, d_a, a_index_base, d_b_shard, nb_total):
         """d_a: this rank's query rows (n x 128 uint8, cuda); d_b_shard: its block of B padded to ceil(nb_total / world) rows.
         Returns (records (n x 5 int32, cuda), milliseconds of the whole pipeline on this rank)."""
