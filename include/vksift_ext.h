@@ -69,11 +69,19 @@ extern "C"
     float scan_ms;                      /* the streaming extrema scan of octave 0 alone (mask clear + the kernel that reads the S+3 planes) */
     uint64_t scan_algorithmic_bytes;    /* 4*(S+2) B per octave-0 pixel, whole batch */
   } vksift_ext_DetectTimings;
+  /* The struct grew once (scan_ms, scan_algorithmic_bytes) and may grow again at its end. The two getters without a size
+   * argument therefore write only the first VKSIFT_EXT_DETECT_TIMINGS_V1_BYTES bytes — the struct of the first release, so a
+   * client compiled against that header is never written past its storage; the ...Sized forms write min(out_bytes, sizeof)
+   * bytes of the current struct (pass sizeof(vksift_ext_DetectTimings) of the header you compiled against). */
+#define VKSIFT_EXT_DETECT_TIMINGS_V1_BYTES 40u
   VKSIFT_EXPORT void vksift_ext_setProfiling(vksift_Instance instance, bool enabled);
   VKSIFT_EXPORT void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *out);
+  VKSIFT_EXPORT void vksift_ext_getDetectTimingsSized(vksift_Instance instance, vksift_ext_DetectTimings *out, size_t out_bytes);
   /* Sums over all detect calls since profiling was enabled (or since the last reset); nb_blur_launches and
    * pyramid_algorithmic_bytes are summed too. Blocking. */
   VKSIFT_EXPORT void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *sum, uint32_t *nb_calls, bool reset);
+  VKSIFT_EXPORT void vksift_ext_getAccumulatedDetectTimingsSized(vksift_Instance instance, vksift_ext_DetectTimings *sum, size_t sum_bytes, uint32_t *nb_calls,
+                                                                  bool reset);
   /* Time (ms) of the last matching pipeline (gather + 2-NN kernel), HIP events; needs profiling on. */
   VKSIFT_EXPORT float vksift_ext_getMatchTime(vksift_Instance instance);
 

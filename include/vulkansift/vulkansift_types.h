@@ -73,7 +73,7 @@ extern "C"
   typedef enum
   {
     VKSIFT_PYRAMID_PRECISION_FLOAT32,
-    VKSIFT_PYRAMID_PRECISION_FLOAT16 /* accepted; this build keeps the pyramid in fp32 */
+    VKSIFT_PYRAMID_PRECISION_FLOAT16 /* every scale-space image holds IEEE binary16 texels, arithmetic stays fp32 */
   } vksift_PyramidPrecisionMode;
 
   typedef enum

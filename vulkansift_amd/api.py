@@ -126,6 +126,8 @@ def lib():
     L.vksift_ext_setProfiling.argtypes = [inst, C.c_bool]
     L.vksift_ext_getDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings)]
     L.vksift_ext_getAccumulatedDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.POINTER(u32), C.c_bool]
+    L.vksift_ext_getDetectTimingsSized.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.c_size_t]
+    L.vksift_ext_getAccumulatedDetectTimingsSized.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.c_size_t, C.POINTER(u32), C.c_bool]
     L.vksift_ext_getMatchTime.argtypes = [inst]
     L.vksift_ext_getMatchTime.restype = C.c_float
     L.vksift_ext_exportDescriptorsDevice.argtypes = [inst, u32, C.c_void_p]
@@ -387,13 +389,13 @@ class Instance:
 
     def getDetectTimings(self):
         t = vksift_ext_DetectTimings()
-        lib().vksift_ext_getDetectTimings(self._h, C.byref(t))
+        lib().vksift_ext_getDetectTimingsSized(self._h, C.byref(t), C.sizeof(t))
         return {f[0]: getattr(t, f[0]) for f in t._fields_}
 
     def getAccumulatedDetectTimings(self, reset=False):
         t = vksift_ext_DetectTimings()
         n = C.c_uint32(0)
-        lib().vksift_ext_getAccumulatedDetectTimings(self._h, C.byref(t), C.byref(n), reset)
+        lib().vksift_ext_getAccumulatedDetectTimingsSized(self._h, C.byref(t), C.sizeof(t), C.byref(n), reset)
         d = {f[0]: getattr(t, f[0]) for f in t._fields_}
         d["nb_calls"] = n.value
         return d

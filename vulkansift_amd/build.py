@@ -1,6 +1,11 @@
 """Build libvulkansift.so in-tree: gcc for the C host, hipcc (gfx950) for the kernels.
 
-    python -m vulkansift_amd.build [--force]
+    python -m vulkansift_amd.build [--force] [--sanitize]
+
+--sanitize builds a second library, lib/libvulkansift_asan.so, whose C host is compiled with
+-fsanitize=address,undefined (the reference's VKSIFT_SANITIZE option, CMakeLists.txt:30-31,91-97); the HIP
+objects are shared with the normal build. Load it with VKSIFT_LIB=<path> and
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) (the sanitizer runtime has to come first in the process).
 
 The shared library lands in vulkansift_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).
 hipcc cross-compiles gfx950 without a GPU, so this also serves as the "does it build" check.
@@ -78,18 +83,22 @@ def _extra_flags(src):
     return []
 
 
-def build(force=False, verbose=False):
+SANITIZE_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+ASAN_LIB_PATH = os.path.join(OUT_DIR, "libvulkansift_asan.so")
+
+
+def build(force=False, verbose=False, sanitize=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = _all_headers()
     objs = []
     for src in HOST_SRCS:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        o = os.path.join(OBJ_DIR, os.path.basename(src) + (".asan.o" if sanitize else ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers):
             if verbose:
                 print("[cc ]", src)
-            _run(["gcc"] + CFLAGS + INCLUDES + ["-DVKSIFT_BUILD", "-c", s, "-o", o])
+            _run(["gcc"] + CFLAGS + (SANITIZE_FLAGS if sanitize else []) + INCLUDES + ["-DVKSIFT_BUILD", "-c", s, "-o", o])
     for src in HIP_SRCS:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
@@ -98,14 +107,19 @@ def build(force=False, verbose=False):
             if verbose:
                 print("[hip]", src)
             _run([HIPCC] + HIPFLAGS + _extra_flags(src) + INCLUDES + ["-c", s, "-o", o])
-    if force or _newer(LIB_PATH, objs):
+    out = ASAN_LIB_PATH if sanitize else LIB_PATH
+    if force or _newer(out, objs):
         if verbose:
-            print("[ld ]", os.path.relpath(LIB_PATH, ROOT))
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs +
+            print("[ld ]", os.path.relpath(out, ROOT))
+        san = []
+        if sanitize:
+            # gcc compiled the instrumented objects, so gcc's runtimes serve them: libubsan linked here, libasan preloaded by the user
+            san = [subprocess.run(["gcc", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()]
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + san +
              ["-L" + os.path.join(ROCM, "lib"), "-lroctx64", "-lm", "-ldl", "-lpthread", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
-    return LIB_PATH
+    return out
 
 
 if __name__ == "__main__":
-    p = build(force="--force" in sys.argv, verbose=True)
+    p = build(force="--force" in sys.argv, verbose=True, sanitize="--sanitize" in sys.argv)
     print(p)

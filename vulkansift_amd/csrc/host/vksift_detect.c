@@ -385,6 +385,16 @@ static int enqueue_detection(DetectCtx *c)
     for (uint32_t o = 0; o < L->n_oct; o++)
       if (o > 0 || !c->pipelined)
         TRY(vksift_hip_stream_wait_event(st, inst->ev_join[0][o]), "octave join");
+  if (c->prof && L->n_oct == 0)
+  {
+    /* an image too small for a single octave launches nothing: the stage events of this call are recorded here, so that its
+     * (zero) intervals are not measured against the events of an earlier detection */
+    for (int i = 2; i <= 5; i++)
+      vksift_hip_event_record(c->PS->ev_t[i], st);
+    vksift_hip_event_record(c->PS->ev_scan, st);
+    vksift_hip_event_record(c->PS->ev_pt[0], st);
+    vksift_hip_event_record(c->PS->ev_pt[1], st);
+  }
   if (inst->pyr_pingpong && !c->capturing)
   {
     /* everything that reads this call's pyramid has been joined into the instance stream (also recorded by the calls that

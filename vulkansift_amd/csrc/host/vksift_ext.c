@@ -2,6 +2,7 @@
  * vksift_ext.c — additive extensions of include/vksift_ext.h (profiling accessors, descriptor export, synthetic inputs)
  */
 #include "vksift_internal.h"
+#include <stddef.h>
 
 /* ------------------------------------------------------------------------------------------------ */
 /* extensions                                                                                       */
@@ -16,9 +17,17 @@ void vksift_ext_setProfiling(vksift_Instance instance, bool enabled)
   instance->acc_calls = 0;
   instance->acc_blur_launches = 0;
   instance->acc_alg_bytes = 0;
+  instance->acc_scan_bytes = 0;
 }
 
-void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *sum, uint32_t *nb_calls, bool reset)
+_Static_assert(offsetof(vksift_ext_DetectTimings, scan_ms) == VKSIFT_EXT_DETECT_TIMINGS_V1_BYTES, "the v1 prefix of vksift_ext_DetectTimings moved");
+
+static void copy_timings(vksift_ext_DetectTimings *dst, size_t dst_bytes, const vksift_ext_DetectTimings *src)
+{
+  memcpy(dst, src, dst_bytes < sizeof(*src) ? dst_bytes : sizeof(*src));
+}
+
+static void accumulated_timings(vksift_Instance instance, vksift_ext_DetectTimings *sum, uint32_t *nb_calls, bool reset)
 {
   memset(sum, 0, sizeof(*sum));
   *nb_calls = 0;
@@ -48,7 +57,19 @@ void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext
   }
 }
 
-void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *out)
+void vksift_ext_getAccumulatedDetectTimingsSized(vksift_Instance instance, vksift_ext_DetectTimings *sum, size_t sum_bytes, uint32_t *nb_calls, bool reset)
+{
+  vksift_ext_DetectTimings t;
+  accumulated_timings(instance, &t, nb_calls, reset);
+  copy_timings(sum, sum_bytes, &t);
+}
+
+void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *sum, uint32_t *nb_calls, bool reset)
+{
+  vksift_ext_getAccumulatedDetectTimingsSized(instance, sum, VKSIFT_EXT_DETECT_TIMINGS_V1_BYTES, nb_calls, reset);
+}
+
+static void last_timings(vksift_Instance instance, vksift_ext_DetectTimings *out)
 {
   memset(out, 0, sizeof(*out));
   const ProfSet *ps = &instance->prof[instance->prof_cur];
@@ -67,6 +88,18 @@ void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimi
   out->scan_algorithmic_bytes = instance->last_scan_bytes;
   out->nb_blur_launches = instance->last_blur_launches;
   out->pyramid_algorithmic_bytes = instance->last_alg_bytes;
+}
+
+void vksift_ext_getDetectTimingsSized(vksift_Instance instance, vksift_ext_DetectTimings *out, size_t out_bytes)
+{
+  vksift_ext_DetectTimings t;
+  last_timings(instance, &t);
+  copy_timings(out, out_bytes, &t);
+}
+
+void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *out)
+{
+  vksift_ext_getDetectTimingsSized(instance, out, VKSIFT_EXT_DETECT_TIMINGS_V1_BYTES);
 }
 
 float vksift_ext_getMatchTime(vksift_Instance instance)

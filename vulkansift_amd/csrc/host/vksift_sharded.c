@@ -12,9 +12,10 @@
  * GPU; the 128-byte unique id travels from rank 0 to the other ranks by whatever host channel the application has
  * (torch.distributed / MPI / a socket).
  */
-#include "vksift_internal.h"
-
+#define _GNU_SOURCE /* RTLD_DEFAULT */
 #include <dlfcn.h>
+
+#include "vksift_internal.h"
 
 typedef struct
 {
