@@ -83,6 +83,10 @@ extern "C"
     uint64_t img_stride; /* texels between consecutive images of the batch */
     uint32_t fp16;       /* 0: fp32 texels; 1: IEEE binary16 texels (VKSIFT_PYRAMID_PRECISION_FLOAT16: stored round-to-nearest-even,
                           * widened exactly on every read, all arithmetic fp32); base then points at 2-byte texels */
+    uint32_t reverse;    /* dispatch-order hint, read from the DESTINATION plane of a launch: 1 = every XCD walks its share of the
+                          * (image, row segment, strip) space back to front. Consecutive launches of a chain alternate it, so that
+                          * a launch starts on the texels its predecessor touched last — the ones still in the 256 MiB Infinity
+                          * Cache — instead of on the ones it evicted first. Results do not depend on it */
   } vksift_hip_Plane;
 
   /* vkCmdCopyBufferToImage + vkCmdBlitImage(LINEAR) of sift_detector.c:881,909-916:
@@ -157,6 +161,8 @@ extern "C"
     uint32_t use_vlfeat;
     const float *desc_fp_tab; /* fixed-point multipliers indexed by R/2 (ComputeDescriptors.comp:116-124) */
     uint32_t desc_fp_tab_len;
+    uint32_t scan_reverse;    /* dispatch-order hint of the streaming extrema scan, like vksift_hip_Plane::reverse: set when the last
+                               * blur launch of the octave ran forward, so that the scan starts on the planes written last */
   } vksift_hip_OctaveJob;
 
   /* ExtractKeypoints.comp (sift_detector.c:1106-1189) as a deterministic, atomic-free pipeline: streaming

@@ -153,6 +153,7 @@ struct ExtremaArgs
   uint32_t *cand_n;    // per image: number of candidates (clamped to cand_cap)
   uint64_t cand_img_stride;
   uint32_t cand_cap;
+  int scan_rev; // the streaming scan walks every XCD's share of the work space back to front (vksift_hip_OctaveJob::scan_reverse)
 };
 
 // Streaming detection pass: one wave owns a 64-column segment and marches down a band of
@@ -396,8 +397,8 @@ __global__ void __launch_bounds__(256, 4) k_extrema_lean(ExtremaArgs a, int band
       const unsigned per_img = gridDim.x * gridDim.y, total = per_img * gridDim.z;
       if ((total & 7u) == 0)
       {
-        const unsigned n = blk + per_img * blockIdx.z;
-        const unsigned wi = (n & 7u) * (total >> 3) + (n >> 3);
+        const unsigned n = blk + per_img * blockIdx.z, per = total >> 3, k = n >> 3;
+        const unsigned wi = (n & 7u) * per + (a.scan_rev ? per - 1u - k : k);
         b = (int)(wi / per_img);
         blk = wi - (unsigned)b * per_img;
       }
@@ -805,6 +806,7 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   a.found = job->found, a.found_img_stride = job->found_img_stride;
   a.cand_xy = job->cand_xy, a.cand_flag = job->cand_flag, a.cand_n = job->cand_n;
   a.cand_img_stride = job->cand_img_stride, a.cand_cap = job->cand_cap;
+  a.scan_rev = (int)job->scan_reverse;
 
   hipStream_t hs = (hipStream_t)s;
   const uint32_t nsegs = job->S * job->h * (uint32_t)a.nseg;

@@ -269,6 +269,7 @@ struct StreamArgs
   float *ds; // also store the NEAREST 2:1 resample (odd rows, odd columns) of the result here (next octave's seed), or NULL
   uint64_t ds_img_stride;
   int ds_pitch;
+  int rev; // walk the work space back to front (vksift_hip_Plane::reverse of the destination)
   Taps taps;
 };
 
@@ -314,10 +315,17 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   uint32_t bs = blockIdx.x, bseg = blockIdx.y, bimg = blockIdx.z;
   {
     const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
+    const uint32_t b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    uint32_t wi = b;
     if ((total & 7u) == 0)
     {
-      const uint32_t b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-      const uint32_t wi = (b & 7u) * (total >> 3) + (b >> 3);
+      const uint32_t per = total >> 3, k = b >> 3;
+      wi = (b & 7u) * per + (a.rev ? per - 1u - k : k);
+    }
+    else if (a.rev)
+      wi = total - 1u - b;
+    if ((total & 7u) == 0 || a.rev)
+    {
       bs = wi % gridDim.x;
       const uint32_t r = wi / gridDim.x;
       bseg = r % gridDim.y;
@@ -734,6 +742,7 @@ extern "C"
     a.src_img_stride = src.img_stride, a.dst_img_stride = dst.img_stride;
     a.spitch = (int)src.pitch, a.dpitch = (int)dst.pitch;
     a.w = (int)src.w, a.h = (int)src.h;
+    a.rev = (int)dst.reverse;
     a.taps = t;
     const dim3 grid = stream_grid(src.w, src.h, batch, 10240u, &a.seg);
     hipStream_t hs = (hipStream_t)s;
@@ -758,7 +767,7 @@ extern "C"
 
   int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, const float *taps, uint32_t ntaps, uint32_t batch, vksift_hip_stream s)
   {
-    const vksift_hip_Plane none = {NULL, 0, 0, 0, 0};
+    const vksift_hip_Plane none = {NULL, 0, 0, 0, 0, 0, 0};
     return blur_impl(src, dst, none, taps, ntaps, batch, s);
   }
 
@@ -784,6 +793,7 @@ extern "C"
     a.src_img_stride = src_img_stride, a.dst_img_stride = dst.img_stride;
     a.spitch = (int)sw, a.dpitch = (int)dst.pitch;
     a.w = (int)W, a.h = (int)H;
+    a.rev = (int)dst.reverse;
     for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
       a.taps.k[i] = i < ntaps ? taps[i] : 0.f;
     uint32_t nseg = (10240u + strips * batch - 1u) / (strips * batch); /* as the other launches (stream_grid): 2560 long-lived waves left the tail to a few CUs */
@@ -828,6 +838,7 @@ extern "C"
     a.src_img_stride = src_img_stride, a.dst_img_stride = dst.img_stride;
     a.spitch = (int)sw, a.dpitch = (int)dst.pitch;
     a.w = (int)W, a.h = (int)H;
+    a.rev = (int)dst.reverse;
     for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
       a.taps.k[i] = i < ntaps ? taps[i] : 0.f;
     const dim3 grid = stream_grid(W, H, batch, 10240u, &a.seg);

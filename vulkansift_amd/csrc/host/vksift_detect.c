@@ -57,6 +57,7 @@ vksift_hip_Plane plane_at(vksift_Instance inst, uint32_t o, uint64_t base_off, u
   vksift_hip_Plane p;
   p.base = pyr_at(inst, base_off + (uint64_t)layer * inst->lay.plane_stride[o]);
   p.fp16 = inst->fp16 ? 1u : 0u;
+  p.reverse = 0;
   p.w = inst->lay.w[o];
   p.h = inst->lay.h[o];
   p.pitch = inst->lay.pitch[o];
@@ -176,6 +177,8 @@ static void build_jobs(DetectCtx *c)
     j->use_vlfeat = inst->cfg.descriptor_format == VKSIFT_DESCRIPTOR_FORMAT_VLFEAT ? 1u : 0u;
     j->desc_fp_tab = inst->d_desc_fp;
     j->desc_fp_tab_len = inst->desc_fp_len;
+    /* the last blur launch of the octave (scale S+2) ran in direction (S+2) & 1: the scan takes the other one */
+    j->scan_reverse = inst->alt_order ? (((inst->S + 2u) & 1u) ^ 1u) : 0u;
   }
 }
 
@@ -237,7 +240,11 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool 
   const uint32_t ready_after = (big && o == 0) ? inst->S + 2 : inst->S;
   for (uint32_t s = 1; s < inst->S + 3; s++)
   {
-    const vksift_hip_Plane srcp = plane_at(inst, o, L->gauss_off[o], s - 1), dstp = plane_at(inst, o, L->gauss_off[o], s);
+    const vksift_hip_Plane srcp = plane_at(inst, o, L->gauss_off[o], s - 1);
+    vksift_hip_Plane dstp = plane_at(inst, o, L->gauss_off[o], s);
+    /* consecutive launches of the chain walk the batch in opposite directions: launch s starts on the planes launch s-1 wrote
+     * last, which are still in the Infinity Cache (a whole-batch plane is 2.5x the cache: in the same direction every read misses) */
+    dstp.reverse = inst->alt_order ? (s & 1u) : 0u;
     int fused_ds = -1;
     if (s == inst->S && o + 1 < L->n_oct)
     {

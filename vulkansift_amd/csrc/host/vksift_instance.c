@@ -206,6 +206,8 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   {
     const char *e = getenv("VKSIFT_SERIAL_OCTAVES"); /* debug: everything on the instance stream */
     inst->serial_octaves = e && e[0] == '1';
+    e = getenv("VKSIFT_PYR_ALTERNATE");
+    inst->alt_order = !(e && e[0] == '0');
     /* hipGraph capture + replay of the detection launch sequence. Measured on MI355X / ROCm 7.2: 10 % faster for one
      * 640x480 image (0.58 vs 0.65 ms), 12 % slower from 1536x1024 up (the graph runs the per-octave branches less
      * concurrently than the streams do) -> by default only small workloads are replayed (graph_max_pixels).

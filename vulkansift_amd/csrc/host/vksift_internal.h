@@ -160,6 +160,7 @@ struct vksift_Instance_T
   bool input_free_valid;
   vksift_hip_event ev_fork[4], ev_join[4][VKSIFT_MAX_OCTAVES], ev_oct_ready[VKSIFT_MAX_OCTAVES];
   bool serial_octaves;
+  bool alt_order; /* VKSIFT_PYR_ALTERNATE (default 1): launches of a blur chain alternate their dispatch direction (vksift_hip_Plane::reverse) */
   vksift_hip_event ev_detect, ev_match;
   bool detect_pending, match_pending;
   uint32_t detect_first_buf, detect_count;
