@@ -21,9 +21,10 @@ same number at N = 1, 2, 4, 8. PyTorch is used for torch.distributed (RCCL) and 
 
 Objects on the JSON line besides the contract fields:
   roofline          octave 0's scale-space construction (k_blur_lean x 6: fused up-sampling+seed blur, 5 scale blurs) plus
-                    the streaming extrema scan (k_extrema_lean) — the launches that produce the Gaussian planes and form the
-                    DoG values. Algorithmic bytes: 72.25 B per octave-0 pixel for pyramid + DoG, + 20 B for the
-                    scan = 92.25 B, divided by the summed duration of those 7 launches, measured with HIP events recorded on
+                    the streaming extrema scan (k_extrema_lean, ONE launch over all octaves) — the launches that produce the
+                    Gaussian planes and form the DoG values. Algorithmic bytes: 72.25 B per octave-0 pixel for
+                    pyramid + DoG, + 20 B per pixel of every octave for the scan, divided by the summed duration of those 7
+                    launches, measured with HIP events recorded on
                     the streams the kernels run on, inside the timed region. `pyramid_only` is the same over the 6 blur launches
                     and 72.25 B (this build never writes the DoG planes, so that figure flatters the blur kernels: the DoG
                     values are formed in the scan). `traffic` / `physical_frac`: HBM bytes from rocprofv3 --pmc passes
@@ -107,7 +108,7 @@ def roofline_from(acc, pmc, label):
     pyr_s = acc["pyramid_ms"] * 1e-3
     scan_s = acc["scan_ms"] * 1e-3
     alg_pyr = float(acc["pyramid_algorithmic_bytes"])                   # 72.25 B per octave-0 pixel, whole run
-    alg_scan = float(acc["scan_algorithmic_bytes"])                    # + 20 B per octave-0 pixel for the extrema scan
+    alg_scan = float(acc["scan_algorithmic_bytes"])                    # + 20 B per pixel of every octave for the extrema scan (one launch)
     n_launch = launches + calls                                        # blur launches + one scan per detection call
     achieved = (alg_pyr + alg_scan) / (pyr_s + scan_s) / 1e9 if pyr_s + scan_s > 0 else 0.0
     pyr_only = alg_pyr / pyr_s / 1e9 if pyr_s > 0 else 0.0
@@ -300,7 +301,7 @@ def c3_roofline(api, torch, dev, steps=5):
     dt = time.perf_counter() - t0
     acc = inst.getAccumulatedDetectTimings()
     inst.close()
-    r = roofline_from(acc, None, "k_blur_lean x6 + k_extrema_lean, octave 0 (3840x2160 planes) of 64 x 1920x1080 frames")
+    r = roofline_from(acc, None, "k_blur_lean x6 on octave 0 (3840x2160 planes) + k_extrema_lean over all octaves, 64 x 1920x1080 frames")
     r.update({"workload": "BASELINE config 3: 64 x 1920x1080 uint8 frames, detect only, default vksift_Config, inputs resident in HBM",
               "steps": steps, "frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "mean_features_per_frame": nfeat,
               "stage_ms_per_step": {k: acc[k] / max(acc["nb_calls"], 1) for k in ("pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")}})
@@ -431,7 +432,7 @@ def main():
                 "parallelism": f"batch split x{world}, no collectives",
                 "input": "host images, upload inside the timed region" if args.host_input else "resident in HBM",
             },
-            "roofline": roofline_from(acc, pmc, "k_blur_lean x6 + k_extrema_lean, octave 0 (1280x960 planes): scale-space construction + the scan that forms the DoG values"),
+            "roofline": roofline_from(acc, pmc, "k_blur_lean x6 on octave 0 (1280x960 planes): scale-space construction, + k_extrema_lean over all octaves: the scan that forms the DoG values"),
             "stage_ms_per_call": {k: acc[k] / max(acc["nb_calls"], 1) for k in
                                   ("upload_ms", "pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")},
             "last_match_ms": match_ms,

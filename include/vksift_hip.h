@@ -175,6 +175,14 @@ extern "C"
   int vksift_hip_orientations(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s);
   /* ComputeDescriptors.comp (sift_detector.c:1243-1259). */
   int vksift_hip_descriptors(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s);
+  /* The same three stages for SEVERAL octaves of one detection in one chain of launches: the reference records the dispatches of
+   * all octaves of a stage into one command buffer (sift_detector.c:1106-1259); here the workgroups of all octaves share one flat
+   * grid per kernel (csrc/hip/multi.h), so a stage costs 1-8 launches whatever the number of octaves, and the small octaves' work
+   * fills the gaps of the large one's instead of trickling through launches of their own. jobs[0..n_jobs): same S, same texel
+   * type, same batch; results are identical to calling the single-octave form once per job. scan_done as above (all octaves). */
+  int vksift_hip_extract_keypoints_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s, vksift_hip_event scan_done);
+  int vksift_hip_orientations_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s);
+  int vksift_hip_descriptors_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s);
 
   /* ------------------------------------------------------------------ matcher */
   /* vksift_Feature records (stride 164 B) -> dense 128-byte descriptor rows (16-byte aligned). Replaces the

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "../detmath.h"
+#include "multi.h"
 #include "vksift_hip.h"
 
 namespace
@@ -153,6 +154,9 @@ struct ExtremaArgs
   uint32_t *cand_n;    // per image: number of candidates (clamped to cand_cap)
   uint64_t cand_img_stride;
   uint32_t cand_cap;
+  int band;        // rows per wave of the streaming scan
+  uint32_t nsegs;  // S * h * nseg: mask segments of one image
+  uint32_t nchunks; // ceil(nsegs / SEG_CHUNK)
   int scan_rev; // the streaming scan walks every XCD's share of the work space back to front (vksift_hip_OctaveJob::scan_reverse)
 };
 
@@ -213,24 +217,27 @@ __device__ __forceinline__ unsigned long long spread32(unsigned long long x)
 }
 
 template <int S>
-__global__ void __launch_bounds__(256) k_extrema_stream(ExtremaArgs a, int band)
+__global__ void __launch_bounds__(256) k_extrema_stream(Multi<ExtremaArgs> m)
 {
+  const VBlock vb = vblock(m);
+  const ExtremaArgs &a = m.oct[vb.o];
+  const int band = a.band;
   // Each lane owns two adjacent columns (x, x+1): one 8-byte load per layer and row, and only one lane-crossing
   // operation per pixel pair and side. A wave covers 128 columns = two 64-pixel mask segments.
   constexpr int NL = S + 2;
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.z;
-  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * band; // 4 independent waves per block, one row band each
+  const int b = vb.z;
+  const int y0 = (vb.y * 4 + (threadIdx.x >> 6)) * band; // 4 independent waves per block, one row band each
   if (y0 >= a.h)
     return;
   const int y1 = min(y0 + band, a.h);
-  const int x0 = blockIdx.x * 128, x = x0 + 2 * lane;
+  const int x0 = vb.x * 128, x = x0 + 2 * lane;
   DogView d{(const float *)((const uint8_t *)a.gauss + (size_t)b * a.img_stride * (a.fp16 ? 2u : 4u)), a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
   const bool in0 = x < a.w, in1 = x + 1 < a.w;
   const int hx = lane == 0 ? x0 - 1 : x0 + 128;
   const bool hok = (lane == 0 || lane == 63) && hx >= 0 && hx < a.w;
   const float pre = a.dog_threshold * 0.8f;
-  const int seg0 = blockIdx.x * 2;
+  const int seg0 = vb.x * 2;
   const bool has_seg1 = seg0 + 1 < a.nseg;
 
   // per layer, rows (y-1, y, y+1): horizontal 3-max / 3-min of both columns; rows (y, y+1): centre and max/min(left,right)
@@ -377,27 +384,30 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 constexpr unsigned EXT_OOB = 0x80000000u;
 
 template <int S, int NSLOT, bool F16>
-__global__ void __launch_bounds__(256, 4) k_extrema_lean(ExtremaArgs a, int band, int strip_major)
+__global__ void __launch_bounds__(256, 4) k_extrema_lean(Multi<ExtremaArgs> m, int strip_major)
 {
+  const VBlock vb = vblock(m);
+  const ExtremaArgs &a = m.oct[vb.o];
+  const int band = a.band;
   constexpr int NL = S + 2;
   constexpr int EB = F16 ? 2 : 4; // bytes per texel
   constexpr int AHEAD = NSLOT - 3; // rows of loads in flight behind the 3-row window
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 4 independent waves per block, one row band each
-  int b = blockIdx.z;
-  int bx = blockIdx.x, by = blockIdx.y * 4 + wv;
+  int b = vb.z;
+  int bx = vb.x, by = vb.y * 4 + wv;
   if (strip_major)
   {
     // the 4 waves of a block take 4 adjacent strips of one band (strips fastest over the flattened wave index)
-    unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
+    unsigned blk = vb.y * vb.gx + vb.x;
     if (strip_major & 2)
     {
       // XCD-contiguous order (workgroup n runs on XCD n % 8, each with its own L2): every XCD takes a contiguous range of the
       // (image, band, strip) space, so the bands that share halo rows are read through the same L2
-      const unsigned per_img = gridDim.x * gridDim.y, total = per_img * gridDim.z;
+      const unsigned per_img = vb.gx * vb.gy, total = per_img * vb.gz;
       if ((total & 7u) == 0)
       {
-        const unsigned n = blk + per_img * blockIdx.z, per = total >> 3, k = n >> 3;
+        const unsigned n = blk + per_img * vb.z, per = total >> 3, k = n >> 3;
         const unsigned wi = (n & 7u) * per + (a.scan_rev ? per - 1u - k : k);
         b = (int)(wi / per_img);
         blk = wi - (unsigned)b * per_img;
@@ -577,15 +587,19 @@ __global__ void __launch_bounds__(256, 4) k_extrema_lean(ExtremaArgs a, int band
 // consumer (k_cand_list) adds base + local offset.
 constexpr uint32_t SEG_CHUNK = 4096;
 
-__global__ void __launch_bounds__(1024) k_segment_scan(const uint64_t *__restrict__ mask, uint32_t *__restrict__ off, uint64_t seg_img_stride, uint32_t n,
-                                                       uint32_t *__restrict__ chunk_tot, uint64_t chunk_img_stride)
+__global__ void __launch_bounds__(1024) k_segment_scan(Multi<ExtremaArgs> m)
 {
   __shared__ uint32_t wave_tot[16];
-  const int b = blockIdx.y;
-  mask += (size_t)b * seg_img_stride;
-  off += (size_t)b * seg_img_stride;
+  const VBlock vb = vblock(m); // virtual grid (chunks, images)
+  const ExtremaArgs &a = m.oct[vb.o];
+  const int b = (int)vb.y;
+  const uint64_t *__restrict__ mask = a.seg_mask + (size_t)b * a.seg_img_stride;
+  uint32_t *__restrict__ off = a.seg_off + (size_t)b * a.seg_img_stride;
+  uint32_t *__restrict__ chunk_tot = a.cand_flag; // the chunk totals / bases live at the start of the flag array until the refinement overwrites it
+  const uint64_t chunk_img_stride = a.cand_img_stride;
+  const uint32_t n = a.nsegs;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t i0 = blockIdx.x * SEG_CHUNK + 4u * threadIdx.x;
+  const uint32_t i0 = vb.x * SEG_CHUNK + 4u * threadIdx.x;
   uint32_t p[4];
 #pragma unroll
   for (int k = 0; k < 4; k++)
@@ -618,25 +632,31 @@ __global__ void __launch_bounds__(1024) k_segment_scan(const uint64_t *__restric
     run += p[k];
   }
   if (threadIdx.x == 0)
-    chunk_tot[(size_t)b * chunk_img_stride + blockIdx.x] = total;
+    chunk_tot[(size_t)b * chunk_img_stride + vb.x] = total;
 }
 
 // In-place exclusive scan of the per-chunk totals of one image (one workgroup per image, the list is short: n / chunk
 // entries); the grand total goes to total_out[b * total_stride]. count_in != NULL: the number of valid entries is
 // ceil(min(count_in[b], count_cap) / per_chunk) (device-side candidate count), else n_entries.
-__global__ void __launch_bounds__(1024) k_chunk_offsets(uint32_t *__restrict__ tot, uint64_t img_stride, uint32_t n_entries, const uint32_t *__restrict__ count_in,
-                                                        uint32_t count_cap, uint32_t per_chunk, uint32_t *__restrict__ total_out, uint32_t total_stride)
+// ACCEPTED = false: the candidate-chunk totals of k_segment_scan (in the flag array) -> chunk bases, grand total -> cand_n[b];
+// ACCEPTED = true: the per-256-candidate accept counts of k_refine_flags (in the segment-offset array) -> bases, total -> found[b].
+template <bool ACCEPTED>
+__global__ void __launch_bounds__(1024) k_chunk_offsets(Multi<ExtremaArgs> m)
 {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
-  const int b = blockIdx.x;
-  tot += (size_t)b * img_stride;
-  uint32_t n = n_entries;
-  if (count_in)
+  const VBlock vb = vblock(m); // virtual grid (images)
+  const ExtremaArgs &a = m.oct[vb.o];
+  const int b = (int)vb.x;
+  uint32_t *__restrict__ tot = ACCEPTED ? a.seg_off + (size_t)b * a.seg_img_stride : a.cand_flag + (size_t)b * a.cand_img_stride;
+  uint32_t *__restrict__ total_out = ACCEPTED ? a.found : a.cand_n;
+  const uint32_t total_stride = ACCEPTED ? a.found_img_stride : 1u;
+  uint32_t n = a.nchunks;
+  if (ACCEPTED)
   {
-    uint32_t c = count_in[b];
-    c = c < count_cap ? c : count_cap;
-    n = (c + per_chunk - 1u) / per_chunk;
+    uint32_t c = a.cand_n[b];
+    c = c < a.cand_cap ? c : a.cand_cap;
+    n = (c + 255u) / 256u;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0)
@@ -673,11 +693,13 @@ __global__ void __launch_bounds__(1024) k_chunk_offsets(uint32_t *__restrict__ t
 }
 
 // One thread per 64-pixel segment: expand its candidate ballot into packed coordinates at offset + rank.
-__global__ void __launch_bounds__(256) k_cand_list(ExtremaArgs a, uint32_t nsegs)
+__global__ void __launch_bounds__(256) k_cand_list(Multi<ExtremaArgs> mu)
 {
-  const uint32_t seg = blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.y;
-  if (seg >= nsegs)
+  const VBlock vb = vblock(mu); // virtual grid (segment blocks, images)
+  const ExtremaArgs &a = mu.oct[vb.o];
+  const uint32_t seg = vb.x * 256 + threadIdx.x;
+  const int b = (int)vb.y;
+  if (seg >= a.nsegs)
     return;
   unsigned long long m = a.seg_mask[seg + (size_t)b * a.seg_img_stride];
   if (m == 0ull)
@@ -702,10 +724,12 @@ __global__ void __launch_bounds__(256) k_cand_list(ExtremaArgs a, uint32_t nsegs
 // stride over the chunks). Besides the accept flags every chunk publishes its number of accepted candidates (into the
 // segment-offset array, free again after k_cand_list) for the two-level scan of k_chunk_offsets / k_cand_emit.
 template <bool F16>
-__global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
+__global__ void __launch_bounds__(256) k_refine_flags(Multi<ExtremaArgs> m)
 {
   __shared__ uint32_t s_cnt[4];
-  const int b = blockIdx.x; // image index fastest: see the launch
+  const VBlock vb = vblock(m); // virtual grid (images, chunks)
+  const ExtremaArgs &a = m.oct[vb.o];
+  const int b = (int)vb.x; // image index fastest: see the launch
   uint32_t n = a.cand_n[b];
   n = n < a.cand_cap ? n : a.cand_cap;
   const uint32_t nch = (n + 255u) / 256u;
@@ -713,7 +737,7 @@ __global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
   const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
   uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
   uint32_t *chunk_sum = a.seg_off + (size_t)b * a.seg_img_stride;
-  for (uint32_t chunk = blockIdx.y; chunk < nch; chunk += gridDim.y)
+  for (uint32_t chunk = vb.y; chunk < nch; chunk += vb.gy)
   {
     const uint32_t i = chunk * 256u + threadIdx.x;
     bool ok = false;
@@ -738,11 +762,13 @@ __global__ void __launch_bounds__(256) k_refine_flags(ExtremaArgs a)
 // order is preserved) if it fits the section. About one candidate in six is accepted: the accepted ones of a chunk are
 // first compacted through LDS, so the recomputation runs on dense lanes (one wave per chunk instead of four sparse ones).
 template <bool F16>
-__global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
+__global__ void __launch_bounds__(256) k_cand_emit(Multi<ExtremaArgs> m)
 {
   __shared__ uint32_t s_cnt[4];
   __shared__ uint32_t s_list[256];
-  const int b = blockIdx.x;
+  const VBlock vb = vblock(m); // virtual grid (images, chunks)
+  const ExtremaArgs &a = m.oct[vb.o];
+  const int b = (int)vb.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t n = a.cand_n[b];
   n = n < a.cand_cap ? n : a.cand_cap;
@@ -751,7 +777,7 @@ __global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
   const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
   const uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
   const uint32_t *chunk_base = a.seg_off + (size_t)b * a.seg_img_stride;
-  for (uint32_t chunk = blockIdx.y; chunk < nch; chunk += gridDim.y)
+  for (uint32_t chunk = vb.y; chunk < nch; chunk += vb.gy)
   {
     const uint32_t i = chunk * 256u + threadIdx.x;
     const bool v = i < n && flag[i] != 0u;
@@ -789,7 +815,7 @@ __global__ void __launch_bounds__(256) k_cand_emit(ExtremaArgs a)
 
 } // namespace
 
-extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s, vksift_hip_event scan_done)
+static int make_extrema_args(const vksift_hip_OctaveJob *job, ExtremaArgs *out)
 {
   if (job->w >= 16384u || job->h >= 16384u || job->S > 14u)
     return (int)hipErrorInvalidValue; /* candidate coordinates are packed 14 + 14 + 4 bits */
@@ -807,94 +833,144 @@ extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uin
   a.cand_xy = job->cand_xy, a.cand_flag = job->cand_flag, a.cand_n = job->cand_n;
   a.cand_img_stride = job->cand_img_stride, a.cand_cap = job->cand_cap;
   a.scan_rev = (int)job->scan_reverse;
-
-  hipStream_t hs = (hipStream_t)s;
-  const uint32_t nsegs = job->S * job->h * (uint32_t)a.nseg;
-
-  /* 1. candidate ballots: only non-empty 64-pixel segments are stored (scattered 8-byte stores were the bottleneck
-   * of this pass), so the mask array is cleared first. The per-image regions are contiguous (seg_img_stride == nsegs). */
-  if (job->seg_img_stride != nsegs)
+  /* 32 rows per wave on the large octaves (3 % halo rows); 16 on the small ones, whose share of a launch is latency bound and
+   * gains more from twice the waves */
+  a.band = job->h > 256u ? 32 : 16;
+  a.nsegs = job->S * job->h * (uint32_t)a.nseg;
+  a.nchunks = (a.nsegs + SEG_CHUNK - 1u) / SEG_CHUNK;
+  /* the per-image mask regions are contiguous (the clear below is one fill per octave), the chunk bases fit the flag array */
+  if (job->seg_img_stride != a.nsegs || a.nchunks > a.cand_cap)
     return (int)hipErrorInvalidValue;
+  *out = a;
+  return 0;
+}
+
+/* the launches of one run of at most MULTI_MAX octaves (same S, same texel type) */
+static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t batch, hipStream_t hs, hipEvent_t scan_done)
+{
+  ExtremaArgs args[MULTI_MAX];
+  for (uint32_t i = 0; i < n; i++)
   {
-    hipError_t me = hipMemsetAsync(a.seg_mask, 0, sizeof(uint64_t) * (size_t)nsegs * batch, hs);
+    const int e = make_extrema_args(&jobs[i], &args[i]);
+    if (e)
+      return e;
+  }
+  const bool f16 = args[0].fp16 != 0;
+  const int S = args[0].S;
+
+  /* 1. candidate ballots: only non-empty 64-pixel segments are stored (scattered 8-byte stores were the bottleneck of this
+   * pass), so the mask arrays are cleared first: one fill when the octaves' regions follow each other (the instance's layout) */
+  for (uint32_t i = 0; i < n;)
+  {
+    uint32_t j = i + 1;
+    size_t bytes = sizeof(uint64_t) * (size_t)args[i].nsegs * batch;
+    while (j < n && (const uint8_t *)args[j].seg_mask == (const uint8_t *)args[i].seg_mask + bytes)
+      bytes += sizeof(uint64_t) * (size_t)args[j].nsegs * batch, j++;
+    const hipError_t me = hipMemsetAsync(args[i].seg_mask, 0, bytes, hs);
     if (me != hipSuccess)
       return (int)me;
+    i = j;
   }
-  static int band_env = -1;
-  if (band_env < 0)
-  {
-    band_env = 0;
-  }
-  /* 32 rows per wave on the large octaves (3 % halo rows); 16 on the small ones, whose launches are latency bound and
-   * gain more from twice the waves (serial kernel time of the coarse octaves -40 %) */
-  const int band = band_env ? band_env : (job->h > 256u ? 32 : 16);
-  dim3 sgrid((a.nseg + 1) / 2, ((job->h + band - 1) / band + 3) / 4, batch);
   static int lean_env = -1;
   if (lean_env < 0)
   {
     const char *e = getenv("VKSIFT_EXTREMA_LEAN"); /* 0: the generic streaming kernel (A/B runs) */
     lean_env = e ? atoi(e) : 1;
   }
-  static int sm_env = -1;
-  if (sm_env < 0)
-  {
-    sm_env = 3; /* bit 0: the 4 waves of a block take adjacent strips (-5 % against adjacent bands), bit 1: XCD-contiguous block order (-3 %) */
-  }
+  /* bit 0: the 4 waves of a block take adjacent strips (-5 % against adjacent bands), bit 1: XCD-contiguous block order (-3 %) */
+  const int sm = 3;
   /* window slots: fp32 texels 4 (one row of loads in flight; two rows spill registers since the slots receive S+3 Gaussian
    * texels), binary16 texels 5 (a row in flight costs half the registers) */
   /* the lean kernel addresses a plane with 32-bit byte offsets */
-  const bool lean = lean_env && (uint64_t)job->pitch * job->h * (job->fp16 ? 2u : 4u) < 0x80000000ull;
-  switch (job->S)
+  bool lean = lean_env != 0;
+  for (uint32_t i = 0; i < n; i++)
+    lean = lean && (uint64_t)jobs[i].pitch * jobs[i].h * (f16 ? 2u : 4u) < 0x80000000ull;
+
+#define VKSIFT_MULTI(M, GX, GY, GZ)                              \
+  Multi<ExtremaArgs> M;                                           \
+  M.n = 0;                                                        \
+  for (uint32_t i = 0; i < n; i++)                                \
+  {                                                               \
+    const ExtremaArgs &a = args[i];                               \
+    (void)a;                                                      \
+    if (!multi_add(M, args[i], (GX), (GY), (GZ)))                 \
+      return (int)hipErrorInvalidValue;                           \
+  }
   {
-#define VKSIFT_CASE(N)                                                         \
-  case N:                                                                      \
-    if (lean && a.fp16)                                                        \
-      hipLaunchKernelGGL((k_extrema_lean<N, 5, true>), sgrid, dim3(256), 0, hs, a, band, sm_env); \
-    else if (lean)                                                             \
-      hipLaunchKernelGGL((k_extrema_lean<N, 4, false>), sgrid, dim3(256), 0, hs, a, band, sm_env); \
-    else                                                                       \
-      hipLaunchKernelGGL(k_extrema_stream<N>, sgrid, dim3(256), 0, hs, a, band); \
+    VKSIFT_MULTI(ms, (uint32_t)(a.nseg + 1) / 2u, ((a.h + a.band - 1) / a.band + 3u) / 4u, batch)
+    const dim3 sgrid(ms.start[ms.n]);
+    switch (S)
+    {
+#define VKSIFT_CASE(N)                                                                \
+  case N:                                                                             \
+    if (lean && f16)                                                                  \
+      hipLaunchKernelGGL((k_extrema_lean<N, 5, true>), sgrid, dim3(256), 0, hs, ms, sm);  \
+    else if (lean)                                                                    \
+      hipLaunchKernelGGL((k_extrema_lean<N, 4, false>), sgrid, dim3(256), 0, hs, ms, sm); \
+    else                                                                              \
+      hipLaunchKernelGGL(k_extrema_stream<N>, sgrid, dim3(256), 0, hs, ms);           \
     break;
-    VKSIFT_CASE(1) VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9)
-    VKSIFT_CASE(10) VKSIFT_CASE(11) VKSIFT_CASE(12) VKSIFT_CASE(13)
+      VKSIFT_CASE(1) VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9)
+      VKSIFT_CASE(10) VKSIFT_CASE(11) VKSIFT_CASE(12) VKSIFT_CASE(13)
 #undef VKSIFT_CASE
-  default:
-    return (int)hipErrorInvalidValue;
+    default:
+      return (int)hipErrorInvalidValue;
+    }
   }
   if (scan_done)
-    (void)hipEventRecord((hipEvent_t)scan_done, hs);
+    (void)hipEventRecord(scan_done, hs);
   /* 2. offsets + candidate count: chunk-local scan, then the (short) scan of the chunk totals; the totals/bases live at
    * the start of the flag array until the refinement overwrites it */
-  const uint32_t nchunks = (nsegs + SEG_CHUNK - 1u) / SEG_CHUNK;
-  if (nchunks > a.cand_cap)
-    return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_segment_scan, dim3(nchunks, batch), dim3(1024), 0, hs, (const uint64_t *)a.seg_mask, a.seg_off, a.seg_img_stride, nsegs, a.cand_flag,
-                     a.cand_img_stride);
-  hipLaunchKernelGGL(k_chunk_offsets, dim3(batch), dim3(1024), 0, hs, a.cand_flag, a.cand_img_stride, nchunks, (const uint32_t *)nullptr, 0u, 1u, a.cand_n,
-                     1u);
-  /* 3. compact list, 4. dense refinement (+ per-chunk accept counts), 5. scan of those counts, 6. accepted -> records */
-  hipLaunchKernelGGL(k_cand_list, dim3((nsegs + 255u) / 256u, batch), dim3(256), 0, hs, a, nsegs);
-  uint32_t rblocks = (a.cand_cap + 255u) / 256u;
-  static uint32_t rb_max = 0;
-  if (!rb_max)
   {
-    rb_max = 512u;
+    VKSIFT_MULTI(m2, a.nchunks, batch, 1u)
+    hipLaunchKernelGGL(k_segment_scan, dim3(m2.start[m2.n]), dim3(1024), 0, hs, m2);
   }
-  if (rblocks > rb_max)
-    rblocks = rb_max;
-  /* grid = (image, chunk): the busy workgroups (chunk < candidates / 256, a small and unknown part of the grid) are then
+  VKSIFT_MULTI(mi, batch, 1u, 1u) /* one workgroup per image */
+  hipLaunchKernelGGL(k_chunk_offsets<false>, dim3(mi.start[mi.n]), dim3(1024), 0, hs, mi);
+  /* 3. compact list, 4. dense refinement (+ per-chunk accept counts), 5. scan of those counts, 6. accepted -> records */
+  {
+    VKSIFT_MULTI(m3, (a.nsegs + 255u) / 256u, batch, 1u)
+    hipLaunchKernelGGL(k_cand_list, dim3(m3.start[m3.n]), dim3(256), 0, hs, m3);
+  }
+  /* virtual grid = (image, chunk): the busy workgroups (chunk < candidates / 256, a small and unknown part of the grid) are then
    * contiguous in dispatch order. With the chunk index fastest they formed a short run at the start of every image's row of
    * 512 workgroups, which the dispatcher's round-robin maps onto the same half of the shader engines of every XCD:
    * measured 221 us instead of 70 us for this launch (and 137 instead of 51 us for k_cand_emit). */
-  if (a.fp16)
-    hipLaunchKernelGGL(k_refine_flags<true>, dim3(batch, rblocks), dim3(256), 0, hs, a);
+  VKSIFT_MULTI(mr, batch, ((a.cand_cap + 255u) / 256u) > 512u ? 512u : ((a.cand_cap + 255u) / 256u), 1u)
+  const dim3 rgrid(mr.start[mr.n]);
+  if (f16)
+    hipLaunchKernelGGL(k_refine_flags<true>, rgrid, dim3(256), 0, hs, mr);
   else
-    hipLaunchKernelGGL(k_refine_flags<false>, dim3(batch, rblocks), dim3(256), 0, hs, a);
-  hipLaunchKernelGGL(k_chunk_offsets, dim3(batch), dim3(1024), 0, hs, a.seg_off, a.seg_img_stride, 0u, (const uint32_t *)a.cand_n, a.cand_cap, 256u, a.found,
-                     a.found_img_stride);
-  if (a.fp16)
-    hipLaunchKernelGGL(k_cand_emit<true>, dim3(batch, rblocks), dim3(256), 0, hs, a);
+    hipLaunchKernelGGL(k_refine_flags<false>, rgrid, dim3(256), 0, hs, mr);
+  hipLaunchKernelGGL(k_chunk_offsets<true>, dim3(mi.start[mi.n]), dim3(1024), 0, hs, mi);
+  if (f16)
+    hipLaunchKernelGGL(k_cand_emit<true>, rgrid, dim3(256), 0, hs, mr);
   else
-    hipLaunchKernelGGL(k_cand_emit<false>, dim3(batch, rblocks), dim3(256), 0, hs, a);
+    hipLaunchKernelGGL(k_cand_emit<false>, rgrid, dim3(256), 0, hs, mr);
+#undef VKSIFT_MULTI
   return (int)hipGetLastError();
+}
+
+extern "C" int vksift_hip_extract_keypoints_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s,
+                                                  vksift_hip_event scan_done)
+{
+  if (n_jobs == 0 || batch == 0)
+    return 0;
+  /* runs of octaves that one launch can serve: same S and texel type (always the case inside one detection), at most MULTI_MAX */
+  for (uint32_t i0 = 0; i0 < n_jobs;)
+  {
+    uint32_t i1 = i0 + 1;
+    while (i1 < n_jobs && i1 - i0 < (uint32_t)MULTI_MAX && jobs[i1].S == jobs[i0].S && jobs[i1].fp16 == jobs[i0].fp16)
+      i1++;
+    const int e = extract_run(jobs + i0, i1 - i0, batch, (hipStream_t)s, i1 == n_jobs ? (hipEvent_t)scan_done : nullptr);
+    if (e)
+      return e;
+    i0 = i1;
+  }
+  return 0;
+}
+
+extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s, vksift_hip_event scan_done)
+{
+  return vksift_hip_extract_keypoints_multi(job, 1, batch, s, scan_done);
 }

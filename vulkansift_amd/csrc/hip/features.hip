@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "../detmath.h"
+#include "multi.h"
 #include "vksift_hip.h"
 
 namespace
@@ -90,21 +91,23 @@ __device__ __forceinline__ float wrap_2pi(float t)
 // Orientation histogram (ComputeOrientation.comp:52-186). grid = (blocks, batch); 4 keypoints/block.
 // -------------------------------------------------------------------------------------------------
 template <bool IMG_FAST, bool F16>
-__global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
+__global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
 {
+  const VBlock vb = vblock(m); // virtual grid (images, blocks) when IMG_FAST, (blocks, images) otherwise
+  const FeatArgs &a = m.oct[vb.o];
   // One wave per keypoint, four independent waves per block: every wave owns its histogram and LDS executes the DS
   // operations of a wave in program order, so no workgroup barrier is needed (a wave with a 15x15 window does not wait
   // for a neighbour with a 29x29 one).
   __shared__ uint32_t s_hist[4][36];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = IMG_FAST ? blockIdx.x : blockIdx.y;
+  const int b = (int)(IMG_FAST ? vb.x : vb.y);
   const uint32_t found = a.found[(size_t)b * a.found_img_stride];
   const uint32_t n0 = found < a.cap ? found : a.cap;
   GaussView g{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride};
   uint8_t *feats = a.feats + (size_t)b * a.feat_img_stride;
   uint32_t *hist = s_hist[wave];
 
-  const uint32_t bk = IMG_FAST ? blockIdx.y : blockIdx.x, nbk = IMG_FAST ? gridDim.y : gridDim.x;
+  const uint32_t bk = IMG_FAST ? vb.y : vb.x, nbk = IMG_FAST ? vb.gy : vb.gx;
   for (uint32_t k = bk * 4 + wave; k < n0; k += nbk * 4)
   {
     if (lane < 36)
@@ -227,11 +230,13 @@ __global__ void __launch_bounds__(256) k_orientation(FeatArgs a)
 // Write main orientations in place and append the extra-orientation copies in (keypoint, bin) order
 // (ComputeOrientation.comp:170-183, made deterministic). One 1024-thread block per image.
 // -------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_orientation_finalize(FeatArgs a)
+__global__ void __launch_bounds__(1024) k_orientation_finalize(Multi<FeatArgs> m)
 {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
-  const int b = blockIdx.x;
+  const VBlock vb = vblock(m); // virtual grid (images)
+  const FeatArgs &a = m.oct[vb.o];
+  const int b = (int)vb.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t found = a.found[(size_t)b * a.found_img_stride];
   const uint32_t n0 = found < a.cap ? found : a.cap;
@@ -443,21 +448,23 @@ __device__ __forceinline__ void desc_fbin2(float xa, float xb, float *fa, float 
 constexpr int DESC_MAX_ROWS = 256; // window rows handled per pass (R <= 127: every stock configuration); taller windows take several passes
 
 template <int NWV, bool IMG_FAST, bool F16>
-__global__ void __launch_bounds__(64 * NWV) k_descriptor(FeatArgs a)
+__global__ void __launch_bounds__(64 * NWV) k_descriptor(Multi<FeatArgs> m)
 {
+  const VBlock vb = vblock(m); // virtual grid (images, blocks) when IMG_FAST, (blocks, images) otherwise
+  const FeatArgs &a = m.oct[vb.o];
   constexpr int NT_ = 64 * NWV;
   __shared__ __attribute__((aligned(8))) uint32_t s_work[DESC_WORK_WORDS]; // see desc_scatter
   __shared__ int s_row_lo[DESC_MAX_ROWS];
   __shared__ uint32_t s_row_cnt[DESC_MAX_ROWS];
   __shared__ uint32_t s_row_pre[NWV][DESC_MAX_ROWS + 1];
   const int tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = IMG_FAST ? blockIdx.x : blockIdx.y;
+  const int b = (int)(IMG_FAST ? vb.x : vb.y);
   const uint32_t found = a.found[(size_t)b * a.found_img_stride];
   const uint32_t n1 = found < a.cap ? found : a.cap;
   GaussView g{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride};
   uint8_t *feats = a.feats + (size_t)b * a.feat_img_stride;
 
-  for (uint32_t k = IMG_FAST ? blockIdx.y : blockIdx.x; k < n1; k += IMG_FAST ? gridDim.y : gridDim.x)
+  for (uint32_t k = IMG_FAST ? vb.y : vb.x; k < n1; k += IMG_FAST ? vb.gy : vb.gx)
   {
     __syncthreads(); // the previous keypoint's epilogue has read the histogram
     for (int i = tid; i < DESC_HIST_WORDS; i += NT_)
@@ -727,85 +734,138 @@ uint32_t expected_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch)
 
 } // namespace
 
-extern "C"
+// the launches of one run of at most MULTI_MAX octaves
+static int orientation_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t batch, hipStream_t hs)
 {
-  int vksift_hip_orientations(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s)
+  Multi<FeatArgs> mo, mf;
+  mo.n = mf.n = 0;
+  const bool f = img_fast(batch, false);
+  for (uint32_t i = 0; i < n; i++)
   {
-    FeatArgs a = make_args(job);
-    /* The keypoint count is only known on the device; the grid is sized for a dense octave (one keypoint per 512 pixels,
-     * twice the usual yield) and strides over whatever is there. Sizing it by the section capacity alone launched 131 k
-     * workgroups per stage on the coarse octaves for a few hundred keypoints: 40-70 us of pure dispatch each. */
-    const uint32_t dense = expected_keypoints(job, batch);
-    uint32_t blocks = ((job->cap < dense ? job->cap : dense) + 3) / 4;
+    const FeatArgs a = make_args(&jobs[i]);
+    /* The keypoint count is only known on the device; an octave's share of the grid is sized for a dense octave (one keypoint per
+     * 512 pixels, twice the usual yield) and strides over whatever is there. Sizing it by the section capacity alone gave the
+     * coarse octaves 131 k workgroups per stage for a few hundred keypoints: 40-70 us of pure dispatch each. */
+    const uint32_t dense = expected_keypoints(&jobs[i], batch);
+    uint32_t blocks = ((jobs[i].cap < dense ? jobs[i].cap : dense) + 3) / 4;
     if (blocks > 1024)
       blocks = 1024;
     if (blocks == 0)
       blocks = 1;
-    if (img_fast(batch, false))
-    {
-      if (a.fp16)
-        hipLaunchKernelGGL((k_orientation<true, true>), dim3(batch, blocks), dim3(256), 0, (hipStream_t)s, a);
-      else
-        hipLaunchKernelGGL((k_orientation<true, false>), dim3(batch, blocks), dim3(256), 0, (hipStream_t)s, a);
-    }
-    else
-    {
-      if (a.fp16)
-        hipLaunchKernelGGL((k_orientation<false, true>), dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
-      else
-        hipLaunchKernelGGL((k_orientation<false, false>), dim3(blocks, batch), dim3(256), 0, (hipStream_t)s, a);
-    }
-    hipLaunchKernelGGL(k_orientation_finalize, dim3(batch), dim3(1024), 0, (hipStream_t)s, a);
-    return (int)hipGetLastError();
+    if (!multi_add(mo, a, f ? batch : blocks, f ? blocks : batch, 1u) || !multi_add(mf, a, batch, 1u, 1u))
+      return (int)hipErrorInvalidValue;
   }
-
-  int vksift_hip_descriptors(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s)
+  const bool f16 = mo.oct[0].fp16 != 0;
+  const dim3 grid(mo.start[mo.n]);
+  if (f)
   {
-    FeatArgs a = make_args(job);
-    const uint32_t dense = expected_keypoints(job, batch);
-    uint32_t blocks = job->cap < dense ? job->cap : dense;
+    if (f16)
+      hipLaunchKernelGGL((k_orientation<true, true>), grid, dim3(256), 0, hs, mo);
+    else
+      hipLaunchKernelGGL((k_orientation<true, false>), grid, dim3(256), 0, hs, mo);
+  }
+  else
+  {
+    if (f16)
+      hipLaunchKernelGGL((k_orientation<false, true>), grid, dim3(256), 0, hs, mo);
+    else
+      hipLaunchKernelGGL((k_orientation<false, false>), grid, dim3(256), 0, hs, mo);
+  }
+  hipLaunchKernelGGL(k_orientation_finalize, dim3(mf.start[mf.n]), dim3(1024), 0, hs, mf);
+  return (int)hipGetLastError();
+}
+
+static int descriptor_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t batch, hipStream_t hs)
+{
+  Multi<FeatArgs> md;
+  md.n = 0;
+  const bool f = img_fast(batch, true);
+  for (uint32_t i = 0; i < n; i++)
+  {
+    const FeatArgs a = make_args(&jobs[i]);
+    const uint32_t dense = expected_keypoints(&jobs[i], batch);
+    uint32_t blocks = jobs[i].cap < dense ? jobs[i].cap : dense;
     if (blocks > 2048)
       blocks = 2048;
     if (blocks == 0)
       blocks = 1;
-    /* waves per keypoint: 4 keep the critical path of a single image short; a batch has keypoints to spare and runs
-     * 3-4 % faster with 2 (less redundant per-keypoint work, measured under the overlapped batch schedule) */
-    static int nwv_env = -1;
-    if (nwv_env < 0)
-    {
-      const char *e = getenv("VKSIFT_DESC_WAVES"); /* 1, 2, 4 or 8 (A/B runs) */
-      nwv_env = e ? atoi(e) : 0;
-    }
-    const int nwv = nwv_env ? nwv_env : (batch >= 8u ? 2 : 4);
-    const bool f = img_fast(batch, true);
-    hipStream_t hs = (hipStream_t)s;
-#define VKSIFT_DESC(N)                                                                          \
-  do                                                                                            \
-  {                                                                                             \
-    if (f)                                                                                      \
-    {                                                                                           \
-      if (a.fp16)                                                                               \
-        hipLaunchKernelGGL((k_descriptor<N, true, true>), dim3(batch, blocks), dim3(64 * N), 0, hs, a);  \
-      else                                                                                      \
-        hipLaunchKernelGGL((k_descriptor<N, true, false>), dim3(batch, blocks), dim3(64 * N), 0, hs, a); \
-    }                                                                                           \
-    else                                                                                        \
-    {                                                                                           \
-      if (a.fp16)                                                                               \
-        hipLaunchKernelGGL((k_descriptor<N, false, true>), dim3(blocks, batch), dim3(64 * N), 0, hs, a); \
-      else                                                                                      \
-        hipLaunchKernelGGL((k_descriptor<N, false, false>), dim3(blocks, batch), dim3(64 * N), 0, hs, a); \
-    }                                                                                           \
-  } while (0)
-    if (nwv == 1)
-      VKSIFT_DESC(1);
-    else if (nwv == 2)
-      VKSIFT_DESC(2);
-    else if (nwv == 8)
-      VKSIFT_DESC(8);
-    else
-      VKSIFT_DESC(4);
-#undef VKSIFT_DESC
-    return (int)hipGetLastError();
+    if (!multi_add(md, a, f ? batch : blocks, f ? blocks : batch, 1u))
+      return (int)hipErrorInvalidValue;
   }
+  /* waves per keypoint: 4 keep the critical path of a single image short; a batch has keypoints to spare and runs
+   * 3-4 % faster with 2 (less redundant per-keypoint work, measured under the overlapped batch schedule) */
+  static int nwv_env = -1;
+  if (nwv_env < 0)
+  {
+    const char *e = getenv("VKSIFT_DESC_WAVES"); /* 1, 2, 4 or 8 (A/B runs) */
+    nwv_env = e ? atoi(e) : 0;
+  }
+  const int nwv = nwv_env ? nwv_env : (batch >= 8u ? 2 : 4);
+  const bool f16 = md.oct[0].fp16 != 0;
+  const dim3 grid(md.start[md.n]);
+#define VKSIFT_DESC(N)                                                                  \
+  do                                                                                    \
+  {                                                                                     \
+    if (f)                                                                              \
+    {                                                                                   \
+      if (f16)                                                                          \
+        hipLaunchKernelGGL((k_descriptor<N, true, true>), grid, dim3(64 * N), 0, hs, md);  \
+      else                                                                              \
+        hipLaunchKernelGGL((k_descriptor<N, true, false>), grid, dim3(64 * N), 0, hs, md); \
+    }                                                                                   \
+    else                                                                                \
+    {                                                                                   \
+      if (f16)                                                                          \
+        hipLaunchKernelGGL((k_descriptor<N, false, true>), grid, dim3(64 * N), 0, hs, md); \
+      else                                                                              \
+        hipLaunchKernelGGL((k_descriptor<N, false, false>), grid, dim3(64 * N), 0, hs, md); \
+    }                                                                                   \
+  } while (0)
+  if (nwv == 1)
+    VKSIFT_DESC(1);
+  else if (nwv == 2)
+    VKSIFT_DESC(2);
+  else if (nwv == 8)
+    VKSIFT_DESC(8);
+  else
+    VKSIFT_DESC(4);
+#undef VKSIFT_DESC
+  return (int)hipGetLastError();
+}
+
+template <typename F>
+static int for_runs(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, F run)
+{
+  for (uint32_t i0 = 0; i0 < n_jobs;)
+  {
+    uint32_t i1 = i0 + 1;
+    while (i1 < n_jobs && i1 - i0 < (uint32_t)MULTI_MAX && jobs[i1].fp16 == jobs[i0].fp16)
+      i1++;
+    const int e = run(jobs + i0, i1 - i0);
+    if (e)
+      return e;
+    i0 = i1;
+  }
+  return 0;
+}
+
+extern "C"
+{
+  int vksift_hip_orientations_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s)
+  {
+    if (batch == 0)
+      return 0;
+    return for_runs(jobs, n_jobs, [&](const vksift_hip_OctaveJob *j, uint32_t n) { return orientation_run(j, n, batch, (hipStream_t)s); });
+  }
+
+  int vksift_hip_descriptors_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s)
+  {
+    if (batch == 0)
+      return 0;
+    return for_runs(jobs, n_jobs, [&](const vksift_hip_OctaveJob *j, uint32_t n) { return descriptor_run(j, n, batch, (hipStream_t)s); });
+  }
+
+  int vksift_hip_orientations(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s) { return vksift_hip_orientations_multi(job, 1, batch, s); }
+
+  int vksift_hip_descriptors(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s) { return vksift_hip_descriptors_multi(job, 1, batch, s); }
 }

@@ -124,15 +124,13 @@ typedef struct
   const PyrLayout *L;
   ProfSet *PS;
   bool prof;      /* HIP-event stage timings requested */
-  bool par;       /* octaves on several streams */
-  bool pipelined; /* per-octave chains (default) instead of joins at every stage boundary */
-  bool overlap;   /* pyramid on its own streams and buffer (ping-pong), see detect_impl */
+  bool overlap;   /* scale-space on its own stream and buffer (ping-pong), see detect_impl */
   bool upload;    /* host images were staged in h_input and have to be copied to d_input */
   bool capturing; /* the sequence is being captured into a hipGraph: no host-visible events inside */
   const uint8_t *d_src;
   uint32_t w, h, count, first_buf;
   size_t img_bytes;
-  uint32_t nblur;
+  uint32_t nblur; /* blur launches of octave 0 (the profiled scale-space interval) */
   vksift_hip_OctaveJob jobs[VKSIFT_MAX_OCTAVES];
 } DetectCtx;
 
@@ -194,7 +192,7 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool 
   vksift_hip_range_push("Scale space construction");
   if (o == 0)
   {
-    if (c->overlap && c->prof)
+    if (c->prof)
       vksift_hip_event_record(c->PS->ev_pt[0], sp);
     /* u8 -> fp32 (2x LINEAR blit when up-sampling) + seed blur: one fused pass when the shape allows it, else the blit goes
      * into the (still unused) layer-1 slot and is seed-blurred into layer 0 */
@@ -225,19 +223,9 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool 
     }
     nb_o++;
   }
-  else
-  {
-    if (c->par)
-      TRY(vksift_hip_stream_wait_event(sp, inst->ev_oct_ready[o - 1]), "octave dependency");
-    if (!*g0_done)
-      TRY(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), c->count, sp), "downsample");
-  }
+  else if (!*g0_done)
+    TRY(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), c->count, sp), "downsample");
   *g0_done = false;
-  /* The next octave needs scale S only. For workloads large enough to be bandwidth bound, octave 1 nevertheless waits for
-   * octave 0's whole pyramid: the two bandwidth-bound chains do not compete (octave 0 runs 5-8 % faster alone) and the
-   * coarse octaves then overlap octave 0's extraction and descriptor stages. A small image is latency bound: earliest start. */
-  const bool big = (uint64_t)c->count * c->w * c->h >= (4u << 20);
-  const uint32_t ready_after = (big && o == 0) ? inst->S + 2 : inst->S;
   for (uint32_t s = 1; s < inst->S + 3; s++)
   {
     const vksift_hip_Plane srcp = plane_at(inst, o, L->gauss_off[o], s - 1);
@@ -258,101 +246,46 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool 
     if (fused_ds < 0)
       TRY(vksift_hip_blur(srcp, dstp, &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], c->count, sp), "blur");
     nb_o++;
-    if (c->par && o + 1 < L->n_oct && s == ready_after)
-      TRY(vksift_hip_event_record(inst->ev_oct_ready[o], sp), "event record");
   }
   vksift_hip_range_pop();
-  if (!c->pipelined || o == 0)
+  if (o == 0)
+  {
     c->nblur += nb_o;
-  if (c->overlap && o == 0 && c->prof)
-    vksift_hip_event_record(c->PS->ev_pt[1], sp);
-  return 0;
-}
-
-/* ExtractKeypoints -> ComputeOrientation -> ComputeDescriptors of octave o on stream so (sift_detector.c:1106-1259);
- * octave 0 carries the stage-timing events */
-static int enqueue_keypoint_chain(DetectCtx *c, uint32_t o, vksift_hip_stream so)
-{
-  vksift_Instance inst = c->inst;
-  const bool timed = o == 0 && c->prof;
-  if (timed)
-    vksift_hip_event_record(c->PS->ev_t[2], inst->stream);
-  vksift_hip_range_push("ExtractKeypoints");
-  TRY(vksift_hip_extract_keypoints(&c->jobs[o], c->count, so, timed ? c->PS->ev_scan : NULL), "keypoint extraction");
-  vksift_hip_range_pop();
-  if (timed)
-    vksift_hip_event_record(c->PS->ev_t[3], inst->stream);
-  vksift_hip_range_push("ComputeOrientation");
-  TRY(vksift_hip_orientations(&c->jobs[o], c->count, so), "orientation");
-  vksift_hip_range_pop();
-  if (timed)
-    vksift_hip_event_record(c->PS->ev_t[4], inst->stream);
-  vksift_hip_range_push("ComputeDescriptors");
-  if (c->overlap && o == 0)
-  {
-    TRY(vksift_hip_event_record(inst->ev_desc_start, inst->stream), "event record");
-    inst->desc_start_valid = true;
+    if (c->prof)
+      vksift_hip_event_record(c->PS->ev_pt[1], sp);
   }
-  TRY(vksift_hip_descriptors(&c->jobs[o], c->count, so), "descriptor");
-  vksift_hip_range_pop();
-  if (timed)
-    vksift_hip_event_record(c->PS->ev_t[5], inst->stream);
-  return 0;
-}
-
-/* one keypoint stage of the stage-synchronous / serial schedules: fork one stream per octave, join back */
-static int extract_untimed(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s) { return vksift_hip_extract_keypoints(job, batch, s, NULL); }
-
-static int enqueue_stage(DetectCtx *c, int g, const char *name, int (*call)(const vksift_hip_OctaveJob *, uint32_t, vksift_hip_stream), const char *what)
-{
-  vksift_Instance inst = c->inst;
-  vksift_hip_stream st = inst->stream;
-  vksift_hip_range_push(name);
-  if (c->par)
-    TRY(vksift_hip_event_record(inst->ev_fork[g], st), "event record");
-  for (uint32_t o = 0; o < c->L->n_oct; o++)
-  {
-    vksift_hip_stream so = (c->par && o > 0) ? inst->oct_stream[o] : st;
-    if (c->par && o > 0)
-      TRY(vksift_hip_stream_wait_event(so, inst->ev_fork[g]), "octave fork");
-    TRY(call(&c->jobs[o], c->count, so), what);
-    if (c->par && o > 0)
-      TRY(vksift_hip_event_record(inst->ev_join[g][o], so), "event record");
-  }
-  if (c->par)
-    for (uint32_t o = 1; o < c->L->n_oct; o++)
-      TRY(vksift_hip_stream_wait_event(st, inst->ev_join[g][o]), "octave join");
-  vksift_hip_range_pop();
   return 0;
 }
 
 /* Everything a detection puts on the GPU, from the image upload to the count read-back: the part a hipGraph captures.
  *
- * Octave o+1 only needs scale S of octave o, and everything after the pyramid is per octave (own SIFT-buffer section,
- * own scratch). Two schedules:
- *   pipelined (default): octave 0 runs on the instance stream, every other octave runs its whole chain
- *     pyramid -> ExtractKeypoints -> ComputeOrientation -> ComputeDescriptors on its own stream, started by the
- *     event "the previous octave's scale S (octave 0: whole pyramid) is ready"; the instance stream joins them before
- *     the count read-back. The latency-bound launch chains of the coarse octaves hide behind the bandwidth-bound work
- *     of the fine ones. Profiling events then time octave 0's stages (the other octaves overlap them).
- *   serial (VKSIFT_SERIAL_OCTAVES=1, and single-octave images): everything on the instance stream. */
+ * Two streams at most. The scale-space of all octaves is built on one (octave o+1 is seeded by scale S of octave o anyway);
+ * then every keypoint stage — ExtractKeypoints, ComputeOrientation, ComputeDescriptors — is ONE chain of launches for all
+ * octaves on the instance stream (vksift_hip_*_multi), like the reference records the dispatches of all octaves of a stage into
+ * one command buffer (sift_detector.c:1106-1259). With two pyramid buffers the scale-space has a stream of its own, ordered
+ * behind the last reader of the buffer it recycles (detect_impl), so that the construction for detection N+1 runs beside the
+ * matching of detection N.
+ * Measured on MI355X (128 x 640x480 per call): anything more concurrent is not faster — per-octave chains on per-octave
+ * streams (rounds 1-2) let the coarse octaves trickle through ~50 launches too small to fill the chip (2.9 ms of a 6.5 ms step
+ * for a third of the pixels), eight hardware queues instead of four cost 10 %: memory-bound and VALU-bound kernels beside each
+ * other take the sum of their times (the blur launches keep the VALUs half busy themselves). */
 static int enqueue_detection(DetectCtx *c)
 {
   vksift_Instance inst = c->inst;
   const PyrLayout *L = c->L;
   vksift_hip_stream st = inst->stream;
+  vksift_hip_stream sp = c->overlap ? inst->pyr_stream : st;
 
   if (c->upload)
   {
-    vksift_hip_stream s_up = c->overlap ? inst->pyr_stream[0] : st;
     /* behind the previous reader of d_input, whichever stream that detection's seed pass ran on */
     if (inst->input_free_valid && !c->capturing)
-      TRY(vksift_hip_stream_wait_event(s_up, inst->ev_input_free), "input buffer recycle");
-    TRY(vksift_hip_memcpy_h2d(inst->d_input, inst->h_input, c->img_bytes * c->count, s_up), "image upload");
+      TRY(vksift_hip_stream_wait_event(sp, inst->ev_input_free), "input buffer recycle");
+    TRY(vksift_hip_memcpy_h2d(inst->d_input, inst->h_input, c->img_bytes * c->count, sp), "image upload");
     if (!c->capturing)
     {
       /* the pinned staging buffer is free again as soon as this copy has run */
-      TRY(vksift_hip_event_record(inst->ev_staging, s_up), "event record");
+      TRY(vksift_hip_event_record(inst->ev_staging, sp), "event record");
       inst->staging_pending = true;
     }
   }
@@ -363,36 +296,42 @@ static int enqueue_detection(DetectCtx *c)
   TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, st), "counter reset");
 
   bool g0_done = false;
-  if (c->par)
-    TRY(vksift_hip_event_record(inst->ev_fork[0], st), "event record");
   for (uint32_t o = 0; o < L->n_oct; o++)
-  {
-    /* so: stream of this octave's keypoint stages; sp: stream of its scale-space construction */
-    vksift_hip_stream so = st;
-    if (c->par && (o > 0 || !c->pipelined))
-    {
-      so = inst->oct_stream[o];
-      TRY(vksift_hip_stream_wait_event(so, inst->ev_fork[0]), "octave fork");
-    }
-    vksift_hip_stream sp = c->overlap ? inst->pyr_stream[o] : so;
-    if (c->overlap && o > 0 && inst->pyr_free_valid[inst->pyr_cur])
-      TRY(vksift_hip_stream_wait_event(sp, inst->ev_pyr_free[inst->pyr_cur]), "pyramid buffer recycle");
     TRY(enqueue_pyramid(c, o, sp, &g0_done), "scale space construction");
+  if (c->overlap)
+  {
+    TRY(vksift_hip_event_record(inst->ev_pyr_done, sp), "event record");
+    TRY(vksift_hip_stream_wait_event(st, inst->ev_pyr_done), "scale space ready");
+  }
+  if (L->n_oct > 0)
+  {
+    if (c->prof)
+      vksift_hip_event_record(c->PS->ev_t[2], st);
+    vksift_hip_range_push("ExtractKeypoints");
+    TRY(vksift_hip_extract_keypoints_multi(c->jobs, L->n_oct, c->count, st, c->prof ? c->PS->ev_scan : NULL), "keypoint extraction");
+    vksift_hip_range_pop();
+    if (c->prof)
+      vksift_hip_event_record(c->PS->ev_t[3], st);
+    vksift_hip_range_push("ComputeOrientation");
+    TRY(vksift_hip_orientations_multi(c->jobs, L->n_oct, c->count, st), "orientation");
+    vksift_hip_range_pop();
+    if (c->prof)
+      vksift_hip_event_record(c->PS->ev_t[4], st);
+    vksift_hip_range_push("ComputeDescriptors");
+    TRY(vksift_hip_descriptors_multi(c->jobs, L->n_oct, c->count, st), "descriptor");
+    vksift_hip_range_pop();
     if (c->overlap)
     {
-      TRY(vksift_hip_event_record(inst->ev_pyr_done[o], sp), "event record");
-      TRY(vksift_hip_stream_wait_event(so, inst->ev_pyr_done[o]), "scale space ready");
+      /* the next detection's scale-space may start here: beside the matching that usually follows, not beside the descriptors.
+       * Gates at the start of the orientation / descriptor stage, or none at all, give the same frames/s within 1 % and turn
+       * every stage interval into a measurement of the contention instead of the kernel. */
+      TRY(vksift_hip_event_record(inst->ev_desc_start, st), "event record");
+      inst->desc_start_valid = true;
     }
-    if (c->pipelined)
-      TRY(enqueue_keypoint_chain(c, o, so), "keypoint stages");
-    if (c->par && so != st)
-      TRY(vksift_hip_event_record(inst->ev_join[0][o], so), "event record");
+    if (c->prof)
+      vksift_hip_event_record(c->PS->ev_t[5], st);
   }
-  if (c->par)
-    for (uint32_t o = 0; o < L->n_oct; o++)
-      if (o > 0 || !c->pipelined)
-        TRY(vksift_hip_stream_wait_event(st, inst->ev_join[0][o]), "octave join");
-  if (c->prof && L->n_oct == 0)
+  else if (c->prof)
   {
     /* an image too small for a single octave launches nothing: the stage events of this call are recorded here, so that its
      * (zero) intervals are not measured against the events of an earlier detection */
@@ -404,36 +343,18 @@ static int enqueue_detection(DetectCtx *c)
   }
   if (inst->pyr_pingpong && !c->capturing)
   {
-    /* everything that reads this call's pyramid has been joined into the instance stream (also recorded by the calls that
-     * do not overlap — tiny images, serial mode — so that a later overlapped call never recycles the buffer under them) */
+    /* everything that reads this call's pyramid runs on the instance stream (also recorded by the calls that do not overlap —
+     * tiny images — so that a later overlapped call never recycles the buffer under them) */
     TRY(vksift_hip_event_record(inst->ev_pyr_free[inst->pyr_cur], st), "event record");
     inst->pyr_free_valid[inst->pyr_cur] = true;
   }
   inst->last_blur_launches = c->nblur;
-  /* profiling: the pyramid interval is octave 0's when pipelined, the whole pyramid's otherwise */
-  inst->last_alg_bytes = algorithmic_pyramid_bytes(inst, c->w, c->h, c->pipelined ? 1u : L->n_oct) * c->count;
-  /* "the extrema scan adds 20 B/px.octave" = one read of the S+2 DoG layers (octave 0: the timed scan) */
-  inst->last_scan_bytes = L->n_oct ? (uint64_t)L->w[0] * L->h[0] * pyr_texel_bytes(inst) * (inst->S + 2) * c->count : 0;
-
-  if (!c->pipelined)
-  {
-    /* Each of the three keypoint stages forks one stream per octave (per-octave scratch, no sharing) and joins back
-     * into the main stream, so stage boundaries (and the stage timings) stay well defined. */
-    if (c->prof)
-      vksift_hip_event_record(c->PS->ev_t[2], st);
-    TRY(enqueue_stage(c, 1, "ExtractKeypoints", extract_untimed, "keypoint extraction"), "keypoint extraction");
-    if (c->prof)
-    {
-      vksift_hip_event_record(c->PS->ev_scan, st); /* this schedule does not time the scan kernel alone: the whole stage stands in */
-      vksift_hip_event_record(c->PS->ev_t[3], st);
-    }
-    TRY(enqueue_stage(c, 2, "ComputeOrientation", vksift_hip_orientations, "orientation"), "orientation");
-    if (c->prof)
-      vksift_hip_event_record(c->PS->ev_t[4], st);
-    TRY(enqueue_stage(c, 3, "ComputeDescriptors", vksift_hip_descriptors, "descriptor"), "descriptor");
-    if (c->prof)
-      vksift_hip_event_record(c->PS->ev_t[5], st);
-  }
+  /* profiling: the scale-space interval is octave 0's (77 % of the bytes), the scan interval covers the scan launch of all octaves */
+  inst->last_alg_bytes = algorithmic_pyramid_bytes(inst, c->w, c->h, 1u) * c->count;
+  /* "the extrema scan adds 20 B/px.octave" = one read of the S+2 DoG layers */
+  inst->last_scan_bytes = 0;
+  for (uint32_t o = 0; o < L->n_oct; o++)
+    inst->last_scan_bytes += (uint64_t)L->w[o] * L->h[o] * pyr_texel_bytes(inst) * (inst->S + 2) * c->count;
 
   /* recCopySIFTCountCmds (sift_detector.c:1261-1291) */
   TRY(vksift_hip_memcpy_d2h(inst->h_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES,
@@ -534,19 +455,17 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   DetectCtx c;
   c.inst = inst, c.L = &inst->lay, c.PS = PS;
   c.prof = inst->profiling;
-  c.par = !inst->serial_octaves && c.L->n_oct > 1;
-  c.pipelined = c.par;
   /* Overlapping detections (VKSIFT_PYR_PINGPONG=1): with two pyramid buffers the scale-space construction of this call
    * does not depend on anything the previous call (or a matching still in flight) reads or writes, so it runs on its own
-   * streams, ordered only behind the last reader of the pyramid buffer it recycles; everything that touches the SIFT
+   * stream, ordered only behind the last reader of the pyramid buffer it recycles; everything that touches the SIFT
    * buffers and the extraction scratch stays in instance-stream order. */
-  c.overlap = inst->pyr_pingpong && c.pipelined;
+  c.overlap = inst->pyr_pingpong && c.L->n_oct > 0;
   c.upload = images != NULL;
   c.w = w, c.h = h, c.count = count, c.first_buf = first_buf;
   c.img_bytes = (size_t)w * h;
   c.nblur = 0;
   c.capturing = false;
-  PS->overlap = c.overlap;
+  PS->overlap = true; /* the scale-space interval is the one between ev_pt[0] and ev_pt[1] (octave 0) */
   if (c.prof)
     vksift_hip_event_record(PS->ev_t[0], st);
   if (c.overlap)
@@ -554,11 +473,10 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     inst->pyr_cur ^= 1;
     inst->d_pyr = inst->d_pyr_buf[inst->pyr_cur];
     if (inst->pyr_free_valid[inst->pyr_cur])
-      HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream[0], inst->ev_pyr_free[inst->pyr_cur]), "pyramid buffer recycle");
-    /* pair the bandwidth-bound pyramid with the compute-bound tail of the previous detection (descriptors, matching),
-     * not with its equally bandwidth-bound extraction stage */
+      HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream, inst->ev_pyr_free[inst->pyr_cur]), "pyramid buffer recycle");
+    /* not before the previous detection's descriptors are done (see enqueue_detection) */
     if (inst->desc_start_valid)
-      HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream[0], inst->ev_desc_start), "overlap gate");
+      HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream, inst->ev_desc_start), "overlap gate");
   }
 
   /* stage the images; the caller may reuse its memory as soon as we return (sift_memory.c:943) */

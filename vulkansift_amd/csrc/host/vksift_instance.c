@@ -183,30 +183,14 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   /* All streams at the default priority: a high-priority instance stream with low-priority octave streams was measured
    * 20 % slower on MI355X (11.3k vs 14.1k frames/s). */
   inst->stream = vksift_hip_stream_create();
-  inst->oct_stream[0] = inst->stream;
-  for (int o = 1; o < VKSIFT_MAX_OCTAVES; o++)
-    inst->oct_stream[o] = vksift_hip_stream_create();
-  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
-  {
-    inst->ev_oct_ready[o] = vksift_hip_event_create();
-    for (int g = 0; g < 4; g++)
-      inst->ev_join[g][o] = vksift_hip_event_create();
-  }
-  for (int g = 0; g < 4; g++)
-    inst->ev_fork[g] = vksift_hip_event_create();
-  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
-  {
-    inst->pyr_stream[o] = vksift_hip_stream_create();
-    inst->ev_pyr_done[o] = vksift_hip_event_create();
-  }
+  inst->pyr_stream = vksift_hip_stream_create();
+  inst->ev_pyr_done = vksift_hip_event_create();
   inst->ev_desc_start = vksift_hip_event_create();
   inst->ev_input_free = vksift_hip_event_create();
   for (int i = 0; i < 2; i++)
     inst->ev_pyr_free[i] = vksift_hip_event_create();
   {
-    const char *e = getenv("VKSIFT_SERIAL_OCTAVES"); /* debug: everything on the instance stream */
-    inst->serial_octaves = e && e[0] == '1';
-    e = getenv("VKSIFT_PYR_ALTERNATE");
+    const char *e = getenv("VKSIFT_PYR_ALTERNATE");
     inst->alt_order = !(e && e[0] == '0');
     /* hipGraph capture + replay of the detection launch sequence. Measured on MI355X / ROCm 7.2: 10 % faster for one
      * 640x480 image (0.58 vs 0.65 ms), 12 % slower from 1536x1024 up (the graph runs the per-octave branches less
@@ -278,13 +262,8 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   assert(*instance_ptr != NULL);
   vksift_Instance inst = *instance_ptr;
   vksift_hip_set_device(inst->device);
-  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
-  {
-    if (o > 0 && inst->oct_stream[o])
-      vksift_hip_stream_sync(inst->oct_stream[o]);
-    if (inst->pyr_stream[o])
-      vksift_hip_stream_sync(inst->pyr_stream[o]);
-  }
+  if (inst->pyr_stream)
+    vksift_hip_stream_sync(inst->pyr_stream);
   if (inst->stream)
     vksift_hip_stream_sync(inst->stream);
   vksift_hip_free(inst->d_pyr_buf[0]);
@@ -335,13 +314,8 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   }
   vksift_hip_event_destroy(inst->ev_m[0]);
   vksift_hip_event_destroy(inst->ev_m[1]);
-  for (int o = 1; o < VKSIFT_MAX_OCTAVES; o++)
-    vksift_hip_stream_destroy(inst->oct_stream[o]);
-  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
-  {
-    vksift_hip_stream_destroy(inst->pyr_stream[o]);
-    vksift_hip_event_destroy(inst->ev_pyr_done[o]);
-  }
+  vksift_hip_stream_destroy(inst->pyr_stream);
+  vksift_hip_event_destroy(inst->ev_pyr_done);
   vksift_hip_event_destroy(inst->ev_desc_start);
   vksift_hip_event_destroy(inst->ev_input_free);
   vksift_hip_event_destroy(inst->prof[0].ev_scan);
@@ -352,14 +326,6 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
     vksift_hip_event_destroy(inst->prof[0].ev_pt[i]);
     vksift_hip_event_destroy(inst->prof[1].ev_pt[i]);
   }
-  for (int o = 0; o < VKSIFT_MAX_OCTAVES; o++)
-  {
-    vksift_hip_event_destroy(inst->ev_oct_ready[o]);
-    for (int g = 0; g < 4; g++)
-      vksift_hip_event_destroy(inst->ev_join[g][o]);
-  }
-  for (int g = 0; g < 4; g++)
-    vksift_hip_event_destroy(inst->ev_fork[g]);
   vksift_hip_stream_destroy(inst->stream);
   free(inst);
   *instance_ptr = NULL;
@@ -403,13 +369,8 @@ int grow_image_scratch(vksift_Instance inst, const PyrLayout *L)
 {
   if (wait_all(inst) != 0)
     return -1;
-  for (uint32_t o = 0; o < VKSIFT_MAX_OCTAVES; o++)
-  {
-    if (o > 0 && inst->oct_stream[o])
-      vksift_hip_stream_sync(inst->oct_stream[o]);
-    if (inst->pyr_stream[o])
-      vksift_hip_stream_sync(inst->pyr_stream[o]);
-  }
+  if (inst->pyr_stream)
+    vksift_hip_stream_sync(inst->pyr_stream);
   for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
   {
     vksift_hip_graph_destroy(inst->graphs[i].exec);

@@ -148,18 +148,13 @@ struct vksift_Instance_T
   BufferInfo *bufs;
 
   vksift_hip_stream stream;
-  /* octave-parallel execution inside a stage: octave o >= 1 runs on oct_stream[o] (oct_stream[0] == stream), forked from
-   * and joined back into the main stream with events, so the latency-bound small octaves overlap the large ones */
-  vksift_hip_stream oct_stream[VKSIFT_MAX_OCTAVES];
-  vksift_hip_stream pyr_stream[VKSIFT_MAX_OCTAVES]; /* scale-space construction of octave o when detections overlap */
-  vksift_hip_event ev_pyr_done[VKSIFT_MAX_OCTAVES];
+  vksift_hip_stream pyr_stream; /* scale-space construction when detections overlap (two pyramid buffers) */
+  vksift_hip_event ev_pyr_done;
   vksift_hip_event ev_pyr_free[2]; /* last reader of pyramid buffer i has finished */
-  vksift_hip_event ev_desc_start;  /* octave 0 of the previous detection has reached its (compute-bound) descriptor stage */
+  vksift_hip_event ev_desc_start;  /* the previous detection's descriptor stage has been issued up to here: the next scale-space may start */
   bool desc_start_valid;
   vksift_hip_event ev_input_free;  /* the last reader of d_input (seed pass of the most recent detection) has run */
   bool input_free_valid;
-  vksift_hip_event ev_fork[4], ev_join[4][VKSIFT_MAX_OCTAVES], ev_oct_ready[VKSIFT_MAX_OCTAVES];
-  bool serial_octaves;
   bool alt_order; /* VKSIFT_PYR_ALTERNATE (default 1): launches of a blur chain alternate their dispatch direction (vksift_hip_Plane::reverse) */
   vksift_hip_event ev_detect, ev_match;
   bool detect_pending, match_pending;
