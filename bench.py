@@ -31,7 +31,9 @@ Objects on the JSON line besides the contract fields:
                     (profiles/*pmc_traffic*.json), accepted only if the kernel sources are the ones the file was measured on.
   roofline_c3       the same for BASELINE config 3 (64 x 1920x1080, detect only), 5 steps
   value_host_input  the reference's own measurement protocol on the same frames (src/perf/wrappers/vulkansift_wrapper.cpp:
-                    30-33): host images in, vksift_getFeaturesNumber + vksift_downloadFeatures (+ matches) out
+                    30-33): host images in, vksift_getFeaturesNumber + vksift_downloadFeatures (+ matches) out, strictly serial
+  value_host_input_pipelined  the same inputs and outputs with two buffer sets: the next batch's detection is queued before
+                    the current batch's results are fetched (the asynchronous API as vulkansift.h:43-47 intends)
   single_image_ms   BASELINE config 2 literally: ONE 640x480 image through plain vksift_detectFeatures (+ matchFeatures),
                     10 warm-up + 100 timed runs as src/perf/perf_runtime.cpp:63-81
   cpu_baseline      the CPU oracle (scalar C port of the same algorithm) rebuilt -O3 -march=native on the box, one frame per
@@ -226,31 +228,74 @@ def cpu_baseline(frames, do_match, per_worker=2):
 # ---------------------------------------------------------------------------------------------------------------------
 def reference_protocol(api, inst, frames, W, H, B, do_match, steps):
     """src/perf/wrappers/vulkansift_wrapper.cpp:30-33 per frame = detect(host image) + getFeaturesNumber + downloadFeatures; here
-    per batch of B frames, followed by the self-match and the download of its records. Returns frames/s."""
+    per batch of B frames, followed by the self-match and the download of its records. Strictly serial: nothing is queued while
+    the host waits or copies. Returns frames/s."""
     lib = api.lib()
     cap = inst.cfg.max_nb_sift_per_buffer
     feat_buf = np.zeros(cap, api.FEATURE_DTYPE)
     match_buf = np.zeros(cap, api.MATCH_DTYPE)
+    ids = list(range(B))
+    ptrs = inst.imagePointerArray(frames)   # what a C caller passes: the marshalling of 128 numpy arrays is not part of the protocol
 
     def step():
-        inst.detectFeaturesBatch(frames, 0)
+        inst.detectFeaturesBatchPtrs(ptrs, B, W, H, 0)
         for i in range(B):
             n = lib.vksift_getFeaturesNumber(inst._h, i)
             if n:
                 lib.vksift_downloadFeatures(inst._h, feat_buf.ctypes.data, i)
         if do_match:
-            for i0 in range(0, B, 64):
-                ids = list(range(i0, min(B, i0 + 64)))
-                inst.matchFeaturesBatch(ids, ids)
-                for k in range(len(ids)):
-                    if lib.vksift_ext_getMatchesNumberBatch(inst._h, k):
-                        lib.vksift_ext_downloadMatchesBatch(inst._h, k, match_buf.ctypes.data)
+            inst.matchFeaturesBatch(ids, ids)
+            for k in range(B):
+                if lib.vksift_ext_getMatchesNumberBatch(inst._h, k):
+                    lib.vksift_ext_downloadMatchesBatch(inst._h, k, match_buf.ctypes.data)
 
     step()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     dt = time.perf_counter() - t0
+    return B * steps / dt
+
+
+def pipelined_protocol(api, dev_index, frames, W, H, B, do_match, steps):
+    """The same inputs and outputs per frame as reference_protocol (host images in; counts, features and match records out), with
+    the asynchronous API used the way include/vulkansift/vulkansift.h:43-47 intends: two sets of B SIFT buffers, the detection of
+    the next batch is queued BEFORE the results of the current one are fetched, so the host's staging and result copies run beside
+    the GPU work instead of in front of and behind it. Accessors wait for the detection that filled the buffer they read, not for
+    the one queued after it. Returns frames/s."""
+    lib = api.lib()
+    cfg = api.default_config(sift_buffer_count=2 * B, gpu_device_index=dev_index, input_image_max_size=max(W * H, 1024))
+    feat_buf = np.zeros(cfg.max_nb_sift_per_buffer, api.FEATURE_DTYPE)
+    match_buf = np.zeros(cfg.max_nb_sift_per_buffer, api.MATCH_DTYPE)
+    with api.Instance(cfg, batch_capacity=B) as inst:
+        ids = [list(range(B)), list(range(B, 2 * B))]
+        ptrs = inst.imagePointerArray(frames)
+
+        def collect(s):
+            for i in ids[s]:
+                if lib.vksift_getFeaturesNumber(inst._h, i):
+                    lib.vksift_downloadFeatures(inst._h, feat_buf.ctypes.data, i)
+            if do_match:
+                for k in range(B):
+                    if lib.vksift_ext_getMatchesNumberBatch(inst._h, k):
+                        lib.vksift_ext_downloadMatchesBatch(inst._h, k, match_buf.ctypes.data)
+
+        def run(n):
+            inst.detectFeaturesBatchPtrs(ptrs, B, W, H, 0)
+            if do_match:
+                inst.matchFeaturesBatch(ids[0], ids[0])
+            for it in range(n):
+                cur, nxt = it & 1, (it & 1) ^ 1
+                if it + 1 < n:
+                    inst.detectFeaturesBatchPtrs(ptrs, B, W, H, nxt * B)   # queued behind the matching of `cur`; staged while the GPU works
+                collect(cur)
+                if it + 1 < n and do_match:
+                    inst.matchFeaturesBatch(ids[nxt], ids[nxt])    # the match slots are free again once `cur`'s records are out
+
+        run(2)
+        t0 = time.perf_counter()
+        run(steps)
+        dt = time.perf_counter() - t0
     return B * steps / dt
 
 
@@ -363,10 +408,10 @@ def main():
                              pyramid_precision_mode=1 if args.fp16 else 0)
     inst = api.Instance(cfg, batch_capacity=B)
 
+    all_ids = list(range(B))
+
     def match_all():
-        for i0 in range(0, B, 64):      # 2-NN self-match of every frame, batched launches of <= 64 pairs
-            ids = list(range(i0, min(B, i0 + 64)))
-            inst.matchFeaturesBatch(ids, ids)
+        inst.matchFeaturesBatch(all_ids, all_ids)      # 2-NN self-match of every frame (the library runs launches of <= 64 pairs)
 
     def step():
         for k in range(NSUB):
@@ -462,8 +507,13 @@ def main():
     if not args.no_extras and world == 1:
         # (before the sharded-match leg: once RCCL has created its streams, HIP maps this library's streams onto the hardware queues
         # differently and the per-stage intervals of an overlapped detection get attributed differently — same step time)
-        extras["value_host_input"] = reference_protocol(api, inst, frames, W, H, B, do_match, 3)
+        extras["value_host_input"] = reference_protocol(api, inst, frames, W, H, B, do_match, 6)
     inst.close()
+    if not args.no_extras and world == 1:
+        try:
+            extras["value_host_input_pipelined"] = pipelined_protocol(api, dev.index, frames, W, H, B, do_match, 12)
+        except Exception as e:  # noqa: BLE001
+            extras["value_host_input_pipelined"] = {"error": repr(e)[:300]}
     if not args.no_extras and world == 1:
         # in a fresh process: how HIP maps an instance's dozen streams onto the four hardware queues depends on the streams the
         # process created before (the 640x480 instance above), and with it the attribution of an overlapped detection's time to

@@ -85,7 +85,7 @@ def test_bench_step_back_to_back_equals_single_image_and_oracle(vk, oracle, prof
         assert m.tobytes() == oracle.match_2nn(feats[b], feats[b]).tobytes(), b
 
 
-def test_bench_step_host_protocol_back_to_back(vk):
+def test_bench_step_host_protocol_back_to_back(vk, oracle):
     """the same three steps through the host-image entry (vksift_ext_detectFeaturesBatch): the staging buffer and d_input are
     recycled by the next call while the previous detection may still be running"""
     B, W, H = 128, 640, 480
@@ -94,12 +94,49 @@ def test_bench_step_host_protocol_back_to_back(vk):
     with vk.Instance(cfg, batch_capacity=B) as inst:
         for k in range(3):
             inst.detectFeaturesBatch(list(sets[k]), 0)
-            for ids in (list(range(0, 64)), list(range(64, 128))):
-                inst.matchFeaturesBatch(ids, ids)
+            inst.matchFeaturesBatch(list(range(B)), list(range(B)))       # one call, 128 pairs (two runs of 64 inside)
+        matches = [inst.downloadMatchesBatch(k) for k in range(B)]      # packed download from the second pair on
         feats = [inst.downloadFeatures(i) for i in range(B)]
     single = _single_image_reference(vk, sets[2], input_image_max_size=W * H)
     for i in range(B):
         assert feats[i].tobytes() == single[i].tobytes(), i
+    for k in (0, 1, 63, 64, 100, 127):
+        assert matches[k].tobytes() == oracle.match_2nn(feats[k], feats[k]).tobytes(), k
+    for k in range(B):                                                   # every pair: shape + self-match property
+        assert len(matches[k]) == len(feats[k]) and np.array_equal(matches[k]["idx_a"], np.arange(len(feats[k]), dtype=np.uint32))
+        assert np.all(matches[k]["dist_a_b1"] == 0)
+
+
+def test_pipelined_two_buffer_sets_like_the_bench_leg(vk, oracle):
+    """bench.py's value_host_input_pipelined: 2 x 128 buffers, detection of the next batch queued before the results of the current
+    one are fetched. Accessors must wait for the detection that filled THEIR buffer (sequence-numbered completion events), results
+    must be those of the right frame set, and vksift_isBufferAvailable must tell the two sets apart."""
+    B, W, H = 128, 640, 480
+    sets = _feat_sets(vk, B, W, H, 0x5EED0000)
+    cfg = vk.default_config(sift_buffer_count=2 * B, input_image_max_size=W * H)
+    ids = [list(range(B)), list(range(B, 2 * B))]
+    got = {}
+    with vk.Instance(cfg, batch_capacity=B) as inst:
+        inst.detectFeaturesBatch(list(sets[0]), 0)
+        inst.matchFeaturesBatch(ids[0], ids[0])
+        for it in range(3):
+            cur, nxt = it & 1, (it & 1) ^ 1
+            if it + 1 < 3:
+                inst.detectFeaturesBatch(list(sets[it + 1]), nxt * B)
+            feats = [inst.downloadFeatures(i) for i in ids[cur]]
+            matches = [inst.downloadMatchesBatch(k) for k in (0, 64, 127)]
+            if it + 1 < 3:
+                # the set just fetched is idle, the set being detected is not (unless the GPU has already finished it)
+                assert inst.isBufferAvailable(ids[cur][5])
+                inst.matchFeaturesBatch(ids[nxt], ids[nxt])
+            got[it] = (feats, matches)
+    for it in (1, 2):
+        single = _single_image_reference(vk, sets[it][::17], input_image_max_size=W * H)
+        feats, matches = got[it]
+        for j, i in enumerate(range(0, B, 17)):
+            assert feats[i].tobytes() == single[j].tobytes(), (it, i)
+        for k, m in zip((0, 64, 127), matches):
+            assert m.tobytes() == oracle.match_2nn(feats[k], feats[k]).tobytes(), (it, k)
 
 
 def test_c5_share_device_input_back_to_back(vk, oracle):

@@ -277,6 +277,17 @@ class Instance:
         lib().vksift_ext_detectFeaturesBatch(self._h, ptrs, len(imgs), w, h, first_gpu_buffer_id)
         _check_pending()
 
+    @staticmethod
+    def imagePointerArray(images):
+        """the `const uint8_t *const *images` argument of vksift_ext_detectFeaturesBatch for a list of C-contiguous uint8 arrays
+        (which must stay alive): a caller that submits the same frame objects again builds it once"""
+        assert all(im.dtype == np.uint8 and im.flags["C_CONTIGUOUS"] for im in images)
+        return (C.c_void_p * len(images))(*[im.ctypes.data for im in images])
+
+    def detectFeaturesBatchPtrs(self, ptrs, count, width, height, first_gpu_buffer_id):
+        lib().vksift_ext_detectFeaturesBatch(self._h, ptrs, count, width, height, first_gpu_buffer_id)
+        _check_pending()
+
     def detectFeaturesBatchDevice(self, dev_ptr, count, width, height, first_gpu_buffer_id):
         lib().vksift_ext_detectFeaturesBatchDevice(self._h, dev_ptr, count, width, height, first_gpu_buffer_id)
         _check_pending()

@@ -9,11 +9,8 @@
 void wait_for_buffer(vksift_Instance inst, uint32_t buf)
 {
   vksift_hip_set_device(inst->device);
-  if (!inst->bufs[buf].counts_valid || (inst->detect_pending && buf >= inst->detect_first_buf && buf < inst->detect_first_buf + inst->detect_count))
-  {
-    vksift_hip_event_sync(inst->ev_detect);
-    mark_detect_done(inst);
-  }
+  if (!counts_valid(inst, buf))
+    wait_detect_seq(inst, inst->bufs[buf].seq); /* the detection that filled THIS buffer, not the latest one */
   if (inst->match_pending && inst->match_busy[buf])
   {
     vksift_hip_event_sync(inst->ev_match);
@@ -67,15 +64,21 @@ uint32_t vksift_getFeaturesNumber(vksift_Instance instance, const uint32_t gpu_b
 static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr, uint32_t buf)
 {
   const BufferInfo *b = &inst->bufs[buf];
-  const uint32_t first = inst->detect_first_buf, count = inst->detect_count;
+  const DetectSlot *det = &inst->det_ring[b->seq % VKSIFT_DETECT_RING];
+  if (b->seq == 0 || det->seq != b->seq)
+    return false; /* filled from the host, or by a detection whose record has left the ring */
+  const uint32_t first = det->first, count = det->count;
   if (count < VKSIFT_DL_BATCH_MIN || buf < first || buf >= first + count || b->nb_sections == 0 || b->is_packed)
     return false;
   /* The packed copy moves EVERY buffer of the detection: a caller that samples one frame of 128 must not pay for the other 127
    * (nor for the staging memory). The first download after a detection therefore takes the per-section copies; a second one
    * says the caller walks the batch, and the rest of it comes out of one packed copy. */
-  if (!inst->dl_valid && inst->dl_hits++ == 0 && !inst->dl_eager)
+  const bool cached = inst->dl_valid && inst->dl_seq == b->seq;
+  if (inst->dl_hits_seq != b->seq)
+    inst->dl_hits_seq = b->seq, inst->dl_hits = 0;
+  if (!cached && inst->dl_hits++ == 0 && !inst->dl_eager)
     return false;
-  if (!(inst->dl_valid && inst->dl_first == first && inst->dl_count == count))
+  if (!cached)
   {
     /* every buffer of the batch shares the section table of `b` (one resolution per batched detection) */
     if (!inst->dl_row)
@@ -86,8 +89,7 @@ static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr,
     for (uint32_t i = 0; i < count; i++)
     {
       const BufferInfo *bi = &inst->bufs[first + i];
-      if (bi->nb_sections != b->nb_sections || bi->is_packed || memcmp(bi->sec_off, b->sec_off, sizeof(uint32_t) * b->nb_sections) != 0 ||
-          memcmp(bi->sec_cap, b->sec_cap, sizeof(uint32_t) * b->nb_sections) != 0)
+      if (bi->seq != b->seq)
         return false; /* a buffer of the range was refilled by something else since */
       const uint32_t n = buffer_counts(inst, first + i, NULL, false);
       inst->dl_row[i] = rows;
@@ -123,14 +125,42 @@ static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr,
       for (uint32_t k = 0; k < n; k++)
         ids[k] = first + i0 + k;
       if (vksift_hip_pack_features(inst->d_feats, inst->buf_stride, ids, inst->dl_row + i0, n, b->nb_sections, b->sec_off, b->sec_cap, inst->d_found,
-                                   VKSIFT_MAX_OCTAVES, inst->d_dl, max_rows, inst->stream) != 0)
+                                   VKSIFT_MAX_OCTAVES, inst->d_dl, max_rows, inst->dl_stream) != 0)
         return false;
     }
-    if (vksift_hip_memcpy_d2h(inst->h_dl, inst->d_dl, bytes, inst->stream) != 0 || vksift_hip_stream_sync(inst->stream) != 0)
-      return false;
-    inst->dl_first = first, inst->dl_count = count, inst->dl_valid = true;
+    /* the copy goes in a few pieces with an event each: a caller that walks the buffers in order copies buffer i out of pinned
+     * memory while the pieces behind it are still on the bus */
+    uint32_t nch = (uint32_t)(bytes / ((size_t)4 << 20)) + 1u;
+    if (nch > VKSIFT_DL_CHUNKS)
+      nch = VKSIFT_DL_CHUNKS;
+    for (uint32_t k = 0; k < nch; k++)
+    {
+      const size_t lo = bytes * k / nch, hi = bytes * (k + 1) / nch;
+      if (hi > lo && vksift_hip_memcpy_d2h(inst->h_dl + lo, inst->d_dl + lo, hi - lo, inst->dl_stream) != 0)
+        return false;
+      if (!inst->dl_ev[k])
+        inst->dl_ev[k] = vksift_hip_event_create();
+      if (!inst->dl_ev[k] || vksift_hip_event_record(inst->dl_ev[k], inst->dl_stream) != 0)
+        return false;
+      inst->dl_chunk_end[k] = hi;
+    }
+    inst->dl_chunks = nch, inst->dl_chunks_done = 0;
+    inst->dl_first = first, inst->dl_count = count, inst->dl_seq = b->seq, inst->dl_valid = true;
   }
   const uint32_t i = buf - first;
+  {
+    /* wait for the pieces that hold this buffer's records */
+    const size_t need = (size_t)inst->dl_row[i + 1] * FEAT_BYTES;
+    while (inst->dl_chunks_done < inst->dl_chunks && (inst->dl_chunks_done == 0 || inst->dl_chunk_end[inst->dl_chunks_done - 1] < need))
+    {
+      if (vksift_hip_event_sync(inst->dl_ev[inst->dl_chunks_done]) != 0)
+      {
+        inst->dl_valid = false;
+        return false;
+      }
+      inst->dl_chunks_done++;
+    }
+  }
   memcpy(feats_ptr, inst->h_dl + (size_t)inst->dl_row[i] * FEAT_BYTES, (size_t)(inst->dl_row[i + 1] - inst->dl_row[i]) * FEAT_BYTES);
   return true;
 }
@@ -151,7 +181,7 @@ void vksift_downloadFeatures(vksift_Instance instance, vksift_Feature *feats_ptr
   const uint8_t *base = inst->d_feats + (uint64_t)gpu_buffer_id * inst->buf_stride;
   if (b->nb_sections == 0)
   {
-    HIP_CHECK(vksift_hip_memcpy_d2h(feats_ptr, base, (size_t)b->nb_stored * FEAT_BYTES, inst->stream), "feature download");
+    HIP_CHECK(vksift_hip_memcpy_d2h(feats_ptr, base, (size_t)b->nb_stored * FEAT_BYTES, inst->dl_stream), "feature download");
   }
   else
   {
@@ -161,12 +191,12 @@ void vksift_downloadFeatures(vksift_Instance instance, vksift_Feature *feats_ptr
     for (uint32_t o = 0; o < b->nb_sections; o++)
     {
       HIP_CHECK(vksift_hip_memcpy_d2h((uint8_t *)feats_ptr + (size_t)out * FEAT_BYTES, base + (size_t)b->sec_off[o] * FEAT_BYTES, (size_t)cnt[o] * FEAT_BYTES,
-                                      inst->stream),
+                                      inst->dl_stream),
                 "feature download");
       out += cnt[o];
     }
   }
-  HIP_CHECK(vksift_hip_stream_sync(inst->stream), "feature download");
+  HIP_CHECK(vksift_hip_stream_sync(inst->dl_stream), "feature download");
   return;
 gpu_error:
   logError(LOG_TAG, "vksift_downloadFeatures(): the device-to-host copy of the features failed.");
@@ -194,9 +224,8 @@ void vksift_uploadFeatures(vksift_Instance instance, const vksift_Feature *feats
   b->is_packed = true;
   b->nb_stored = nb_feats;
   inst->cache_valid[gpu_buffer_id] = false;
-  inst->dl_valid = false;
   b->nb_sections = 0;
-  b->counts_valid = true;
+  b->seq = 0; /* host-filled: nothing to wait for, and no longer part of a detection's packed download */
   return;
 gpu_error:
   logError(LOG_TAG, "vksift_uploadFeatures(): the host-to-device copy of the features failed.");

@@ -4,8 +4,11 @@
 #include "vksift_internal.h"
 #include <pthread.h>
 
-/* Host copy of the caller's images into the pinned staging buffer. A batch is tens of megabytes: one thread moves ~10 GB/s,
- * which made this copy as long as the detection itself (39 MB per 128 VGA frames: 4 ms); up to four threads share it. */
+/* Host copy of the caller's images into the pinned staging buffer (the caller may reuse its memory as soon as the call returns,
+ * sift_memory.c:943). A batch is tens of megabytes: one thread moves ~10 GB/s, which made this copy as long as the detection
+ * itself (39 MB per 128 VGA frames: 4 ms). A small pool of persistent workers shares it (creating threads per call cost as
+ * much as a chunk's copy), and the batch goes chunk by chunk: the host-to-device copy of chunk i runs while chunk i+1 is staged. */
+enum { STAGE_MAXT = 8 };
 typedef struct
 {
   uint8_t *dst;
@@ -14,38 +17,88 @@ typedef struct
   size_t img_bytes;
 } StageJob;
 
-static void *stage_worker(void *p)
+static struct
 {
-  const StageJob *j = (const StageJob *)p;
+  pthread_mutex_t user;     /* one staging operation at a time (instances on different threads share the pool) */
+  pthread_mutex_t mu;
+  pthread_cond_t cv_work, cv_done;
+  pthread_t th[STAGE_MAXT];
+  StageJob job[STAGE_MAXT];
+  uint64_t gen[STAGE_MAXT]; /* generation each worker has to run (0: none yet) */
+  uint64_t cur;
+  uint32_t pending, nworkers;
+  bool started;
+} g_stage = {.user = PTHREAD_MUTEX_INITIALIZER, .mu = PTHREAD_MUTEX_INITIALIZER, .cv_work = PTHREAD_COND_INITIALIZER, .cv_done = PTHREAD_COND_INITIALIZER};
+
+static void stage_copy(const StageJob *j)
+{
   for (uint32_t i = j->i0; i < j->i1; i++)
     memcpy(j->dst + (size_t)i * j->img_bytes, j->images[i], j->img_bytes);
+}
+
+static void *stage_worker(void *p)
+{
+  const uint32_t id = (uint32_t)(uintptr_t)p;
+  uint64_t seen = 0;
+  pthread_mutex_lock(&g_stage.mu);
+  for (;;)
+  {
+    while (g_stage.gen[id] == seen)
+      pthread_cond_wait(&g_stage.cv_work, &g_stage.mu);
+    seen = g_stage.gen[id];
+    const StageJob j = g_stage.job[id];
+    pthread_mutex_unlock(&g_stage.mu);
+    stage_copy(&j);
+    pthread_mutex_lock(&g_stage.mu);
+    if (--g_stage.pending == 0)
+      pthread_cond_signal(&g_stage.cv_done);
+  }
   return NULL;
 }
 
-static void stage_images(uint8_t *dst, const uint8_t *const *images, uint32_t count, size_t img_bytes)
+/* images [i0, i1) -> dst, shared by the caller and up to STAGE_MAXT - 1 workers; returns when all of it is in place */
+static void stage_images(uint8_t *dst, const uint8_t *const *images, uint32_t i0, uint32_t i1, size_t img_bytes)
 {
-  enum { MAXT = 4 };
-  uint32_t nt = 1;
-  if ((size_t)count * img_bytes >= ((size_t)8 << 20) && count >= 2 * MAXT)
-    nt = MAXT;
-  StageJob job[MAXT];
-  pthread_t th[MAXT];
-  bool started[MAXT] = {false};
-  for (uint32_t t = 0; t < nt; t++)
+  const uint32_t n = i1 - i0;
+  StageJob all = {dst, images, i0, i1, img_bytes};
+  if ((size_t)n * img_bytes < ((size_t)2 << 20) || n < 2)
   {
-    job[t].dst = dst, job[t].images = images, job[t].img_bytes = img_bytes;
-    job[t].i0 = (uint32_t)((uint64_t)count * t / nt), job[t].i1 = (uint32_t)((uint64_t)count * (t + 1) / nt);
+    stage_copy(&all);
+    return;
   }
-  for (uint32_t t = 1; t < nt; t++)
-    started[t] = pthread_create(&th[t], NULL, stage_worker, &job[t]) == 0;
-  stage_worker(&job[0]);
-  for (uint32_t t = 1; t < nt; t++)
+  pthread_mutex_lock(&g_stage.user);
+  if (!g_stage.started)
   {
-    if (started[t])
-      pthread_join(th[t], NULL);
-    else
-      stage_worker(&job[t]); /* no thread: this one does the share */
+    g_stage.started = true;
+    for (uint32_t t = 0; t + 1 < STAGE_MAXT; t++)
+      if (pthread_create(&g_stage.th[g_stage.nworkers], NULL, stage_worker, (void *)(uintptr_t)g_stage.nworkers) == 0)
+      {
+        pthread_detach(g_stage.th[g_stage.nworkers]);
+        g_stage.nworkers++;
+      }
   }
+  uint32_t parts = g_stage.nworkers + 1u;
+  if (parts > n)
+    parts = n;
+  pthread_mutex_lock(&g_stage.mu);
+  g_stage.cur++;
+  g_stage.pending = parts - 1u;
+  for (uint32_t t = 1; t < parts; t++)
+  {
+    StageJob *j = &g_stage.job[t - 1];
+    *j = all;
+    j->i0 = i0 + (uint32_t)((uint64_t)n * t / parts), j->i1 = i0 + (uint32_t)((uint64_t)n * (t + 1) / parts);
+    g_stage.gen[t - 1] = g_stage.cur;
+  }
+  pthread_cond_broadcast(&g_stage.cv_work);
+  pthread_mutex_unlock(&g_stage.mu);
+  all.i1 = i0 + (uint32_t)((uint64_t)n / parts);
+  stage_copy(&all); /* the caller takes the first share */
+  pthread_mutex_lock(&g_stage.mu);
+  while (g_stage.pending != 0)
+    pthread_cond_wait(&g_stage.cv_done, &g_stage.mu);
+  pthread_mutex_unlock(&g_stage.mu);
+  pthread_mutex_unlock(&g_stage.user);
 }
 
 
@@ -127,6 +180,7 @@ typedef struct
   bool overlap;   /* scale-space on its own stream and buffer (ping-pong), see detect_impl */
   bool upload;    /* host images were staged in h_input and have to be copied to d_input */
   bool capturing; /* the sequence is being captured into a hipGraph: no host-visible events inside */
+  const uint8_t *const *images; /* upload: the caller's images, staged chunk by chunk while the sequence is enqueued */
   const uint8_t *d_src;
   uint32_t w, h, count, first_buf;
   size_t img_bytes;
@@ -184,39 +238,49 @@ static void build_jobs(DetectCtx *c)
  * (sift_detector.c:1039-1079) has no counterpart: the extrema stage forms D[s] = G[s+1] - G[s] from the Gaussian planes.
  * *g0_done: plane 0 of this octave was already written by the previous octave's scale-S pass; on return it tells the same
  * for the next octave. */
-static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool *g0_done)
+/* images [first, first + count) of the batch only: the same launches on a slice of the planes */
+static vksift_hip_Plane plane_sub(vksift_Instance inst, vksift_hip_Plane p, uint32_t first)
+{
+  p.base = (float *)((uint8_t *)p.base + (uint64_t)first * p.img_stride * pyr_texel_bytes(inst));
+  return p;
+}
+
+enum { PYR_FIRST_GROUP = 1, PYR_LAST_GROUP = 2 };
+static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint32_t first, uint32_t count, int group_flags, bool *g0_done)
 {
   vksift_Instance inst = c->inst;
   const PyrLayout *L = c->L;
   uint32_t nb_o = 0;
+#define PL(oct, layer) plane_sub(inst, plane_at(inst, (oct), L->gauss_off[(oct)], (layer)), first)
   vksift_hip_range_push("Scale space construction");
   if (o == 0)
   {
-    if (c->prof)
+    if (c->prof && (group_flags & PYR_FIRST_GROUP))
       vksift_hip_event_record(c->PS->ev_pt[0], sp);
     /* u8 -> fp32 (2x LINEAR blit when up-sampling) + seed blur: one fused pass when the shape allows it, else the blit goes
      * into the (still unused) layer-1 slot and is seed-blurred into layer 0 */
+    const uint8_t *src = c->d_src + (size_t)first * c->img_bytes;
     int fused = -1;
     if (L->w[0] == 2 * c->w && L->h[0] == 2 * c->h)
     {
-      fused = vksift_hip_seed_upsampled(c->d_src, c->w, c->h, c->img_bytes, plane_at(inst, 0, L->gauss_off[0], 0), &inst->taps[0], inst->ntaps[0], c->count, sp);
+      fused = vksift_hip_seed_upsampled(src, c->w, c->h, c->img_bytes, PL(0, 0), &inst->taps[0], inst->ntaps[0], count, sp);
       if (fused > 0)
         TRY(fused, "fused up-sampling + seed blur");
     }
     else if (L->w[0] == c->w && L->h[0] == c->h)
     {
-      fused = vksift_hip_seed_direct(c->d_src, c->w, c->h, c->img_bytes, plane_at(inst, 0, L->gauss_off[0], 0), &inst->taps[0], inst->ntaps[0], c->count, sp);
+      fused = vksift_hip_seed_direct(src, c->w, c->h, c->img_bytes, PL(0, 0), &inst->taps[0], inst->ntaps[0], count, sp);
       if (fused > 0)
         TRY(fused, "fused input conversion + seed blur");
     }
     if (fused < 0)
     {
-      vksift_hip_Plane tmp = plane_at(inst, 0, L->gauss_off[0], 1);
-      TRY(vksift_hip_input_blit(c->d_src, c->w, c->h, c->img_bytes, tmp, c->count, sp), "input blit");
-      TRY(vksift_hip_blur(tmp, plane_at(inst, 0, L->gauss_off[0], 0), &inst->taps[0], inst->ntaps[0], c->count, sp), "seed blur");
+      vksift_hip_Plane tmp = PL(0, 1);
+      TRY(vksift_hip_input_blit(src, c->w, c->h, c->img_bytes, tmp, count, sp), "input blit");
+      TRY(vksift_hip_blur(tmp, PL(0, 0), &inst->taps[0], inst->ntaps[0], count, sp), "seed blur");
     }
     /* d_input has been consumed: the next upload (possibly on another stream) may overwrite it after this point */
-    if (!c->capturing)
+    if (!c->capturing && (group_flags & PYR_LAST_GROUP))
     {
       TRY(vksift_hip_event_record(inst->ev_input_free, sp), "event record");
       inst->input_free_valid = true;
@@ -224,12 +288,12 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool 
     nb_o++;
   }
   else if (!*g0_done)
-    TRY(vksift_hip_downsample(plane_at(inst, o - 1, L->gauss_off[o - 1], inst->S), plane_at(inst, o, L->gauss_off[o], 0), c->count, sp), "downsample");
+    TRY(vksift_hip_downsample(PL(o - 1, inst->S), PL(o, 0), count, sp), "downsample");
   *g0_done = false;
   for (uint32_t s = 1; s < inst->S + 3; s++)
   {
-    const vksift_hip_Plane srcp = plane_at(inst, o, L->gauss_off[o], s - 1);
-    vksift_hip_Plane dstp = plane_at(inst, o, L->gauss_off[o], s);
+    const vksift_hip_Plane srcp = PL(o, s - 1);
+    vksift_hip_Plane dstp = PL(o, s);
     /* consecutive launches of the chain walk the batch in opposite directions: launch s starts on the planes launch s-1 wrote
      * last, which are still in the Infinity Cache (a whole-batch plane is 2.5x the cache: in the same direction every read misses) */
     dstp.reverse = inst->alt_order ? (s & 1u) : 0u;
@@ -237,21 +301,22 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, bool 
     if (s == inst->S && o + 1 < L->n_oct)
     {
       /* scale S also seeds the next octave (sift_detector.c:1003-1034): stored by the same pass when the sizes halve exactly */
-      fused_ds = vksift_hip_blur_downsample(srcp, dstp, plane_at(inst, o + 1, L->gauss_off[o + 1], 0), &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], c->count, sp);
+      fused_ds = vksift_hip_blur_downsample(srcp, dstp, PL(o + 1, 0), &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, sp);
       if (fused_ds > 0)
         TRY(fused_ds, "blur + down-sampling");
       if (fused_ds == 0)
         *g0_done = true;
     }
     if (fused_ds < 0)
-      TRY(vksift_hip_blur(srcp, dstp, &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], c->count, sp), "blur");
+      TRY(vksift_hip_blur(srcp, dstp, &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, sp), "blur");
     nb_o++;
   }
+#undef PL
   vksift_hip_range_pop();
   if (o == 0)
   {
     c->nblur += nb_o;
-    if (c->prof)
+    if (c->prof && (group_flags & PYR_LAST_GROUP))
       vksift_hip_event_record(c->PS->ev_pt[1], sp);
   }
   return 0;
@@ -276,17 +341,51 @@ static int enqueue_detection(DetectCtx *c)
   vksift_hip_stream st = inst->stream;
   vksift_hip_stream sp = c->overlap ? inst->pyr_stream : st;
 
+  bool g0_done = false, oct0_done = false;
   if (c->upload)
   {
-    /* behind the previous reader of d_input, whichever stream that detection's seed pass ran on */
+    /* The copies run on a stream of their own, behind the previous reader of d_input only (the seed pass of the previous
+     * detection, whichever stream it ran on) — not behind the gates of the scale-space stream: the staging buffer is then free
+     * again (ev_staging) as soon as the bus has taken the images, and a caller that queues the next batch early is not held up
+     * until this detection's turn on the GPU has come. Captured sequences keep everything on the capturing stream.
+     * The batch goes in groups: stage a group, queue its copy, queue octave 0's scale-space for THAT group behind the copy, stage
+     * the next group meanwhile. 128 VGA frames are 39 MB = 1.6 ms on the bus: as one copy in front of whole-batch launches that
+     * is 1.6 ms of idle GPU; in 4 groups of 32 the bus and the blur chain work side by side and octave 0 is complete 0.4 ms
+     * after the last byte has arrived. (Groups below 32 frames lose more in launch efficiency than they hide.) */
+    vksift_hip_stream su = c->capturing ? sp : inst->up_stream;
     if (inst->input_free_valid && !c->capturing)
-      TRY(vksift_hip_stream_wait_event(sp, inst->ev_input_free), "input buffer recycle");
-    TRY(vksift_hip_memcpy_h2d(inst->d_input, inst->h_input, c->img_bytes * c->count, sp), "image upload");
+      TRY(vksift_hip_stream_wait_event(su, inst->ev_input_free), "input buffer recycle");
+    uint32_t per = (uint32_t)((((size_t)4 << 20) + c->img_bytes - 1) / c->img_bytes); /* >= 4 MB per copy */
+    if (per < (c->count + VKSIFT_UP_GROUPS - 1u) / VKSIFT_UP_GROUPS)
+      per = (c->count + VKSIFT_UP_GROUPS - 1u) / VKSIFT_UP_GROUPS;
+    if (per < 32u)
+      per = 32u;
+    const bool grouped = !c->capturing && L->n_oct > 0 && c->count >= 2u * per;
+    if (!grouped)
+      per = c->count;
+    for (uint32_t i0 = 0, g = 0; i0 < c->count; g++)
+    {
+      uint32_t i1 = i0 + per;
+      if (i1 >= c->count || c->count - i1 < per / 2u)
+        i1 = c->count; /* a tail shorter than half a group joins the last one */
+      stage_images(inst->h_input, c->images, i0, i1, c->img_bytes);
+      TRY(vksift_hip_memcpy_h2d(inst->d_input + (size_t)i0 * c->img_bytes, inst->h_input + (size_t)i0 * c->img_bytes, c->img_bytes * (i1 - i0), su), "image upload");
+      if (grouped)
+      {
+        TRY(vksift_hip_event_record(inst->ev_up[g], su), "event record");
+        TRY(vksift_hip_stream_wait_event(sp, inst->ev_up[g]), "image upload");
+        TRY(enqueue_pyramid(c, 0, sp, i0, i1 - i0, (i0 == 0 ? PYR_FIRST_GROUP : 0) | (i1 == c->count ? PYR_LAST_GROUP : 0), &g0_done), "scale space construction");
+        oct0_done = true;
+      }
+      i0 = i1;
+    }
     if (!c->capturing)
     {
-      /* the pinned staging buffer is free again as soon as this copy has run */
-      TRY(vksift_hip_event_record(inst->ev_staging, sp), "event record");
+      /* the pinned staging buffer is free again as soon as these copies have run; the seed pass waits for them */
+      TRY(vksift_hip_event_record(inst->ev_staging, su), "event record");
       inst->staging_pending = true;
+      if (!grouped)
+        TRY(vksift_hip_stream_wait_event(sp, inst->ev_staging), "image upload");
     }
   }
   if (c->prof)
@@ -295,9 +394,8 @@ static int enqueue_detection(DetectCtx *c)
   /* recClearBufferDataCmds (sift_detector.c:1081-1104) */
   TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, st), "counter reset");
 
-  bool g0_done = false;
-  for (uint32_t o = 0; o < L->n_oct; o++)
-    TRY(enqueue_pyramid(c, o, sp, &g0_done), "scale space construction");
+  for (uint32_t o = oct0_done ? 1u : 0u; o < L->n_oct; o++)
+    TRY(enqueue_pyramid(c, o, sp, 0, c->count, PYR_FIRST_GROUP | PYR_LAST_GROUP, &g0_done), "scale space construction");
   if (c->overlap)
   {
     TRY(vksift_hip_event_record(inst->ev_pyr_done, sp), "event record");
@@ -444,13 +542,13 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     inst->cur_h = h;
   }
   inst->cur_batch = count;
+  const uint64_t seq = inst->det_seq + 1u;
   for (uint32_t i = 0; i < count; i++)
   {
     set_buffer_sections(inst, first_buf + i, inst->lay.n_oct, w, h);
+    inst->bufs[first_buf + i].seq = seq;       /* its counters are valid once detection `seq` has completed */
     inst->cache_valid[first_buf + i] = false; /* the matcher's view of the buffer is rebuilt on its next matching */
   }
-  inst->dl_valid = false; /* and so is the batched download */
-  inst->dl_hits = 0;
 
   DetectCtx c;
   c.inst = inst, c.L = &inst->lay, c.PS = PS;
@@ -479,13 +577,10 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
       HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream, inst->ev_desc_start), "overlap gate");
   }
 
-  /* stage the images; the caller may reuse its memory as soon as we return (sift_memory.c:943) */
-  c.d_src = d_images;
-  if (images)
-  {
-    stage_images(inst->h_input, images, count, c.img_bytes);
-    c.d_src = inst->d_input;
-  }
+  /* host images are staged into pinned memory while the sequence is enqueued (enqueue_detection): the caller may reuse its
+   * memory as soon as we return (sift_memory.c:943) */
+  c.images = images;
+  c.d_src = images ? inst->d_input : d_images;
   build_jobs(&c);
 
   /* host-visible events (staging, completion, profiling) stay outside a captured region; a captured graph holds the address
@@ -494,6 +589,8 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   DetectGraph *dg = replay ? graph_lookup(inst, &c) : NULL;
   if (dg && dg->exec)
   {
+    if (images) /* the upload is a node of the graph: the staging buffer has to be filled before the replay */
+      stage_images(inst->h_input, images, 0, count, c.img_bytes);
     HIP_CHECK(vksift_hip_graph_launch(dg->exec, st), "detection graph launch");
     inst->graph_miss_run = 0;
   }
@@ -542,10 +639,12 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     PS->alg_bytes = inst->last_alg_bytes;
     PS->scan_bytes = inst->last_scan_bytes;
   }
-  HIP_CHECK(vksift_hip_event_record(inst->ev_detect, st), "event record");
-  inst->detect_pending = true;
-  inst->detect_first_buf = first_buf;
-  inst->detect_count = count;
+  {
+    DetectSlot *d = &inst->det_ring[seq % VKSIFT_DETECT_RING];
+    d->seq = seq, d->first = first_buf, d->count = count;
+    inst->det_seq = seq; /* from here on the buffers are "pending" even if the record below fails (wait_detect_seq then syncs a stale event: harmless) */
+    HIP_CHECK(vksift_hip_event_record(d->ev, st), "event record");
+  }
   return;
 
 gpu_error:

@@ -46,7 +46,6 @@ void set_buffer_sections(vksift_Instance inst, uint32_t buf, uint32_t n_oct, uin
   b->nb_sections = n_oct;
   b->in_w = w;
   b->in_h = h;
-  b->counts_valid = false;
   vksift_hm_section_caps(inst->cfg.max_nb_sift_per_buffer, n_oct, b->sec_cap);
   uint32_t off = 0;
   for (uint32_t o = 0; o < n_oct; o++)
@@ -184,6 +183,8 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
    * 20 % slower on MI355X (11.3k vs 14.1k frames/s). */
   inst->stream = vksift_hip_stream_create();
   inst->pyr_stream = vksift_hip_stream_create();
+  inst->dl_stream = vksift_hip_stream_create();
+  inst->up_stream = vksift_hip_stream_create();
   inst->ev_pyr_done = vksift_hip_event_create();
   inst->ev_desc_start = vksift_hip_event_create();
   inst->ev_input_free = vksift_hip_event_create();
@@ -200,9 +201,12 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     inst->use_graphs = !(e && e[0] == '0');
     inst->graph_max_pixels = (e && e[0] == '1') ? ~(uint64_t)0 : (uint64_t)640 * 480;
   }
-  inst->ev_detect = vksift_hip_event_create();
+  for (int i = 0; i < VKSIFT_DETECT_RING; i++)
+    inst->det_ring[i].ev = vksift_hip_event_create();
   inst->ev_match = vksift_hip_event_create();
   inst->ev_staging = vksift_hip_event_create();
+  for (uint32_t g = 0; g < VKSIFT_UP_GROUPS; g++)
+    inst->ev_up[g] = vksift_hip_event_create();
   for (int i = 0; i < 8; i++)
   {
     inst->prof[0].ev_t[i] = vksift_hip_event_create();
@@ -217,7 +221,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   inst->prof[1].ev_scan = vksift_hip_event_create();
   inst->ev_m[0] = vksift_hip_event_create();
   inst->ev_m[1] = vksift_hip_event_create();
-  ok = ok && inst->stream && inst->ev_detect && inst->ev_match;
+  ok = ok && inst->stream && inst->det_ring[0].ev && inst->det_ring[VKSIFT_DETECT_RING - 1].ev && inst->ev_match && inst->pyr_stream && inst->dl_stream && inst->up_stream;
   if (!ok)
   {
     logError(LOG_TAG, "vksift_createInstance() failed: device / pinned memory reservation");
@@ -240,10 +244,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   inst->cur_batch = 1;
   inst->lay = L;
   for (uint32_t b = 0; b < config->sift_buffer_count; b++)
-  {
-    set_buffer_sections(inst, b, L.n_oct, side, side);
-    inst->bufs[b].counts_valid = true;
-  }
+    set_buffer_sections(inst, b, L.n_oct, side, side); /* seq 0: nothing pending, the (zeroed) counters are valid */
 
   logInfo(LOG_TAG, "vksift_createInstance() success");
   return VKSIFT_SUCCESS;
@@ -264,6 +265,10 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_set_device(inst->device);
   if (inst->pyr_stream)
     vksift_hip_stream_sync(inst->pyr_stream);
+  if (inst->dl_stream)
+    vksift_hip_stream_sync(inst->dl_stream);
+  if (inst->up_stream)
+    vksift_hip_stream_sync(inst->up_stream);
   if (inst->stream)
     vksift_hip_stream_sync(inst->stream);
   vksift_hip_free(inst->d_pyr_buf[0]);
@@ -292,6 +297,8 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_free(inst->d_dl);
   vksift_hip_host_free(inst->h_dl);
   free(inst->dl_row);
+  for (uint32_t k = 0; k < VKSIFT_DL_CHUNKS; k++)
+    vksift_hip_event_destroy(inst->dl_ev[k]);
   for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
     vksift_hip_graph_destroy(inst->graphs[i].exec);
   vksift_hip_free(inst->rev.matches);
@@ -304,9 +311,12 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_host_free(inst->h_matches);
   free(inst->bufs);
   free(inst->match_busy);
-  vksift_hip_event_destroy(inst->ev_detect);
+  for (int i = 0; i < VKSIFT_DETECT_RING; i++)
+    vksift_hip_event_destroy(inst->det_ring[i].ev);
   vksift_hip_event_destroy(inst->ev_match);
   vksift_hip_event_destroy(inst->ev_staging);
+  for (uint32_t g = 0; g < VKSIFT_UP_GROUPS; g++)
+    vksift_hip_event_destroy(inst->ev_up[g]);
   for (int i = 0; i < 8; i++)
   {
     vksift_hip_event_destroy(inst->prof[0].ev_t[i]);
@@ -315,6 +325,8 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_event_destroy(inst->ev_m[0]);
   vksift_hip_event_destroy(inst->ev_m[1]);
   vksift_hip_stream_destroy(inst->pyr_stream);
+  vksift_hip_stream_destroy(inst->dl_stream);
+  vksift_hip_stream_destroy(inst->up_stream);
   vksift_hip_event_destroy(inst->ev_pyr_done);
   vksift_hip_event_destroy(inst->ev_desc_start);
   vksift_hip_event_destroy(inst->ev_input_free);
@@ -334,23 +346,37 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
 /* ------------------------------------------------------------------------------------------------ */
 /* synchronisation helpers (fences of the reference)                                                */
 /* ------------------------------------------------------------------------------------------------ */
-/* The stream is in-order: once the most recent detection has completed, every earlier one has too, so all the
- * host-side counter mirrors are valid. */
-void mark_detect_done(vksift_Instance inst)
-{
-  inst->detect_pending = false;
-  for (uint32_t b = 0; b < inst->cfg.sift_buffer_count; b++)
-    inst->bufs[b].counts_valid = true;
-}
+/* The stream is in-order: once a detection has completed, every earlier one has too, and the host mirrors of their counters
+ * are valid (counts_valid()). */
+void mark_detect_done(vksift_Instance inst) { inst->det_done = inst->det_seq; }
+
+/* polls the detections in flight; true while the LATEST one is still running */
 bool detect_running(vksift_Instance inst)
 {
-  if (!inst->detect_pending)
+  if (inst->det_done >= inst->det_seq)
     return false;
-  if (vksift_hip_event_busy(inst->ev_detect) == 1)
-    return true;
-  mark_detect_done(inst);
-  return false;
+  for (int i = 0; i < VKSIFT_DETECT_RING; i++)
+  {
+    const DetectSlot *d = &inst->det_ring[i];
+    if (d->seq > inst->det_done && vksift_hip_event_busy(d->ev) != 1)
+      inst->det_done = d->seq;
+  }
+  return inst->det_done < inst->det_seq;
 }
+
+/* blocks until detection `seq` has completed. Its ring slot may have been taken over by a later detection (more than
+ * VKSIFT_DETECT_RING in flight): waiting for that one is conservative, never wrong. */
+int wait_detect_seq(vksift_Instance inst, uint64_t seq)
+{
+  if (seq <= inst->det_done)
+    return 0;
+  const DetectSlot *d = &inst->det_ring[seq % VKSIFT_DETECT_RING];
+  const int e = vksift_hip_event_sync(d->ev);
+  if (d->seq > inst->det_done)
+    inst->det_done = d->seq;
+  return e;
+}
+
 bool match_running(vksift_Instance inst)
 {
   if (!inst->match_pending)
@@ -433,7 +459,8 @@ bool vksift_isBufferAvailable(vksift_Instance instance, const uint32_t gpu_buffe
   vksift_hip_set_device(instance->device);
   if (gpu_buffer_id >= instance->cfg.sift_buffer_count)
     return true;
-  if (detect_running(instance) && !instance->bufs[gpu_buffer_id].counts_valid)
+  (void)detect_running(instance);
+  if (!counts_valid(instance, gpu_buffer_id))
     return false;
   if (match_running(instance) && instance->match_busy[gpu_buffer_id])
     return false;

@@ -23,6 +23,8 @@
 #define LOG_TAG "VulkanSift"
 
 #define VKSIFT_DL_BATCH_MIN 8u
+#define VKSIFT_DL_CHUNKS 8u
+#define VKSIFT_UP_GROUPS 8u
 #define FEAT_BYTES 164u
 #define MATCH_BYTES 20u
 #define PITCH_ALIGN 64u
@@ -36,8 +38,20 @@ typedef struct
   uint32_t sec_off[VKSIFT_MAX_OCTAVES]; /* in features */
   uint32_t sec_cap[VKSIFT_MAX_OCTAVES];
   uint32_t in_w, in_h;  /* resolution of that detection */
-  bool counts_valid;    /* the host mirror of the per-octave counters is up to date */
+  uint64_t seq;         /* sequence number of the detection that last filled the buffer (0: filled from the host / never). The host
+                         * mirror of its per-octave counters is valid once that detection has completed (seq <= det_done) */
 } BufferInfo;
+
+/* One slot per detection in flight. A caller that pipelines (detection N+1 queued while it downloads the results of detection N,
+ * the way vksift_isBufferAvailable is meant to be used) waits for the detection that filled the buffer it reads, not for the
+ * latest one. The instance stream is in-order: a later detection's completion implies every earlier one's. */
+#define VKSIFT_DETECT_RING 4
+typedef struct
+{
+  vksift_hip_event ev;
+  uint64_t seq;
+  uint32_t first, count; /* SIFT buffers it filled */
+} DetectSlot;
 
 typedef struct
 {
@@ -144,11 +158,15 @@ struct vksift_Instance_T
   uint64_t redo_slot_stride;                    /* u32 elements */
   uint32_t match_slots_used;
   vksift_hip_event ev_staging;      /* host image staging buffer consumed by the H2D copy */
+  vksift_hip_event ev_up[VKSIFT_UP_GROUPS]; /* group g of a batch has arrived in d_input */
   bool staging_pending;
   BufferInfo *bufs;
 
   vksift_hip_stream stream;
   vksift_hip_stream pyr_stream; /* scale-space construction when detections overlap (two pyramid buffers) */
+  vksift_hip_stream up_stream;  /* host-to-device copies of the input images */
+  vksift_hip_stream dl_stream;  /* result downloads: the accessors have waited for the pipeline that produced what they read; their copies must
+                                 * not queue behind a LATER detection already on the instance stream (a caller that pipelines) */
   vksift_hip_event ev_pyr_done;
   vksift_hip_event ev_pyr_free[2]; /* last reader of pyramid buffer i has finished */
   vksift_hip_event ev_desc_start;  /* the previous detection's descriptor stage has been issued up to here: the next scale-space may start */
@@ -156,9 +174,10 @@ struct vksift_Instance_T
   vksift_hip_event ev_input_free;  /* the last reader of d_input (seed pass of the most recent detection) has run */
   bool input_free_valid;
   bool alt_order; /* VKSIFT_PYR_ALTERNATE (default 1): launches of a blur chain alternate their dispatch direction (vksift_hip_Plane::reverse) */
-  vksift_hip_event ev_detect, ev_match;
-  bool detect_pending, match_pending;
-  uint32_t detect_first_buf, detect_count;
+  vksift_hip_event ev_match;
+  bool match_pending;
+  DetectSlot det_ring[VKSIFT_DETECT_RING];
+  uint64_t det_seq, det_done; /* last detection issued / highest one known to have completed */
   /* batched download: the first vksift_downloadFeatures() after a detection of VKSIFT_DL_BATCH_MIN images and more packs the
    * features of ALL its buffers on the device and fetches them with one copy into pinned memory; the downloads of the
    * other buffers are host copies out of it (one copy per section and buffer costs 80 us per buffer otherwise) */
@@ -167,8 +186,17 @@ struct vksift_Instance_T
   uint32_t *dl_row;    /* sift_buffer_count + 1 row offsets of the cached buffers */
   uint32_t dl_first, dl_count;
   bool dl_valid;
-  uint32_t dl_hits; /* vksift_downloadFeatures calls on buffers of the last batched detection, before its packed copy exists */
+  vksift_hip_event dl_ev[VKSIFT_DL_CHUNKS]; /* the packed copy arrives in pieces */
+  size_t dl_chunk_end[VKSIFT_DL_CHUNKS];
+  uint32_t dl_chunks, dl_chunks_done;
+  uint64_t dl_seq;      /* the detection the packed copy belongs to */
+  uint64_t dl_hits_seq; /* the detection dl_hits counts for */
+  uint32_t dl_hits; /* vksift_downloadFeatures calls on buffers of that detection, before its packed copy exists */
   bool dl_eager;    /* vksift_ext_setBatchedDownload(true): the first download of a batched detection already packs */
+  /* packed download of the records of a batched matching (h_matches: pinned) */
+  size_t md_cap, md_pitch;
+  bool md_valid;
+  uint32_t md_hits;
   bool *match_busy; /* per SIFT buffer: read by the matching pipeline in flight (all pairs of a batched call) */
   uint32_t curr_nb_matches;
 
@@ -202,6 +230,8 @@ static inline size_t pyr_texel_bytes(const struct vksift_Instance_T *inst) { ret
 /* address of texel `off` (texels from the start of the pyramid buffer) */
 static inline float *pyr_at(const struct vksift_Instance_T *inst, uint64_t off) { return (float *)((uint8_t *)inst->d_pyr + off * pyr_texel_bytes(inst)); }
 
+static inline bool counts_valid(const struct vksift_Instance_T *inst, uint32_t buf) { return inst->bufs[buf].seq <= inst->det_done; }
+
 /* vksift_api.c */
 extern VKSIFT_INTERNAL bool vksift_g_loaded;
 VKSIFT_INTERNAL bool config_is_valid(const vksift_Config *c);
@@ -214,6 +244,8 @@ VKSIFT_INTERNAL void compute_layout(vksift_Instance inst, uint32_t w, uint32_t h
 VKSIFT_INTERNAL void set_buffer_sections(vksift_Instance inst, uint32_t buf, uint32_t n_oct, uint32_t w, uint32_t h);
 VKSIFT_INTERNAL void mark_detect_done(vksift_Instance inst);
 VKSIFT_INTERNAL bool detect_running(vksift_Instance inst);
+VKSIFT_INTERNAL int wait_detect_seq(vksift_Instance inst, uint64_t seq);
+static inline bool counts_valid(const struct vksift_Instance_T *inst, uint32_t buf);
 VKSIFT_INTERNAL bool match_running(vksift_Instance inst);
 VKSIFT_INTERNAL int wait_all(vksift_Instance inst);
 VKSIFT_INTERNAL int grow_image_scratch(vksift_Instance inst, const PyrLayout *L);
