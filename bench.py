@@ -36,6 +36,8 @@ Objects on the JSON line besides the contract fields:
                     the current batch's results are fetched (the asynchronous API as vulkansift.h:43-47 intends)
   single_image_ms   BASELINE config 2 literally: ONE 640x480 image through plain vksift_detectFeatures (+ matchFeatures),
                     10 warm-up + 100 timed runs as src/perf/perf_runtime.cpp:63-81
+  config5           BASELINE config 5 at --gpus N: per rank 64 x 1920x1080 (up-sampling on) detect + the 32 consecutive pairs matched in
+                    both directions, weak-scaled, resident and host inputs, per-rank CRC-32 of fixed frames (must not depend on N)
   cpu_baseline      the CPU oracle (scalar C port of the same algorithm) rebuilt -O3 -march=native on the box, one frame per
                     host core on all host cores, rank 0, N=1
 """
@@ -353,6 +355,70 @@ def c3_roofline(api, torch, dev, steps=5):
     return r
 
 
+def c5_leg(api, torch, dist, dev, rank, world, steps=3, distinct=16):
+    """BASELINE config 5 (512 x 1920x1080, up-sampling on, detect + match of the consecutive pairs (2i, 2i+1) in both directions as
+    src/examples/test_sift_match.cpp:67-80 does, split over 8 GPUs = 64 frames per GPU): every rank runs one GPU's share on ITS
+    frames (seeds 0x5EED0000 + rank*64 + i), weak scaling, no collective in the data path. Timed like the headline (barrier +
+    synchronize on both sides, maximum over ranks), resident inputs and host inputs. For comparing N = 1, 2, 4, 8 bit for bit:
+    a CRC-32 per rank over the feature bytes of four fixed frames and the records of pair 0 — rank r's value must not depend on N."""
+    W, H, B = 1920, 1080, 64
+    # `distinct` different frames per rank, cycled (host-side generation costs 0.6 s per 1080p frame): consecutive frames differ
+    base = [api.gen_synthetic_image(0x5EED0000 + rank * B + i, W, H) for i in range(distinct)]
+    frames = [base[i % distinct] for i in range(B)]
+    d_frames = torch.from_numpy(np.stack(frames)).to(dev)
+    cfg = api.default_config(sift_buffer_count=B, gpu_device_index=dev.index, input_image_max_size=W * H)
+    even, odd = list(range(0, B, 2)), list(range(1, B, 2))
+    out = {}
+    with api.Instance(cfg, batch_capacity=B) as inst:
+        ptrs = inst.imagePointerArray(frames)
+
+        def step(host):
+            if host:
+                inst.detectFeaturesBatchPtrs(ptrs, B, W, H, 0)
+            else:
+                inst.detectFeaturesBatchDevice(d_frames.data_ptr(), B, W, H, 0)
+            inst.matchFeaturesBatch(even, odd)
+            inst.matchFeaturesBatch(odd, even)
+
+        for host in (False, True):
+            step(host)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(host)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            out["frames_per_s_host_input" if host else "frames_per_s"] = world * B * steps / dt
+            out["ms_per_step_host_input" if host else "ms_per_step"] = dt / steps * 1e3
+        crc = 0
+        nfeat = []
+        for i in (0, 5, 10, 15):
+            f = inst.downloadFeatures(i)
+            nfeat.append(len(f))
+            crc = zlib.crc32(f.tobytes(), crc)
+        crc = zlib.crc32(inst.downloadMatchesBatch(0).tobytes(), crc) & 0xFFFFFFFF      # pair (1, 0) of the last call
+    crcs = [crc]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.int64, device=dev)
+        t[rank] = crc
+        dist.all_reduce(t)
+        crcs = [int(x) for x in t.tolist()]
+    out.update({"workload": f"BASELINE config 5, one GPU's share per rank: {B} x {W}x{H} (up-sampling on, 7 octaves) detect + the {len(even)} consecutive pairs "
+                            f"matched in both directions, x{world} ranks (weak scaling: 512 frames at 8 GPUs)",
+                "steps": steps, "frames_per_rank": B, "distinct_frames_per_rank": distinct, "mean_features_per_frame": float(np.mean(nfeat)),
+                "crc32_by_rank": crcs})
+    return out
+
+
 def sharded_match(api, torch, dist, dev, rank, world, rows):
     """BASELINE config 4 through the C entry vksift_ext_matchSharded: query rows of A sharded over the ranks, the reference set B
     all-gathered once (RCCL, uint8 rows) inside the library, every rank scans all of B. Returns (ms, CRC-32 of all records)."""
@@ -536,6 +602,12 @@ def main():
                                    "pyramid_only_frac": d16["roofline"]["pyramid_only"]["frac"], "stage_ms_per_call": d16["stage_ms_per_call"]}
         except Exception as e:  # noqa: BLE001
             extras["fp16_mode"] = {"error": repr(e)[:300]}
+    if not args.no_extras:
+        # BASELINE config 5 (north_star's multi-GPU workload): every rank, weak scaling; its collectives are timing barriers only
+        try:
+            extras["config5"] = c5_leg(api, torch, dist, dev, rank, world)
+        except Exception as e:  # noqa: BLE001
+            extras["config5"] = {"error": repr(e)[:300]}
     if not args.no_extras:
         # every rank takes part (the all-gather is a collective); a failure of this leg must not cost the headline line
         try:
