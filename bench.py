@@ -348,7 +348,7 @@ def c3_roofline(api, torch, dev, steps=5):
     dt = time.perf_counter() - t0
     acc = inst.getAccumulatedDetectTimings()
     inst.close()
-    r = roofline_from(acc, None, "k_blur_lean x6 on octave 0 (3840x2160 planes) + k_extrema_lean over all octaves, 64 x 1920x1080 frames")
+    r = roofline_from(acc, pmc_traffic(W, H, B), "k_blur_lean x6 on octave 0 (3840x2160 planes) + k_extrema_lean over all octaves, 64 x 1920x1080 frames")
     r.update({"workload": "BASELINE config 3: 64 x 1920x1080 uint8 frames, detect only, default vksift_Config, inputs resident in HBM",
               "steps": steps, "frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "mean_features_per_frame": nfeat,
               "stage_ms_per_step": {k: acc[k] / max(acc["nb_calls"], 1) for k in ("pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")}})

@@ -18,7 +18,8 @@ SCAN = "k_extrema_lean"
 
 
 def pmc(dirpath, counter, gridx, kernel=KERNEL):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), dirpath, counter, kernel, str(gridx)], capture_output=True, text=True)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), dirpath, counter, kernel] + ([str(gridx)] if gridx else []),
+                         capture_output=True, text=True)
     return json.loads(out.stdout)
 
 
@@ -37,10 +38,11 @@ def main():
     os.makedirs(dst, exist_ok=True)
     if os.path.exists(os.path.join(src, "bench.json")):
         shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+    have_trace = os.path.isdir(os.path.join(src, "trace"))
     csvs = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     for p in csvs:
         shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats.csv"))
-    if not csvs:
+    if not csvs and have_trace:
         # this rocprofv3 writes a rocpd database instead of csv files: rebuild the --stats table from its kernel records
         import sqlite3
         from collections import defaultdict
@@ -53,18 +55,18 @@ def main():
             f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
             for name, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
                 f.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (name, len(v), sum(v), sum(v) / len(v), 100.0 * sum(v) / tot, min(v), max(v)))
-    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(src, "trace"), KERNEL],
-                          capture_output=True, text=True).stdout
-    open(os.path.join(dst, f"{tag}_kernel_summary.txt"), "w").write(summ)
+    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(src, "trace"), KERNEL + "," + SCAN + ",k_descriptor,k_orientation<"],
+                          capture_output=True, text=True).stdout if have_trace else ""
+    if have_trace:
+        open(os.path.join(dst, f"{tag}_kernel_summary.txt"), "w").write(summ)
     if os.path.isdir(os.path.join(src, "pmc_fetch")) and os.path.isdir(os.path.join(src, "pmc_write")):
         # octave-0 launches only (the launches bench.py's roofline is quoted on): grid.x = strips * 64 work-items
         gridx = ((2 * w + 127) // 128) * 64
         f = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", gridx)
         wr = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", gridx)
-        # the streaming extrema scan of octave 0: grid.x = ceil(nseg / 2) workgroups of 256 work-items, nseg = ceil(2w / 64)
-        sgridx = ((((2 * w + 63) // 64) + 1) // 2) * 256
-        sf = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", sgridx, SCAN)
-        sw_ = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", sgridx, SCAN)
+        # the streaming extrema scan: ONE launch per detection over all octaves (flat grid) since round 3 — every dispatch of the kernel
+        sf = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", None, SCAN)
+        sw_ = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", None, SCAN)
         calls = sum(v["calls"] for v in f.values())
         fetch_kb = sum(v["sum"] for v in f.values())
         write_kb = sum(v["sum"] for v in wr.values())
@@ -76,7 +78,7 @@ def main():
         per_launch = (2.0 * fetch_kb / max(calls, 1) + write_kb / max(wcalls, 1)) * 1024.0
         scan_launch = (2.0 * sum(v["sum"] for v in sf.values()) / scalls + sum(v["sum"] for v in sw_.values()) / swcalls) * 1024.0
         blur_per_call = calls / scalls          # blur launches of octave 0 per detection call (= per scan launch)
-        rec = {"width": w, "height": h, "batch": batch, "kernel": KERNEL + " + " + SCAN + " (octave-0 launches)", "kernel_source_sha": kernel_source_sha(),
+        rec = {"width": w, "height": h, "batch": batch, "kernel": KERNEL + " (octave-0 launches) + " + SCAN + " (one launch over all octaves)", "kernel_source_sha": kernel_source_sha(),
                "launches_fetch_pass": calls, "launches_write_pass": wcalls, "scan_launches": scalls,
                "FETCH_SIZE_KiB_sum": fetch_kb, "WRITE_SIZE_KiB_sum": write_kb, "fetch_correction": 2.0,
                "hbm_bytes_per_blur_launch": per_launch, "hbm_bytes_per_scan_launch": scan_launch,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace output directory (csv or rocpd sqlite) per kernel / per grid.
-usage: prof_summary.py <dir> [name-filter]"""
+usage: prof_summary.py <dir> [name-filter[,name-filter...]]   (per-grid breakdown of the kernels matching any of the filters)"""
 import csv
 import glob
 import os
@@ -40,10 +40,11 @@ def main():
         t = sum(r["dur"] for r in rs)
         print(f"{name[:72]:72s} {len(rs):7d} {t/1e6:10.3f} {t/len(rs)/1e3:9.2f} {100*t/tot:6.1f}")
     if flt:
-        print(f"\nper-grid breakdown of kernels matching '{flt}':")
+        flts = [f for f in flt.split(",") if f]
+        print(f"\nper-grid breakdown of kernels matching {flts}:")
         g = defaultdict(list)
         for r in rows:
-            if flt in r["name"]:
+            if any(f in r["name"] for f in flts):
                 g[(r["name"][:60], r["grid"], r["lds"], r["vgpr"])].append(r["dur"])
         for k, v in sorted(g.items(), key=lambda kv: (-kv[0][1][0] * kv[0][1][1], kv[0][0])):
             print(f"  {k[0]:60s} grid={k[1]} lds={k[2]} vgpr={k[3]} calls={len(v)} avg_us={sum(v)/len(v)/1e3:.2f} min_us={min(v)/1e3:.2f}")
