@@ -18,7 +18,7 @@ extra=""
 [ "$file" = match ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-gpu-rdc $extra \
   -Iinclude -Ivulkansift_amd/csrc/host -Ivulkansift_amd/csrc "$@" -c ${SRC:-vulkansift_amd/csrc/hip/$file.hip} -o /tmp/variant_${name}_$file.o
-objs=$(ls $OBJ/*.o | grep -v "/$file.hip.o")
+objs=$(ls $OBJ/*.o | grep -v "/$file.hip.o" | grep -v "\.asan\.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o vulkansift_amd/lib/variants/lib_$name.so $objs /tmp/variant_${name}_$file.o \
   -L/opt/rocm/lib -lroctx64 -lm -ldl -Wl,-rpath,/opt/rocm/lib
 echo vulkansift_amd/lib/variants/lib_$name.so

@@ -67,6 +67,13 @@ HIP_EXTRA = {
     # MFMA results straight into VGPRs: the matcher's epilogue reads every accumulator element once, and the default AGPR
     # form costs one v_accvgpr_read per element (2 of ~18 VALU instructions per MFMA) for nothing — it has registers to spare
     "hip/match.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    # no SLP vectoriser: it packs the atan2 / exp polynomials of the two samples a descriptor iteration handles into v_pk_fma_f32
+    # chains — each packed op issues like two scalar ones AND waits for its predecessor (s_nop after every one), where the two
+    # scalar chains interleave without wait states. Same operations, same results; descriptor kernel -5.6 % (1.98 -> 1.87 ms)
+    "hip/features.hip": ["-fno-slp-vectorize"],
+    # the same for the blur kernels, whose unrolled filters are written with explicit two-row interleaving already: 128 x 640x480
+    # detect + match +1.8 % (the whole detection 5.33 -> 5.01 ms per call, most of it in the coarse octaves' launches)
+    "hip/pyramid.hip": ["-fno-slp-vectorize"],
 }
 
 
