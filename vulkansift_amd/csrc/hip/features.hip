@@ -151,30 +151,11 @@ __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
       // lane l visits window pixels l, l + 64, ...: (row, column) advance by (64 / box, 64 % box) with at most one carry
       const int step_q = 64 / box, step_r = 64 - step_q * box;
       int py = lane / box, px = lane - py * box;
-      for (int pix = lane; pix < npix; pix += 64)
-      {
-        const int dy = py - r, dx = px - r;
-        px += step_r, py += step_q;
-        if (px >= box)
-          px -= box, py++;
-        int gx = (int)rsx + dx, gy = (int)rsy + dy;
-        float sdx = (rsx + (float)dx) - scale_x;
-        float sdy = (rsy + (float)dy) - scale_y;
-        float d2 = (sdx * sdx) + (sdy * sdy);
-        if ((gx < 1 || gx >= (g.w - 1) || gy < 1 || gy >= (g.h - 1)) && (d2 > (float)(r * r)))
-          continue; // quirk Q2 ('&&')
-        // imageLoad semantics (0 outside the image, quirk Q2 relies on it) through the layer's buffer resource: a tap
-        // outside the image gets an out-of-range offset, which the hardware answers with 0 — no branches, 32-bit offsets
-        const bool xin = (unsigned)gx < (unsigned)g.w, yin = (unsigned)gy < (unsigned)g.h;
-        // (each row offset from its own, in-range, row index: the 24-bit multiply must not see a negative row)
-        const unsigned o0 = (__umul24((unsigned)gy, (unsigned)g.pitch) + (unsigned)gx) * 4u;
-        const unsigned o_r = (yin && (unsigned)(gx + 1) < (unsigned)g.w) ? o0 + 4u : 0x80000000u;
-        const unsigned o_l = (yin && (unsigned)(gx - 1) < (unsigned)g.w) ? o0 - 4u : 0x80000000u;
-        const unsigned o_d = (xin && (unsigned)(gy + 1) < (unsigned)g.h) ? (__umul24((unsigned)(gy + 1), (unsigned)g.pitch) + (unsigned)gx) * 4u : 0x80000000u;
-        const unsigned o_u = (xin && (unsigned)(gy - 1) < (unsigned)g.h) ? (__umul24((unsigned)(gy - 1), (unsigned)g.pitch) + (unsigned)gx) * 4u : 0x80000000u;
-        float gradX = 0.5f * (tap_ld<F16>(rs, o_r, 0) - tap_ld<F16>(rs, o_l, 0));
-        float gradY = 0.5f * (tap_ld<F16>(rs, o_d, 0) - tap_ld<F16>(rs, o_u, 0));
-        float mag = dm_expf_nb_nonpos(d2 * es) /* d2 >= 0 > es */ * sqrtf((gradX * gradX) + (gradY * gradY));
+      // the contribution of one window texel given its gradient taps (ComputeOrientation.comp:102-121)
+      auto accumulate = [&](float sdx2, float tr, float tl, float td, float tu) {
+        float gradX = 0.5f * (tr - tl);
+        float gradY = 0.5f * (td - tu);
+        float mag = dm_expf_nb_nonpos(sdx2 * es) /* d2 >= 0 > es */ * sqrtf((gradX * gradX) + (gradY * gradY));
         float ori = wrap_2pi(dm_atan2f(gradY, gradX));
         int bin = (int)(dm_div_2pi(ori * 36.f)); // == ori * 36 / (2 pi)
         if (bin < 0)
@@ -182,7 +163,51 @@ __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
         else if (bin >= 36)
           bin -= 36;
         atomicAdd(&hist[bin], (uint32_t)(mag * fp));
+      };
+      const int cxi = (int)rsx, cyi = (int)rsy;
+      const int pitch4 = g.pitch * 4;
+      // (wave-uniform: one keypoint per wave) the whole window and its taps inside the image interior — all but the keypoints
+      // within r + 1 texels of a border: no texel is skipped (quirk Q2's test needs a texel outside the interior) and no tap needs
+      // the out-of-image handling, which is a third of the general loop's instructions
+      if (cxi - r >= 1 && cxi + r <= g.w - 2 && cyi - r >= 1 && cyi + r <= g.h - 2)
+      {
+        for (int pix = lane; pix < npix; pix += 64)
+        {
+          const int dy = py - r, dx = px - r;
+          px += step_r, py += step_q;
+          if (px >= box)
+            px -= box, py++;
+          const float sdx = (rsx + (float)dx) - scale_x;
+          const float sdy = (rsy + (float)dy) - scale_y;
+          // byte offset of texel (x - 1, y - 1): the four taps are immediate / scalar offsets from it (scalar offsets are unsigned)
+          const unsigned v0 = (__umul24((unsigned)(cyi + dy - 1), (unsigned)g.pitch) + (unsigned)(cxi + dx - 1)) * 4u;
+          accumulate((sdx * sdx) + (sdy * sdy), tap_ld<F16>(rs, v0 + 8u, pitch4), tap_ld<F16>(rs, v0, pitch4), tap_ld<F16>(rs, v0 + 4u, 2 * pitch4), tap_ld<F16>(rs, v0 + 4u, 0));
+        }
       }
+      else
+        for (int pix = lane; pix < npix; pix += 64)
+        {
+          const int dy = py - r, dx = px - r;
+          px += step_r, py += step_q;
+          if (px >= box)
+            px -= box, py++;
+          int gx = cxi + dx, gy = cyi + dy;
+          float sdx = (rsx + (float)dx) - scale_x;
+          float sdy = (rsy + (float)dy) - scale_y;
+          float d2 = (sdx * sdx) + (sdy * sdy);
+          if ((gx < 1 || gx >= (g.w - 1) || gy < 1 || gy >= (g.h - 1)) && (d2 > (float)(r * r)))
+            continue; // quirk Q2 ('&&')
+          // imageLoad semantics (0 outside the image, quirk Q2 relies on it) through the layer's buffer resource: a tap
+          // outside the image gets an out-of-range offset, which the hardware answers with 0 — no branches, 32-bit offsets
+          const bool xin = (unsigned)gx < (unsigned)g.w, yin = (unsigned)gy < (unsigned)g.h;
+          // (each row offset from its own, in-range, row index: the 24-bit multiply must not see a negative row)
+          const unsigned o0 = (__umul24((unsigned)gy, (unsigned)g.pitch) + (unsigned)gx) * 4u;
+          const unsigned o_r = (yin && (unsigned)(gx + 1) < (unsigned)g.w) ? o0 + 4u : 0x80000000u;
+          const unsigned o_l = (yin && (unsigned)(gx - 1) < (unsigned)g.w) ? o0 - 4u : 0x80000000u;
+          const unsigned o_d = (xin && (unsigned)(gy + 1) < (unsigned)g.h) ? (__umul24((unsigned)(gy + 1), (unsigned)g.pitch) + (unsigned)gx) * 4u : 0x80000000u;
+          const unsigned o_u = (xin && (unsigned)(gy - 1) < (unsigned)g.h) ? (__umul24((unsigned)(gy - 1), (unsigned)g.pitch) + (unsigned)gx) * 4u : 0x80000000u;
+          accumulate(d2, tap_ld<F16>(rs, o_r, 0), tap_ld<F16>(rs, o_l, 0), tap_ld<F16>(rs, o_d, 0), tap_ld<F16>(rs, o_u, 0));
+        }
     }
     __builtin_amdgcn_wave_barrier();
     {
