@@ -960,7 +960,7 @@ extern "C" int vksift_hip_extract_keypoints_multi(const vksift_hip_OctaveJob *jo
   for (uint32_t i0 = 0; i0 < n_jobs;)
   {
     uint32_t i1 = i0 + 1;
-    while (i1 < n_jobs && i1 - i0 < (uint32_t)MULTI_MAX && jobs[i1].S == jobs[i0].S && jobs[i1].fp16 == jobs[i0].fp16)
+    while (i1 < n_jobs && i1 - i0 < multi_run_max() && jobs[i1].S == jobs[i0].S && jobs[i1].fp16 == jobs[i0].fp16)
       i1++;
     const int e = extract_run(jobs + i0, i1 - i0, batch, (hipStream_t)s, i1 == n_jobs ? (hipEvent_t)scan_done : nullptr);
     if (e)

@@ -864,7 +864,7 @@ static int for_runs(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, F run)
   for (uint32_t i0 = 0; i0 < n_jobs;)
   {
     uint32_t i1 = i0 + 1;
-    while (i1 < n_jobs && i1 - i0 < (uint32_t)MULTI_MAX && jobs[i1].fp16 == jobs[i0].fp16)
+    while (i1 < n_jobs && i1 - i0 < multi_run_max() && jobs[i1].fp16 == jobs[i0].fp16)
       i1++;
     const int e = run(jobs + i0, i1 - i0);
     if (e)

@@ -9,6 +9,7 @@
 // refinement chunks) holds per octave as before.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 constexpr int MULTI_MAX = 8; // octaves per launch (a 1920x1080 frame with up-sampling has 7); longer lists are cut in runs
 
@@ -47,6 +48,20 @@ __device__ __forceinline__ VBlock vblock(const Multi<A> &m)
   v.y = r % v.gy;
   v.z = r / v.gy;
   return v;
+}
+
+// host side: octaves per launch. VKSIFT_MULTI_MAX=1..8 lowers it (tests: the cutting of longer octave lists into runs is otherwise
+// only reached by images of 4097 pixels and more on the shortest side)
+static inline uint32_t multi_run_max()
+{
+  static int v = -1;
+  if (v < 0)
+  {
+    const char *e = getenv("VKSIFT_MULTI_MAX");
+    const int n = e ? atoi(e) : MULTI_MAX;
+    v = n >= 1 && n <= MULTI_MAX ? n : MULTI_MAX;
+  }
+  return (uint32_t)v;
 }
 
 // host side: append entry i with its virtual grid; returns false if the flat grid would overflow 2^31 workgroups
