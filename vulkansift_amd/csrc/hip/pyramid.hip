@@ -33,6 +33,15 @@ struct Taps
 // Scale-space texels are fp32, or (VKSIFT_PYRAMID_PRECISION_FLOAT16, F16 = true) IEEE binary16: stored with round-to-nearest-even
 // from the fp32 result, widened exactly on every read; all arithmetic is fp32 either way (the oracle's pyramid_fp16 mode).
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+// fp32 -> binary16 of a value that was ROUNDED TO fp32 first: the compiler otherwise folds "fptrunc(fma(...))" into
+// v_fma_mixlo_f16, which rounds the exact fma result to binary16 once — one ulp off the defined semantics (fp32 arithmetic,
+// then round to nearest even on store) in rare cases. (With the SLP vectoriser on, the packed fma happened to keep the two
+// roundings apart; the scalar form does not.) The empty asm pins the fp32 value in a register.
+__device__ __forceinline__ _Float16 to_h(float v)
+{
+  asm volatile("" : "+v"(v));
+  return (_Float16)v;
+}
 template <bool F16>
 __device__ __forceinline__ float ld_px(const float *base, size_t idx)
 {
@@ -44,7 +53,7 @@ template <bool F16>
 __device__ __forceinline__ void st_px(float *base, size_t idx, float v)
 {
   if (F16)
-    ((_Float16 *)base)[idx] = (_Float16)v;
+    ((_Float16 *)base)[idx] = to_h(v);
   else
     base[idx] = v;
 }
@@ -61,7 +70,7 @@ __device__ __forceinline__ const float *img_ptr(const float *base, size_t texels
 }
 __device__ __forceinline__ unsigned pack_h2(float a, float b)
 {
-  const h2v h{(_Float16)a, (_Float16)b};
+  const h2v h{to_h(a), to_h(b)};
   return __builtin_bit_cast(unsigned, h);
 }
 __device__ __forceinline__ void unpack_h2(unsigned u, float &a, float &b)
@@ -214,7 +223,7 @@ __global__ void __launch_bounds__(256) k_blur_tile(const float *__restrict__ src
     float acc = p[0] * k0;
     for (int i = 1; i < ntaps; i++)
       acc = fmaf(p[i] + p[-i], taps.k[i], acc);
-    s_mid[r * TILE + lane] = F16 ? (float)(_Float16)acc : acc; // the blur temporary is an image of the pyramid format
+    s_mid[r * TILE + lane] = F16 ? (float)to_h(acc) : acc; // the blur temporary is an image of the pyramid format
   }
   __syncthreads();
 
@@ -471,7 +480,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
             const float r1 = fmaf(aw, t1[i0 + 1], (1.f - aw) * t1[i0]);
             res[k] = fmaf(b, r1, (1.f - b) * r0);
             if (F16)
-              res[k] = (float)(_Float16)res[k]; // the blit target is an image of the pyramid format
+              res[k] = (float)to_h(res[k]); // the blit target is an image of the pyramid format
           }
           v = u32x4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
         }
@@ -483,7 +492,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
           {
             res[k] = s_lut[(v.x >> (8 * k)) & 0xffu];
             if (F16)
-              res[k] = (float)(_Float16)res[k]; // the blit target is an image of the pyramid format
+              res[k] = (float)to_h(res[k]); // the blit target is an image of the pyramid format
           }
           v = u32x4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
         }
@@ -531,7 +540,7 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
           b1 = fmaf(vb2[C0 + 1 + i] + vb2[C0 + 1 - i], a.taps.k[i], b1);
         }
         if (F16) // the horizontal pass's output is an image of the pyramid format too (the reference's blur temporary)
-          a0 = (float)(_Float16)a0, a1 = (float)(_Float16)a1, b0 = (float)(_Float16)b0, b1 = (float)(_Float16)b1;
+          a0 = (float)to_h(a0), a1 = (float)to_h(a1), b0 = (float)to_h(b0), b1 = (float)to_h(b1);
         wv[2 * R + j] = make_float2(a0, a1);
         wv[2 * R + j + 1] = make_float2(b0, b1);
         __builtin_amdgcn_sched_barrier(0);
@@ -637,7 +646,7 @@ __global__ void __launch_bounds__(256) k_dog_plane(const float *__restrict__ lo,
   const float l = ld_px<F16>(lo, (size_t)y * pitch + x);
   float d = hi ? ld_px<F16>(hi, (size_t)y * pitch + x) - l : l;
   if (F16 && hi)
-    d = (float)(_Float16)d; // the DoG image of an fp16 pyramid is a binary16 image too
+    d = (float)to_h(d); // the DoG image of an fp16 pyramid is a binary16 image too
   out[(size_t)y * w + x] = d;
 }
 
