@@ -132,6 +132,118 @@ __device__ bool refine_texel(const DogView &d, int x, int y, int s, float dog_th
   return true;
 }
 
+// The same refinement through a BUFFER RESOURCE over the octave of one image (32-bit byte offsets, the rows as scalar offsets, the
+// columns as immediates): refine_texel() above addresses every DoG value with two 64-bit multiply-adds and an exec-mask branch for
+// the layer test — 300 of its 700 VALU instructions and 38 branches per iteration are addressing. Here an iteration loads the 28
+// GAUSSIAN texels of its neighbourhood once (5 + 9 + 9 + 5 over the four layers; the pointer form loads 38 + 38) and forms the 19
+// DoG values from them with the same subtraction; the acceptance tests reuse the last iteration's values (the position does not
+// move after the last loads). Same operations on the same operands in the same order: bit-identical. The caller guarantees
+// (S + 3) * plane * texel bytes < 2^31.
+template <bool F16>
+__device__ bool refine_texel_buf(const __amdgpu_buffer_rsrc_t rsrc, int W, int H, int pitch, unsigned plane, int S, int x, int y, int s, float dog_threshold,
+                                 float edge_limit, float seed_sigma, int octave_idx, KpRecord *kp)
+{
+  constexpr unsigned EB = F16 ? 2u : 4u;
+  const int pitch_b = pitch * (int)EB;
+  const unsigned plane_b = plane * EB;
+  auto tex = [&](unsigned base, int row_off) -> float {
+    if (F16)
+      return (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, base, row_off, 0));
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, base, row_off, 0));
+  };
+  auto dog = [&](float hi, float lo) -> float { return F16 ? (float)(_Float16)(hi - lo) : hi - lo; };
+  float oX = 0.f, oY = 0.f, oS = 0.f, gX = 0.f, gY = 0.f, gS = 0.f;
+  float vc = 0.f, xp = 0.f, xm = 0.f, yp = 0.f, ym = 0.f, h23 = 0.f;
+  int rx = x, ry = y, rs = s;
+  for (int step = 0; step < 5; step++)
+  {
+    // byte offset of Gaussian texel (rx - 1, ry - 1) of layer rs; rs >= 1, rx >= 1, ry >= 1 always
+    const unsigned b0 = ((unsigned)rs * plane + (unsigned)(ry - 1) * (unsigned)pitch + (unsigned)(rx - 1)) * EB;
+    const unsigned bm = b0 - plane_b, b1 = b0 + plane_b, b2 = b1 + plane_b; // layers rs - 1, rs + 1, rs + 2 (past the last layer: reads 0)
+    // Gaussian texels: the full 3x3 of layers rs and rs + 1, the cross of layers rs - 1 and rs + 2
+    float g0[3][3], g1[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+      {
+        g0[j][i] = tex(b0 + (unsigned)i * EB, j * pitch_b);
+        g1[j][i] = tex(b1 + (unsigned)i * EB, j * pitch_b);
+      }
+    const float gm_c = tex(bm + EB, pitch_b), gm_xm = tex(bm, pitch_b), gm_xp = tex(bm + 2u * EB, pitch_b), gm_ym = tex(bm + EB, 0), gm_yp = tex(bm + EB, 2 * pitch_b);
+    const float g2_c = tex(b2 + EB, pitch_b), g2_xm = tex(b2, pitch_b), g2_xp = tex(b2 + 2u * EB, pitch_b), g2_ym = tex(b2 + EB, 0), g2_yp = tex(b2 + EB, 2 * pitch_b);
+    // DoG layer rs + 1 exists up to S + 1 (quirk Q1: beyond it the reference's image load returns 0)
+    const bool up = rs + 1 <= S + 1;
+    const float sp = up ? dog(g2_c, g1[1][1]) : 0.f, sm = dog(g0[1][1], gm_c);
+    const float p_xp = up ? dog(g2_xp, g1[1][2]) : 0.f, p_xm = up ? dog(g2_xm, g1[1][0]) : 0.f;
+    const float p_yp = up ? dog(g2_yp, g1[2][1]) : 0.f, p_ym = up ? dog(g2_ym, g1[0][1]) : 0.f;
+    const float m_xp = dog(g0[1][2], gm_xp), m_xm = dog(g0[1][0], gm_xm), m_yp = dog(g0[2][1], gm_yp), m_ym = dog(g0[0][1], gm_ym);
+    float d0[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+        d0[j][i] = dog(g1[j][i], g0[j][i]);
+    vc = d0[1][1];
+    xp = d0[1][2], xm = d0[1][0], yp = d0[2][1], ym = d0[0][1];
+    gS = 0.5f * (sp - sm);
+    gX = 0.5f * (xp - xm);
+    gY = 0.5f * (yp - ym);
+    float h11 = sp + sm - 2.f * vc;
+    float h22 = xp + xm - 2.f * vc;
+    float h33 = yp + ym - 2.f * vc;
+    float h12 = 0.25f * (p_xp - p_xm - m_xp + m_xm);
+    float h13 = 0.25f * (p_yp - p_ym - m_yp + m_ym);
+    h23 = 0.25f * (d0[2][2] - d0[0][2] - d0[2][0] + d0[0][0]);
+
+    float det = h11 * ((h22 * h33) - (h23 * h23)) - h12 * ((h12 * h33) - (h13 * h23)) + h13 * ((h12 * h23) - (h13 * h22));
+    if (det == 0.0f)
+      return false;
+    float i11 = ((h22 * h33) - (h23 * h23)) / det;
+    float i12 = -1.f * ((h12 * h33) - (h13 * h23)) / det;
+    float i13 = ((h12 * h23) - (h13 * h22)) / det;
+    float i22 = ((h11 * h33) - (h13 * h13)) / det;
+    float i23 = -1.f * ((h11 * h23) - (h13 * h12)) / det;
+    float i33 = ((h11 * h22) - (h12 * h12)) / det;
+    oS = -i11 * gS - i12 * gX - i13 * gY;
+    oX = -i12 * gS - i22 * gX - i23 * gY;
+    oY = -i13 * gS - i23 * gX - i33 * gY;
+
+    if (fabsf(oX) < 0.6f && fabsf(oY) < 0.6f && fabsf(oS) < 0.6f)
+      break;
+    else if (step < 4)
+    {
+      rx += ((oX >= 0.6f && rx < (W - 2)) ? 1 : 0) + ((oX <= -0.6f && rx > 1) ? -1 : 0);
+      ry += ((oY >= 0.6f && ry < (H - 2)) ? 1 : 0) + ((oY <= -0.6f && ry > 1) ? -1 : 0);
+      rs += ((oS >= 0.6f && rs < (S + 1)) ? 1 : 0) + ((oS <= -0.6f && rs > 1) ? -1 : 0);
+    }
+  }
+  // (rx, ry, rs) is where the last neighbourhood was loaded: vc, the axis neighbours and h23's diagonal differences are current
+  float sx = (float)rx + oX, sy = (float)ry + oY, ss = (float)rs + oS;
+  float nv = vc + 0.5f * (gX * oX + gY * oY + gS * oS);
+  if (!(fabsf(nv) > dog_threshold && fabsf(oX) < 1.5f && fabsf(oY) < 1.5f && fabsf(oS) < 1.5f && sx >= 0 && sx < (float)W && sy >= 0 && sy < (float)H &&
+        ss >= 0 && ss <= (float)(S + 1)))
+    return false;
+  float e11 = xp + xm - 2.f * vc;
+  float e22 = yp + ym - 2.f * vc;
+  float e12 = h23;
+  float edgeness = ((e11 + e22) * (e11 + e22)) / ((e11 * e22) - (e12 * e12));
+  if (!((edgeness < edge_limit) && (edgeness >= 0)))
+    return false;
+
+  float scale_factor = octave_idx >= 0 ? dm_pow2i(octave_idx) : 1.f / dm_pow2i(-octave_idx);
+  kp->scale_x = sx;
+  kp->scale_y = sy;
+  kp->scale_idx = (uint32_t)roundf(ss);
+  kp->octave_idx = octave_idx;
+  kp->sigma = seed_sigma * dm_exp2f(ss / (float)S) * scale_factor;
+  kp->orientation = 0.f;
+  kp->intensity = nv;
+  kp->x = sx * scale_factor;
+  kp->y = sy * scale_factor;
+  return true;
+}
+
 struct ExtremaArgs
 {
   const float *gauss; // Gaussian layer 0 of image 0 of the octave (S+3 layers, plane_stride apart)
@@ -723,7 +835,7 @@ __global__ void __launch_bounds__(256) k_cand_list(Multi<ExtremaArgs> mu)
 // Dense refinement: thread t of a 256-candidate chunk refines candidate chunk*256 + t (count read from HBM, workgroups
 // stride over the chunks). Besides the accept flags every chunk publishes its number of accepted candidates (into the
 // segment-offset array, free again after k_cand_list) for the two-level scan of k_chunk_offsets / k_cand_emit.
-template <bool F16>
+template <bool F16, bool BUF>
 __global__ void __launch_bounds__(256) k_refine_flags(Multi<ExtremaArgs> m)
 {
   __shared__ uint32_t s_cnt[4];
@@ -734,6 +846,9 @@ __global__ void __launch_bounds__(256) k_refine_flags(Multi<ExtremaArgs> m)
   n = n < a.cand_cap ? n : a.cand_cap;
   const uint32_t nch = (n + 255u) / 256u;
   DogView d{(const float *)((const uint8_t *)a.gauss + (size_t)b * a.img_stride * (a.fp16 ? 2u : 4u)), a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
+  // the octave of this image as one buffer (BUF: the launcher has checked that it stays below 2 GiB)
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)d.base, 0, (int)((unsigned)(a.S + 3) * (unsigned)a.plane_stride * (F16 ? 2u : 4u)), 0x00020000);
   const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
   uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
   uint32_t *chunk_sum = a.seg_off + (size_t)b * a.seg_img_stride;
@@ -745,7 +860,9 @@ __global__ void __launch_bounds__(256) k_refine_flags(Multi<ExtremaArgs> m)
     {
       const uint32_t c = xy[i];
       KpRecord kp;
-      ok = refine_texel<F16>(d, (int)(c & 0x3fffu), (int)((c >> 14) & 0x3fffu), (int)(c >> 28), a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
+      const int cx = (int)(c & 0x3fffu), cy = (int)((c >> 14) & 0x3fffu), cs = (int)(c >> 28);
+      ok = BUF ? refine_texel_buf<F16>(rsrc, a.w, a.h, a.pitch, (unsigned)a.plane_stride, a.S, cx, cy, cs, a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp)
+               : refine_texel<F16>(d, cx, cy, cs, a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
       flag[i] = ok ? 1u : 0u;
     }
     const unsigned long long bal = __ballot(ok);
@@ -761,7 +878,7 @@ __global__ void __launch_bounds__(256) k_refine_flags(Multi<ExtremaArgs> m)
 // Accepted candidates recompute their record (bit-identical) and store it at chunk base + rank inside the chunk (raster
 // order is preserved) if it fits the section. About one candidate in six is accepted: the accepted ones of a chunk are
 // first compacted through LDS, so the recomputation runs on dense lanes (one wave per chunk instead of four sparse ones).
-template <bool F16>
+template <bool F16, bool BUF>
 __global__ void __launch_bounds__(256) k_cand_emit(Multi<ExtremaArgs> m)
 {
   __shared__ uint32_t s_cnt[4];
@@ -774,6 +891,9 @@ __global__ void __launch_bounds__(256) k_cand_emit(Multi<ExtremaArgs> m)
   n = n < a.cand_cap ? n : a.cand_cap;
   const uint32_t nch = (n + 255u) / 256u;
   DogView d{(const float *)((const uint8_t *)a.gauss + (size_t)b * a.img_stride * (a.fp16 ? 2u : 4u)), a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
+  // the octave of this image as one buffer (BUF: the launcher has checked that it stays below 2 GiB)
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)d.base, 0, (int)((unsigned)(a.S + 3) * (unsigned)a.plane_stride * (F16 ? 2u : 4u)), 0x00020000);
   const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
   const uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
   const uint32_t *chunk_base = a.seg_off + (size_t)b * a.seg_img_stride;
@@ -797,7 +917,11 @@ __global__ void __launch_bounds__(256) k_cand_emit(Multi<ExtremaArgs> m)
     {
       const uint32_t c = s_list[threadIdx.x];
       KpRecord kp;
-      refine_texel<F16>(d, (int)(c & 0x3fffu), (int)((c >> 14) & 0x3fffu), (int)(c >> 28), a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
+      const int cx = (int)(c & 0x3fffu), cy = (int)((c >> 14) & 0x3fffu), cs = (int)(c >> 28);
+      if (BUF)
+        refine_texel_buf<F16>(rsrc, a.w, a.h, a.pitch, (unsigned)a.plane_stride, a.S, cx, cy, cs, a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
+      else
+        refine_texel<F16>(d, cx, cy, cs, a.dog_threshold, a.edge_limit, a.seed_sigma, a.octave_idx, &kp);
       uint32_t *rec = (uint32_t *)(a.feats + (size_t)b * a.feat_img_stride + (size_t)idx * 164);
       rec[0] = __float_as_uint(kp.x);
       rec[1] = __float_as_uint(kp.y);
@@ -938,15 +1062,34 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
    * measured 221 us instead of 70 us for this launch (and 137 instead of 51 us for k_cand_emit). */
   VKSIFT_MULTI(mr, batch, ((a.cand_cap + 255u) / 256u) > 512u ? 512u : ((a.cand_cap + 255u) / 256u), 1u)
   const dim3 rgrid(mr.start[mr.n]);
-  if (f16)
-    hipLaunchKernelGGL(k_refine_flags<true>, rgrid, dim3(256), 0, hs, mr);
+  /* the refinement addresses an image's octave through one buffer resource with 32-bit offsets where it fits (always, short of
+   * 4096 x 4096 octaves with many scales); the pointer form serves the rest */
+  static int buf_env = -1;
+  if (buf_env < 0)
+  {
+    const char *e = getenv("VKSIFT_REFINE_BUF"); /* 0: the pointer form everywhere (A/B runs, tests of the fallback) */
+    buf_env = e ? atoi(e) : 1;
+  }
+  bool buf = buf_env != 0;
+  for (uint32_t i = 0; i < n; i++)
+    buf = buf && (uint64_t)(args[i].S + 3) * args[i].plane_stride * (f16 ? 2u : 4u) < 0x7FFF0000ull;
+  if (f16 && buf)
+    hipLaunchKernelGGL((k_refine_flags<true, true>), rgrid, dim3(256), 0, hs, mr);
+  else if (f16)
+    hipLaunchKernelGGL((k_refine_flags<true, false>), rgrid, dim3(256), 0, hs, mr);
+  else if (buf)
+    hipLaunchKernelGGL((k_refine_flags<false, true>), rgrid, dim3(256), 0, hs, mr);
   else
-    hipLaunchKernelGGL(k_refine_flags<false>, rgrid, dim3(256), 0, hs, mr);
+    hipLaunchKernelGGL((k_refine_flags<false, false>), rgrid, dim3(256), 0, hs, mr);
   hipLaunchKernelGGL(k_chunk_offsets<true>, dim3(mi.start[mi.n]), dim3(1024), 0, hs, mi);
-  if (f16)
-    hipLaunchKernelGGL(k_cand_emit<true>, rgrid, dim3(256), 0, hs, mr);
+  if (f16 && buf)
+    hipLaunchKernelGGL((k_cand_emit<true, true>), rgrid, dim3(256), 0, hs, mr);
+  else if (f16)
+    hipLaunchKernelGGL((k_cand_emit<true, false>), rgrid, dim3(256), 0, hs, mr);
+  else if (buf)
+    hipLaunchKernelGGL((k_cand_emit<false, true>), rgrid, dim3(256), 0, hs, mr);
   else
-    hipLaunchKernelGGL(k_cand_emit<false>, rgrid, dim3(256), 0, hs, mr);
+    hipLaunchKernelGGL((k_cand_emit<false, false>), rgrid, dim3(256), 0, hs, mr);
 #undef VKSIFT_MULTI
   return (int)hipGetLastError();
 }
