@@ -107,6 +107,28 @@ def test_bench_step_host_protocol_back_to_back(vk, oracle):
         assert np.all(matches[k]["dist_a_b1"] == 0)
 
 
+def test_filtered_matching_of_128_pairs_in_one_call(vk, oracle):
+    """vksift_ext_matchFeaturesFiltered beyond one 64-slot launch sequence: 128 pairs (i, i+1 mod 128) with cross-check, the
+    forward + reverse matchings and the filter run in two runs of 64 slots; sampled pairs of both runs against the CPU filter"""
+    B, W, H = 128, 640, 480
+    frames = _frames(vk, B, W, H, 0x5EED0000)
+    cfg = vk.default_config(sift_buffer_count=B, input_image_max_size=W * H)
+    a = list(range(B))
+    b = [(i + 1) % B for i in a]
+    with vk.Instance(cfg, batch_capacity=B) as inst:
+        inst.detectFeaturesBatch(list(frames), 0)
+        inst.matchFeaturesFiltered(a, b, 0.8, True)
+        got = {k: inst.downloadFilteredMatches(k) for k in (0, 63, 64, 127)}
+        fwd = {k: inst.downloadMatchesBatch(k) for k in (0, 63, 64, 127)}
+        feats = {i: inst.downloadFeatures(i) for i in (0, 1, 63, 64, 65, 127)}
+    for k in (0, 63, 64, 127):
+        fa, fb = feats[a[k]], feats[b[k]]
+        m12, m21 = oracle.match_2nn(fa, fb), oracle.match_2nn(fb, fa)
+        assert fwd[k].tobytes() == m12.tobytes(), k
+        ra, rb = oracle.filter_matches(m12, m21, 0.8, True)
+        assert np.array_equal(got[k]["idx_a"], ra) and np.array_equal(got[k]["idx_b"], rb), k
+
+
 def test_pipelined_two_buffer_sets_like_the_bench_leg(vk, oracle):
     """bench.py's value_host_input_pipelined: 2 x 128 buffers, detection of the next batch queued before the results of the current
     one are fetched. Accessors must wait for the detection that filled THEIR buffer (sequence-numbered completion events), results
