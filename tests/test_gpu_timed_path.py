@@ -1,8 +1,8 @@
 """Parity of the path bench.py times — not of a path that resembles it.
 
-bench.py's step is: a batch_capacity = 128 instance (two pyramid buffers, overlapped detections),
-vksift_ext_detectFeaturesBatchDevice on 128 device-resident 640x480 frames, vksift_ext_matchFeaturesBatch(ids, ids) in two
-64-slot calls, the next step queued right behind it WITHOUT a host synchronisation. The reference makes a new detection wait
+bench.py's step is: a batch_capacity = 512 instance (two pyramid buffers, overlapped detections),
+vksift_ext_detectFeaturesBatchDevice on 512 device-resident 640x480 frames, vksift_ext_matchFeaturesBatch(ids, ids) of all 512
+self-pairs (launch sequences of 64 inside), the next step queued right behind it WITHOUT a host synchronisation. The reference makes a new detection wait
 for the running pipelines (src/vulkansift/vulkansift.c:326-327, include/vulkansift/vulkansift.h:43-47); here the ordering is done
 with events between streams (vksift_detect.c: ev_pyr_free, ev_desc_start, ev_input_free), which is exactly what these tests load:
 
@@ -46,27 +46,35 @@ def _single_image_reference(vk, frames, **cfg_kw):
     return out
 
 
-@pytest.mark.parametrize("profiling,last_half_first", [(True, False), (False, True)], ids=["profiled", "unprofiled_halves_swapped"])
-def test_bench_step_back_to_back_equals_single_image_and_oracle(vk, oracle, profiling, last_half_first):
+def _bench_frames(vk, B, W, H):
+    """bench.py's frame set: 128 generated frames and their three mirror images"""
+    gen = _frames(vk, 128, W, H, 0x5EED0000)
+    variants = [gen, gen[:, :, ::-1], gen[:, ::-1, :], gen[:, ::-1, ::-1]]
+    return np.ascontiguousarray(np.concatenate([variants[k % 4] for k in range(B // 128)]))
+
+
+@pytest.mark.parametrize("profiling,two_calls", [(True, False), (False, True)], ids=["profiled", "unprofiled_two_match_calls"])
+def test_bench_step_back_to_back_equals_single_image_and_oracle(vk, oracle, profiling, two_calls):
+    """bench.py's default step: 512 device-resident frames per detection call, one 512-pair self-matching (or two of 256)"""
     import torch
 
-    B, W, H = 128, 640, 480
-    sets = _feat_sets(vk, B, W, H, 0x5EED0000)
-    d_sets = [torch.from_numpy(s).cuda() for s in sets]
+    B, W, H = 512, 640, 480
+    last = _bench_frames(vk, B, W, H)
+    sets = [np.roll(last, 2 * 128, axis=0), np.roll(last, 128, axis=0), last]     # every buffer sees three different frames
+    d_sets = [torch.from_numpy(np.ascontiguousarray(s)).cuda() for s in sets]
     torch.cuda.synchronize()
-    halves = [list(range(0, 64)), list(range(64, 128))]
-    if last_half_first:
-        halves.reverse()
+    calls = [list(range(0, 256)), list(range(256, 512))] if two_calls else [list(range(B))]
     cfg = vk.default_config(sift_buffer_count=B, input_image_max_size=W * H)
     with vk.Instance(cfg, batch_capacity=B) as inst:
         inst.setProfiling(profiling)
         for k in range(3):                       # bench.py's step(), three times, nothing in between
             inst.detectFeaturesBatchDevice(d_sets[k].data_ptr(), B, W, H, 0)
-            for ids in halves:
+            for ids in calls:
                 inst.matchFeaturesBatch(ids, ids)
-        # the matches of the last 64-slot call first (the accessors below synchronise)
-        ids = halves[-1]
-        matches = {ids[k]: inst.downloadMatchesBatch(k) for k in (0, 1, 31, 62, 63)}
+        # the matches of the last call first (the accessors below synchronise)
+        ids = calls[-1]
+        picks = (0, 1, 63, 64, 200, len(ids) - 1)
+        matches = {ids[k]: inst.downloadMatchesBatch(k) for k in picks}
         counts = [inst.getFeaturesNumber(i) for i in range(B)]
         feats = [inst.downloadFeatures(i) for i in range(B)]
         if profiling:
@@ -78,7 +86,7 @@ def test_bench_step_back_to_back_equals_single_image_and_oracle(vk, oracle, prof
         assert counts[i] == len(single[i]), i
         assert feats[i].tobytes() == single[i].tobytes(), i
     ocfg = oracle.default_config(math_mode=1)
-    for i in (0, 17, 38, 63, 64, 90, 111, 127):
+    for i in (0, 17, 127, 128, 300, 383, 384, 511):
         ref, _ = oracle.detect(ocfg, sets[2][i])
         assert feats[i].tobytes() == ref.tobytes(), i
     for b, m in matches.items():
