@@ -80,6 +80,7 @@ def parse_args():
     ap.add_argument("--host-input", action="store_true", help="time the PCIe-inclusive protocol as the main loop (not the headline value)")
     ap.add_argument("--fp16", action="store_true", help="VKSIFT_PYRAMID_PRECISION_FLOAT16: binary16 scale-space storage (not the headline configuration)")
     ap.add_argument("--extras-timeout", type=float, default=300.0, help="seconds the legs after the timed region may take before the headline line is printed without them")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1: exercises every collective branch of the multi-GPU path on one GPU")
     ap.add_argument("--match-rows", type=int, default=50000, help="rows of A and of B in the sharded 2-NN leg (BASELINE config 4)")
     return ap.parse_args()
 
@@ -356,12 +357,13 @@ def c3_roofline(api, torch, dev, steps=5):
     return r
 
 
-def c5_leg(api, torch, dist, dev, rank, world, steps=3, distinct=16):
+def c5_leg(api, torch, dist, dev, rank, world, steps=3, distinct=16, use_dist=None):
     """BASELINE config 5 (512 x 1920x1080, up-sampling on, detect + match of the consecutive pairs (2i, 2i+1) in both directions as
     src/examples/test_sift_match.cpp:67-80 does, split over 8 GPUs = 64 frames per GPU): every rank runs one GPU's share on ITS
     frames (seeds 0x5EED0000 + rank*64 + i), weak scaling, no collective in the data path. Timed like the headline (barrier +
     synchronize on both sides, maximum over ranks), resident inputs and host inputs. For comparing N = 1, 2, 4, 8 bit for bit:
     a CRC-32 per rank over the feature bytes of four fixed frames and the records of pair 0 — rank r's value must not depend on N."""
+    use_dist = world > 1 if use_dist is None else use_dist
     W, H, B = 1920, 1080, 64
     # `distinct` different frames per rank, cycled (host-side generation costs 0.6 s per 1080p frame): consecutive frames differ
     base = [api.gen_synthetic_image(0x5EED0000 + rank * B + i, W, H) for i in range(distinct)]
@@ -384,17 +386,17 @@ def c5_leg(api, torch, dist, dev, rank, world, steps=3, distinct=16):
         for host in (False, True):
             step(host)
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
                 step(host)
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             dt = time.perf_counter() - t0
-            if world > 1:
+            if use_dist:
                 t = torch.tensor([dt], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
@@ -408,7 +410,7 @@ def c5_leg(api, torch, dist, dev, rank, world, steps=3, distinct=16):
             crc = zlib.crc32(f.tobytes(), crc)
         crc = zlib.crc32(inst.downloadMatchesBatch(0).tobytes(), crc) & 0xFFFFFFFF      # pair (1, 0) of the last call
     crcs = [crc]
-    if world > 1:
+    if use_dist:
         t = torch.zeros(world, dtype=torch.int64, device=dev)
         t[rank] = crc
         dist.all_reduce(t)
@@ -451,12 +453,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
 
     from vulkansift_amd import api
 
@@ -502,18 +510,18 @@ def main():
     nfeat = [inst.getFeaturesNumber(i) for i in range(B)]
 
     inst.setProfiling(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -613,14 +621,14 @@ def main():
     if not args.no_extras:
         # BASELINE config 5 (north_star's multi-GPU workload): every rank, weak scaling; its collectives are timing barriers only
         try:
-            extras["config5"] = c5_leg(api, torch, dist, dev, rank, world)
+            extras["config5"] = c5_leg(api, torch, dist, dev, rank, world, use_dist=use_dist)
         except Exception as e:  # noqa: BLE001
             extras["config5"] = {"error": repr(e)[:300]}
     if not args.no_extras:
         # every rank takes part (the all-gather is a collective); a failure of this leg must not cost the headline line
         try:
             ms, crc = sharded_match(api, torch, dist, dev, rank, world, args.match_rows)
-            if world > 1:
+            if use_dist:
                 t = torch.tensor([ms], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 ms = float(t.item())
@@ -639,7 +647,7 @@ def main():
     if rank == 0:
         emit(out)
 
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
