@@ -100,6 +100,12 @@ extern "C"
    * mirrored-repeat addressing. src and dst must not alias. */
   int vksift_hip_blur(vksift_hip_Plane src, vksift_hip_Plane dst, const float *taps, uint32_t ntaps, uint32_t batch, vksift_hip_stream s);
 
+  /* TWO consecutive scale steps in one launch: dst1 = blur(src, taps1), dst2 = blur(dst1, taps2) — the source plane is read once and
+   * scale s never re-read (12 bytes per texel instead of 16). Bit-identical to two vksift_hip_blur calls. Returns -1 without
+   * launching anything when the tap counts, the texel type or the shape are not covered: the caller then issues the two calls. */
+  int vksift_hip_blur_pair(vksift_hip_Plane src, vksift_hip_Plane dst1, vksift_hip_Plane dst2, const float *taps1, uint32_t ntaps1, const float *taps2,
+                           uint32_t ntaps2, uint32_t batch, vksift_hip_stream s);
+
   /* vksift_hip_blur that also seeds the next octave: next(x, y) = dst(2x+1, 2y+1), the vkCmdBlitImage(NEAREST) of
    * sift_detector.c:1003-1034 for exactly halved sizes, stored from the registers that hold the blurred rows (the separate
    * pass re-reads the whole plane). Bit-identical to vksift_hip_blur + vksift_hip_downsample. Returns -1 without launching

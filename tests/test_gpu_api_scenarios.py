@@ -411,7 +411,7 @@ def test_every_runtime_switch_is_bit_identical(vk):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     variants = [{}, {"VKSIFT_BLUR_KERNEL": "tile"}, {"VKSIFT_PYR_PINGPONG": "1"}, {"VKSIFT_PYR_PINGPONG": "0"},
                 {"VKSIFT_GRAPH": "1"}, {"VKSIFT_GRAPH": "0"}, {"VKSIFT_DESC_WAVES": "1"}, {"VKSIFT_DESC_WAVES": "2"}, {"VKSIFT_DESC_WAVES": "8"},
-                {"VKSIFT_EXTREMA_LEAN": "0"}, {"VKSIFT_PYR_ALTERNATE": "0"}, {"VKSIFT_MULTI_MAX": "2"}, {"VKSIFT_MULTI_MAX": "1"}, {"VKSIFT_REFINE_BUF": "0"}, {"VKSIFT_PYR_PINGPONG": "1", "VKSIFT_EXTREMA_LEAN": "0", "VKSIFT_PYR_ALTERNATE": "0"}]
+                {"VKSIFT_EXTREMA_LEAN": "0"}, {"VKSIFT_PYR_ALTERNATE": "0"}, {"VKSIFT_MULTI_MAX": "2"}, {"VKSIFT_MULTI_MAX": "1"}, {"VKSIFT_REFINE_BUF": "0"}, {"VKSIFT_BLUR_PAIR": "0"}, {"VKSIFT_PYR_PINGPONG": "1", "VKSIFT_EXTREMA_LEAN": "0", "VKSIFT_PYR_ALTERNATE": "0"}]
     digests = {}
     for v in variants:
         env = dict(os.environ)

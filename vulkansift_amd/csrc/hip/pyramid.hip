@@ -615,6 +615,265 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_blur_pair — TWO consecutive scales in one launch: reads plane s-1 once, writes planes s and s+1 (12 B per texel instead
+// of 16 for the two launches of k_blur_lean; the chain of an octave is memory bound in its narrow-tap launches).
+//
+// Same strip march as k_blur_lean (fp32 planes, plane source). A wave COMPUTES scale s on 128 columns and OWNS the inner
+// 128 - 2 HC of them (HC = the second filter's radius rounded up to 4): the outer columns are the horizontal halo the second
+// filter needs, recomputed by the neighbouring strips (blurring a mirrored row gives the mirrored blurred row bit for bit —
+// symmetric taps, commutative adds — so halo columns beyond the image edge need no special case either). Per group of 8 source
+// rows: stage -> H pass 1 -> register window 1 -> V pass 1 = 8 rows of scale s -> (own columns / own rows) to HBM and (all 128
+// columns) to a second LDS buffer -> H pass 2 from it -> register window 2 -> V pass 2 = 8 rows of scale s+1, R2 rows behind.
+// The segment's march starts R1 + R2 rows early; rows of scale s above / below the segment are the vertical halo of the second
+// filter (computed, not stored: the neighbouring segment stores them). Every value that is stored went through exactly the
+// operations of the two separate launches, in the same order.
+// ---------------------------------------------------------------------------------------------
+struct PairArgs
+{
+  const float *src;
+  float *dst1, *dst2;
+  uint64_t src_img_stride, dst1_img_stride, dst2_img_stride;
+  int spitch, d1pitch, d2pitch;
+  int w, h;
+  int seg; // output rows per workgroup (multiple of 8)
+  int rev; // walk the work space back to front
+  Taps t1, t2;
+};
+
+template <int NT1, int NT2>
+__global__ void __launch_bounds__(64) k_blur_pair(PairArgs a)
+{
+  constexpr int NR = 8;
+  constexpr int R1 = NT1 - 1, R2 = NT2 - 1;
+  constexpr int RA1 = (R1 + 3) & ~3;
+  constexpr int HC = (R2 + 3) & ~3;
+  constexpr int TW = 128, OW = TW - 2 * HC;
+  constexpr int SW = TW + 2 * RA1;
+  constexpr int NV4 = SW / 4;
+  constexpr int OFS1 = (RA1 - R1) & 1, NP1 = R1 + 1 + OFS1, C01 = R1 + OFS1;
+  constexpr int OFS2 = R2 & 1, NP2 = R2 + 1 + OFS2, C02 = R2 + OFS2;
+  constexpr int PAD = (R2 + OFS2 + 3) & ~3; // floats of padding on both sides of a scale-s row in LDS
+  constexpr int G1S = TW + 2 * PAD;         // its row stride
+  static_assert(R2 + OFS2 <= PAD, "padding of the second stage's LDS rows");
+  constexpr int NWIN1 = 2 * R1 + NR, NWIN2 = 2 * R2 + NR;
+  __shared__ __attribute__((aligned(16))) float s_grp[NR * SW];
+  __shared__ __attribute__((aligned(16))) float s_g1[NR * G1S];
+
+  const int lane = threadIdx.x;
+  const int W = a.w, H = a.h;
+  uint32_t bs = blockIdx.x, bseg = blockIdx.y, bimg = blockIdx.z;
+  {
+    const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
+    const uint32_t b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    uint32_t wi = b;
+    if ((total & 7u) == 0)
+    {
+      const uint32_t per = total >> 3, k = b >> 3;
+      wi = (b & 7u) * per + (a.rev ? per - 1u - k : k);
+    }
+    else if (a.rev)
+      wi = total - 1u - b;
+    bs = wi % gridDim.x;
+    const uint32_t r = wi / gridDim.x;
+    bseg = r % gridDim.y;
+    bimg = r / gridDim.y;
+  }
+  const int x0 = (int)bs * OW - HC; // first computed column (virtual: negative on the first strip)
+  const int y0 = bseg * a.seg;
+  const int y1 = min(y0 + a.seg, H);
+  const __amdgpu_buffer_rsrc_t rs = plane_rsrc<false>(a.src, (size_t)bimg * a.src_img_stride, a.spitch, H);
+  const __amdgpu_buffer_rsrc_t rd1 = plane_rsrc<false>(a.dst1, (size_t)bimg * a.dst1_img_stride, a.d1pitch, H);
+  const __amdgpu_buffer_rsrc_t rd2 = plane_rsrc<false>(a.dst2, (size_t)bimg * a.dst2_img_stride, a.d2pitch, H);
+
+  // ---- lane constants
+  const int gx4 = x0 - RA1 + 4 * lane;
+  unsigned ld_off = BUF_OOB;
+  bool rev = false;
+  if (lane < NV4)
+  {
+    if (gx4 >= 0 && gx4 + 3 < W)
+      ld_off = (unsigned)gx4 * 4u;
+    else
+    {
+      ld_off = (unsigned)mirror_idx(gx4 + 3, W) * 4u; // the four virtual columns map to m3+3, m3+2, m3+1, m3
+      rev = true;
+    }
+  }
+  const int px = x0 + 2 * lane;
+  const bool own = 2 * lane >= HC && 2 * lane < TW - HC;
+  const unsigned st_off = (own && px >= 0 && px + 1 < W) ? (unsigned)px * 4u : BUF_OOB;
+  const int spitch4 = a.spitch * 4, d1pitch4 = a.d1pitch * 4, d2pitch4 = a.d2pitch * 4;
+  const float k10 = a.t1.k[0], k20 = a.t2.k[0];
+
+  u32x4 pf[NR];
+  auto prefetch = [&](int r0) {
+    if (r0 >= 0 && r0 + NR <= H)
+    {
+      int so = r0 * spitch4;
+#pragma unroll
+      for (int j = 0; j < NR; j++, so += spitch4)
+        pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, so, 0);
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+        pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, mirror_idx(r0 + j, H) * spitch4, 0);
+    }
+  };
+
+  int rg = y0 - R1 - R2; // first virtual source row of the current group
+  prefetch(rg);
+
+  float2 wv1[NWIN1], wv2[NWIN2];
+#pragma unroll
+  for (int k = 0; k < NWIN1; k++)
+    wv1[k] = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < NWIN2; k++)
+    wv2[k] = make_float2(0.f, 0.f);
+
+  for (; rg - R1 - R2 < y1; rg += NR)
+  {
+    // ---- stage the prefetched group, then prefetch the next one
+    __syncthreads();
+    if (lane < NV4)
+    {
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+      {
+        u32x4 v = pf[j];
+        if (rev)
+          v = u32x4{v.w, v.z, v.y, v.x};
+        *(u32x4 *)(s_grp + j * SW + 4 * lane) = v;
+      }
+    }
+    prefetch(rg + NR);
+    __syncthreads();
+
+    // ---- first filter, horizontal: the new rows into the top of window 1 (two rows at a time, see k_blur_lean)
+    {
+      const float *hb = s_grp + (RA1 - R1 - OFS1) + 2 * lane;
+#pragma unroll
+      for (int j = 0; j < NR; j += 2)
+      {
+        const v2f *pa = (const v2f *)(hb + j * SW);
+        const v2f *pb = (const v2f *)(hb + (j + 1) * SW);
+        float va[2 * NP1], vb2[2 * NP1];
+#pragma unroll
+        for (int q = 0; q < NP1; q++)
+        {
+          v2f ta = pa[q], tb = pb[q];
+          va[2 * q] = ta.x, va[2 * q + 1] = ta.y;
+          vb2[2 * q] = tb.x, vb2[2 * q + 1] = tb.y;
+        }
+        float a0 = va[C01] * k10, a1 = va[C01 + 1] * k10;
+        float b0 = vb2[C01] * k10, b1 = vb2[C01 + 1] * k10;
+#pragma unroll
+        for (int i = 1; i < NT1; i++)
+        {
+          a0 = fmaf(va[C01 + i] + va[C01 - i], a.t1.k[i], a0);
+          a1 = fmaf(va[C01 + 1 + i] + va[C01 + 1 - i], a.t1.k[i], a1);
+          b0 = fmaf(vb2[C01 + i] + vb2[C01 - i], a.t1.k[i], b0);
+          b1 = fmaf(vb2[C01 + 1 + i] + vb2[C01 + 1 - i], a.t1.k[i], b1);
+        }
+        wv1[2 * R1 + j] = make_float2(a0, a1);
+        wv1[2 * R1 + j + 1] = make_float2(b0, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- first filter, vertical: rows yb1 .. yb1+7 of scale s (all 128 columns: the second filter's horizontal halo included)
+    const int yb1 = rg - R1;
+    {
+      int so_d = yb1 * d1pitch4;
+#pragma unroll
+      for (int j = 0; j < NR; j += 2, so_d += 2 * d1pitch4)
+      {
+        float a0 = wv1[R1 + j].x * k10, a1 = wv1[R1 + j].y * k10;
+        float b0 = wv1[R1 + j + 1].x * k10, b1 = wv1[R1 + j + 1].y * k10;
+#pragma unroll
+        for (int i = 1; i < NT1; i++)
+        {
+          a0 = fmaf(wv1[R1 + j + i].x + wv1[R1 + j - i].x, a.t1.k[i], a0);
+          a1 = fmaf(wv1[R1 + j + i].y + wv1[R1 + j - i].y, a.t1.k[i], a1);
+          b0 = fmaf(wv1[R1 + j + 1 + i].x + wv1[R1 + j + 1 - i].x, a.t1.k[i], b0);
+          b1 = fmaf(wv1[R1 + j + 1 + i].y + wv1[R1 + j + 1 - i].y, a.t1.k[i], b1);
+        }
+        *(v2f *)(s_g1 + j * G1S + PAD + 2 * lane) = v2f{a0, a1};
+        *(v2f *)(s_g1 + (j + 1) * G1S + PAD + 2 * lane) = v2f{b0, b1};
+        // the segment's own rows of scale s (wave-uniform tests)
+        if (yb1 + j >= y0 && yb1 + j < y1)
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(a0), __float_as_uint(a1)}, rd1, st_off, so_d, 0);
+        if (yb1 + j + 1 >= y0 && yb1 + j + 1 < y1)
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(b0), __float_as_uint(b1)}, rd1, st_off, so_d + d1pitch4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * R1; k++)
+      wv1[k] = wv1[k + NR];
+    __syncthreads();
+
+    // ---- second filter, horizontal, from the rows of scale s just written to LDS (lanes outside the owned columns read into the
+    // padding: their results are never stored)
+    {
+      const float *hb = s_g1 + (PAD - R2 - OFS2) + 2 * lane;
+#pragma unroll
+      for (int j = 0; j < NR; j += 2)
+      {
+        const v2f *pa = (const v2f *)(hb + j * G1S);
+        const v2f *pb = (const v2f *)(hb + (j + 1) * G1S);
+        float va[2 * NP2], vb2[2 * NP2];
+#pragma unroll
+        for (int q = 0; q < NP2; q++)
+        {
+          v2f ta = pa[q], tb = pb[q];
+          va[2 * q] = ta.x, va[2 * q + 1] = ta.y;
+          vb2[2 * q] = tb.x, vb2[2 * q + 1] = tb.y;
+        }
+        float a0 = va[C02] * k20, a1 = va[C02 + 1] * k20;
+        float b0 = vb2[C02] * k20, b1 = vb2[C02 + 1] * k20;
+#pragma unroll
+        for (int i = 1; i < NT2; i++)
+        {
+          a0 = fmaf(va[C02 + i] + va[C02 - i], a.t2.k[i], a0);
+          a1 = fmaf(va[C02 + 1 + i] + va[C02 + 1 - i], a.t2.k[i], a1);
+          b0 = fmaf(vb2[C02 + i] + vb2[C02 - i], a.t2.k[i], b0);
+          b1 = fmaf(vb2[C02 + 1 + i] + vb2[C02 + 1 - i], a.t2.k[i], b1);
+        }
+        wv2[2 * R2 + j] = make_float2(a0, a1);
+        wv2[2 * R2 + j + 1] = make_float2(b0, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- second filter, vertical: rows yb2 .. yb2+7 of scale s+1
+    const int yb2 = yb1 - R2;
+    if (yb2 + NR > y0)
+    {
+      int so_d = yb2 * d2pitch4;
+#pragma unroll
+      for (int j = 0; j < NR; j++, so_d += d2pitch4)
+      {
+        if (yb2 + j < y0 || yb2 + j >= y1)
+          continue;
+        float acc0 = wv2[R2 + j].x * k20, acc1 = wv2[R2 + j].y * k20;
+#pragma unroll
+        for (int i = 1; i < NT2; i++)
+        {
+          acc0 = fmaf(wv2[R2 + j + i].x + wv2[R2 + j - i].x, a.t2.k[i], acc0);
+          acc1 = fmaf(wv2[R2 + j + i].y + wv2[R2 + j - i].y, a.t2.k[i], acc1);
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc0), __float_as_uint(acc1)}, rd2, st_off, so_d, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * R2; k++)
+      wv2[k] = wv2[k + NR];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Nearest-neighbour resample (2:1 -> odd source texels), one thread per destination pixel.
 // ---------------------------------------------------------------------------------------------
 template <bool F16>
@@ -771,6 +1030,47 @@ extern "C"
     default:
       return (int)hipErrorInvalidValue;
     }
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_blur_pair(vksift_hip_Plane src, vksift_hip_Plane dst1, vksift_hip_Plane dst2, const float *taps1, uint32_t ntaps1, const float *taps2,
+                           uint32_t ntaps2, uint32_t batch, vksift_hip_stream s)
+  {
+    static int pair_env = -1;
+    if (pair_env < 0)
+    {
+      const char *e = getenv("VKSIFT_BLUR_PAIR"); /* 0: every scale its own launch (A/B runs, tests) */
+      pair_env = e ? atoi(e) : 1;
+    }
+    const bool combo = ntaps1 == 5 && ntaps2 == 7; /* scales 1 and 2 of the default configuration (3 scales per octave, sampler-interpolated taps) */
+    if (!pair_env || !combo || src.fp16 || dst1.fp16 || dst2.fp16 || src.base == NULL || dst1.base == NULL || dst2.base == NULL || getenv("VKSIFT_BLUR_KERNEL"))
+      return -1;
+    const uint32_t W = src.w, H = src.h;
+    const uint32_t r2 = ntaps2 - 1u, hc = (r2 + 3u) & ~3u, ow = 128u - 2u * hc, ra1 = ((ntaps1 - 1u) + 3u) & ~3u;
+    const uint32_t strips = (W + ow - 1u) / ow;
+    /* one mirror reflection has to cover every staged column and every virtual row of a march */
+    if ((W % 4u) != 0 || hc + ra1 > W || (strips - 1u) * ow + 128u + ra1 > 2u * W + hc || H < 64u || dst1.w != W || dst2.w != W || dst1.h != H || dst2.h != H)
+      return -1;
+    PairArgs a;
+    a.src = src.base, a.dst1 = dst1.base, a.dst2 = dst2.base;
+    a.src_img_stride = src.img_stride, a.dst1_img_stride = dst1.img_stride, a.dst2_img_stride = dst2.img_stride;
+    a.spitch = (int)src.pitch, a.d1pitch = (int)dst1.pitch, a.d2pitch = (int)dst2.pitch;
+    a.w = (int)W, a.h = (int)H;
+    a.rev = (int)dst2.reverse;
+    for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
+      a.t1.k[i] = i < ntaps1 ? taps1[i] : 0.f, a.t2.k[i] = i < ntaps2 ? taps2[i] : 0.f;
+    /* row segments as stream_grid(): the strip count differs (128 - 2 HC owned columns per wave) */
+    uint32_t nseg = (10240u + strips * batch - 1u) / (strips * batch);
+    const uint32_t max_seg = (H + 63u) / 64u;
+    if (nseg > max_seg)
+      nseg = max_seg;
+    if (nseg < 1)
+      nseg = 1;
+    const uint32_t seg = ((H + nseg - 1u) / nseg + 7u) & ~7u;
+    nseg = (H + seg - 1u) / seg;
+    a.seg = (int)seg;
+    const dim3 grid(strips, nseg, batch);
+    hipLaunchKernelGGL((k_blur_pair<5, 7>), grid, dim3(64), 0, (hipStream_t)s, a);
     return (int)hipGetLastError();
   }
 

@@ -229,8 +229,7 @@ static void build_jobs(DetectCtx *c)
     j->use_vlfeat = inst->cfg.descriptor_format == VKSIFT_DESCRIPTOR_FORMAT_VLFEAT ? 1u : 0u;
     j->desc_fp_tab = inst->d_desc_fp;
     j->desc_fp_tab_len = inst->desc_fp_len;
-    /* the last blur launch of the octave (scale S+2) ran in direction (S+2) & 1: the scan takes the other one */
-    j->scan_reverse = inst->alt_order ? (((inst->S + 2u) & 1u) ^ 1u) : 0u;
+    j->scan_reverse = 0; /* set by enqueue_pyramid: the direction opposite to the octave's last blur launch */
   }
 }
 
@@ -290,13 +289,33 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint3
   else if (!*g0_done)
     TRY(vksift_hip_downsample(PL(o - 1, inst->S), PL(o, 0), count, sp), "downsample");
   *g0_done = false;
+  /* consecutive launches of the chain walk the batch in opposite directions: a launch starts on the planes its predecessor wrote
+   * last, which are still in the Infinity Cache (a whole-batch plane is 2.5x the cache: in the same direction every read misses);
+   * the extrema scan continues the alternation */
+  uint32_t li = 0;
   for (uint32_t s = 1; s < inst->S + 3; s++)
   {
     const vksift_hip_Plane srcp = PL(o, s - 1);
     vksift_hip_Plane dstp = PL(o, s);
-    /* consecutive launches of the chain walk the batch in opposite directions: launch s starts on the planes launch s-1 wrote
-     * last, which are still in the Infinity Cache (a whole-batch plane is 2.5x the cache: in the same direction every read misses) */
-    dstp.reverse = inst->alt_order ? (s & 1u) : 0u;
+    li++;
+    dstp.reverse = inst->alt_order ? (li & 1u) : 0u;
+    /* two scales in one launch where the kernels cover the tap counts (the source plane is read once, scale s never re-read):
+     * not across scale S, which also seeds the next octave */
+    if (s + 1 < inst->S + 3 && s != inst->S && s + 1 != inst->S)
+    {
+      vksift_hip_Plane dst2 = PL(o, s + 1);
+      dst2.reverse = dstp.reverse;
+      const int pe = vksift_hip_blur_pair(srcp, dstp, dst2, &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], &inst->taps[(s + 1) * VKSIFT_MAX_TAPS],
+                                          inst->ntaps[s + 1], count, sp);
+      if (pe > 0)
+        TRY(pe, "two-scale blur");
+      if (pe == 0)
+      {
+        s++;
+        nb_o++;
+        continue;
+      }
+    }
     int fused_ds = -1;
     if (s == inst->S && o + 1 < L->n_oct)
     {
@@ -311,6 +330,7 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint3
       TRY(vksift_hip_blur(srcp, dstp, &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], count, sp), "blur");
     nb_o++;
   }
+  c->jobs[o].scan_reverse = inst->alt_order ? ((li & 1u) ^ 1u) : 0u;
 #undef PL
   vksift_hip_range_pop();
   if (o == 0)
