@@ -55,15 +55,19 @@ def main():
             f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
             for name, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
                 f.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (name, len(v), sum(v), sum(v) / len(v), 100.0 * sum(v) / tot, min(v), max(v)))
-    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(src, "trace"), KERNEL + "," + SCAN + ",k_descriptor,k_orientation<"],
+    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(src, "trace"), KERNEL + ",k_blur_pair," + SCAN + ",k_descriptor,k_orientation<"],
                           capture_output=True, text=True).stdout if have_trace else ""
     if have_trace:
         open(os.path.join(dst, f"{tag}_kernel_summary.txt"), "w").write(summ)
     if os.path.isdir(os.path.join(src, "pmc_fetch")) and os.path.isdir(os.path.join(src, "pmc_write")):
-        # octave-0 launches only (the launches bench.py's roofline is quoted on): grid.x = strips * 64 work-items
+        # octave-0 launches only (the launches bench.py's roofline is quoted on): k_blur_lean with grid.x = strips * 64 work-items
+        # (128-column strips) and k_blur_pair (two scales per launch, 112 owned columns per strip)
         gridx = ((2 * w + 127) // 128) * 64
+        gridx_pair = ((2 * w + 111) // 112) * 64
         f = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", gridx)
         wr = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", gridx)
+        f.update(pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", gridx_pair, "k_blur_pair"))
+        wr.update(pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", gridx_pair, "k_blur_pair"))
         # the streaming extrema scan: ONE launch per detection over all octaves (flat grid) since round 3 — every dispatch of the kernel
         sf = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", None, SCAN)
         sw_ = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", None, SCAN)
@@ -78,7 +82,7 @@ def main():
         per_launch = (2.0 * fetch_kb / max(calls, 1) + write_kb / max(wcalls, 1)) * 1024.0
         scan_launch = (2.0 * sum(v["sum"] for v in sf.values()) / scalls + sum(v["sum"] for v in sw_.values()) / swcalls) * 1024.0
         blur_per_call = calls / scalls          # blur launches of octave 0 per detection call (= per scan launch)
-        rec = {"width": w, "height": h, "batch": batch, "kernel": KERNEL + " (octave-0 launches) + " + SCAN + " (one launch over all octaves)", "kernel_source_sha": kernel_source_sha(),
+        rec = {"width": w, "height": h, "batch": batch, "kernel": KERNEL + " / k_blur_pair (octave-0 launches) + " + SCAN + " (one launch over all octaves)", "kernel_source_sha": kernel_source_sha(),
                "launches_fetch_pass": calls, "launches_write_pass": wcalls, "scan_launches": scalls,
                "FETCH_SIZE_KiB_sum": fetch_kb, "WRITE_SIZE_KiB_sum": write_kb, "fetch_correction": 2.0,
                "hbm_bytes_per_blur_launch": per_launch, "hbm_bytes_per_scan_launch": scan_launch,
