@@ -563,6 +563,10 @@ def main():
             "stage_ms_per_call": {k: acc[k] / max(acc["nb_calls"], 1) for k in
                                   ("upload_ms", "pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")},
             "last_match_ms": match_ms,
+            # K5 / K6 carry no roofline claim (latency / LDS-atomic / VALU bound, sparse reads): time per 1000 output
+            # features, the unit of the reference's own figure (0.38 ms per 1000 features for K5 + K6 on an RTX 2060)
+            "keypoint_stages_ms_per_1000_features": {
+                k: acc[k + "_ms"] / max(acc["nb_calls"], 1) / max(B * float(np.mean(nfeat)), 1.0) * 1000.0 for k in ("orientation", "descriptor")},
         }
 
     emitted = threading.Lock()
