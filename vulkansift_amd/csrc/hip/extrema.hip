@@ -1060,7 +1060,10 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
    * contiguous in dispatch order. With the chunk index fastest they formed a short run at the start of every image's row of
    * 512 workgroups, which the dispatcher's round-robin maps onto the same half of the shader engines of every XCD:
    * measured 221 us instead of 70 us for this launch (and 137 instead of 51 us for k_cand_emit). */
-  VKSIFT_MULTI(mr, batch, ((a.cand_cap + 255u) / 256u) > 512u ? 512u : ((a.cand_cap + 255u) / 256u), 1u)
+  /* at most 512 chunk workgroups per image, and ~64 k per octave whatever the batch (they stride over the chunks; idle ones only
+   * cost dispatch: 512 frames with 512 per image 1.25 ms for the stage without the scan, with 128 per image 0.86 ms) */
+  const uint32_t rcap = 65536u / batch < 16u ? 16u : (65536u / batch > 512u ? 512u : 65536u / batch);
+  VKSIFT_MULTI(mr, batch, ((a.cand_cap + 255u) / 256u) > rcap ? rcap : ((a.cand_cap + 255u) / 256u), 1u)
   const dim3 rgrid(mr.start[mr.n]);
   /* the refinement addresses an image's octave through one buffer resource with 32-bit offsets where it fits (always, short of
    * 4096 x 4096 octaves with many scales); the pointer form serves the rest */
