@@ -7,11 +7,11 @@
 
 Metric (BASELINE.json): SIFT detect+match frames/s on 640x480 frames with ~2k keypoints.
 
-One "step" = one pass of the hot path over one batch of `--sub-batches` x `--batch` (default 2 x 512 = 1024) synthetic
+One "step" = one pass of the hot path over one batch of `--sub-batches` x `--batch` (default 3 x 512 = 1536) synthetic
 640x480 frames that are already resident in HBM: per 512 frames one batched detection (default vksift_Config: 2x
 up-sampling, automatic octave count = 5, 3 scales/octave) followed by the 2-NN self-match of every frame
 (matchFeatures(i, i) of BASELINE config 2, issued through the batched extension). Every step recomputes everything;
-nothing is cached between steps. 20 steps are ~0.9 s of timed GPU work. (512 frames per call: 40 GB of scale-space for the two
+nothing is cached between steps. 20 steps are ~1.3 s of timed GPU work. (512 frames per call: 40 GB of scale-space for the two
 pyramid buffers of an instance — sized for 288 GB of HBM; 128 per call is 7 % slower, 1024 no faster.)
 
 Multi-GPU: one process per GPU; each rank owns its own frames (weak scaling: detection is per image and needs no
@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="frames per batched detection call")
-    ap.add_argument("--sub-batches", type=int, default=2, help="batched detection calls per step (frames per step = batch x sub-batches)")
+    ap.add_argument("--sub-batches", type=int, default=3, help="batched detection calls per step (frames per step = batch x sub-batches)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-match", action="store_true", help="detect only")
