@@ -397,6 +397,12 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 
   u32x4 pf[NR];
   float vb[NR]; // UPS: vertical weight of the lower source row (wave-uniform)
+  // UPS, group away from the top and bottom edges: output rows 2m+1 and 2m+2 interpolate between the SAME two source rows
+  // (m, m+1) with weights 0.25 / 0.75, so the 8 rows of a group need 5 or 6 distinct source rows, not 16: each is loaded,
+  // sent through the table and interpolated horizontally once (the same expressions on the same values: bit-identical).
+  // Groups start on rows of the parity of R (segments start on multiples of 8).
+  constexpr int UPS_PAR = R & 1, UPS_NSRC = UPS_PAR ? 5 : 6;
+  auto ups_shared = [&](int r0) { return r0 >= 2 && r0 + NR + 2 <= H; };
   // four texels of a source row: one 16-byte load (fp32) or one 8-byte load (fp16: .x, .y carry the four halves)
   auto load4 = [&](int so) -> u32x4 {
     if (F16)
@@ -407,7 +413,14 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
     return __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, so, 0);
   };
   auto prefetch = [&](int r0) {
-    if (UPS)
+    if (UPS && ups_shared(r0))
+    {
+      const int so0 = (UPS_PAR ? (r0 - 1) / 2 : r0 / 2 - 1) * a.spitch;
+#pragma unroll
+      for (int s = 0; s < UPS_NSRC; s++)
+        pf[s].x = __builtin_amdgcn_raw_buffer_load_b32(rs, ld_off, so0 + s * a.spitch, 0);
+    }
+    else if (UPS)
     {
       const int sh = H / 2, sw = a.spitch;
 #pragma unroll
@@ -454,7 +467,48 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   {
     // ---- stage the prefetched group, then prefetch the next one
     __syncthreads();
-    if (lane < NV4)
+    if (UPS && ups_shared(rg))
+    {
+      if (lane < NV4)
+      {
+        float hr[UPS_NSRC][4];
+#pragma unroll
+        for (int s = 0; s < UPS_NSRC; s++)
+        {
+          const unsigned d = __builtin_amdgcn_perm(pf[s].x, pf[s].x, perm_sel);
+          float t[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            t[k] = s_lut[(d >> (8 * k)) & 0xffu];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+          {
+            const int i0 = (k + 1) / 2;
+            const float aw = (k & 1) ? 0.25f : 0.75f;
+            hr[s][k] = fmaf(aw, t[i0 + 1], (1.f - aw) * t[i0]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NR; j++)
+        {
+          const int p = UPS_PAR ? j / 2 : (j + 1) / 2;           // rows (p, p+1) of hr
+          const float b = ((j + UPS_PAR) & 1) ? 0.25f : 0.75f;   // odd output rows sit nearer the upper source row
+          float res[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+          {
+            res[k] = fmaf(b, hr[p + 1][k], (1.f - b) * hr[p][k]);
+            if (F16)
+              res[k] = (float)to_h(res[k]);
+          }
+          u32x4 v = u32x4{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
+          if (rev)
+            v = u32x4{v.w, v.z, v.y, v.x};
+          *(u32x4 *)(s_grp + j * SW + 4 * lane) = v;
+        }
+      }
+    }
+    else if (lane < NV4)
     {
 #pragma unroll
       for (int j = 0; j < NR; j++)
