@@ -82,7 +82,60 @@ def parse_args():
     ap.add_argument("--extras-timeout", type=float, default=300.0, help="seconds the legs after the timed region may take before the headline line is printed without them")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1: exercises every collective branch of the multi-GPU path on one GPU")
     ap.add_argument("--match-rows", type=int, default=50000, help="rows of A and of B in the sharded 2-NN leg (BASELINE config 4)")
+    ap.add_argument("--dry-launch", action="store_true", help="bring the N ranks up (gloo when there is no GPU), print who came up, run nothing: checks the launch path")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: become the launcher. Re-executes this script under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` (one rank per GPU, the
+    same command line the driver uses) and returns its exit code. Refuses, loudly and with a non-zero status, when the box has fewer
+    than N GPUs: a line that says n_gpus 1 for --gpus 8 would be a flat fake scaling curve."""
+    import socket
+
+    if not args.dry_launch:
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} asked for, but this box has {have} visible GPU(s): refusing to run "
+                             f"(one rank per GPU; nothing is reported for a world size that did not run)\n")
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stderr.write("bench.py: launching " + " ".join(cmd[1:]) + "\n")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(args, rank, local_rank, world):
+    """--dry-launch: every rank joins a process group (RCCL when each rank has its GPU, gloo otherwise), the ranks' LOCAL_RANKs are
+    gathered, rank 0 prints one JSON line. Nothing of the benchmark runs."""
+    import torch
+    import torch.distributed as dist
+
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        t = torch.tensor([local_rank], dtype=torch.int64, device=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend="gloo")
+        t = torch.tensor([local_rank], dtype=torch.int64)
+    got = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(got, t)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "backend": "nccl" if use_gpu else "gloo",
+                          "local_ranks": [int(x.item()) for x in got], "gpus_visible": torch.cuda.device_count() if torch.cuda.is_available() else 0}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -442,6 +495,15 @@ def sharded_match(api, torch, dist, dev, rank, world, rows):
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))                       # this process becomes the launcher of N ranks
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: the launcher's --nproc-per-node and --gpus must agree")
+    if args.dry_launch:
+        sys.exit(dry_launch(args, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), env_world))
     # The contract is ONE JSON line on stdout. Libraries loaded below write banners there through C stdio (RCCL prints its version
     # block on communicator creation): everything written to fd 1 before the result line goes to stderr instead.
     sys.stdout.flush()
@@ -454,6 +516,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = world > 1 or args.force_dist
+    if not torch.cuda.is_available() or torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):
+        sys.stderr.write(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) has no GPU: {torch.cuda.device_count() if torch.cuda.is_available() else 0} "
+                         f"visible, world size {world} needs one per rank\n")
+        sys.exit(2)
     if use_dist:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -108,6 +108,21 @@ extern "C"
   VKSIFT_EXPORT vksift_Result vksift_ext_shardGetUniqueId(uint8_t id[VKSIFT_EXT_SHARD_ID_BYTES]);
   VKSIFT_EXPORT vksift_Result vksift_ext_shardGroupCreate(vksift_ext_ShardGroup *group_ptr, int gpu_device_index, uint32_t world, uint32_t rank,
                                                           const uint8_t id[VKSIFT_EXT_SHARD_ID_BYTES]);
+  /* The same group over the APPLICATION's transport instead of RCCL (an MPI job, a host-staged exchange, a test harness): the
+   * callback stands in for ncclAllGather and has its contract — every rank contributes bytes_per_rank bytes at d_send, rank r's
+   * block lands at d_recv + r * bytes_per_rank on every rank (d_send may already BE this rank's slot of d_recv), ordered on
+   * hip_stream (a hipStream_t): it must see everything queued on hip_stream before the call, and work queued on hip_stream after
+   * it returns must see the gathered data (a blocking implementation synchronises hip_stream first). Returns 0 on success. Not
+   * collective itself; RCCL is neither loaded nor needed. */
+  typedef int (*vksift_ext_AllGatherFn)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, uint32_t rank, uint32_t world,
+                                        void *hip_stream);
+  VKSIFT_EXPORT vksift_Result vksift_ext_shardGroupCreateWithTransport(vksift_ext_ShardGroup *group_ptr, int gpu_device_index, uint32_t world, uint32_t rank,
+                                                                       vksift_ext_AllGatherFn all_gather, void *user);
+  /* The block layout of the reference set that vksift_ext_matchSharded all-gathers: block_rows = ceil(n_total / world) (= nb_shard),
+   * rank `rank` holds rows [first_row, first_row + nb_rows) of B (nb_rows <= block_rows; the rest of its block is padding). Pure
+   * arithmetic (no GPU needed); callers that shard the query rows the same way use first_row as a_index_base. */
+  VKSIFT_EXPORT void vksift_ext_shardGroupLayout(uint32_t n_total, uint32_t world, uint32_t rank, uint32_t *block_rows, uint32_t *first_row,
+                                                 uint32_t *nb_rows);
   VKSIFT_EXPORT void vksift_ext_shardGroupDestroy(vksift_ext_ShardGroup *group_ptr);
   /* Local, not collective: reserves the device scratch for matchings of up to max_na local query rows against up to max_nb_total
    * reference rows. A vksift_ext_matchSharded within the reservation allocates nothing, so it cannot fail for resources before its

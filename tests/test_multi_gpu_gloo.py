@@ -52,6 +52,96 @@ def _worker(rank, world, port, na, nb, q):
     dist.destroy_process_group()
 
 
+class _StubGroup:
+    """Stands in for multigpu.ShardGroup where there is no GPU: the same match() contract — this rank's query rows, its PADDED block of
+    B, nb_total — with the exchange over gloo and the oracle as the compute step. Everything around it (block size from the C layout,
+    padding, barriers, repeats, record gather) is multigpu.sharded_match_timed's own code."""
+
+    def __init__(self, world, rank):
+        self.world, self.rank, self.calls = world, rank, 0
+
+    def match(self, d_a, a_index_base, d_b_shard, nb_total):
+        from vulkansift_amd import multigpu
+
+        blk = multigpu.shard_layout(nb_total, self.world, self.rank)[0]
+        assert d_b_shard.shape[0] == blk and d_b_shard.is_contiguous()      # what vksift_ext_matchSharded validates as nb_shard
+        full = torch.empty((self.world * blk, 128), dtype=torch.uint8)
+        dist.all_gather_into_tensor(full, d_b_shard)
+        self.calls += 1
+        return _oracle_match_fn(d_a, a_index_base, full[:nb_total]), 1.0 / self.calls
+
+    def close(self):
+        pass
+
+
+def _timed_worker(rank, world, port, na, nb, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vulkansift_amd import api, multigpu
+
+    a = api.gen_synthetic_descriptors(41, na)
+    b = api.gen_synthetic_descriptors(42, nb)
+    b[1] = b[0]
+    # bench.py's sharded_match(): A and B both split with the C block layout
+    lo, hi = multigpu.shard_bounds(na, world, rank)
+    blo, bhi = multigpu.shard_bounds(nb, world, rank)
+    groups = []
+
+    def factory(w, r):
+        groups.append(_StubGroup(w, r))
+        return groups[-1]
+
+    ms, rec = multigpu.sharded_match_timed(torch.from_numpy(a[lo:hi]), lo, torch.from_numpy(b[blo:bhi]), nb, world, rank, repeats=3, group_factory=factory)
+    rec_all = multigpu.gather_records(rec, na, world, rank)
+    q.put((rank, lo, hi, ms, groups[0].calls, rec_all.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("na,nb", [(101, 77), (9, 3), (64, 64)])
+def test_sharded_match_timed_flow_world2(oracle, vk, na, nb):
+    """bench.py's sharded leg at world size 2 with only the C entry's device work stubbed: C block layout (vksift_ext_shardGroupLayout)
+    for A and B, padding of the short last block, a_index_base = first row, best-of-repeats, and the all-gather of the records."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timed_worker, args=(r, world, port, na, nb, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from vulkansift_amd import multigpu
+
+    a = vk.gen_synthetic_descriptors(41, na)
+    b = vk.gen_synthetic_descriptors(42, nb)
+    b[1] = b[0]
+    ref = oracle.match_2nn(a, b)
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == na          # the two A shards tile [0, na)
+    for rank, lo, hi, ms, calls, rec_all in res:
+        assert calls == 3 and abs(ms - 1.0 / 3) < 1e-9                             # three repeats, the best one reported
+        got = multigpu.records_to_struct(rec_all)                                  # every rank holds ALL records after the gather
+        assert got.tobytes() == ref.tobytes()
+
+
+def test_shard_layout_is_the_c_arithmetic(vk):
+    from vulkansift_amd import multigpu
+
+    for n in (0, 1, 2, 3, 7, 64, 50000, 50001, 2**32 - 1):
+        for world in (1, 2, 3, 8):
+            blk = (n + world - 1) // world
+            rows = 0
+            for r in range(world):
+                b, lo, cnt = multigpu.shard_layout(n, world, r)
+                assert b == blk and lo == min(n, r * blk) and cnt == min(n, lo + blk) - lo
+                rows += cnt
+            assert rows == n
+
+
 @pytest.mark.parametrize("na,nb", [(101, 77), (8, 3), (5, 2)])
 def test_sharded_match_equals_single_process(oracle, vk, na, nb):
     world = 2

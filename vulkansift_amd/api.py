@@ -145,7 +145,16 @@ def lib():
     L.vksift_ext_shardGroupReserve.restype = C.c_int
     L.vksift_ext_shardGroupSynchronize.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.vksift_ext_shardGroupSynchronize.restype = C.c_int
+    L.vksift_ext_shardGroupCreateWithTransport.argtypes = [C.POINTER(C.c_void_p), C.c_int, u32, u32, C.c_void_p, C.c_void_p]
+    L.vksift_ext_shardGroupCreateWithTransport.restype = C.c_int
+    L.vksift_ext_shardGroupLayout.argtypes = [u32, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.vksift_ext_shardGroupLayout.restype = None
     # kernel-layer C-ABI (include/vksift_hip.h) entry points used directly by bench.py / tests
+    for name in ("vksift_hip_memcpy_h2d", "vksift_hip_memcpy_d2h", "vksift_hip_memcpy_d2d"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        getattr(L, name).restype = C.c_int
+    L.vksift_hip_stream_sync.argtypes = [C.c_void_p]
+    L.vksift_hip_stream_sync.restype = C.c_int
     L.vksift_hip_match_2nn_desc.argtypes = [C.c_void_p, u32, u32, C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.vksift_hip_match_2nn_desc.restype = C.c_int
     L.vksift_hip_gather_descriptors.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p]

@@ -90,6 +90,8 @@ struct vksift_ext_ShardGroup_T
   int device;
   uint32_t world, rank;
   rccl_Comm comm;
+  vksift_ext_AllGatherFn transport; /* non-NULL: the application's own all-gather stands in for ncclAllGather (comm == NULL) */
+  void *transport_user;
   vksift_hip_stream stream, comm_stream;
   vksift_hip_event ev_fork, ev_gathered, ev_t0, ev_t1;
   uint8_t *d_b_full;
@@ -114,12 +116,13 @@ vksift_Result vksift_ext_shardGetUniqueId(uint8_t id[VKSIFT_EXT_SHARD_ID_BYTES])
   return VKSIFT_SUCCESS;
 }
 
-vksift_Result vksift_ext_shardGroupCreate(vksift_ext_ShardGroup *out, int gpu_device_index, uint32_t world, uint32_t rank,
-                                          const uint8_t id[VKSIFT_EXT_SHARD_ID_BYTES])
+/* id != NULL: RCCL communicator (collective: ncclCommInitRank); id == NULL: the caller's transport */
+static vksift_Result shard_group_create(vksift_ext_ShardGroup *out, int gpu_device_index, uint32_t world, uint32_t rank, const uint8_t *id,
+                                        vksift_ext_AllGatherFn transport, void *transport_user)
 {
-  if (!out || *out != NULL || world == 0 || rank >= world || !id)
+  if (!out || *out != NULL || world == 0 || rank >= world || (!id && !transport))
     return VKSIFT_INVALID_INPUT_ERROR;
-  if (!vksift_g_loaded || !rccl_load())
+  if (!vksift_g_loaded || (id && !rccl_load()))
     return VKSIFT_VULKAN_ERROR;
   if (gpu_device_index < 0 || gpu_device_index >= vksift_hip_device_count() || vksift_hip_set_device(gpu_device_index) != 0)
     return VKSIFT_VULKAN_ERROR;
@@ -127,14 +130,18 @@ vksift_Result vksift_ext_shardGroupCreate(vksift_ext_ShardGroup *out, int gpu_de
   if (!g)
     return VKSIFT_VULKAN_ERROR;
   g->device = gpu_device_index, g->world = world, g->rank = rank;
-  rccl_UniqueId u;
-  memcpy(u.internal, id, VKSIFT_EXT_SHARD_ID_BYTES);
-  const int e = g_rccl.CommInitRank(&g->comm, (int)world, u, (int)rank);
-  if (e != 0)
+  g->transport = id ? NULL : transport, g->transport_user = transport_user;
+  if (id)
   {
-    logError(LOG_TAG, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
-    free(g);
-    return VKSIFT_VULKAN_ERROR;
+    rccl_UniqueId u;
+    memcpy(u.internal, id, VKSIFT_EXT_SHARD_ID_BYTES);
+    const int e = g_rccl.CommInitRank(&g->comm, (int)world, u, (int)rank);
+    if (e != 0)
+    {
+      logError(LOG_TAG, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+      free(g);
+      return VKSIFT_VULKAN_ERROR;
+    }
   }
   g->stream = vksift_hip_stream_create();
   g->comm_stream = vksift_hip_stream_create();
@@ -154,6 +161,53 @@ vksift_Result vksift_ext_shardGroupCreate(vksift_ext_ShardGroup *out, int gpu_de
   return VKSIFT_SUCCESS;
 }
 
+vksift_Result vksift_ext_shardGroupCreate(vksift_ext_ShardGroup *out, int gpu_device_index, uint32_t world, uint32_t rank,
+                                          const uint8_t id[VKSIFT_EXT_SHARD_ID_BYTES])
+{
+  if (!id)
+    return VKSIFT_INVALID_INPUT_ERROR;
+  return shard_group_create(out, gpu_device_index, world, rank, id, NULL, NULL);
+}
+
+vksift_Result vksift_ext_shardGroupCreateWithTransport(vksift_ext_ShardGroup *out, int gpu_device_index, uint32_t world, uint32_t rank,
+                                                       vksift_ext_AllGatherFn all_gather, void *user)
+{
+  if (!all_gather)
+    return VKSIFT_INVALID_INPUT_ERROR;
+  return shard_group_create(out, gpu_device_index, world, rank, NULL, all_gather, user);
+}
+
+void vksift_ext_shardGroupLayout(uint32_t n_total, uint32_t world, uint32_t rank, uint32_t *block_rows, uint32_t *first_row, uint32_t *nb_rows)
+{
+  /* equal blocks of ceil(n_total / world) rows: what vksift_ext_matchSharded all-gathers (the last blocks may be short or empty) */
+  const uint32_t blk = world ? (uint32_t)(((uint64_t)n_total + world - 1) / world) : 0;
+  const uint64_t lo64 = (uint64_t)rank * blk;
+  const uint32_t lo = lo64 < n_total ? (uint32_t)lo64 : n_total;
+  const uint32_t hi = (uint64_t)lo + blk < n_total ? lo + blk : n_total;
+  if (block_rows)
+    *block_rows = blk;
+  if (first_row)
+    *first_row = lo;
+  if (nb_rows)
+    *nb_rows = hi - lo;
+}
+
+/* the exchange: ncclAllGather on the communicator, or the application's transport */
+static int shard_all_gather(vksift_ext_ShardGroup g, const void *send, void *recv, size_t bytes_per_rank, vksift_hip_stream s)
+{
+  if (g->transport)
+  {
+    const int te = g->transport(g->transport_user, send, recv, bytes_per_rank, g->rank, g->world, s);
+    if (te != 0)
+      logError(LOG_TAG, "the all-gather transport failed (%d)", te);
+    return te;
+  }
+  const int ne = g_rccl.AllGather(send, recv, bytes_per_rank, RCCL_UINT8, g->comm, s);
+  if (ne != 0)
+    logError(LOG_TAG, "ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(ne) : "?");
+  return ne;
+}
+
 void vksift_ext_shardGroupDestroy(vksift_ext_ShardGroup *gp)
 {
   if (!gp || !*gp)
@@ -164,7 +218,7 @@ void vksift_ext_shardGroupDestroy(vksift_ext_ShardGroup *gp)
     vksift_hip_stream_sync(g->comm_stream);
   if (g->stream)
     vksift_hip_stream_sync(g->stream);
-  if (g->comm)
+  if (g->comm && g_rccl.CommDestroy)
     g_rccl.CommDestroy(g->comm);
   vksift_hip_free(g->d_b_full);
   vksift_hip_free(g->d_scratch);
@@ -257,12 +311,8 @@ vksift_Result vksift_ext_matchSharded(vksift_ext_ShardGroup g, const uint8_t *d_
     e = vksift_hip_stream_wait_event(g->comm_stream, g->ev_fork);
   {
     /* entered even when the event calls above failed: the peers are (or will be) inside it */
-    const int ne = g_rccl.AllGather(send, g->d_b_full, (size_t)nb_shard * 128u, RCCL_UINT8, g->comm, g->comm_stream);
-    if (ne != 0)
-    {
-      logError(LOG_TAG, "ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(ne) : "?");
+    if (shard_all_gather(g, send, g->d_b_full, (size_t)nb_shard * 128u, g->comm_stream) != 0)
       e = -1;
-    }
   }
   if (e == 0)
     e = vksift_hip_event_record(g->ev_gathered, g->comm_stream);

@@ -25,12 +25,21 @@ def shard_range(n, world, rank):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def shard_layout(n, world, rank):
+    """vksift_ext_shardGroupLayout: (block_rows, first_row, nb_rows) of rank `rank` in the equal-block layout of the reference set
+    that vksift_ext_matchSharded all-gathers. The arithmetic lives in the C library (vksift_sharded.c); this is its binding."""
+    from . import api
+
+    blk, lo, cnt = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    api.lib().vksift_ext_shardGroupLayout(n, world, rank, C.byref(blk), C.byref(lo), C.byref(cnt))
+    return int(blk.value), int(lo.value), int(cnt.value)
+
+
 def shard_bounds(n, world, rank):
     """Equal blocks of ceil(n / world) rows — the layout of the reference set B that vksift_ext_matchSharded all-gathers
     (the last blocks may be short or empty; the caller pads them to the block size)."""
-    blk = (n + world - 1) // world
-    lo = min(n, rank * blk)
-    return lo, min(n, lo + blk)
+    _, lo, cnt = shard_layout(n, world, rank)
+    return lo, lo + cnt
 
 
 def split_batch(items, world, rank):
@@ -57,16 +66,60 @@ def hip_match_fn(desc_a, a_index_base, desc_b):
     return out
 
 
-class ShardGroup:
-    """vksift_ext_ShardGroup: the library's own RCCL communicator. `dist` (torch.distributed, initialised) only broadcasts the id."""
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p)
 
-    def __init__(self, device_index, world, rank, dist=None):
+
+def host_staged_transport(dist, group=None):
+    """A vksift_ext_AllGatherFn over ANY torch.distributed backend (gloo included): synchronise the stream, copy this rank's block
+    to the host, all-gather on the host, copy the gathered set back. Slow by construction — it exists so that the world-size > 1
+    code path of vksift_ext_matchSharded (block layout, in-place send slot, a_index_base, stream fork / join) can run where RCCL
+    cannot: several ranks sharing one GPU. Returns the Python callable for ShardGroup(transport=...)."""
+    import torch
+
+    from . import api
+
+    def all_gather(user, d_send, d_recv, nbytes, rank, world, stream):
+        try:
+            L = api.lib()
+            if L.vksift_hip_stream_sync(stream) != 0:
+                return 1
+            mine = np.empty(nbytes, np.uint8)
+            if L.vksift_hip_memcpy_d2h(mine.ctypes.data, d_send, nbytes, stream) != 0 or L.vksift_hip_stream_sync(stream) != 0:
+                return 2
+            full = torch.empty(world * nbytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(full, torch.from_numpy(mine), group=group)
+            host = full.numpy()
+            if L.vksift_hip_memcpy_h2d(d_recv, host.ctypes.data, world * nbytes, stream) != 0 or L.vksift_hip_stream_sync(stream) != 0:
+                return 3
+            return 0
+        except Exception:  # noqa: BLE001 - an exception must not unwind through the C frames of the library
+            import traceback
+
+            traceback.print_exc()
+            return -1
+
+    return all_gather
+
+
+class ShardGroup:
+    """vksift_ext_ShardGroup: the library's own RCCL communicator (`dist` — torch.distributed, initialised — only broadcasts the
+    id), or, with `transport` (a Python callable with the vksift_ext_AllGatherFn signature), the application's own all-gather."""
+
+    def __init__(self, device_index, world, rank, dist=None, transport=None):
         import torch
 
         from . import api
 
         self._api = api
         api.load()
+        self.world, self.rank = world, rank
+        self._h = C.c_void_p(None)
+        if transport is not None:
+            self._cb = ALL_GATHER_FN(transport)      # keep the thunk alive as long as the group
+            r = api.lib().vksift_ext_shardGroupCreateWithTransport(C.byref(self._h), device_index, world, rank, self._cb, None)
+            if r != 0:
+                raise RuntimeError(f"vksift_ext_shardGroupCreateWithTransport failed ({r})")
+            return
         ident = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             buf = (C.c_uint8 * 128)()
@@ -78,11 +131,9 @@ class ShardGroup:
             dist.broadcast(ident, src=0)
             ident = ident.cpu()
         raw = (C.c_uint8 * 128)(*ident.tolist())
-        self._h = C.c_void_p(None)
         r = api.lib().vksift_ext_shardGroupCreate(C.byref(self._h), device_index, world, rank, raw)
         if r != 0:
             raise RuntimeError(f"vksift_ext_shardGroupCreate failed ({r})")
-        self.world, self.rank = world, rank
 
     def reserve(self, max_na, max_nb_total):
         """vksift_ext_shardGroupReserve: device scratch up front, so that match() within these sizes allocates nothing (a rank that
@@ -130,13 +181,14 @@ def pad_rows(rows, n):
     return out
 
 
-def sharded_match_timed(d_a, a_index_base, d_b_block, nb_total, world, rank, repeats=3):
-    """bench.py helper: best-of-`repeats` time of vksift_ext_matchSharded on this rank + its records."""
-    import torch
+def sharded_match_timed(d_a, a_index_base, d_b_block, nb_total, world, rank, repeats=3, group_factory=None):
+    """bench.py helper: best-of-`repeats` time of vksift_ext_matchSharded on this rank + its records. group_factory(world, rank)
+    (default: an RCCL ShardGroup on d_a's device) lets the CPU tests run this exact flow — block size from the C layout, padding,
+    barriers, repeats — with a stand-in group."""
     import torch.distributed as dist
 
-    blk = (nb_total + world - 1) // world
-    grp = ShardGroup(d_a.device.index, world, rank, dist if world > 1 else None)
+    blk = shard_layout(nb_total, world, rank)[0]
+    grp = group_factory(world, rank) if group_factory else ShardGroup(d_a.device.index, world, rank, dist if world > 1 else None)
     try:
         d_b = pad_rows(d_b_block, blk)
         best, rec = None, None
@@ -157,7 +209,7 @@ def gather_records(rec_local, n_total, world, rank):
 
     if world == 1:
         return rec_local
-    blk = (n_total + world - 1) // world
+    blk = shard_layout(n_total, world, rank)[0]
     pad = torch.zeros((blk, 5), dtype=rec_local.dtype, device=rec_local.device)
     pad[: rec_local.shape[0]] = rec_local
     full = torch.empty((world * blk, 5), dtype=rec_local.dtype, device=rec_local.device)
