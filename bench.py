@@ -21,15 +21,14 @@ RCCL all-gather of the reference descriptors) and rank 0 prints the CRC-32 of th
 same number at N = 1, 2, 4, 8. PyTorch is used for torch.distributed (RCCL) and device buffers only.
 
 Objects on the JSON line besides the contract fields:
-  roofline          octave 0's scale-space construction (k_blur_lean x 6: fused up-sampling+seed blur, 5 scale blurs) plus
-                    the streaming extrema scan (k_extrema_lean, ONE launch over all octaves) — the launches that produce the
-                    Gaussian planes and form the DoG values. Algorithmic bytes: 72.25 B per octave-0 pixel for
-                    pyramid + DoG, + 20 B per pixel of every octave for the scan, divided by the summed duration of those 7
-                    launches, measured with HIP events recorded on
-                    the streams the kernels run on, inside the timed region. `pyramid_only` is the same over the 6 blur launches
-                    and 72.25 B (this build never writes the DoG planes, so that figure flatters the blur kernels: the DoG
-                    values are formed in the scan). `traffic` / `physical_frac`: HBM bytes from rocprofv3 --pmc passes
-                    (profiles/*pmc_traffic*.json), accepted only if the kernel sources are the ones the file was measured on.
+  roofline          octave 0's scale-space construction (fused up-sampling + seed blur, the two-scale launch, three more scale blurs)
+                    plus the streaming extrema scan (k_extrema_lean, ONE launch over all octaves) — the launches that produce the
+                    Gaussian planes and form the DoG values; durations from HIP events recorded on the streams the kernels run on,
+                    inside the timed region. `frac` is what the hardware moved: HBM bytes from the rocprofv3 --pmc capture of the same
+                    kernel sources (profiles/*pmc_traffic*.json, refused for any other source hash) / those durations / 8 TB/s, with
+                    `per_launch` rows (bytes, us, fraction per launch kind) from that capture. `algorithmic` = this build's own minimum
+                    (41.25 B per octave-0 pixel + 24 B per scanned pixel; <= traffic by construction); `survey_8d` = SURVEY.md 8(d)'s
+                    pricing of the reference's schedule (72.25 + 20 B/px), kept for comparison with earlier rounds only.
   roofline_c3       the same for BASELINE config 3 (64 x 1920x1080, detect only), 5 steps
   value_host_input  the reference's own measurement protocol on the same frames (src/perf/wrappers/vulkansift_wrapper.cpp:
                     30-33): host images in, vksift_getFeaturesNumber + vksift_downloadFeatures (+ matches) out, strictly serial
@@ -162,36 +161,58 @@ def pmc_traffic(w, h, batch):
 
 
 def roofline_from(acc, pmc, label):
+    """The scale-space + DoG pass of octave 0 (blur launches) and the extrema scan over all octaves (one launch), HIP-event durations
+    from inside the timed region.
+      frac / achieved  what the HARDWARE moved: HBM bytes of these launches from the rocprofv3 --pmc capture of the same kernel
+                       sources (profiles/*pmc_traffic*.json) / their measured duration / 8 TB/s. Without a matching capture they fall
+                       back to this build's own algorithmic minimum (below) — never to the reference-schedule pricing.
+      algorithmic      this build's minimum for the same result: octave 0: 1 B read (u8) + 6 planes written + 5 plane reads (4 with the
+                       two-scale launch) + 1 B/px-of-octave-1 seed = 41.25 B per octave-0 pixel; scan: the 6 Gaussian planes read once =
+                       24 B per pixel of every octave. By construction <= traffic (halo re-reads are the difference).
+      survey_8d        SURVEY.md 8(d)'s pricing of the REFERENCE's schedule (72.25 B per octave-0 pixel incl. 20 B/px of DoG writes + 20
+                       B/px DoG reads in the scan): kept for comparison with earlier rounds; this build performs neither, so the
+                       figure overstates what the hardware does and is not `frac`."""
     calls = max(acc["nb_calls"], 1)
     launches = max(acc["nb_blur_launches"], 1)
     pyr_s = acc["pyramid_ms"] * 1e-3
     scan_s = acc["scan_ms"] * 1e-3
+    t = pyr_s + scan_s
     alg_pyr = float(acc["pyramid_algorithmic_bytes"])                   # 72.25 B per octave-0 pixel (SURVEY.md 8d), whole run
     alg_scan = float(acc["scan_algorithmic_bytes"])                    # + 20 B per pixel of every octave for the extrema scan (one launch)
     n_launch = launches + calls                                        # blur launches + one scan per detection call
-    achieved = (alg_pyr + alg_scan) / (pyr_s + scan_s) / 1e9 if pyr_s + scan_s > 0 else 0.0
-    pyr_only = alg_pyr / pyr_s / 1e9 if pyr_s > 0 else 0.0
+    own_pyr = alg_pyr * (41.25 / 72.25)                                 # this build's minimum, same pixel counts
+    own_scan = alg_scan * (24.0 / 20.0)
+    own = (own_pyr + own_scan) / t / 1e9 if t > 0 else 0.0
+    survey = (alg_pyr + alg_scan) / t / 1e9 if t > 0 else 0.0
     out = {
         "bound": "hbm",
         "kernel": label,
-        "achieved": achieved,
+        "achieved": own,
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBPS,
+        "frac": own / HBM_PEAK_GBPS,
+        "basis": "algorithmic minimum of this build (no PMC capture of these kernel sources)",
         "traffic": None,
-        "algorithmic_bytes_per_launch": (alg_pyr + alg_scan) / n_launch,
-        "avg_launch_us": (pyr_s + scan_s) / n_launch * 1e6,
+        "avg_launch_us": t / n_launch * 1e6,
         "launches_per_call": n_launch / calls,
-        "pyramid_only": {"achieved": pyr_only, "frac": pyr_only / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg_pyr / launches,
-                         "avg_launch_us": pyr_s / launches * 1e6, "launches_per_call": launches / calls,
-                         "note": "SURVEY.md 8(d) counts 20 B/px of DoG writes that this build never performs (DoG values are formed in the scan)"},
-        "scan_only": {"achieved": alg_scan / scan_s / 1e9 if scan_s > 0 else 0.0, "avg_launch_us": scan_s / calls * 1e6},
+        "algorithmic": {"bytes_per_launch": (own_pyr + own_scan) / n_launch, "achieved": own, "frac": own / HBM_PEAK_GBPS,
+                        "note": "41.25 B per octave-0 pixel (blur launches) + 24 B per pixel of every octave (scan): what this build must move"},
+        "survey_8d": {"bytes_per_launch": (alg_pyr + alg_scan) / n_launch, "achieved": survey, "frac": survey / HBM_PEAK_GBPS,
+                      "note": "reference-schedule pricing (72.25 + 20 B/px): counts DoG writes / reads this build does not perform; not the headline fraction"},
+        "blur_launches": {"avg_us": pyr_s / launches * 1e6, "per_call": launches / calls},
+        "scan_launch": {"avg_us": scan_s / calls * 1e6},
     }
     if pmc is not None:
         per_call = pmc["hbm_bytes_per_call"]
-        out["traffic"] = per_call / (n_launch / calls)                 # HBM bytes per launch, like algorithmic_bytes_per_launch
-        out["physical_frac"] = per_call * calls / (pyr_s + scan_s) / 1e9 / HBM_PEAK_GBPS
+        phys = per_call * calls / t / 1e9 if t > 0 else 0.0
+        out["traffic"] = per_call / (n_launch / calls)                 # HBM bytes per launch (PMC)
+        out["achieved"] = phys
+        out["frac"] = phys / HBM_PEAK_GBPS
+        out["basis"] = "HBM bytes from rocprofv3 --pmc (FETCH_SIZE x 2 + WRITE_SIZE) of the same kernel sources / HIP-event duration in this run"
         out["traffic_source"] = pmc.get("_path", "profiles/")
+        out["traffic_over_algorithmic"] = per_call * calls / (own_pyr + own_scan)
+        if pmc.get("per_launch"):
+            out["per_launch"] = pmc["per_launch"]                       # bytes, us and fraction of each launch kind, from the capture itself
     return out
 
 
@@ -220,6 +241,46 @@ def usable_cores():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def opencv_probe():
+    """SURVEY.md 8(d)(2): the reference's CPU comparison is cv::SIFT::create() defaults + BFMatcher knnMatch(k=2)
+    (src/perf/wrappers/opencv_wrapper.cpp:5,16, src/perf/perf_common.cpp:113-119). Timed only if OpenCV is importable on this box;
+    otherwise said so — never fabricated."""
+    try:
+        import cv2  # noqa: F401
+    except Exception as e:  # noqa: BLE001
+        return {"available": False, "reason": f"import cv2 failed: {type(e).__name__}", "pkg_config": bool(subprocess.run(
+            "pkg-config --exists opencv4", shell=True, capture_output=True).returncode == 0)}
+    return {"available": True, "version": cv2.__version__}
+
+
+def opencv_baseline(frames, do_match, runs=5):
+    import cv2
+
+    sift = cv2.SIFT_create(0, 3, 0.04, 10, 1.6)
+    bf = cv2.BFMatcher(cv2.NORM_L2)
+    sift.detectAndCompute(frames[0], None)
+    t0 = time.perf_counter()
+    n = 0
+    for i in range(runs):
+        kp, des = sift.detectAndCompute(frames[i % len(frames)], None)
+        if do_match and des is not None and len(des) >= 2:
+            bf.knnMatch(des, des, k=2)
+        n += len(kp)
+    dt = time.perf_counter() - t0
+    return {"value": runs / dt, "unit": "frames/s", "threads": cv2.getNumThreads(), "features_per_frame": n / runs,
+            "what": "cv::SIFT::create(0,3,0.04,10,1.6) detectAndCompute" + (" + BFMatcher(NORM_L2).knnMatch(k=2) self-match" if do_match else "")}
+
+
 def _cpu_worker(job):
     """one PROCESS per core (own heap: the oracle allocates its pyramid per call, and threads of one process serialised in malloc/
     page-fault handling — round 2 measured 9.6x on 256 threads)"""
@@ -236,6 +297,16 @@ def _cpu_worker(job):
             O.match_2nn(feats, feats)
         n += len(feats)
     return n
+
+
+def _opencv_leg(frames, do_match):
+    probe = opencv_probe()
+    if not probe["available"]:
+        return dict(probe, note="OpenCV unavailable on this box: the reference's OpenCV-SIFT comparison was not run")
+    try:
+        return dict(probe, **opencv_baseline(frames, do_match))
+    except Exception as e:  # noqa: BLE001
+        return dict(probe, error=repr(e)[:200])
 
 
 def cpu_baseline(frames, do_match, per_worker=2):
@@ -275,6 +346,8 @@ def cpu_baseline(frames, do_match, per_worker=2):
         "single_thread_value": 1.0 / t_single,
         "scaling_vs_one_core": (total / dt) * t_single,
         "machine_logical_cpus": os.cpu_count(),
+        "cpu_model": cpu_model(),
+        "opencv": _opencv_leg(frames, do_match),
         "build": build,
         "sample": f"{total} frames of the benchmark's {frames[0].shape[1]}x{frames[0].shape[0]} workload ({per_worker} per worker process, one process per usable core), detect"
                   + ("+self-match" if do_match else "") + f", {int(sum(nfeat) / total)} features/frame, {dt:.1f} s wall ({dt * cores:.0f} core-seconds); "
@@ -624,6 +697,11 @@ def main():
                 "mean_features_per_frame": float(np.mean(nfeat)),
                 "parallelism": f"batch split x{world}, no collectives",
                 "input": "host images, upload inside the timed region" if args.host_input else "resident in HBM",
+                "protocols": "value: batched detection on HBM-resident frames, nothing downloaded (kernel-side figure, the bench contract's "
+                             "definition). value_host_input: the REFERENCE's own protocol (src/perf/wrappers/vulkansift_wrapper.cpp:30-33: host "
+                             "image in, count + features + matches downloaded, strictly serial) — the figure to compare with the reference's "
+                             "published runtimes. value_host_input_pipelined: the same inputs and outputs with the asynchronous API. "
+                             "single_image_ms: BASELINE config 2 literally (one image per call)",
             },
             "roofline": roofline_from(acc, pmc, "k_blur_lean x6 on octave 0 (1280x960 planes): scale-space construction, + k_extrema_lean over all octaves: the scan that forms the DoG values"),
             "stage_ms_per_call": {k: acc[k] / max(acc["nb_calls"], 1) for k in
@@ -684,8 +762,8 @@ def main():
                                 "--width", str(W), "--height", str(H), "--batch", str(B)], capture_output=True, text=True, timeout=300)
             d16 = json.loads(r.stdout.strip().splitlines()[-1])
             extras["fp16_mode"] = {"value": d16["value"], "unit": d16["unit"], "dtype": d16["dtype"], "mean_features_per_frame": d16["config"]["mean_features_per_frame"],
-                                   "roofline_frac": d16["roofline"]["frac"], "roofline_achieved": d16["roofline"]["achieved"],
-                                   "pyramid_only_frac": d16["roofline"]["pyramid_only"]["frac"], "stage_ms_per_call": d16["stage_ms_per_call"]}
+                                   "roofline_frac": d16["roofline"]["frac"], "roofline_achieved": d16["roofline"]["achieved"], "roofline_basis": d16["roofline"]["basis"],
+                                   "stage_ms_per_call": d16["stage_ms_per_call"]}
         except Exception as e:  # noqa: BLE001
             extras["fp16_mode"] = {"error": repr(e)[:300]}
     if not args.no_extras:

@@ -82,6 +82,14 @@ extern "C"
   VKSIFT_EXPORT void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext_DetectTimings *sum, uint32_t *nb_calls, bool reset);
   VKSIFT_EXPORT void vksift_ext_getAccumulatedDetectTimingsSized(vksift_Instance instance, vksift_ext_DetectTimings *sum, size_t sum_bytes, uint32_t *nb_calls,
                                                                   bool reset);
+  /* Clients compiled against THIS header get every field: the unsized names expand to the ...Sized forms with the size of the
+   * struct they were compiled with. The exported symbols of the same names keep the 40-byte behaviour for binaries built against
+   * the first release (which pass a 40-byte struct). */
+#ifndef VKSIFT_BUILD
+#define vksift_ext_getDetectTimings(instance, out) vksift_ext_getDetectTimingsSized((instance), (out), sizeof(vksift_ext_DetectTimings))
+#define vksift_ext_getAccumulatedDetectTimings(instance, sum, nb_calls, reset) \
+  vksift_ext_getAccumulatedDetectTimingsSized((instance), (sum), sizeof(vksift_ext_DetectTimings), (nb_calls), (reset))
+#endif
   /* Time (ms) of the last matching pipeline (gather + 2-NN kernel), HIP events; needs profiling on. */
   VKSIFT_EXPORT float vksift_ext_getMatchTime(vksift_Instance instance);
 

@@ -33,12 +33,19 @@ def test_stale_pmc_capture_is_refused(monkeypatch):
 
 def test_roofline_object_fields():
     b = _bench()
-    acc = {"nb_calls": 8, "nb_blur_launches": 48, "pyramid_ms": 14.0, "scan_ms": 6.0, "pyramid_algorithmic_bytes": 8 * 11.36e9, "scan_algorithmic_bytes": 8 * 3.15e9}
+    acc = {"nb_calls": 8, "nb_blur_launches": 40, "pyramid_ms": 14.0, "scan_ms": 6.0, "pyramid_algorithmic_bytes": 8 * 11.36e9, "scan_algorithmic_bytes": 8 * 3.15e9}
+    own = 8 * 11.36e9 * 41.25 / 72.25 + 8 * 3.15e9 * 24.0 / 20.0
     r = b.roofline_from(acc, None, "label")
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] is None
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert abs(r["achieved"] - (8 * 11.36e9 + 8 * 3.15e9) / 20.0e-3 / 1e9) < 1e-6
-    assert r["launches_per_call"] == 7.0 and abs(r["algorithmic_bytes_per_launch"] - (8 * 11.36e9 + 8 * 3.15e9) / 56) < 1.0
-    pmc = {"hbm_bytes_per_call": 12.0e9, "_path": "profiles/x.json"}
+    # without a PMC capture: this build's own algorithmic minimum, never the reference-schedule pricing
+    assert abs(r["achieved"] - own / 20.0e-3 / 1e9) < 1e-6 and r["algorithmic"]["frac"] == r["frac"]
+    assert abs(r["survey_8d"]["achieved"] - (8 * 11.36e9 + 8 * 3.15e9) / 20.0e-3 / 1e9) < 1e-6
+    assert r["launches_per_call"] == 6.0 and abs(r["algorithmic"]["bytes_per_launch"] - own / 48) < 1.0
+    assert "pyramid_only" not in r
+    # with one: frac IS the hardware figure (HBM bytes of the capture / the durations of this run), and traffic >= algorithmic
+    pmc = {"hbm_bytes_per_call": 12.0e9, "_path": "profiles/x.json", "per_launch": [{"kernel": "k", "hbm_bytes": 1.0, "avg_us": 1.0}]}
     r2 = b.roofline_from(acc, pmc, "label")
-    assert abs(r2["traffic"] - 12.0e9 / 7.0) < 1.0 and abs(r2["physical_frac"] - 12.0e9 * 8 / 20.0e-3 / 1e9 / 8000.0) < 1e-9
+    assert abs(r2["traffic"] - 12.0e9 / 6.0) < 1.0 and abs(r2["frac"] - 12.0e9 * 8 / 20.0e-3 / 1e9 / 8000.0) < 1e-9
+    assert abs(r2["frac"] - r2["achieved"] / r2["peak"]) < 1e-12 and r2["algorithmic"]["frac"] == r["frac"]
+    assert abs(r2["traffic_over_algorithmic"] - 12.0e9 * 8 / own) < 1e-9 and r2["per_launch"] == pmc["per_launch"]

@@ -82,7 +82,27 @@ def main():
         per_launch = (2.0 * fetch_kb / max(calls, 1) + write_kb / max(wcalls, 1)) * 1024.0
         scan_launch = (2.0 * sum(v["sum"] for v in sf.values()) / scalls + sum(v["sum"] for v in sw_.values()) / swcalls) * 1024.0
         blur_per_call = calls / scalls          # blur launches of octave 0 per detection call (= per scan launch)
-        rec = {"width": w, "height": h, "batch": batch, "kernel": KERNEL + " / k_blur_pair (octave-0 launches) + " + SCAN + " (one launch over all octaves)", "kernel_source_sha": kernel_source_sha(),
+        # per launch kind: HBM bytes (PMC) / average and minimum duration of the same launch shape in the kernel trace
+        per_launch_rows = []
+        if have_trace:
+            import sqlite3
+            durs = {}
+            for dbp in glob.glob(os.path.join(src, "trace", "**", "*.db"), recursive=True):
+                for name, st, en, gx in sqlite3.connect(dbp).execute("select name, start, end, grid_x from kernels"):
+                    durs.setdefault((name, int(gx)), []).append(en - st)
+            for name in list(f.keys()) + list(sf.keys()):
+                is_scan = name in sf
+                fk = (sf if is_scan else f)[name]
+                wk = (sw_ if is_scan else wr).get(name, {"avg": 0.0})
+                gx = None if is_scan else (gridx_pair if "k_blur_pair" in name else gridx)
+                dd = [v for (n, g), vs in durs.items() if n == name and (gx is None or g == gx) for v in vs]
+                if not dd:
+                    continue
+                hbm = (2.0 * fk["avg"] + wk["avg"]) * 1024.0
+                avg_us, min_us = sum(dd) / len(dd) / 1e3, min(dd) / 1e3
+                per_launch_rows.append({"kernel": name.replace("void (anonymous namespace)::", "").split("(")[0], "hbm_bytes": hbm, "avg_us": avg_us, "min_us": min_us,
+                                        "frac_of_8TBps": hbm / (avg_us * 1e-6) / 8e12, "frac_at_min_duration": hbm / (min_us * 1e-6) / 8e12, "launches_in_trace": len(dd)})
+        rec = {"per_launch": per_launch_rows, "width": w, "height": h, "batch": batch, "kernel": KERNEL + " / k_blur_pair (octave-0 launches) + " + SCAN + " (one launch over all octaves)", "kernel_source_sha": kernel_source_sha(),
                "launches_fetch_pass": calls, "launches_write_pass": wcalls, "scan_launches": scalls,
                "FETCH_SIZE_KiB_sum": fetch_kb, "WRITE_SIZE_KiB_sum": write_kb, "fetch_correction": 2.0,
                "hbm_bytes_per_blur_launch": per_launch, "hbm_bytes_per_scan_launch": scan_launch,

@@ -10,6 +10,7 @@ LD_PRELOAD=$(gcc -print-file-name=libasan.so) (the sanitizer runtime has to come
 The shared library lands in vulkansift_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).
 hipcc cross-compiles gfx950 without a GPU, so this also serves as the "does it build" check.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -42,6 +43,52 @@ def _newer(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+_TOOL_VERSION = {}
+
+
+def _tool_version(tool):
+    if tool not in _TOOL_VERSION:
+        r = subprocess.run([tool, "--version"], capture_output=True, text=True)
+        _TOOL_VERSION[tool] = (r.stdout + r.stderr).strip()
+    return _TOOL_VERSION[tool]
+
+
+def _signature(cmd, src, headers):
+    """What an object file was built FROM: the full command line (every flag), the compiler's version banner, the bytes of the source
+    and of every header it may include. Kept in a sidecar next to the object (<obj>.sig); an object is rebuilt when the sidecar
+    differs — a changed flag reaches the object file even when no time stamp moved (round 3: -fno-slp-vectorize did not reach
+    pyramid.hip.o until a header happened to change)."""
+    h = hashlib.sha256()
+    # paths relative to the checkout: the same tree under another root (the GPU box's copy) has the same signature
+    h.update(("\0".join(cmd).replace(ROOT, "<root>") + "\0" + _tool_version(cmd[0])).encode())
+    for path in [src] + sorted(headers):
+        h.update(os.path.relpath(path, ROOT).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(obj, sig):
+    try:
+        return not os.path.exists(obj) or open(obj + ".sig").read().strip() != sig
+    except OSError:
+        return True
+
+
+def _compile(cmd, src, obj, headers, force, verbose, tag):
+    sig = _signature(cmd, src, headers)
+    if force or _stale(obj, sig):
+        if verbose:
+            print(tag, os.path.relpath(src, CSRC))
+        if os.path.exists(obj + ".sig"):
+            os.remove(obj + ".sig")
+        _run(cmd)
+        with open(obj + ".sig", "w") as f:
+            f.write(sig + "\n")
+        return True
+    return False
 
 
 def _all_headers():
@@ -98,24 +145,19 @@ def build(force=False, verbose=False, sanitize=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = _all_headers()
     objs = []
+    rebuilt = False
     for src in HOST_SRCS:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ_DIR, os.path.basename(src) + (".asan.o" if sanitize else ".o"))
         objs.append(o)
-        if force or _newer(o, [s] + headers):
-            if verbose:
-                print("[cc ]", src)
-            _run(["gcc"] + CFLAGS + (SANITIZE_FLAGS if sanitize else []) + INCLUDES + ["-DVKSIFT_BUILD", "-c", s, "-o", o])
+        rebuilt |= _compile(["gcc"] + CFLAGS + (SANITIZE_FLAGS if sanitize else []) + INCLUDES + ["-DVKSIFT_BUILD", "-c", s, "-o", o], s, o, headers, force, verbose, "[cc ]")
     for src in HIP_SRCS:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
         objs.append(o)
-        if force or _newer(o, [s] + headers):
-            if verbose:
-                print("[hip]", src)
-            _run([HIPCC] + HIPFLAGS + _extra_flags(src) + INCLUDES + ["-c", s, "-o", o])
+        rebuilt |= _compile([HIPCC] + HIPFLAGS + _extra_flags(src) + INCLUDES + ["-c", s, "-o", o], s, o, headers, force, verbose, "[hip]")
     out = ASAN_LIB_PATH if sanitize else LIB_PATH
-    if force or _newer(out, objs):
+    if force or rebuilt or _newer(out, objs):
         if verbose:
             print("[ld ]", os.path.relpath(out, ROOT))
         san = []

@@ -6,8 +6,8 @@
  * src/vulkansift/sift_memory.c (octave geometry, SIFT-buffer sections, packed/sectioned state,
  * count read-back), with Vulkan objects replaced by plain HBM allocations:
  *
- *   pyramid   one allocation; per image: for each octave (S+3) Gaussian planes then (S+2) DoG planes,
- *             fp32, row pitch padded to 64 floats (256 B)
+ *   pyramid   one allocation (two for batch instances); per image: for each octave (S+3) Gaussian planes, fp32 (binary16 in the
+ *             FLOAT16 mode), row pitch padded to 64 texels. No DoG planes: D[s] = G[s+1] - G[s] is formed where it is consumed
  *   buffers   sift_buffer_count x max_nb_sift_per_buffer records of 164 B; after a detection a buffer
  *             is "sectioned" (one section per octave, capacities from sift_memory.c:40-87), after an
  *             upload it is one packed section

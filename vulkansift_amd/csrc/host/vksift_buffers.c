@@ -76,10 +76,13 @@ static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr,
   const bool cached = inst->dl_valid && inst->dl_seq == b->seq;
   if (inst->dl_hits_seq != b->seq)
     inst->dl_hits_seq = b->seq, inst->dl_hits = 0;
-  if (!cached && inst->dl_hits++ == 0 && !inst->dl_eager)
+  if (!cached && inst->dl_hits++ == 0)
     return false;
   if (!cached)
   {
+    /* the rebuild below overwrites dl_row[] and may reallocate the staging pair before any of its early exits: whatever was
+     * cached (for another detection) is gone from here on, and the cache is valid again only once every copy and event is queued */
+    inst->dl_valid = false;
     /* every buffer of the batch shares the section table of `b` (one resolution per batched detection) */
     if (!inst->dl_row)
       inst->dl_row = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)inst->cfg.sift_buffer_count + 1u));

@@ -505,6 +505,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
 {
   vksift_hip_stream st = inst->stream;
   bool capturing = false;
+  bool seq_assigned = false; /* the target buffers already carry the sequence number of this (not yet queued) detection */
 
   bool valid = count >= 1 && count <= inst->batch_cap && buffer_idx_valid(inst, first_buf) && buffer_idx_valid(inst, first_buf + count - 1) &&
                resolution_valid(inst, w, h);
@@ -569,6 +570,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     inst->bufs[first_buf + i].seq = seq;       /* its counters are valid once detection `seq` has completed */
     inst->cache_valid[first_buf + i] = false; /* the matcher's view of the buffer is rebuilt on its next matching */
   }
+  seq_assigned = true;
 
   DetectCtx c;
   c.inst = inst, c.L = &inst->lay, c.PS = PS;
@@ -673,6 +675,22 @@ gpu_error:
     vksift_hip_graph dead = NULL;
     (void)vksift_hip_capture_end(st, &dead);
     vksift_hip_graph_destroy(dead);
+  }
+  if (seq_assigned)
+  {
+    /* The detection never got its sequence number (det_seq and the ring slot advance on success only): left as they are the
+     * buffers would wait for a detection that does not exist — vksift_isBufferAvailable() false for ever, the accessors syncing
+     * a foreign ring event — and the next successful detection would alias the number. They become completed, EMPTY buffers:
+     * whatever part of the chain was queued may still write counters, so the stream is drained before the host mirror is zeroed. */
+    (void)vksift_hip_stream_sync(st);
+    if (inst->pyr_stream)
+      (void)vksift_hip_stream_sync(inst->pyr_stream);
+    for (uint32_t i = 0; i < count; i++)
+    {
+      inst->bufs[first_buf + i].seq = 0;
+      memset(inst->h_found + (size_t)(first_buf + i) * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES);
+    }
+    (void)vksift_hip_memset(inst->d_found + (size_t)first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * count, st);
   }
   logError(LOG_TAG, "%s error: Failed to start the detection pipeline.", fn);
   inst->error_cb(VKSIFT_VULKAN_ERROR);

@@ -192,7 +192,6 @@ struct vksift_Instance_T
   uint64_t dl_seq;      /* the detection the packed copy belongs to */
   uint64_t dl_hits_seq; /* the detection dl_hits counts for */
   uint32_t dl_hits; /* vksift_downloadFeatures calls on buffers of that detection, before its packed copy exists */
-  bool dl_eager;    /* vksift_ext_setBatchedDownload(true): the first download of a batched detection already packs */
   /* packed download of the records of a batched matching (h_matches: pinned) */
   size_t md_cap, md_pitch;
   bool md_valid;
