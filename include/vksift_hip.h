@@ -31,6 +31,7 @@ extern "C"
 #define VKSIFT_HIP_MATCH_CHUNKS 32   /* partial top-2 lists per A row of the single-pair matcher (merged exactly) */
 #define VKSIFT_HIP_MATCH_SMALL_NA 1536u /* single pairs with N_A <= this (and, where the host knows it, N_B <= ..._SMALL_NB) */
 #define VKSIFT_HIP_MATCH_SMALL_NB 4096u /* take the one-launch small kernel and need no partial lists */
+#define VKSIFT_HIP_MATCH_PK_NB 4096u   /* batched pairs whose reference set has at most this many rows take the packed-key kernel (12 index bits) */
 #define VKSIFT_HIP_MAX_ORI 18  /* a 36-bin circular histogram has at most 18 strict local maxima */
 
   typedef void *vksift_hip_stream;

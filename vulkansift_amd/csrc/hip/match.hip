@@ -206,6 +206,7 @@ struct SlotStrides
   uint64_t redo;           // u32
   uint32_t slot_fast;      // k_match_mfma: blockIdx.x is the slot, blockIdx.y the row block
   uint32_t use_ids;        // descriptor / norm strides address the per-buffer cache: entry = SlotIds::a/b[slot] instead of the slot
+  uint32_t pk_nb_max;      // slots with N_B <= this are matched by k_match_pk: the pruning kernels of the same launch sequence skip them
 };
 
 // SIFT buffer (= cache entry) matched by each slot of a batched launch
@@ -264,6 +265,18 @@ bool match_use32()
   return cached == 1;
 }
 
+// VKSIFT_MATCH_PK=0: batches of pairs go through the pruning kernels only (A/B switch, same results)
+bool match_use_pk()
+{
+  static int cached = -1;
+  if (cached < 0)
+  {
+    const char *e = getenv("VKSIFT_MATCH_PK");
+    cached = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return cached == 1;
+}
+
 struct Top2
 {
   uint32_t q1, k1, q2, k2; // squared distances and index keys of best / second
@@ -295,6 +308,9 @@ __device__ __forceinline__ void merge_ror(uint32_t &m1, uint32_t &m2)
   m1 = min(m1, r1);
   m2 = min(hi, min(m2, r2));
 } // below this, integer order of d2 == order of sqrtf(float(d2))
+
+// median of three = the second largest of {m1, m2, x} when m1 >= m2 (v_med3_u32)
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
 
 __device__ __forceinline__ bool lex_less(uint32_t qa, uint32_t ka, uint32_t qb, uint32_t kb) { return qa < qb || (qa == qb && ka < kb); }
 
@@ -355,7 +371,7 @@ __global__ void __launch_bounds__(64 * NW) k_match_mfma(const uint32_t *__restri
     // serves na in (na_lo, na_hi] (the host launches one kernel per regime, the others exit here)
     na = n_dev[0];
     nb = n_dev[1] < 2u ? 2u : n_dev[1];
-    if (na <= na_lo || na > na_hi)
+    if (na <= na_lo || na > na_hi || nb <= ss.pk_nb_max)
       return;
   }
   // Operand roles are swapped with respect to the textbook A x B^T: the B descriptors are the MFMA's A operand and the query
@@ -667,7 +683,7 @@ __global__ void __launch_bounds__(64 * NW) k_match32(const uint32_t *__restrict_
     n_dev += (size_t)slot * ss.n;
     na = n_dev[0];
     nb = n_dev[1] < 2u ? 2u : n_dev[1];
-    if (na <= na_lo || na > na_hi)
+    if (na <= na_lo || na > na_hi || nb <= ss.pk_nb_max)
       return;
   }
   __shared__ __attribute__((aligned(16))) uint8_t s_b2[2][BTT * 128];
@@ -927,6 +943,220 @@ __global__ void __launch_bounds__(64 * NW) k_match32(const uint32_t *__restrict_
   } // row-block loop
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_match_pk: the matcher for SMALL reference sets (N_B <= 4096: the pairs of a batched matching, a few thousand features each).
+//
+// At this size pruning never pays: a row sees ~2 ln N_B = 15 insertions in 1.9 k columns, the bound stays loose, and the
+// event-driven kernels spend their time in the candidate path (k_match_mfma<1,4,64> on 512 self-matches of 1.9 k x 1.9 k: 0.95 ms
+// = 12.8 % of the matrix peak, the MFMAs a sixteenth of the issued instructions). Here every candidate is folded into the row's
+// top-2 with THREE branch-free VALU instructions, by packing (d2, index) into one 32-bit key whose unsigned order is the
+// reference's order:
+//       K = ((2^20 - 1 - d2) << 12) | (4095 - index)      larger K = smaller d2, then smaller index (strict '<': earlier wins)
+//   top-2 of a multiset of keys:   K2 = med3(K1, K2, K);  K1 = max(K1, K)       (order independent: a set, not a scan)
+// With d2 = |a'|^2 + |b'|^2 - 2 a'.b' the key is linear in the dot product:
+//       K = ((dot + Ra) << 13) + ck[col] + (pa << 12),    2 Ra + pa = 2^20 - 1 - |a'|^2,   ck[col] = 4095 - col - (|b'|^2 << 12)
+// Ra rides in the MFMA's C operand (one register set per wave, constant over the scan), ck is a per-column word staged beside the
+// B tile, pa (a per-row constant below one key step) is added after the scan: per candidate v_lshl_add_u32, v_med3_u32, v_max_u32.
+// All arithmetic is modulo 2^32 and exact whenever d2 < 2^20 - 1 (real SIFT descriptors: d2 <= |a|^2 + |b|^2 <= 2^19; a key below
+// 4096 — field 0 — is never trusted: columns beyond B are forced to key 0). For anything
+// else the result is VERIFIED instead of assumed: the d2 of the two reported columns are recomputed exactly (2 x 128 bytes per
+// row) and compared with the keys' fields; because the top-2 of a multiset does not depend on arrival order, two genuine keys at
+// the top prove that no wrapped key (d2 >= 2^20, which can only look closer than it is) was ahead of them. A mismatch sends the
+// row to k_match_redo, like d2 >= 2^22 in the other kernels. Quirk Q7: the tie of columns 0 and 1 is read off their two keys.
+// Layout, staging and swizzle as in k_match32 (32x32x32 i8 MFMA, operand roles swapped, one query row per lane pair).
+template <int NW, int BTT>
+__global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
+                                                  uint32_t a_index_base, const uint32_t *__restrict__ desc_b, const uint32_t *__restrict__ norm_b,
+                                                  uint32_t nb, uint32_t *__restrict__ matches, uint32_t *__restrict__ redo,
+                                                  const uint32_t *__restrict__ n_dev, SlotStrides ss, SlotIds ids)
+{
+  static_assert(BTT % 32 == 0, "whole 32-column sub-blocks");
+  constexpr uint32_t ROWS = 32u * NW;
+  const uint32_t slot = ss.slot_fast ? blockIdx.x : blockIdx.y;
+  const uint32_t rb0 = ss.slot_fast ? blockIdx.y : blockIdx.x, rb_step = ss.slot_fast ? gridDim.y : gridDim.x;
+  const uint32_t ea = ss.use_ids ? ids.a[slot] : slot, eb = ss.use_ids ? ids.b[slot] : slot;
+  desc_a += (size_t)ea * ss.desc_a, desc_b += (size_t)eb * ss.desc_b;
+  norm_a += (size_t)ea * ss.norm_a, norm_b += (size_t)eb * ss.norm_b;
+  matches += (size_t)slot * ss.matches;
+  redo += (size_t)slot * ss.redo;
+  if (n_dev)
+  {
+    n_dev += (size_t)slot * ss.n;
+    na = n_dev[0];
+    nb = n_dev[1] < 2u ? 2u : n_dev[1];
+  }
+  if (nb > VKSIFT_HIP_MATCH_PK_NB || na == 0)
+    return; // 12 index bits: larger reference sets belong to the pruning kernels (they skip what this one takes: ss.pk_nb_max)
+  __shared__ __attribute__((aligned(16))) uint8_t s_b2[2][BTT * 128];
+  __shared__ __attribute__((aligned(16))) uint32_t s_ck2[2][BTT];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  constexpr int NTH = 64 * NW, NLD = (BTT * 8 + NTH - 1) / NTH;
+  struct TileRegs
+  {
+    uint4 d[NLD];
+    uint32_t n;
+  };
+  auto fetch_tile = [&](uint32_t t0, TileRegs &pf) {
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
+    {
+      const int i = threadIdx.x + q * NTH;
+      const int r = i >> 3, c = i & 7;
+      pf.d[q] = make_uint4(0, 0, 0, 0);
+      if (i < BTT * 8 && t0 + r < nb)
+        pf.d[q] = ((const uint4 *)(desc_b + (size_t)(t0 + r) * 32))[c];
+    }
+    pf.n = (threadIdx.x < BTT && t0 + threadIdx.x < nb) ? norm_b[t0 + threadIdx.x] : 0u;
+  };
+  auto stage_tile = [&](uint32_t t0, int bufi, const TileRegs &pf) {
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
+    {
+      const int i = threadIdx.x + q * NTH;
+      const int r = i >> 3, c = i & 7;
+      uint4 v = pf.d[q];
+      v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
+      if (i < BTT * 8)
+        *(uint4 *)(s_b2[bufi] + r * 128 + swz(r, c) * 16) = v;
+    }
+    if ((int)threadIdx.x < BTT)
+      s_ck2[bufi][threadIdx.x] = 4095u - (t0 + threadIdx.x) - (pf.n << 12);
+  };
+
+  for (uint32_t rb = rb0; rb * ROWS < na; rb += rb_step)
+  {
+    const uint32_t row_base = (rb * NW + wave) * 32u;
+    uint32_t r = row_base + j;
+    if (r >= na)
+      r = na - 1;
+    v4i afrag[4];
+    {
+      const uint4 *p = (const uint4 *)(desc_a + (size_t)r * 32);
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+      {
+        const uint4 v = p[2 * s + h];
+        afrag[s] = v4i{(int)(v.x ^ 0x80808080u), (int)(v.y ^ 0x80808080u), (int)(v.z ^ 0x80808080u), (int)(v.w ^ 0x80808080u)};
+      }
+    }
+    const uint32_t an = norm_a[r];
+    const int ra = (int)((1u << 20) - 1u - an) >> 1;  // arithmetic: floor((2^20 - 1 - an) / 2)
+    const uint32_t pa = ((1u << 20) - 1u - an) & 1u;
+    v16i cra;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      cra[i] = ra;
+    uint32_t k1 = 0, k2 = 0;
+    uint32_t sw = 0; // quirk Q7: d2(b0) == d2(b1)
+
+    TileRegs pf0;
+    __syncthreads(); // the previous row block has finished reading both buffers
+    fetch_tile(0, pf0);
+    stage_tile(0, 0, pf0);
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t t0 = 0; t0 < nb; t0 += BTT, buf ^= 1)
+    {
+      const bool more = t0 + BTT < nb;
+      if (more)
+        fetch_tile(t0 + BTT, pf0);
+      const uint8_t *s_b = s_b2[buf];
+      const uint32_t *s_ck = s_ck2[buf];
+      const bool partial_tile = t0 + BTT > nb; // columns beyond B in this tile: their keys are forced to 0 (below every real key)
+#pragma unroll
+      for (int sub = 0; sub < BTT / 32; sub++)
+      {
+        if (t0 + sub * 32 >= nb)
+          break;
+        const uint8_t *prow = s_b + (sub * 32 + j) * 128;
+        v4i bf[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          bf[s] = *(const v4i *)(prow + swz(j, 2 * s + h) * 16);
+        uint32_t ck[16];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+        {
+          const uint4 c4 = *(const uint4 *)(s_ck + sub * 32 + 8 * b + 4 * h);
+          ck[4 * b + 0] = c4.x, ck[4 * b + 1] = c4.y, ck[4 * b + 2] = c4.z, ck[4 * b + 3] = c4.w;
+        }
+        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[0], afrag[0], cra, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < 4; s++)
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[s], afrag[s], acc, 0, 0, 0);
+        uint32_t key[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          key[i] = ((uint32_t)acc[i] << 13) + ck[i];
+        if (partial_tile)
+        {
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+            if (t0 + sub * 32 + 8 * (i >> 2) + 4 * h + (i & 3) >= nb)
+              key[i] = 0u;
+        }
+        if (sub == 0 && t0 == 0)
+          sw = (h == 0 && (key[0] >> 12) == (key[1] >> 12)) ? 1u : 0u;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+          k2 = umed3(k1, k2, key[i]);
+          k1 = max(k1, key[i]);
+        }
+      }
+      if (more)
+        stage_tile(t0 + BTT, buf ^ 1, pf0);
+      __syncthreads();
+    }
+
+    // the two lanes of a row: top-2 of the union of their keys, then the per-row parity term
+    {
+      const uint32_t o1 = __shfl_xor(k1, 32, 64), o2 = __shfl_xor(k2, 32, 64);
+      const uint32_t hi = max(k1, o1);
+      k2 = max(min(k1, o1), max(k2, o2));
+      k1 = hi;
+      sw |= __shfl_xor(sw, 32, 64);
+    }
+    k1 += pa << 12, k2 += pa << 12;
+    const uint32_t i1 = 4095u - (k1 & 4095u), i2 = 4095u - (k2 & 4095u);
+    const uint32_t f1 = (1u << 20) - 1u - (k1 >> 12), f2 = (1u << 20) - 1u - (k2 >> 12); // the d2 the keys claim
+    // verification: exact d2 of the two reported columns from the descriptor bytes (this lane's half of K, the partner's by shuffle)
+    uint32_t qx[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+    {
+      const uint32_t col = min(c == 0 ? i1 : i2, nb - 1u);
+      const uint4 *pb = (const uint4 *)(desc_b + (size_t)col * 32);
+      int dot = 0;
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+      {
+        const uint4 v = pb[2 * s + h];
+        dot = __builtin_amdgcn_sdot4(afrag[s][0], (int)(v.x ^ 0x80808080u), dot, false);
+        dot = __builtin_amdgcn_sdot4(afrag[s][1], (int)(v.y ^ 0x80808080u), dot, false);
+        dot = __builtin_amdgcn_sdot4(afrag[s][2], (int)(v.z ^ 0x80808080u), dot, false);
+        dot = __builtin_amdgcn_sdot4(afrag[s][3], (int)(v.w ^ 0x80808080u), dot, false);
+      }
+      dot += __shfl_xor(dot, 32, 64);
+      qx[c] = an + norm_b[col] - 2u * (uint32_t)dot;
+    }
+    const bool ok = i1 < nb && i2 < nb && i1 != i2 && qx[0] == f1 && qx[1] == f2 && k1 >= 4096u && k2 >= 4096u;
+    const uint32_t rr = row_base + j;
+    if (h == 0 && rr < na)
+    {
+      uint32_t *m = matches + (size_t)rr * 5;
+      m[0] = a_index_base + rr;
+      m[1] = (sw && i1 < 2) ? (i1 ^ 1u) : i1;
+      m[2] = (sw && i2 < 2) ? (i2 ^ 1u) : i2;
+      m[3] = __float_as_uint(sqrtf((float)f1));
+      m[4] = __float_as_uint(sqrtf((float)f2));
+      redo[rr] = ok ? 0u : 1u;
+    }
+  }
+}
+
 // Exact combination of the per-chunk partial top-2 lists of k_match_mfma (gridDim.z > 1): one thread per A row.
 __global__ void __launch_bounds__(256) k_match_merge(const uint32_t *__restrict__ partial, uint32_t na, uint32_t nchunks, uint32_t a_index_base,
                                                      uint32_t *__restrict__ matches, uint32_t *__restrict__ redo, const uint32_t *__restrict__ n_dev,
@@ -990,7 +1220,7 @@ __global__ void __launch_bounds__(256) k_match_mfma_split(const uint32_t *__rest
     n_dev += (size_t)blockIdx.y * ss.n;
     na = n_dev[0];
     nb = n_dev[1] < 2u ? 2u : n_dev[1];
-    if (na <= na_lo || na > na_hi)
+    if (na <= na_lo || na > na_hi || nb <= ss.pk_nb_max)
       return;
   }
   if (blockIdx.x * 16u >= na)
@@ -1324,7 +1554,7 @@ extern "C"
     hipStream_t hs = (hipStream_t)s;
     uint32_t *redo = scratch;
     const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
-    const SlotStrides z{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const SlotStrides z{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const SlotIds noids{};
     /* A small problem (a few hundred thousand distances): 16 A rows per workgroup with B split over its waves, one launch.
      * Everything else: the stream decomposition (see k_match_mfma) — 8 waves x 32 rows per workgroup, 128-row B tiles, two
@@ -1447,6 +1677,7 @@ extern "C"
     ss.redo = redo_slot_stride;
     ss.slot_fast = 0;
     ss.use_ids = 1;
+    ss.pk_nb_max = 0;
     hipStream_t hs = (hipStream_t)s;
     const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
     if (nslots == 1 && partial_scratch)
@@ -1483,6 +1714,37 @@ extern "C"
       const uint32_t S1 = nslots >= 8 ? 1024u : 8192u, S2 = 32768u;
       /* regimes 2/3 loop over their row blocks, so their grids stay small even when only the capacity is known */
       auto bounded = [](uint32_t blocks, uint32_t slots) { uint32_t lim = slots >= 8 ? 64u : 1024u; return blocks < lim ? blocks : lim; };
+      /* reference sets of up to 4096 rows — the frames of a batch — take the branch-free packed-key kernel (k_match_pk): 256 query
+       * rows per workgroup, looping over the row blocks of its slot; the pruning kernels below skip those slots (ss.pk_nb_max) */
+      if (match_use_pk())
+      {
+        ss.pk_nb_max = VKSIFT_HIP_MATCH_PK_NB;
+        SlotStrides sp = ss;
+        sp.slot_fast = nslots > 1 ? 1u : 0u;
+        static int variant = -1;
+        if (variant < 0)
+        {
+          const char *e = getenv("VKSIFT_PK_VARIANT");
+          variant = e ? atoi(e) : 0;
+        }
+#define PK_LAUNCH(NWV, BTV)                                                                                                                                   \
+  {                                                                                                                                                          \
+    const uint32_t gp = bounded((max_na + 32u * NWV - 1u) / (32u * NWV), nslots);                                                                            \
+    hipLaunchKernelGGL((k_match_pk<NWV, BTV>), sp.slot_fast ? dim3(nslots, gp) : dim3(gp, nslots), dim3(64 * NWV), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, \
+                       (uint32_t *)matches, redo, n_dev, sp, ids);                                                                                           \
+  }
+        if (variant == 1)
+          PK_LAUNCH(4, 128)
+        else if (variant == 2)
+          PK_LAUNCH(4, 64)
+        else if (variant == 3)
+          PK_LAUNCH(2, 64)
+        else if (variant == 4)
+          PK_LAUNCH(2, 128)
+        else
+          PK_LAUNCH(8, 128)
+#undef PK_LAUNCH
+      }
       const uint32_t n1 = max_na < S1 ? max_na : S1;
       hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev,
                          0u, S1, ss, ids);
