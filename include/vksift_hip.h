@@ -31,6 +31,7 @@ extern "C"
 #define VKSIFT_HIP_MATCH_CHUNKS 32   /* partial top-2 lists per A row of the single-pair matcher (merged exactly) */
 #define VKSIFT_HIP_MATCH_SMALL_NA 1536u /* single pairs with N_A <= this (and, where the host knows it, N_B <= ..._SMALL_NB) */
 #define VKSIFT_HIP_MATCH_SMALL_NB 4096u /* take the one-launch small kernel and need no partial lists */
+#define VKSIFT_HIP_MATCH_SLOTS 256u    /* pairs one vksift_hip_match_2nn_async launch sequence serves */
 #define VKSIFT_HIP_MATCH_PK_NB 4096u   /* batched pairs whose reference set has at most this many rows take the packed-key kernel (12 index bits) */
 #define VKSIFT_HIP_MAX_ORI 18  /* a 36-bin circular histogram has at most 18 strict local maxima */
 
@@ -225,7 +226,7 @@ extern "C"
    * to 16 sections whose stored counts are min(found[o], sec_cap[o]) (or fixed_counts[o] when found_base is NULL), writes
    * the dense descriptor rows in download order to desc + id*desc_stride, their shifted norms to norms + id*norm_stride and
    * the row total to n_out_dev[id*n_stride]; rows below pad_rows_to are zero-filled (quirk Q6). max_rows bounds the launch.
-   * match_2nn_async: slot i matches cache entry ids_a[i] against ids_b[i]; it first writes {N_A, N_B} of every slot to
+   * match_2nn_async (nslots <= VKSIFT_HIP_MATCH_SLOTS): slot i matches cache entry ids_a[i] against ids_b[i]; it first writes {N_A, N_B} of every slot to
    * n_dev[i*n_slot_stride + 0..1] (read by the kernels, the filter and the host). Strides in bytes for desc/matches and in
    * u32 elements for norms/redo/n. partial_scratch (may be NULL): 5*max_na*VKSIFT_HIP_MATCH_CHUNKS u32 used by the
    * stream-decomposed single-pair kernel (nslots == 1; without it a single pair takes the batch kernels). redo: max_na u32 per slot of row flags for the exact scalar replay. */

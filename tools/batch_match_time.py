@@ -24,6 +24,9 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / rep
 ops = 2.0 * B * nf * nf * 128
 print(f"batch match {B} x ({nf:.0f} x {nf:.0f}): {dt*1e3:.3f} ms per call  {ops/dt/1e12:.0f} TOPS  {ops/dt/1e12/3944*100:.1f} %")
+if len(sys.argv) > 3 and sys.argv[3] == "match-only":
+    inst.close()
+    sys.exit(0)
 t0 = time.perf_counter()
 for _ in range(rep):
     inst.detectFeaturesBatchDevice(d.data_ptr(), B, W, H, 0)

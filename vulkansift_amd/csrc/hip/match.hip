@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "vksift_hip.h"
 
@@ -212,7 +213,7 @@ struct SlotStrides
 // SIFT buffer (= cache entry) matched by each slot of a batched launch
 struct SlotIds
 {
-  uint32_t a[64], b[64];
+  uint32_t a[VKSIFT_HIP_MATCH_SLOTS], b[VKSIFT_HIP_MATCH_SLOTS];
 };
 
 // {N_A, N_B} of every slot, from the per-buffer row counts of the cache (the matcher kernels and the host read them per slot)
@@ -1048,7 +1049,9 @@ __global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict
 #pragma unroll
     for (int i = 0; i < 16; i++)
       cra[i] = ra;
-    uint32_t k1 = 0, k2 = 0;
+    // four independent (best, second) pairs, merged after the scan: the med3 / max updates of one pair form a dependent chain
+    // (16 steps per sub-block otherwise); a multiset's top-2 does not care how it was partitioned
+    uint32_t k1[4] = {0, 0, 0, 0}, k2[4] = {0, 0, 0, 0};
     uint32_t sw = 0; // quirk Q7: d2(b0) == d2(b1)
 
     TileRegs pf0;
@@ -1064,7 +1067,9 @@ __global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict
         fetch_tile(t0 + BTT, pf0);
       const uint8_t *s_b = s_b2[buf];
       const uint32_t *s_ck = s_ck2[buf];
-      const bool partial_tile = t0 + BTT > nb; // columns beyond B in this tile: their keys are forced to 0 (below every real key)
+      const bool partial_tile = t0 + BTT > nb; // columns beyond B in this tile (staged as zero rows): their keys are forced to 0
+      // (issuing the MFMAs of sub-block s+1 between the key updates of sub-block s — a second accumulator set, sched_group_barrier —
+      // was tried: 200+ VGPRs whatever the unrolling, two waves per SIMD, 0.55 -> 0.61 ms per 512 pairs; not kept)
 #pragma unroll
       for (int sub = 0; sub < BTT / 32; sub++)
       {
@@ -1075,6 +1080,10 @@ __global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict
 #pragma unroll
         for (int s = 0; s < 4; s++)
           bf[s] = *(const v4i *)(prow + swz(j, 2 * s + h) * 16);
+        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[0], afrag[0], cra, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < 4; s++)
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[s], afrag[s], acc, 0, 0, 0);
         uint32_t ck[16];
 #pragma unroll
         for (int b = 0; b < 4; b++)
@@ -1082,10 +1091,6 @@ __global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict
           const uint4 c4 = *(const uint4 *)(s_ck + sub * 32 + 8 * b + 4 * h);
           ck[4 * b + 0] = c4.x, ck[4 * b + 1] = c4.y, ck[4 * b + 2] = c4.z, ck[4 * b + 3] = c4.w;
         }
-        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[0], afrag[0], cra, 0, 0, 0);
-#pragma unroll
-        for (int s = 1; s < 4; s++)
-          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[s], afrag[s], acc, 0, 0, 0);
         uint32_t key[16];
 #pragma unroll
         for (int i = 0; i < 16; i++)
@@ -1102,8 +1107,8 @@ __global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict
 #pragma unroll
         for (int i = 0; i < 16; i++)
         {
-          k2 = umed3(k1, k2, key[i]);
-          k1 = max(k1, key[i]);
+          k2[i & 3] = umed3(k1[i & 3], k2[i & 3], key[i]);
+          k1[i & 3] = max(k1[i & 3], key[i]);
         }
       }
       if (more)
@@ -1112,20 +1117,26 @@ __global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict
     }
 
     // the two lanes of a row: top-2 of the union of their keys, then the per-row parity term
+    uint32_t kb = k1[0], ks = k2[0];
+#pragma unroll
+    for (int c = 1; c < 4; c++)
     {
-      const uint32_t o1 = __shfl_xor(k1, 32, 64), o2 = __shfl_xor(k2, 32, 64);
-      const uint32_t hi = max(k1, o1);
-      k2 = max(min(k1, o1), max(k2, o2));
-      k1 = hi;
+      ks = max(min(kb, k1[c]), max(ks, k2[c]));
+      kb = max(kb, k1[c]);
+    }
+    {
+      const uint32_t o1 = __shfl_xor(kb, 32, 64), o2 = __shfl_xor(ks, 32, 64);
+      ks = max(min(kb, o1), max(ks, o2));
+      kb = max(kb, o1);
       sw |= __shfl_xor(sw, 32, 64);
     }
-    k1 += pa << 12, k2 += pa << 12;
-    const uint32_t i1 = 4095u - (k1 & 4095u), i2 = 4095u - (k2 & 4095u);
-    const uint32_t f1 = (1u << 20) - 1u - (k1 >> 12), f2 = (1u << 20) - 1u - (k2 >> 12); // the d2 the keys claim
+    kb += pa << 12, ks += pa << 12;
+    const uint32_t i1 = 4095u - (kb & 4095u), i2 = 4095u - (ks & 4095u);
+    const uint32_t f1 = (1u << 20) - 1u - (kb >> 12), f2 = (1u << 20) - 1u - (ks >> 12); // the d2 the keys claim
     // verification: exact d2 of the two reported columns from the descriptor bytes (this lane's half of K, the partner's by shuffle)
     uint32_t qx[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++)
+#pragma unroll 1
+    for (int c = 0; c < 2; c++) // not unrolled: the epilogue must not set the kernel's register count
     {
       const uint32_t col = min(c == 0 ? i1 : i2, nb - 1u);
       const uint4 *pb = (const uint4 *)(desc_b + (size_t)col * 32);
@@ -1140,9 +1151,13 @@ __global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict
         dot = __builtin_amdgcn_sdot4(afrag[s][3], (int)(v.w ^ 0x80808080u), dot, false);
       }
       dot += __shfl_xor(dot, 32, 64);
-      qx[c] = an + norm_b[col] - 2u * (uint32_t)dot;
+      const uint32_t qc = an + norm_b[col] - 2u * (uint32_t)dot;
+      if (c == 0)
+        qx[0] = qc;
+      else
+        qx[1] = qc;
     }
-    const bool ok = i1 < nb && i2 < nb && i1 != i2 && qx[0] == f1 && qx[1] == f2 && k1 >= 4096u && k2 >= 4096u;
+    const bool ok = i1 < nb && i2 < nb && i1 != i2 && qx[0] == f1 && qx[1] == f2 && kb >= 4096u && ks >= 4096u;
     const uint32_t rr = row_base + j;
     if (h == 0 && rr < na)
     {
@@ -1659,12 +1674,12 @@ extern "C"
                                  uint64_t cache_norm_stride, uint64_t redo_slot_stride, uint64_t match_slot_stride, uint32_t n_slot_stride,
                                  uint32_t *partial_scratch, vksift_hip_stream s)
   {
-    if (nslots < 1 || nslots > 64)
+    if (nslots < 1 || nslots > VKSIFT_HIP_MATCH_SLOTS)
       return (int)hipErrorInvalidValue;
     SlotIds ids;
-    for (uint32_t i = 0; i < 64; i++)
+    for (uint32_t i = 0; i < VKSIFT_HIP_MATCH_SLOTS; i++)
       ids.a[i] = i < nslots ? ids_a[i] : 0u, ids.b[i] = i < nslots ? ids_b[i] : 0u;
-    hipLaunchKernelGGL(k_slot_counts, dim3(1), dim3(64), 0, (hipStream_t)s, cache_n, 1u, ids, nslots, n_dev, n_slot_stride);
+    hipLaunchKernelGGL(k_slot_counts, dim3((nslots + 63u) / 64u), dim3(64), 0, (hipStream_t)s, cache_n, 1u, ids, nslots, n_dev, n_slot_stride);
     if (max_na == 0)
       return (int)hipGetLastError();
     const uint8_t *desc_a = cache_desc, *desc_b = cache_desc;
@@ -1711,43 +1726,33 @@ extern "C"
        * The B-split kernel exists to keep every CU busy when few pairs of a few thousand rows are matched; a batch of 8 and
        * more pairs has enough workgroups anyway and runs 24 % faster with 64 rows per workgroup (measured: 64 pairs of
        * 1.9k x 1.9k, 0.285 -> 0.217 ms). */
-      const uint32_t S1 = nslots >= 8 ? 1024u : 8192u, S2 = 32768u;
+      uint32_t S1 = nslots >= 8 ? 1024u : 8192u;
+      const uint32_t S2 = 32768u;
       /* regimes 2/3 loop over their row blocks, so their grids stay small even when only the capacity is known */
-      auto bounded = [](uint32_t blocks, uint32_t slots) { uint32_t lim = slots >= 8 ? 64u : 1024u; return blocks < lim ? blocks : lim; };
+      uint32_t lim = nslots >= 8 ? 64u : 1024u;
       /* reference sets of up to 4096 rows — the frames of a batch — take the branch-free packed-key kernel (k_match_pk): 256 query
-       * rows per workgroup, looping over the row blocks of its slot; the pruning kernels below skip those slots (ss.pk_nb_max) */
-      if (match_use_pk())
+       * rows per workgroup, looping over the row blocks of its slot; the pruning kernels below skip those slots (ss.pk_nb_max).
+       * What is left for them in such a batch is the odd pair with a large reference set: one kernel for all N_A <= 32768 (the
+       * B-split kernel is not launched) on a grid of 16 row blocks per slot — every launch of a mostly idle grid costs the batch
+       * 4-5 us (4096 workgroups that only read their slot's counts) */
+      const bool pk = match_use_pk();
+      if (pk)
       {
         ss.pk_nb_max = VKSIFT_HIP_MATCH_PK_NB;
         SlotStrides sp = ss;
         sp.slot_fast = nslots > 1 ? 1u : 0u;
-        static int variant = -1;
-        if (variant < 0)
-        {
-          const char *e = getenv("VKSIFT_PK_VARIANT");
-          variant = e ? atoi(e) : 0;
-        }
-#define PK_LAUNCH(NWV, BTV)                                                                                                                                   \
-  {                                                                                                                                                          \
-    const uint32_t gp = bounded((max_na + 32u * NWV - 1u) / (32u * NWV), nslots);                                                                            \
-    hipLaunchKernelGGL((k_match_pk<NWV, BTV>), sp.slot_fast ? dim3(nslots, gp) : dim3(gp, nslots), dim3(64 * NWV), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, \
-                       (uint32_t *)matches, redo, n_dev, sp, ids);                                                                                           \
-  }
-        if (variant == 1)
-          PK_LAUNCH(4, 128)
-        else if (variant == 2)
-          PK_LAUNCH(4, 64)
-        else if (variant == 3)
-          PK_LAUNCH(2, 64)
-        else if (variant == 4)
-          PK_LAUNCH(2, 128)
-        else
-          PK_LAUNCH(8, 128)
-#undef PK_LAUNCH
+        uint32_t gp = (max_na + 255u) / 256u;
+        gp = gp < 16u ? gp : 16u;
+        hipLaunchKernelGGL((k_match_pk<8, 128>), sp.slot_fast ? dim3(nslots, gp) : dim3(gp, nslots), dim3(512), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+                           (uint32_t *)matches, redo, n_dev, sp, ids);
+        S1 = 0u;
+        lim = nslots >= 8 ? 16u : lim;
       }
+      auto bounded = [lim](uint32_t blocks) { return blocks < lim ? blocks : lim; };
       const uint32_t n1 = max_na < S1 ? max_na : S1;
-      hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev,
-                         0u, S1, ss, ids);
+      if (n1 > 0)
+        hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev,
+                           0u, S1, ss, ids);
       if (max_na > S1)
       {
         const uint32_t n2 = max_na < S2 ? max_na : S2;
@@ -1755,7 +1760,7 @@ extern "C"
          * order instead of a short run at the start of every slot's row (see features.hip: img_fast) */
         SlotStrides s2 = ss;
         s2.slot_fast = nslots > 1 ? 1u : 0u;
-        const uint32_t gb = bounded((n2 + 63u) / 64u, nslots);
+        const uint32_t gb = bounded((n2 + 63u) / 64u);
         if (match_use32())
           hipLaunchKernelGGL((k_match32<1, 2, 64>), s2.slot_fast ? dim3(nslots, gb) : dim3(gb, nslots), dim3(128), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
                              (uint32_t *)matches, redo, n_dev, S1, S2, s2, (uint32_t *)nullptr, ids, 0u);
@@ -1764,15 +1769,16 @@ extern "C"
                              (uint32_t *)matches, redo, n_dev, S1, S2, s2, (uint32_t *)nullptr, ids, 0u);
       }
       if (max_na > S2 && match_use32())
-        hipLaunchKernelGGL((k_match32<2, 2, 64>), dim3(bounded((max_na + 127u) / 128u, nslots), nslots), dim3(128), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+        hipLaunchKernelGGL((k_match32<2, 2, 64>), dim3(bounded((max_na + 127u) / 128u), nslots), dim3(128), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
                            (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, (uint32_t *)nullptr, ids, 0u);
       else if (max_na > S2)
-        hipLaunchKernelGGL(k_match_mfma<2>, dim3(bounded((max_na + 127u) / 128u, nslots), nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+        hipLaunchKernelGGL(k_match_mfma<2>, dim3(bounded((max_na + 127u) / 128u), nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
                            (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, (uint32_t *)nullptr, ids, 0u);
     }
     uint32_t rblocks = (max_na + 63u) / 64u;
-    if (rblocks > 64u)
-      rblocks = 64u;
+    const uint32_t rlim = nslots > 64u ? 16u : 64u; /* grid-stride over the rows: the flags are all zero for real descriptors */
+    if (rblocks > rlim)
+      rblocks = rlim;
     hipLaunchKernelGGL(k_match_redo, dim3(rblocks, nslots), dim3(64), 0, hs, da, 0u, 0u, db, 0u, (uint32_t *)matches, (const uint32_t *)redo, n_dev, ss, ids);
     return (int)hipGetLastError();
   }

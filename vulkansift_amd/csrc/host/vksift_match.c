@@ -171,9 +171,9 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
   vksift_hip_range_push("Matching");
   range_open = true;
   const MatchScratch fwd = fwd_scratch(inst);
-  /* one launch sequence serves up to 64 pairs; a longer list goes in runs of 64, run r into the slots from r on */
-  for (uint32_t r = 0; r < count; r += 64u)
-    HIP_CHECK(match_slots(inst, &fwd, ids_a + r, ids_b + r, count - r < 64u ? count - r : 64u, r), "2-NN matching");
+  /* one launch sequence serves up to VKSIFT_HIP_MATCH_SLOTS pairs; a longer list goes in runs of that many, run r into the slots from r on */
+  for (uint32_t r = 0; r < count; r += VKSIFT_HIP_MATCH_SLOTS)
+    HIP_CHECK(match_slots(inst, &fwd, ids_a + r, ids_b + r, count - r < VKSIFT_HIP_MATCH_SLOTS ? count - r : VKSIFT_HIP_MATCH_SLOTS, r), "2-NN matching");
   HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n, inst->d_match_n, sizeof(uint32_t) * 4 * count, inst->stream), "match count read-back");
   inst->filtered_slots_used = 0;
   inst->md_valid = false, inst->md_hits = 0;
@@ -185,9 +185,9 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
       logError(LOG_TAG, "%s error: out of device memory for the filtered-matching scratch.", fn);
       goto gpu_error;
     }
-    for (uint32_t r = 0; r < count; r += 64u)
+    for (uint32_t r = 0; r < count; r += VKSIFT_HIP_MATCH_SLOTS)
     {
-      const uint32_t n = count - r < 64u ? count - r : 64u;
+      const uint32_t n = count - r < VKSIFT_HIP_MATCH_SLOTS ? count - r : VKSIFT_HIP_MATCH_SLOTS;
       if (cross_check)
         HIP_CHECK(match_slots(inst, &inst->rev, ids_b + r, ids_a + r, n, r), "reverse 2-NN matching");
       HIP_CHECK(vksift_hip_filter_matches(inst->d_matches + (uint64_t)r * inst->match_slot_stride, inst->match_slot_stride,
