@@ -32,7 +32,7 @@ extern "C"
 #define VKSIFT_HIP_MATCH_SMALL_NA 1536u /* single pairs with N_A <= this (and, where the host knows it, N_B <= ..._SMALL_NB) */
 #define VKSIFT_HIP_MATCH_SMALL_NB 4096u /* take the one-launch small kernel and need no partial lists */
 #define VKSIFT_HIP_MATCH_SLOTS 256u    /* pairs one vksift_hip_match_2nn_async launch sequence serves */
-#define VKSIFT_HIP_MATCH_PK_NB 4096u   /* batched pairs whose reference set has at most this many rows take the packed-key kernel (12 index bits) */
+#define VKSIFT_HIP_MATCH_PK_NB 32768u  /* reference sets of at most this many rows take the branch-free packed-key kernel (k_match_pk) */
 #define VKSIFT_HIP_MAX_ORI 18  /* a 36-bin circular histogram has at most 18 strict local maxima */
 
   typedef void *vksift_hip_stream;

@@ -945,7 +945,8 @@ __global__ void __launch_bounds__(64 * NW) k_match32(const uint32_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// k_match_pk: the matcher for SMALL reference sets (N_B <= 4096: the pairs of a batched matching, a few thousand features each).
+// k_match_pk: the matcher for reference sets of up to VKSIFT_HIP_MATCH_PK_NB rows (the pairs of a batched matching; single pairs
+// below the size where pruning starts to pay).
 //
 // At this size pruning never pays: a row sees ~2 ln N_B = 15 insertions in 1.9 k columns, the bound stays loose, and the
 // event-driven kernels spend their time in the candidate path (k_match_mfma<1,4,64> on 512 self-matches of 1.9 k x 1.9 k: 0.95 ms
@@ -965,14 +966,19 @@ __global__ void __launch_bounds__(64 * NW) k_match32(const uint32_t *__restrict_
 // the top prove that no wrapped key (d2 >= 2^20, which can only look closer than it is) was ahead of them. A mismatch sends the
 // row to k_match_redo, like d2 >= 2^22 in the other kernels. Quirk Q7: the tie of columns 0 and 1 is read off their two keys.
 // Layout, staging and swizzle as in k_match32 (32x32x32 i8 MFMA, operand roles swapped, one query row per lane pair).
+// Reference sets beyond 4096 rows: the scan goes in SUPER-CHUNKS of 4096 columns (the index field holds the column modulo 4096);
+// after each one the four chains are folded into a running exact (d2, index) top-2 and restart from zero — a merge of exact
+// top-2 lists, so the multiset argument above carries over to the union. A single large pair is also split over blockIdx.z
+// (whole super-chunks, strided) so that the grid fills the chip; every (row, z) piece then leaves a partial list in the format of
+// the stream-decomposed kernel and k_match_merge combines them.
 template <int NW, int BTT>
-__global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) k_match_pk(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
                                                   uint32_t a_index_base, const uint32_t *__restrict__ desc_b, const uint32_t *__restrict__ norm_b,
                                                   uint32_t nb, uint32_t *__restrict__ matches, uint32_t *__restrict__ redo,
-                                                  const uint32_t *__restrict__ n_dev, SlotStrides ss, SlotIds ids)
+                                                  const uint32_t *__restrict__ n_dev, SlotStrides ss, SlotIds ids, uint32_t *__restrict__ partial)
 {
-  static_assert(BTT % 32 == 0, "whole 32-column sub-blocks");
-  constexpr uint32_t ROWS = 32u * NW;
+  static_assert(BTT % 32 == 0 && 4096 % BTT == 0, "whole 32-column sub-blocks, whole tiles per super-chunk");
+  constexpr uint32_t ROWS = 32u * NW, SC = 4096u;
   const uint32_t slot = ss.slot_fast ? blockIdx.x : blockIdx.y;
   const uint32_t rb0 = ss.slot_fast ? blockIdx.y : blockIdx.x, rb_step = ss.slot_fast ? gridDim.y : gridDim.x;
   const uint32_t ea = ss.use_ids ? ids.a[slot] : slot, eb = ss.use_ids ? ids.b[slot] : slot;
@@ -985,14 +991,17 @@ __global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict
     n_dev += (size_t)slot * ss.n;
     na = n_dev[0];
     nb = n_dev[1] < 2u ? 2u : n_dev[1];
+    if (nb > ss.pk_nb_max)
+      return; // larger reference sets belong to the pruning kernels (which skip what this one takes)
   }
-  if (nb > VKSIFT_HIP_MATCH_PK_NB || na == 0)
-    return; // 12 index bits: larger reference sets belong to the pruning kernels (they skip what this one takes: ss.pk_nb_max)
+  if (na == 0)
+    return;
   __shared__ __attribute__((aligned(16))) uint8_t s_b2[2][BTT * 128];
   __shared__ __attribute__((aligned(16))) uint32_t s_ck2[2][BTT];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
+  const uint32_t nz = gridDim.z, z = blockIdx.z;
   constexpr int NTH = 64 * NW, NLD = (BTT * 8 + NTH - 1) / NTH;
   struct TileRegs
   {
@@ -1023,7 +1032,7 @@ __global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict
         *(uint4 *)(s_b2[bufi] + r * 128 + swz(r, c) * 16) = v;
     }
     if ((int)threadIdx.x < BTT)
-      s_ck2[bufi][threadIdx.x] = 4095u - (t0 + threadIdx.x) - (pf.n << 12);
+      s_ck2[bufi][threadIdx.x] = 4095u - ((t0 + threadIdx.x) & 4095u) - (pf.n << 12);
   };
 
   for (uint32_t rb = rb0; rb * ROWS < na; rb += rb_step)
@@ -1049,96 +1058,125 @@ __global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict
 #pragma unroll
     for (int i = 0; i < 16; i++)
       cra[i] = ra;
-    // four independent (best, second) pairs, merged after the scan: the med3 / max updates of one pair form a dependent chain
-    // (16 steps per sub-block otherwise); a multiset's top-2 does not care how it was partitioned
-    uint32_t k1[4] = {0, 0, 0, 0}, k2[4] = {0, 0, 0, 0};
-    uint32_t sw = 0; // quirk Q7: d2(b0) == d2(b1)
+    Top2 st{QMAX, QMAX, QMAX, QMAX}; // exact (d2, column) pairs of the super-chunks done so far
+    uint32_t bad = 0;                // a folded key that cannot be genuine (field below 2): the row is replayed
+    uint32_t sw = 0;                 // quirk Q7: d2(b0) == d2(b1)
 
-    TileRegs pf0;
-    __syncthreads(); // the previous row block has finished reading both buffers
-    fetch_tile(0, pf0);
-    stage_tile(0, 0, pf0);
-    __syncthreads();
-    int buf = 0;
-    for (uint32_t t0 = 0; t0 < nb; t0 += BTT, buf ^= 1)
+    for (uint32_t sc0 = z * SC; sc0 < nb; sc0 += nz * SC)
     {
-      const bool more = t0 + BTT < nb;
-      if (more)
-        fetch_tile(t0 + BTT, pf0);
-      const uint8_t *s_b = s_b2[buf];
-      const uint32_t *s_ck = s_ck2[buf];
-      const bool partial_tile = t0 + BTT > nb; // columns beyond B in this tile (staged as zero rows): their keys are forced to 0
-      // (issuing the MFMAs of sub-block s+1 between the key updates of sub-block s — a second accumulator set, sched_group_barrier —
-      // was tried: 200+ VGPRs whatever the unrolling, two waves per SIMD, 0.55 -> 0.61 ms per 512 pairs; not kept)
-#pragma unroll
-      for (int sub = 0; sub < BTT / 32; sub++)
+      const uint32_t sc_end = min(nb, sc0 + SC);
+      // four independent (best, second) pairs, merged after the super-chunk: the med3 / max updates of one pair form a dependent chain
+      // (16 steps per sub-block otherwise); a multiset's top-2 does not care how it was partitioned
+      uint32_t k1[4] = {0, 0, 0, 0}, k2[4] = {0, 0, 0, 0};
+      TileRegs pf0;
+      __syncthreads(); // the previous scan has finished reading both buffers
+      fetch_tile(sc0, pf0);
+      stage_tile(sc0, 0, pf0);
+      __syncthreads();
+      int buf = 0;
+      for (uint32_t t0 = sc0; t0 < sc_end; t0 += BTT, buf ^= 1)
       {
-        if (t0 + sub * 32 >= nb)
-          break;
-        const uint8_t *prow = s_b + (sub * 32 + j) * 128;
-        v4i bf[4];
+        const bool more = t0 + BTT < sc_end;
+        if (more)
+          fetch_tile(t0 + BTT, pf0);
+        const uint8_t *s_b = s_b2[buf];
+        const uint32_t *s_ck = s_ck2[buf];
+        const bool partial_tile = t0 + BTT > nb; // columns beyond B in this tile (staged as zero rows): their keys are forced to 0
+        // (issuing the MFMAs of sub-block s+1 between the key updates of sub-block s — a second accumulator set, sched_group_barrier —
+        // was tried: 200+ VGPRs whatever the unrolling, two waves per SIMD, 0.55 -> 0.61 ms per 512 pairs; not kept)
 #pragma unroll
-        for (int s = 0; s < 4; s++)
-          bf[s] = *(const v4i *)(prow + swz(j, 2 * s + h) * 16);
-        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[0], afrag[0], cra, 0, 0, 0);
-#pragma unroll
-        for (int s = 1; s < 4; s++)
-          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[s], afrag[s], acc, 0, 0, 0);
-        uint32_t ck[16];
-#pragma unroll
-        for (int b = 0; b < 4; b++)
+        for (int sub = 0; sub < BTT / 32; sub++)
         {
-          const uint4 c4 = *(const uint4 *)(s_ck + sub * 32 + 8 * b + 4 * h);
-          ck[4 * b + 0] = c4.x, ck[4 * b + 1] = c4.y, ck[4 * b + 2] = c4.z, ck[4 * b + 3] = c4.w;
-        }
-        uint32_t key[16];
+          if (t0 + sub * 32 >= nb)
+            break;
+          const uint8_t *prow = s_b + (sub * 32 + j) * 128;
+          v4i bf[4];
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-          key[i] = ((uint32_t)acc[i] << 13) + ck[i];
-        if (partial_tile)
-        {
+          for (int s = 0; s < 4; s++)
+            bf[s] = *(const v4i *)(prow + swz(j, 2 * s + h) * 16);
+          v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[0], afrag[0], cra, 0, 0, 0);
+#pragma unroll
+          for (int s = 1; s < 4; s++)
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[s], afrag[s], acc, 0, 0, 0);
+          uint32_t ck[16];
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+          {
+            const uint4 c4 = *(const uint4 *)(s_ck + sub * 32 + 8 * b + 4 * h);
+            ck[4 * b + 0] = c4.x, ck[4 * b + 1] = c4.y, ck[4 * b + 2] = c4.z, ck[4 * b + 3] = c4.w;
+          }
+          uint32_t key[16];
 #pragma unroll
           for (int i = 0; i < 16; i++)
-            if (t0 + sub * 32 + 8 * (i >> 2) + 4 * h + (i & 3) >= nb)
-              key[i] = 0u;
-        }
-        if (sub == 0 && t0 == 0)
-          sw = (h == 0 && (key[0] >> 12) == (key[1] >> 12)) ? 1u : 0u;
+            key[i] = ((uint32_t)acc[i] << 13) + ck[i];
+          if (partial_tile)
+          {
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-        {
-          k2[i & 3] = umed3(k1[i & 3], k2[i & 3], key[i]);
-          k1[i & 3] = max(k1[i & 3], key[i]);
+            for (int i = 0; i < 16; i++)
+              if (t0 + sub * 32 + 8 * (i >> 2) + 4 * h + (i & 3) >= nb)
+                key[i] = 0u;
+          }
+          if (sub == 0 && t0 == 0)
+            sw = (h == 0 && (key[0] >> 12) == (key[1] >> 12)) ? 1u : 0u;
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+          {
+            k2[i & 3] = umed3(k1[i & 3], k2[i & 3], key[i]);
+            k1[i & 3] = max(k1[i & 3], key[i]);
+          }
         }
+        if (more)
+          stage_tile(t0 + BTT, buf ^ 1, pf0);
+        __syncthreads();
       }
-      if (more)
-        stage_tile(t0 + BTT, buf ^ 1, pf0);
-      __syncthreads();
+      // fold the super-chunk: its two best keys (a key below 8192 before the parity term is "no column": field < 2 is never trusted)
+      uint32_t kb = k1[0], ks = k2[0];
+#pragma unroll
+      for (int c = 1; c < 4; c++)
+      {
+        ks = max(min(kb, k1[c]), max(ks, k2[c]));
+        kb = max(kb, k1[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+      {
+        const uint32_t k = c == 0 ? kb : ks;
+        if (k >= 8192u)
+        {
+          const uint32_t kk = k + (pa << 12);
+          const uint32_t q = (1u << 20) - 1u - (kk >> 12), idx = sc0 + 4095u - (kk & 4095u);
+          // keys arrive best first and super-chunks in index order: equal d2 keeps the earlier column (insert_seq's rule)
+          if (q < st.q2 || (q == st.q2 && idx < st.k2))
+          {
+            if (q < st.q1 || (q == st.q1 && idx < st.k1))
+              st.q2 = st.q1, st.k2 = st.k1, st.q1 = q, st.k1 = idx;
+            else
+              st.q2 = q, st.k2 = idx;
+          }
+        }
+        else if (k != 0u) // 0: no column (this lane saw fewer than two columns of the super-chunk)
+          bad = 1u;
+      }
     }
 
-    // the two lanes of a row: top-2 of the union of their keys, then the per-row parity term
-    uint32_t kb = k1[0], ks = k2[0];
-#pragma unroll
-    for (int c = 1; c < 4; c++)
+    // the two lanes of a row
     {
-      ks = max(min(kb, k1[c]), max(ks, k2[c]));
-      kb = max(kb, k1[c]);
-    }
-    {
-      const uint32_t o1 = __shfl_xor(kb, 32, 64), o2 = __shfl_xor(ks, 32, 64);
-      ks = max(min(kb, o1), max(ks, o2));
-      kb = max(kb, o1);
+      Top2 o;
+      o.q1 = __shfl_xor(st.q1, 32, 64), o.k1 = __shfl_xor(st.k1, 32, 64);
+      o.q2 = __shfl_xor(st.q2, 32, 64), o.k2 = __shfl_xor(st.k2, 32, 64);
+      st = merge2(st, o);
       sw |= __shfl_xor(sw, 32, 64);
+      bad |= __shfl_xor(bad, 32, 64);
     }
-    kb += pa << 12, ks += pa << 12;
-    const uint32_t i1 = 4095u - (kb & 4095u), i2 = 4095u - (ks & 4095u);
-    const uint32_t f1 = (1u << 20) - 1u - (kb >> 12), f2 = (1u << 20) - 1u - (ks >> 12); // the d2 the keys claim
-    // verification: exact d2 of the two reported columns from the descriptor bytes (this lane's half of K, the partner's by shuffle)
-    uint32_t qx[2];
+    // verification: exact d2 of the two reported columns from the descriptor bytes (this lane's half of K, the partner's by shuffle).
+    // A piece (z) that holds fewer than two columns of B reports QMAX entries: nothing to verify there.
+    bool ok = bad == 0u;
 #pragma unroll 1
     for (int c = 0; c < 2; c++) // not unrolled: the epilogue must not set the kernel's register count
     {
-      const uint32_t col = min(c == 0 ? i1 : i2, nb - 1u);
+      const uint32_t qc = c == 0 ? st.q1 : st.q2, kc = c == 0 ? st.k1 : st.k2;
+      const bool have = qc != QMAX;
+      const uint32_t col = have ? min(kc, nb - 1u) : 0u;
       const uint4 *pb = (const uint4 *)(desc_b + (size_t)col * 32);
       int dot = 0;
 #pragma unroll
@@ -1151,23 +1189,31 @@ __global__ void __launch_bounds__(64 * NW) k_match_pk(const uint32_t *__restrict
         dot = __builtin_amdgcn_sdot4(afrag[s][3], (int)(v.w ^ 0x80808080u), dot, false);
       }
       dot += __shfl_xor(dot, 32, 64);
-      const uint32_t qc = an + norm_b[col] - 2u * (uint32_t)dot;
-      if (c == 0)
-        qx[0] = qc;
-      else
-        qx[1] = qc;
+      const uint32_t qt = an + norm_b[col] - 2u * (uint32_t)dot;
+      if (have && (kc >= nb || qt != qc))
+        ok = false;
     }
-    const bool ok = i1 < nb && i2 < nb && i1 != i2 && qx[0] == f1 && qx[1] == f2 && kb >= 4096u && ks >= 4096u;
+    if (st.q1 != QMAX && st.q2 != QMAX && st.k1 == st.k2)
+      ok = false;
     const uint32_t rr = row_base + j;
     if (h == 0 && rr < na)
     {
-      uint32_t *m = matches + (size_t)rr * 5;
-      m[0] = a_index_base + rr;
-      m[1] = (sw && i1 < 2) ? (i1 ^ 1u) : i1;
-      m[2] = (sw && i2 < 2) ? (i2 ^ 1u) : i2;
-      m[3] = __float_as_uint(sqrtf((float)f1));
-      m[4] = __float_as_uint(sqrtf((float)f2));
-      redo[rr] = ok ? 0u : 1u;
+      if (nz > 1)
+      {
+        uint32_t *pp = partial + ((size_t)rr * nz + z) * 4;
+        pp[0] = st.q1, pp[1] = st.k1, pp[2] = st.q2, pp[3] = st.k2;
+        partial[(size_t)na * nz * 4 + (size_t)rr * nz + z] = (z == 0 ? sw : 0u) | ((ok ? 0u : 1u) << 1);
+      }
+      else
+      {
+        uint32_t *m = matches + (size_t)rr * 5;
+        m[0] = a_index_base + rr;
+        m[1] = (sw && st.k1 < 2) ? (st.k1 ^ 1u) : st.k1;
+        m[2] = (sw && st.k2 < 2) ? (st.k2 ^ 1u) : st.k2;
+        m[3] = __float_as_uint(sqrtf((float)st.q1));
+        m[4] = __float_as_uint(sqrtf((float)st.q2));
+        redo[rr] = (ok && st.q2 != QMAX) ? 0u : 1u;
+      }
     }
   }
 }
@@ -1576,7 +1622,40 @@ extern "C"
      * workgroups per CU, every workgroup the same number of tiles. Measured on MI355X against the three size regimes it
      * replaced (rows x rows, whole call): 2k 0.033 -> 0.028 ms, 8k 0.099 -> 0.062, 16k 0.23 -> 0.126, 32k 0.50 -> 0.28,
      * 50k 0.60 -> 0.51 (31.7 % of the dense int8 peak), 100k 1.78 -> 1.48 (44 %). */
-    if (na <= VKSIFT_HIP_MATCH_SMALL_NA && nb <= VKSIFT_HIP_MATCH_SMALL_NB)
+    if (match_use_pk() && nb <= VKSIFT_HIP_MATCH_PK_NB && (uint64_t)na * nb >= 64000000ull)
+    {
+      /* 8 k x 8 k up to 32 k reference rows: the branch-free packed-key kernel (its rate does not depend on the size: 13 k x 13 k
+       * 0.103 -> 0.078 ms, 32 k 0.275 -> 0.243; the pruning kernel passes it beyond 32 k rows, below 8 k the launches dominate). Row blocks x strided pieces of B (whole super-chunks of 4096 columns) sized to put ~2 workgroups on every
+       * CU; more than one piece per row block: partial lists + k_match_merge. Scratch: redo[na], then 5 * na * pieces u32
+       * (pieces <= 8 <= VKSIFT_HIP_MATCH_CHUNKS). */
+      uint32_t *partial = redo + na;
+      const uint32_t nsc = (nb + 4095u) / 4096u, want = 2u * device_cus();
+      SlotStrides zp = z;
+      zp.pk_nb_max = VKSIFT_HIP_MATCH_PK_NB;
+      if (na <= 4096u)
+      {
+        const uint32_t nrb = (na + 63u) / 64u;
+        uint32_t nz = (want + nrb - 1u) / nrb;
+        nz = nz < nsc ? nz : nsc;
+        hipLaunchKernelGGL((k_match_pk<2, 64>), dim3(nrb, 1, nz), dim3(128), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
+                           (const uint32_t *)nullptr, zp, noids, partial);
+        if (nz > 1)
+          hipLaunchKernelGGL(k_match_merge, dim3((na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial, na, nz, a_index_base, (uint32_t *)matches, redo,
+                             (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, 0u, nb, 0u, 0u);
+      }
+      else
+      {
+        const uint32_t nrb = (na + 127u) / 128u;
+        uint32_t nz = (want + nrb - 1u) / nrb;
+        nz = nz < nsc ? nz : nsc;
+        hipLaunchKernelGGL((k_match_pk<4, 128>), dim3(nrb, 1, nz), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
+                           (const uint32_t *)nullptr, zp, noids, partial);
+        if (nz > 1)
+          hipLaunchKernelGGL(k_match_merge, dim3((na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial, na, nz, a_index_base, (uint32_t *)matches, redo,
+                             (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, 0u, nb, 0u, 0u);
+      }
+    }
+    else if (na <= VKSIFT_HIP_MATCH_SMALL_NA && nb <= VKSIFT_HIP_MATCH_SMALL_NB)
       hipLaunchKernelGGL(k_match_mfma_split, dim3((na + 15u) / 16u), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
                          (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, noids);
     else
@@ -1744,7 +1823,7 @@ extern "C"
         uint32_t gp = (max_na + 255u) / 256u;
         gp = gp < 16u ? gp : 16u;
         hipLaunchKernelGGL((k_match_pk<8, 128>), sp.slot_fast ? dim3(nslots, gp) : dim3(gp, nslots), dim3(512), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
-                           (uint32_t *)matches, redo, n_dev, sp, ids);
+                           (uint32_t *)matches, redo, n_dev, sp, ids, (uint32_t *)nullptr);
         S1 = 0u;
         lim = nslots >= 8 ? 16u : lim;
       }
