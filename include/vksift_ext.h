@@ -146,6 +146,13 @@ extern "C"
   /* Deterministic synthetic test image: 128 + sum of Gaussian blobs + uniform noise,
    * splitmix64-seeded, clamped to [0,255]. nb_blobs == 0 picks the density used by the benchmarks. */
   VKSIFT_EXPORT void vksift_ext_genSyntheticImage(uint64_t seed, uint32_t width, uint32_t height, uint32_t nb_blobs, uint8_t *out);
+  /* Further deterministic image families (the parity tests' second and third opinion on what an image looks like):
+   * BLOBS = vksift_ext_genSyntheticImage with the benchmark density; EDGES = flat rotated rectangles and checker patches over a
+   * ramp (long step edges, corners, junctions, shapes cut by the border); FRACTAL = 1/f value noise (texture at every scale). */
+#define VKSIFT_EXT_SYNTH_BLOBS 0u
+#define VKSIFT_EXT_SYNTH_EDGES 1u
+#define VKSIFT_EXT_SYNTH_FRACTAL 2u
+  VKSIFT_EXPORT void vksift_ext_genSyntheticImageFamily(uint64_t seed, uint32_t width, uint32_t height, uint32_t family, uint8_t *out);
   /* Deterministic SIFT-like descriptor rows: min(255, trunc(512*|g|/||g||)), g ~ N(0,1)^128. */
   VKSIFT_EXPORT void vksift_ext_genSyntheticDescriptors(uint64_t seed, uint32_t rows, uint8_t *out);
 

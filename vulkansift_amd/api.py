@@ -134,6 +134,8 @@ def lib():
     L.vksift_ext_exportDescriptorsDevice.restype = u32
     L.vksift_ext_genSyntheticImage.argtypes = [C.c_uint64, u32, u32, u32, C.c_void_p]
     L.vksift_ext_genSyntheticDescriptors.argtypes = [C.c_uint64, u32, C.c_void_p]
+    L.vksift_ext_genSyntheticImageFamily.argtypes = [C.c_uint64, u32, u32, u32, C.c_void_p]
+    L.vksift_ext_genSyntheticImageFamily.restype = None
     L.vksift_ext_shardGetUniqueId.argtypes = [C.c_void_p]
     L.vksift_ext_shardGetUniqueId.restype = C.c_int
     L.vksift_ext_shardGroupCreate.argtypes = [C.POINTER(C.c_void_p), C.c_int, u32, u32, C.c_void_p]
@@ -225,6 +227,16 @@ def available_gpus():
 def gen_synthetic_image(seed, width, height, nb_blobs=0):
     out = np.empty((height, width), np.uint8)
     lib().vksift_ext_genSyntheticImage(seed, width, height, nb_blobs, out.ctypes.data)
+    return out
+
+
+SYNTH_BLOBS, SYNTH_EDGES, SYNTH_FRACTAL = 0, 1, 2
+
+
+def gen_synthetic_image_family(seed, width, height, family):
+    """vksift_ext_genSyntheticImageFamily: SYNTH_EDGES (step edges, corners, checker patches) or SYNTH_FRACTAL (1/f noise)"""
+    out = np.empty((height, width), np.uint8)
+    lib().vksift_ext_genSyntheticImageFamily(seed, width, height, family, out.ctypes.data)
     return out
 
 
