@@ -32,6 +32,7 @@ class Config(C.Structure):
         ("use_hardware_interpolated_blur", C.c_int32),
         ("math_mode", C.c_int32),
         ("pyramid_fp16", C.c_int32),
+        ("sampler_model", C.c_int32),
     ]
 
 

@@ -86,6 +86,7 @@ void orc_default_config(orc_Config *cfg)
   cfg->use_hardware_interpolated_blur = 1;
   cfg->math_mode = 0;
   cfg->pyramid_fp16 = 0;
+  cfg->sampler_model = 0;
 }
 
 /* sift_memory.c:644-660 */
@@ -342,6 +343,42 @@ static void blur_plane(const float *src, float *dst, float *tmp, int w, int h, c
   }
 }
 
+/* The same blur as a texture unit would run it (orc_Config.sampler_model): k is the reference's interpolated kernel — k[0] the
+ * centre weight, then (weight, offset) pairs (sift_detector.c:119-135). A fetch at texel-centre distance `off` = d + f interpolates
+ * texels d and d + 1 (on the minus side: -d and -d - 1) with weight alpha = round(f * 256) / 256 on the farther one, as
+ * t0 + alpha * (t1 - t0); the two fetches are added, then multiplied by the pair's weight (GaussianBlurInterpolated.comp:34-37). */
+static void blur_plane_sampler(const float *src, float *dst, float *tmp, int w, int h, const float *k, int ksize)
+{
+  for (int pass = 0; pass < 2; pass++)
+  {
+    const float *in = pass == 0 ? src : tmp;
+    float *out = pass == 0 ? tmp : dst;
+    const int n = pass == 0 ? w : h;
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++)
+      {
+        const int c = pass == 0 ? x : y;
+        float acc = in[(size_t)y * w + x] * k[0];
+        for (int i = 2; i < ksize; i += 2)
+        {
+          const float off = k[i + 1];
+          const int d = (int)floorf(off);
+          const float alpha = floorf((off - (float)d) * 256.f + 0.5f) / 256.f;
+          float t[4];
+          const int idx[4] = {c + d, c + d + 1, c - d, c - d - 1};
+          for (int q = 0; q < 4; q++)
+          {
+            const int m = mirror_idx(idx[q], n);
+            t[q] = pass == 0 ? in[(size_t)y * w + m] : in[(size_t)m * w + x];
+          }
+          const float sp = t[0] + alpha * (t[1] - t[0]), sm = t[2] + alpha * (t[3] - t[2]);
+          acc += (sp + sm) * k[i];
+        }
+        out[(size_t)y * w + x] = acc;
+      }
+  }
+}
+
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 /* vkCmdBlitImage R8_UNORM -> R32F, VK_FILTER_LINEAR (sift_detector.c:909-916). */
@@ -400,6 +437,10 @@ orc_Pyramid *orc_pyramid_build(const orc_Config *cfg, const uint8_t *img, uint32
   float taps[ORC_MAX_KERNEL * 16];
   uint32_t ntaps[16];
   orc_effective_taps(cfg, taps, ntaps);
+  float kern[ORC_MAX_KERNEL * 16];
+  uint32_t ksz[16];
+  orc_gaussian_kernels(cfg, kern, ksz, NULL);
+  const int sampler = cfg->sampler_model && cfg->use_hardware_interpolated_blur && !cfg->pyramid_fp16;
 
   float *tmp = (float *)malloc(sizeof(float) * (size_t)p->w[0] * p->h[0]);
   for (uint32_t o = 0; o < p->nb_octaves; o++)
@@ -416,14 +457,22 @@ orc_Pyramid *orc_pyramid_build(const orc_Config *cfg, const uint8_t *img, uint32
       if (cfg->pyramid_fp16)
         store_as_f16(g, px);
       /* seed blur in place on layer 0: H layer0 -> tmp, V tmp -> layer0 (sift_detector.c:927-952) */
-      blur_plane(g, g, tmp, (int)p->w[0], (int)p->h[0], &taps[0], (int)ntaps[0], cfg->pyramid_fp16);
+      if (sampler)
+        blur_plane_sampler(g, g, tmp, (int)p->w[0], (int)p->h[0], &kern[0], (int)ksz[0]);
+      else
+        blur_plane(g, g, tmp, (int)p->w[0], (int)p->h[0], &taps[0], (int)ntaps[0], cfg->pyramid_fp16);
     }
     else
     {
       blit_nearest(p->gauss[o - 1] + (size_t)S * p->w[o - 1] * p->h[o - 1], (int)p->w[o - 1], (int)p->h[o - 1], g, (int)p->w[o], (int)p->h[o]);
     }
     for (uint32_t s = 1; s < S + 3; s++)
-      blur_plane(g + (s - 1) * px, g + s * px, tmp, (int)p->w[o], (int)p->h[o], &taps[s * ORC_MAX_KERNEL], (int)ntaps[s], cfg->pyramid_fp16);
+    {
+      if (sampler)
+        blur_plane_sampler(g + (s - 1) * px, g + s * px, tmp, (int)p->w[o], (int)p->h[o], &kern[s * ORC_MAX_KERNEL], (int)ksz[s]);
+      else
+        blur_plane(g + (s - 1) * px, g + s * px, tmp, (int)p->w[o], (int)p->h[o], &taps[s * ORC_MAX_KERNEL], (int)ntaps[s], cfg->pyramid_fp16);
+    }
     /* DifferenceOfGaussian.comp:13-17 */
     for (uint32_t s = 0; s < S + 2; s++)
       for (size_t i = 0; i < px; i++)

@@ -48,6 +48,13 @@ extern "C"
      * scale-space layers and the DoG layers — holds IEEE binary16 texels (round-to-nearest-even of the fp32 result), every
      * read widens exactly, all arithmetic stays fp32. */
     int32_t pyramid_fp16;
+    /* 0: the interpolated blur's bilinear fetches are exact arithmetic taps (what the HIP kernels compute, bit for bit).
+     * 1: a model of what a GPU's texture unit does with GaussianBlurInterpolated.comp:32-44 — every fetch interpolates its two
+     *    texels with the fractional offset rounded to 8 bits (1/256 steps, the sub-texel precision of current desktop GPUs; Vulkan
+     *    only guarantees >= 4 bits), and the two fetches of a tap pair are summed before the multiplication by the pair's weight.
+     *    Measurement aid only (tests/test_sampler_model.py bounds how far the keypoints and descriptors move); nothing is
+     *    bit-exact against it. */
+    int32_t sampler_model;
   } orc_Config;
 
   /* 164-byte feature record == vksift_Feature. */

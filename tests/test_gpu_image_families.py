@@ -20,11 +20,12 @@ def _same(feats, ref):
 def test_detection_bit_exact_on_family(vk, oracle, family, w, h, kw):
     fam = vk.SYNTH_EDGES if family == "edges" else vk.SYNTH_FRACTAL
     img = vk.gen_synthetic_image_family(31 + w, w, h, fam)
+    okw = {"use_input_upsampling": int(kw.get("use_input_upsampling", True)), "use_vlfeat_format": int(kw.get("descriptor_format", 0))}
     cfg = vk.default_config(input_image_max_size=w * h, max_nb_sift_per_buffer=200000, **kw)
     with vk.Instance(cfg) as inst:
         inst.detectFeatures(img, 0)
         feats = inst.downloadFeatures(0)
-    ref, _ = oracle.detect(oracle.default_config(math_mode=1, max_nb_sift_per_buffer=200000, **kw), img)
+    ref, _ = oracle.detect(oracle.default_config(math_mode=1, max_nb_sift_per_buffer=200000, **okw), img)
     _same(feats, ref)
 
 

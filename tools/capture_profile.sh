@@ -2,7 +2,7 @@
 # Run on the GPU box (gpurun): rocprofv3 kernel trace + the two PMC passes first, the report (profiles/<tag>_*) from them, then the
 # official bench line — in that order so that the line's roofline.traffic comes from the PMC capture of the same kernel sources.
 # usage: bash tools/capture_profile.sh <tag> [width height batch]   -> gpurun_out/<tag>/{trace,pmc_fetch,pmc_write,profiles/,bench.json}
-TAG=${1:-r02}; W=${2:-640}; H=${3:-480}; B=${4:-128}
+TAG=${1:-r04}; W=${2:-640}; H=${3:-480}; B=${4:-512}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
