@@ -40,6 +40,7 @@ def compare(img, **kw):
     return {"features_exact": len(a), "features_sampler": len(b), "paired": len(pairs), "unpaired_frac": 1.0 - 2.0 * len(pairs) / (len(a) + len(b)),
             "pos_rms_px": float(np.sqrt((pos ** 2).mean())), "pos_max_px": float(pos.max()), "desc_rms_of_norm_mean": float(rms.mean()),
             "desc_rms_of_norm_p99": float(np.quantile(rms, 0.99)), "desc_rms_of_norm_max": float(rms.max()),
+            "desc_per_element_rms_over_512_median": float(np.median(rms / np.sqrt(128.0))), "desc_per_element_rms_over_512_p99": float(np.quantile(rms / np.sqrt(128.0), 0.99)),
             "sigma_rel_max": float(np.abs(a["sigma"][ia] / b["sigma"][ib] - 1).max())}
 
 
