@@ -266,6 +266,18 @@ bool match_use32()
   return cached == 1;
 }
 
+// VKSIFT_MATCH_SCAN=0: single pairs with large reference sets take the stream-decomposed pruning kernel instead of the cell scan
+bool match_use_scan()
+{
+  static int cached = -1;
+  if (cached < 0)
+  {
+    const char *e = getenv("VKSIFT_MATCH_SCAN");
+    cached = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return cached == 1;
+}
+
 // VKSIFT_MATCH_PK=0: batches of pairs go through the pruning kernels only (A/B switch, same results)
 bool match_use_pk()
 {
@@ -942,6 +954,410 @@ __global__ void __launch_bounds__(64 * NW) k_match32(const uint32_t *__restrict_
       }
     }
   } // row-block loop
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_match_scan32 + k_match_fix + k_match_redo_rows: the matcher for LARGE reference sets (beyond VKSIFT_HIP_MATCH_PK_NB rows).
+//
+// Every pruning kernel above pays for an insertion with a wave-wide detour, and a row sees ~2 ln N of them whatever the bound
+// (k_match_mfma: 7 of its 10 issued instructions per MFMA are that detour; k_match32: 9 of 12). This scan has no detour and no
+// index arithmetic at all. A lane (one query row per tile, 16 accumulators per 32-column sub-block = one CELL) only keeps, branch
+// free, its two best cells: the largest accumulator of the sub-block (8 v_max3) folded into (M1, cell1, M2, cell2) by compares and
+// selects — 20 VALU per 4 MFMAs (128 matrix-pipe cycles). Which columns of those cells are the two nearest neighbours, and their
+// exact distances, is settled afterwards by k_match_fix from the descriptor bytes: 4 cells x 16 columns per row at most.
+// Why that is exact. acc = a'.b' - (|b'|^2 >> 1), d2 = |a'|^2 + (|b'|^2 & 1) - 2 acc. Let T be the second largest cell maximum of a
+// row (over both lanes, all pieces). Two different columns reach acc >= T, so the second smallest d2 is <= |a'|^2 + 1 - 2 T, and a
+// column that beats or ties it has acc >= T: it lies in a cell whose maximum is >= T. A lane's cells arrive in column order and a
+// later cell only replaces an earlier one when strictly larger, so the recorded cells are the earliest ones among equals. A lane
+// keeps its THREE best cells and the VALUE of the fourth: a dropped cell is at most the lane's fourth maximum, which is at most T; it
+// can only matter (on the parity bit) when it EQUALS T, i.e. when the lane's second, third and fourth all equal T. Those rows — and rows whose second
+// distance reaches 2^22 (quirk Q8: float sqrt order) — go to the exact replay (k_match_redo_rows, one workgroup per row).
+constexpr uint32_t CELL_NONE = 0x7FFFFFFFu;
+constexpr int CELL_MIN = -2147483647 - 1;
+struct Cell3
+{
+  int m1, m2, m3;
+  uint32_t i1, i2, i3;
+  int m4; // the fourth largest cell maximum, value only: "did the lane drop a cell that reaches the row's threshold?"
+};
+__device__ __forceinline__ int smed3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
+// fold cell (m, idx) into the three best of a lane; cells arrive in column order, a later cell replaces an earlier one only when
+// strictly larger (14 VALU: 3 compares, 5 selects, 2 min, 3 max, med3)
+__device__ __forceinline__ void cell_update(Cell3 &s, int m, uint32_t idx)
+{
+  const bool c1 = m > s.m1, c2 = m > s.m2, c3 = m > s.m3;
+  s.i3 = c2 ? s.i2 : (c3 ? idx : s.i3);
+  s.i2 = c1 ? s.i1 : (c2 ? idx : s.i2);
+  s.i1 = c1 ? idx : s.i1;
+  s.m4 = max(s.m4, min(s.m3, m));
+  s.m3 = max(s.m3, min(s.m2, m));
+  s.m2 = smed3(s.m1, s.m2, m);
+  s.m1 = max(s.m1, m);
+}
+
+// Partial lists: 16 words per (row, piece): per lane h two uint4 [m1 i1 m2 i2][m3 i3 m4 -]. Work decomposition, staging and LDS layout of k_match32.
+template <int AT, int NW, int BTT>
+__global__ void __launch_bounds__(64 * NW) k_match_scan32(const uint32_t *__restrict__ desc_a, uint32_t na, const uint32_t *__restrict__ desc_b,
+                                                      const uint32_t *__restrict__ norm_b, uint32_t nb, uint32_t *__restrict__ partial)
+{
+  constexpr uint32_t ROWS = 32u * AT * NW;
+  constexpr uint32_t nchunks = VKSIFT_HIP_MATCH_CHUNKS;
+  __shared__ __attribute__((aligned(16))) uint8_t s_b2[2][BTT * 128];
+  __shared__ __attribute__((aligned(16))) int s_nbh2[2][BTT]; // -(bn >> 1), ACC_DEAD for rows beyond B: the MFMA's C operand
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const uint32_t tiles = (nb + BTT - 1) / BTT;
+  const uint32_t nblocks = (na + ROWS - 1u) / ROWS;
+  const uint32_t span = stream_span(nblocks, tiles, gridDim.x);
+  uint32_t pos = blockIdx.x * span;
+  const uint32_t pos_end = min(pos + span, nblocks * tiles);
+
+  constexpr int NTH = 64 * NW, NLD = (BTT * 8 + NTH - 1) / NTH;
+  struct TileRegs
+  {
+    uint4 d[NLD];
+    uint32_t n;
+  };
+  auto fetch_tile = [&](uint32_t t0, TileRegs &pf) {
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
+    {
+      const int i = threadIdx.x + q * NTH;
+      const int r = i >> 3, c = i & 7;
+      pf.d[q] = make_uint4(0, 0, 0, 0);
+      if (i < BTT * 8 && t0 + r < nb)
+        pf.d[q] = ((const uint4 *)(desc_b + (size_t)(t0 + r) * 32))[c];
+    }
+    pf.n = (threadIdx.x < BTT && t0 + threadIdx.x < nb) ? norm_b[t0 + threadIdx.x] : 0u;
+  };
+  auto stage_tile = [&](uint32_t t0, int bufi, const TileRegs &pf) {
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
+    {
+      const int i = threadIdx.x + q * NTH;
+      const int r = i >> 3, c = i & 7;
+      uint4 v = pf.d[q];
+      v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
+      if (i < BTT * 8)
+        *(uint4 *)(s_b2[bufi] + r * 128 + swz(r, c) * 16) = v;
+    }
+    if ((int)threadIdx.x < BTT)
+      s_nbh2[bufi][threadIdx.x] = t0 + threadIdx.x < nb ? -(int)(pf.n >> 1) : ACC_DEAD;
+  };
+
+  while (pos < pos_end)
+  {
+    const uint32_t rb = pos / tiles;
+    const uint32_t t_first = pos - rb * tiles, t_cnt = min(tiles - t_first, pos_end - pos);
+    const uint32_t tb = t_first * BTT, te = min(nb, (t_first + t_cnt) * BTT);
+    const uint32_t chunk = blockIdx.x - (rb * tiles) / span;
+    pos += t_cnt;
+    const uint32_t row_base = (rb * NW + wave) * (32 * AT);
+
+    v4i afrag[AT][4];
+#pragma unroll
+    for (int t = 0; t < AT; t++)
+    {
+      uint32_t r = row_base + t * 32 + j;
+      if (r >= na)
+        r = na - 1;
+      const uint4 *p = (const uint4 *)(desc_a + (size_t)r * 32);
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+      {
+        const uint4 v = p[2 * s + h];
+        afrag[t][s] = v4i{(int)(v.x ^ 0x80808080u), (int)(v.y ^ 0x80808080u), (int)(v.z ^ 0x80808080u), (int)(v.w ^ 0x80808080u)};
+      }
+    }
+    Cell3 st[AT];
+#pragma unroll
+    for (int t = 0; t < AT; t++)
+      st[t] = Cell3{CELL_MIN, CELL_MIN, CELL_MIN, CELL_NONE, CELL_NONE, CELL_NONE, CELL_MIN};
+
+    TileRegs pf0;
+    __syncthreads(); // the previous piece has finished reading both buffers
+    fetch_tile(tb, pf0);
+    stage_tile(tb, 0, pf0);
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t t0 = tb; t0 < te; t0 += BTT, buf ^= 1)
+    {
+      const bool more = t0 + BTT < te;
+      if (more)
+        fetch_tile(t0 + BTT, pf0);
+      const uint8_t *s_b = s_b2[buf];
+      const int *s_nbh = s_nbh2[buf];
+      auto issue = [&](int sub, v16i *acc) {
+        const uint8_t *prow = s_b + (sub * 32 + j) * 128;
+        v4i bf[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          bf[s] = *(const v4i *)(prow + swz(j, 2 * s + h) * 16);
+        v16i cinit;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+        {
+          const v4i c4 = *(const v4i *)(s_nbh + sub * 32 + 8 * b + 4 * h);
+          cinit[4 * b + 0] = c4[0], cinit[4 * b + 1] = c4[1], cinit[4 * b + 2] = c4[2], cinit[4 * b + 3] = c4[3];
+        }
+#pragma unroll
+        for (int t = 0; t < AT; t++)
+          acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[0], afrag[t][0], cinit, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < 4; s++)
+#pragma unroll
+          for (int t = 0; t < AT; t++)
+            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[s], afrag[t][s], acc[t], 0, 0, 0);
+      };
+      v16i accp[2][AT];
+      issue(0, accp[0]);
+      const uint32_t cell0 = t0 / 32u;
+#pragma unroll
+      for (int sub = 0; sub < BTT / 32; sub++)
+      {
+        if (sub + 1 < BTT / 32)
+          issue(sub + 1, accp[(sub + 1) & 1]); // the matrix pipe works on the next sub-block while the VALU folds this one
+        const v16i *acc = accp[sub & 1];
+#pragma unroll
+        for (int t = 0; t < AT; t++)
+        {
+          // the largest of the 16 accumulators: 8 three-operand maxima
+          int m = max(max(acc[t][0], acc[t][1]), acc[t][2]);
+#pragma unroll
+          for (int i = 3; i + 1 < 16; i += 2)
+            m = max(max(m, acc[t][i]), acc[t][i + 1]);
+          m = max(m, acc[t][15]);
+          cell_update(st[t], m, cell0 + (uint32_t)sub);
+        }
+      }
+      if (more)
+        stage_tile(t0 + BTT, buf ^ 1, pf0);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < AT; t++)
+    {
+      const uint32_t r = row_base + t * 32 + j;
+      if (r < na)
+      {
+        uint4 *pp = (uint4 *)(partial + (((size_t)r * nchunks + chunk) * 2 + h) * 8);
+        pp[0] = make_uint4((uint32_t)st[t].m1, st[t].i1, (uint32_t)st[t].m2, st[t].i2);
+        pp[1] = make_uint4((uint32_t)st[t].m3, st[t].i3, (uint32_t)st[t].m4, 0u);
+      }
+    }
+  }
+}
+
+// The exact finish of k_match_scan32: per row, merge the pieces' cell lists of each lane (in column order, same rule), take the
+// cells at or above the row's second largest cell maximum T, recompute the exact d2 of their columns from the descriptor bytes and
+// keep the two smallest (d2, column) pairs — the reference's strict '<' scan order. A lane keeps THREE cells and the value of its
+// fourth best: a cell it dropped can only matter when it equals T, and then the lane's second, third and fourth maxima all equal T
+// (~1e-5 of the rows of random descriptors; a two-way tie at T, ~1 % of the rows, is simply evaluated). That and a second distance of
+// 2^22 or more (quirk Q8) send the row to the exact replay. 32 rows per workgroup: 64 threads merge, then each wave finishes 8 rows with one column per lane (4 cells x 16 columns
+// per round; a second round when more than four cells reach T).
+__global__ void __launch_bounds__(256) k_match_fix(const uint32_t *__restrict__ partial, const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a,
+                                                   uint32_t na, uint32_t a_index_base, const uint32_t *__restrict__ desc_b, const uint32_t *__restrict__ norm_b,
+                                                   uint32_t nb, uint32_t stream_grid, uint32_t tile_rows, uint32_t block_rows, uint32_t *__restrict__ matches,
+                                                   uint32_t *__restrict__ redo_list)
+{
+  __shared__ int s_m[32][6];      // cell maxima of a row: lane 0's three, lane 1's three
+  __shared__ uint32_t s_i[32][6]; // their cell indices
+  __shared__ int s_m4[32][2];     // the lanes' fourth largest maxima
+  const uint32_t row0 = blockIdx.x * 32u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 64)
+  {
+    const uint32_t r = row0 + (threadIdx.x >> 1), hh = threadIdx.x & 1u;
+    Cell3 s{CELL_MIN, CELL_MIN, CELL_MIN, CELL_NONE, CELL_NONE, CELL_NONE, CELL_MIN};
+    int v4[4] = {CELL_MIN, CELL_MIN, CELL_MIN, CELL_MIN}; // the four largest cell maxima of the lane over all pieces (values only)
+    auto val_insert = [&](int v) {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+      {
+        const int hi = max(v4[q], v), lo = min(v4[q], v);
+        v4[q] = hi, v = lo;
+      }
+    };
+    if (r < na)
+    {
+      const uint32_t tiles = (nb + tile_rows - 1u) / tile_rows;
+      const uint32_t span = stream_span((na + block_rows - 1u) / block_rows, tiles, stream_grid);
+      const uint32_t rb = r / block_rows;
+      const uint32_t n = ((rb + 1u) * tiles - 1u) / span - (rb * tiles) / span + 1u;
+      const uint4 *pp = (const uint4 *)(partial + (size_t)r * VKSIFT_HIP_MATCH_CHUNKS * 16u);
+      for (uint32_t c = 0; c < n; c++)
+      {
+        const uint4 v = pp[(c * 2u + hh) * 2u], w = pp[(c * 2u + hh) * 2u + 1u];
+        if ((int)v.x != CELL_MIN)
+          cell_update(s, (int)v.x, v.y);
+        if ((int)v.z != CELL_MIN)
+          cell_update(s, (int)v.z, v.w);
+        if ((int)w.x != CELL_MIN)
+          cell_update(s, (int)w.x, w.y);
+        val_insert((int)v.x), val_insert((int)v.z), val_insert((int)w.x), val_insert((int)w.z);
+      }
+    }
+    const int lr = threadIdx.x >> 1;
+    s_m4[lr][hh] = v4[3];
+    s_m[lr][3 * hh + 0] = s.m1, s_m[lr][3 * hh + 1] = s.m2, s_m[lr][3 * hh + 2] = s.m3;
+    s_i[lr][3 * hh + 0] = s.i1, s_i[lr][3 * hh + 1] = s.i2, s_i[lr][3 * hh + 2] = s.i3;
+  }
+  __syncthreads();
+  for (int k = 0; k < 8; k++)
+  {
+    const int lr = wave * 8 + k;
+    const uint32_t r = row0 + (uint32_t)lr;
+    if (r >= na)
+      break;
+    // T = second largest of the six maxima (each lane's list is sorted: the two largest are among m1, m2 of both lanes)
+    const int a1 = s_m[lr][0], a2 = s_m[lr][1], b1 = s_m[lr][3], b2 = s_m[lr][4];
+    const int T = max(min(a1, b1), max(a2, b2));
+    // a cell a lane did not record reaches T (then the lane's second, third and fourth maxima all equal T)
+    const bool tie = (s_m4[lr][0] != CELL_MIN && s_m4[lr][0] >= T) || (s_m4[lr][1] != CELL_MIN && s_m4[lr][1] >= T);
+    // the cells at or above T, in slot order (uniform): at most six
+    int on_slot[6];
+    int n_on = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+      if (s_m[lr][c] != CELL_MIN && s_m[lr][c] >= T && s_i[lr][c] != CELL_NONE)
+        on_slot[n_on++] = c;
+    Top2 s{QMAX, QMAX, QMAX, QMAX};
+    uint32_t sw = 0;
+    const int cq = lane >> 4, i = lane & 15;
+    for (int round = 0; round * 4 < n_on; round++)
+    {
+      const int which = round * 4 + cq;
+      const int slot = which < n_on ? on_slot[which < 6 ? which : 5] : -1;
+      const int hh = slot >= 3 ? 1 : 0;
+      const uint32_t col = slot >= 0 ? s_i[lr][slot] * 32u + 8u * (uint32_t)(i >> 2) + 4u * (uint32_t)hh + (uint32_t)(i & 3) : 0u;
+      const bool on = slot >= 0 && col < nb;
+      uint32_t q = QMAX;
+      {
+        const uint4 *pa = (const uint4 *)(desc_a + (size_t)r * 32);
+        const uint4 *pb = (const uint4 *)(desc_b + (size_t)(on ? col : 0u) * 32);
+        int dot = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+        {
+          const uint4 va = pa[c], vb = pb[c];
+          dot = __builtin_amdgcn_sdot4((int)(va.x ^ 0x80808080u), (int)(vb.x ^ 0x80808080u), dot, false);
+          dot = __builtin_amdgcn_sdot4((int)(va.y ^ 0x80808080u), (int)(vb.y ^ 0x80808080u), dot, false);
+          dot = __builtin_amdgcn_sdot4((int)(va.z ^ 0x80808080u), (int)(vb.z ^ 0x80808080u), dot, false);
+          dot = __builtin_amdgcn_sdot4((int)(va.w ^ 0x80808080u), (int)(vb.w ^ 0x80808080u), dot, false);
+        }
+        if (on)
+          q = norm_a[r] + norm_b[col] - 2u * (uint32_t)dot;
+      }
+      // quirk Q7: d2(b0) == d2(b1) (columns 0 and 1 share a cell: evaluated together or not at all)
+      const unsigned long long m0 = __ballot(on && col == 0u), m1 = __ballot(on && col == 1u);
+      if (m0 != 0ull && m1 != 0ull)
+      {
+        const uint32_t q0 = __shfl(q, __ffsll((long long)m0) - 1, 64), q1 = __shfl(q, __ffsll((long long)m1) - 1, 64);
+        sw = q0 == q1 ? 1u : 0u;
+      }
+      Top2 t2{q, on ? col : QMAX, QMAX, QMAX};
+#pragma unroll
+      for (int x = 1; x < 64; x <<= 1)
+      {
+        Top2 o;
+        o.q1 = __shfl_xor(t2.q1, x, 64), o.k1 = __shfl_xor(t2.k1, x, 64);
+        o.q2 = __shfl_xor(t2.q2, x, 64), o.k2 = __shfl_xor(t2.k2, x, 64);
+        t2 = merge2(t2, o);
+      }
+      s = merge2(s, t2);
+    }
+    if (lane == 0)
+    {
+      uint32_t *m = matches + (size_t)r * 5;
+      m[0] = a_index_base + r;
+      m[1] = (sw && s.k1 < 2) ? (s.k1 ^ 1u) : s.k1;
+      m[2] = (sw && s.k2 < 2) ? (s.k2 ^ 1u) : s.k2;
+      m[3] = __float_as_uint(sqrtf((float)s.q1));
+      m[4] = __float_as_uint(sqrtf((float)s.q2));
+      if (tie || s.q2 >= Q_EXACT || s.k2 == QMAX)
+        redo_list[1u + atomicAdd(redo_list, 1u)] = r;
+    }
+  }
+}
+
+// Exact replay of Get2NearestNeighbors.comp:43-103 for the rows listed by k_match_fix: one workgroup per row, a thread scans the
+// columns t, t + 256, ... in increasing order with the reference's float loop, the 256 partial results are merged by
+// (distance, column) — the order a strict '<' scan produces; quirk Q7 relabels columns 0 and 1 when their float distances are equal.
+__global__ void __launch_bounds__(256) k_match_redo_rows(const uint32_t *__restrict__ desc_a, uint32_t a_index_base, const uint32_t *__restrict__ desc_b, uint32_t nb,
+                                                         uint32_t *__restrict__ matches, const uint32_t *__restrict__ redo_list)
+{
+  __shared__ float s_d[256][2];
+  __shared__ uint32_t s_i[256][2];
+  __shared__ float s_d01[2];
+  const uint32_t n = redo_list[0];
+  for (uint32_t k = blockIdx.x; k < n; k += gridDim.x)
+  {
+    const uint32_t row = redo_list[1u + k];
+    uint32_t a[32];
+    uint32_t na2 = 0;
+#pragma unroll
+    for (int jj = 0; jj < 32; jj++)
+    {
+      a[jj] = desc_a[(size_t)row * 32 + jj];
+      na2 = __builtin_amdgcn_udot4(a[jj], a[jj], na2, false);
+    }
+    float bd = __builtin_inff(), sd = __builtin_inff();
+    uint32_t bi = QMAX, si = QMAX;
+    for (uint32_t c = threadIdx.x; c < nb; c += 256u)
+    {
+      const uint4 *pb = (const uint4 *)(desc_b + (size_t)c * 32);
+      uint32_t dot = 0, nb2 = 0;
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++)
+      {
+        const uint4 v = pb[jj];
+        dot = __builtin_amdgcn_udot4(a[4 * jj + 0], v.x, dot, false), nb2 = __builtin_amdgcn_udot4(v.x, v.x, nb2, false);
+        dot = __builtin_amdgcn_udot4(a[4 * jj + 1], v.y, dot, false), nb2 = __builtin_amdgcn_udot4(v.y, v.y, nb2, false);
+        dot = __builtin_amdgcn_udot4(a[4 * jj + 2], v.z, dot, false), nb2 = __builtin_amdgcn_udot4(v.z, v.z, nb2, false);
+        dot = __builtin_amdgcn_udot4(a[4 * jj + 3], v.w, dot, false), nb2 = __builtin_amdgcn_udot4(v.w, v.w, nb2, false);
+      }
+      const float d = sqrtf((float)(na2 + nb2 - 2u * dot));
+      if (c < 2u)
+        s_d01[c] = d;
+      if (d < bd)
+        sd = bd, si = bi, bd = d, bi = c;
+      else if (d < sd)
+        sd = d, si = c;
+    }
+    s_d[threadIdx.x][0] = bd, s_d[threadIdx.x][1] = sd;
+    s_i[threadIdx.x][0] = bi, s_i[threadIdx.x][1] = si;
+    __syncthreads();
+    for (uint32_t step = 128; step >= 1; step >>= 1)
+    {
+      if (threadIdx.x < step)
+      {
+        const uint32_t o = threadIdx.x + step;
+        float a1 = s_d[threadIdx.x][0], a2 = s_d[threadIdx.x][1], b1 = s_d[o][0], b2 = s_d[o][1];
+        uint32_t ai1 = s_i[threadIdx.x][0], ai2 = s_i[threadIdx.x][1], bi1 = s_i[o][0], bi2 = s_i[o][1];
+        auto less = [](float x, uint32_t xi, float y, uint32_t yi) { return x < y || (x == y && xi < yi); };
+        const bool af = less(a1, ai1, b1, bi1);
+        const float w1 = af ? a1 : b1, w2 = af ? a2 : b2, l1 = af ? b1 : a1;
+        const uint32_t wi1 = af ? ai1 : bi1, wi2 = af ? ai2 : bi2, li1 = af ? bi1 : ai1;
+        const bool w2f = less(w2, wi2, l1, li1);
+        s_d[threadIdx.x][0] = w1, s_i[threadIdx.x][0] = wi1;
+        s_d[threadIdx.x][1] = w2f ? w2 : l1, s_i[threadIdx.x][1] = w2f ? wi2 : li1;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+      const bool sw = s_d01[0] == s_d01[1];
+      const uint32_t k1 = s_i[0][0], k2 = s_i[0][1];
+      uint32_t *m = matches + (size_t)row * 5;
+      m[0] = a_index_base + row;
+      m[1] = (sw && k1 < 2) ? (k1 ^ 1u) : k1;
+      m[2] = (sw && k2 < 2) ? (k2 ^ 1u) : k2;
+      m[3] = __float_as_uint(s_d[0][0]);
+      m[4] = __float_as_uint(s_d[0][1]);
+    }
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1658,6 +2074,20 @@ extern "C"
     else if (na <= VKSIFT_HIP_MATCH_SMALL_NA && nb <= VKSIFT_HIP_MATCH_SMALL_NB)
       hipLaunchKernelGGL(k_match_mfma_split, dim3((na + 15u) / 16u), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
                          (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, noids);
+    else if (match_use_scan())
+    {
+      /* large reference sets: the branch-free cell scan, the exact finish from the descriptor bytes, the (rare) replay of tied rows.
+       * Scratch: [row list: 1 + na][pad to 16 B][cell lists: 16 * na * VKSIFT_HIP_MATCH_CHUNKS] (VKSIFT_HIP_MATCH_SCRATCH_U32). */
+      uint32_t *list = scratch;
+      uint32_t *cells = (uint32_t *)(((uintptr_t)(scratch + na + 1u) + 15u) & ~(uintptr_t)15u); /* 16 words per (row, piece) */
+      const uint32_t G = 2u * device_cus();
+      (void)hipMemsetAsync(list, 0, sizeof(uint32_t), hs);
+      hipLaunchKernelGGL((k_match_scan32<2, 4, 128>), dim3(G), dim3(256), 0, hs, da, na, db, norm_b, nb, cells);
+      hipLaunchKernelGGL(k_match_fix, dim3((na + 31u) / 32u), dim3(256), 0, hs, (const uint32_t *)cells, da, norm_a, na, a_index_base, db, norm_b, nb, G, 128u, 256u,
+                         (uint32_t *)matches, list);
+      hipLaunchKernelGGL(k_match_redo_rows, dim3(2048), dim3(256), 0, hs, da, a_index_base, db, nb, (uint32_t *)matches, (const uint32_t *)list);
+      return (int)hipGetLastError();
+    }
     else
     {
       uint32_t *partial = redo + na;

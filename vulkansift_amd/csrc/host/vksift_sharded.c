@@ -238,7 +238,7 @@ static int shard_reserve(vksift_ext_ShardGroup g, uint32_t na, size_t nb_rows)
 {
   const size_t b_bytes = nb_rows * 128u;
   /* norms of A, norms of B (padded rows included), redo flags, partial lists of the stream-decomposed kernel */
-  const size_t scratch = (size_t)2 * na + nb_rows + 64 + (size_t)na * 5u * VKSIFT_HIP_MATCH_CHUNKS;
+  const size_t scratch = VKSIFT_HIP_MATCH_SCRATCH_U32(na, nb_rows);
   if (b_bytes <= g->b_cap && scratch <= g->scratch_cap)
     return 0;
   vksift_hip_stream_sync(g->comm_stream);
