@@ -1,0 +1,96 @@
+/* The host-protocol legs of bench.py as a C caller runs them (bench.py's Python loops cost 4-8 us of interpreter time per frame —
+ * a fifth of a 26 ms batch — which a C application of the reference does not pay). Public API only: the reference's per-frame
+ * accessors (vulkansift.h) and the batched detect / match entries of vksift_ext.h. Built by bench.py with gcc into a small shared
+ * object next to libvulkansift.so and called through ctypes; returns seconds for `steps` batches of `n` frames.
+ *
+ * proto_serial     src/perf/wrappers/vulkansift_wrapper.cpp:30-33 per frame = detect(host image) + getFeaturesNumber +
+ *                  downloadFeatures; here per batch of n frames, then the self-match of every frame and the download of its
+ *                  records. Strictly serial: nothing is queued while the host waits or copies.
+ * proto_pipelined  the same inputs and outputs with two sets of n SIFT buffers: the detection of the next batch is queued before the
+ *                  results of the current one are fetched (vulkansift.h:43-47: detection and matching calls are asynchronous). */
+#include <stdint.h>
+#include <stdlib.h>
+#include <time.h>
+
+#include <vulkansift/vulkansift.h>
+
+#include "vksift_ext.h"
+
+static double now_s(void)
+{
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+static void collect(vksift_Instance inst, uint32_t first, uint32_t n, int do_match, vksift_Feature *feat_buf, vksift_Match_2NN *match_buf)
+{
+  for (uint32_t i = 0; i < n; i++)
+    if (vksift_getFeaturesNumber(inst, first + i))
+      vksift_downloadFeatures(inst, feat_buf, first + i);
+  if (do_match)
+    for (uint32_t k = 0; k < n; k++)
+      if (vksift_ext_getMatchesNumberBatch(inst, k))
+        vksift_ext_downloadMatchesBatch(inst, k, match_buf);
+}
+
+double proto_serial(vksift_Instance inst, const uint8_t *const *images, uint32_t n, uint32_t w, uint32_t h, int do_match, uint32_t steps,
+                    vksift_Feature *feat_buf, vksift_Match_2NN *match_buf)
+{
+  uint32_t *ids = (uint32_t *)malloc(sizeof(uint32_t) * n);
+  for (uint32_t i = 0; i < n; i++)
+    ids[i] = i;
+  double t0 = 0.0;
+  for (uint32_t s = 0; s <= steps; s++) /* step 0 is the warm-up */
+  {
+    if (s == 1)
+      t0 = now_s();
+    vksift_ext_detectFeaturesBatch(inst, images, n, w, h, 0u);
+    for (uint32_t i = 0; i < n; i++)
+      if (vksift_getFeaturesNumber(inst, i))
+        vksift_downloadFeatures(inst, feat_buf, i);
+    if (do_match)
+    {
+      vksift_ext_matchFeaturesBatch(inst, n, ids, ids);
+      for (uint32_t k = 0; k < n; k++)
+        if (vksift_ext_getMatchesNumberBatch(inst, k))
+          vksift_ext_downloadMatchesBatch(inst, k, match_buf);
+    }
+  }
+  const double dt = now_s() - t0;
+  free(ids);
+  return dt;
+}
+
+static void run_pipelined(vksift_Instance inst, const uint8_t *const *images, uint32_t n, uint32_t w, uint32_t h, int do_match, uint32_t iters,
+                          uint32_t *ids0, uint32_t *ids1, vksift_Feature *feat_buf, vksift_Match_2NN *match_buf)
+{
+  vksift_ext_detectFeaturesBatch(inst, images, n, w, h, 0u);
+  if (do_match)
+    vksift_ext_matchFeaturesBatch(inst, n, ids0, ids0);
+  for (uint32_t it = 0; it < iters; it++)
+  {
+    const uint32_t cur = it & 1u, nxt = cur ^ 1u;
+    if (it + 1 < iters)
+      vksift_ext_detectFeaturesBatch(inst, images, n, w, h, nxt * n); /* queued behind the matching of `cur`; staged while the GPU works */
+    collect(inst, cur * n, n, do_match, feat_buf, match_buf);
+    if (it + 1 < iters && do_match)
+      vksift_ext_matchFeaturesBatch(inst, n, nxt ? ids1 : ids0, nxt ? ids1 : ids0); /* the match slots are free again once `cur`'s records are out */
+  }
+}
+
+/* inst must have been created with sift_buffer_count >= 2 n and a batch capacity of n */
+double proto_pipelined(vksift_Instance inst, const uint8_t *const *images, uint32_t n, uint32_t w, uint32_t h, int do_match, uint32_t steps,
+                       vksift_Feature *feat_buf, vksift_Match_2NN *match_buf)
+{
+  uint32_t *ids0 = (uint32_t *)malloc(sizeof(uint32_t) * n), *ids1 = (uint32_t *)malloc(sizeof(uint32_t) * n);
+  for (uint32_t i = 0; i < n; i++)
+    ids0[i] = i, ids1[i] = n + i;
+  run_pipelined(inst, images, n, w, h, do_match, 2, ids0, ids1, feat_buf, match_buf);
+  const double t0 = now_s();
+  run_pipelined(inst, images, n, w, h, do_match, steps, ids0, ids1, feat_buf, match_buf);
+  const double dt = now_s() - t0;
+  free(ids0);
+  free(ids1);
+  return dt;
+}

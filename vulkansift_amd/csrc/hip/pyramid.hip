@@ -1115,7 +1115,11 @@ extern "C"
       a.t1.k[i] = i < ntaps1 ? taps1[i] : 0.f, a.t2.k[i] = i < ntaps2 ? taps2[i] : 0.f;
     /* row segments as stream_grid(): the strip count differs (128 - 2 HC owned columns per wave) */
     uint32_t nseg = (10240u + strips * batch - 1u) / (strips * batch);
-    const uint32_t max_seg = (H + 63u) / 64u;
+    /* launches that cannot fill the GPU (a single image, the coarse octaves of a small batch) are latency bound: shorter marches,
+     * as stream_grid() — one 640x480 image: 4 pair launches of 27 us each with 64-row segments */
+    const uint32_t waves64 = strips * batch * ((H + 63u) / 64u);
+    const uint32_t seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u);
+    const uint32_t max_seg = (H + seg_rows - 1u) / seg_rows;
     if (nseg > max_seg)
       nseg = max_seg;
     if (nseg < 1)
@@ -1160,7 +1164,9 @@ extern "C"
     for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
       a.taps.k[i] = i < ntaps ? taps[i] : 0.f;
     uint32_t nseg = (10240u + strips * batch - 1u) / (strips * batch); /* as the other launches (stream_grid): 2560 long-lived waves left the tail to a few CUs */
-    uint32_t max_seg = (H + 63u) / 64u;
+    const uint32_t waves64 = strips * batch * ((H + 63u) / 64u);
+    const uint32_t seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u); /* latency-bound launches: shorter marches (stream_grid) */
+    uint32_t max_seg = (H + seg_rows - 1u) / seg_rows;
     if (nseg > max_seg)
       nseg = max_seg;
     if (nseg < 1)
