@@ -23,15 +23,35 @@ static double now_s(void)
   return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 
+/* PROTO_TRACE=1: where the host's time goes in the pipelined leg, per phase (stderr) */
+#include <stdio.h>
+static double g_t[8];
 static void collect(vksift_Instance inst, uint32_t first, uint32_t n, int do_match, vksift_Feature *feat_buf, vksift_Match_2NN *match_buf)
 {
+  double t = now_s();
   for (uint32_t i = 0; i < n; i++)
-    if (vksift_getFeaturesNumber(inst, first + i))
+  {
+    const uint32_t nf = vksift_getFeaturesNumber(inst, first + i);
+    if (i == 0)
+      g_t[1] += now_s() - t, t = now_s(); /* the wait for the detection */
+    if (nf)
       vksift_downloadFeatures(inst, feat_buf, first + i);
+    if (i == 0)
+      g_t[2] += now_s() - t, t = now_s(); /* the first download (plain copies to the caller's pageable buffer) */
+    if (i == 1)
+      g_t[3] += now_s() - t, t = now_s(); /* the second: starts the packed copy */
+  }
+  g_t[4] += now_s() - t, t = now_s();     /* the other downloads */
   if (do_match)
     for (uint32_t k = 0; k < n; k++)
-      if (vksift_ext_getMatchesNumberBatch(inst, k))
+    {
+      const uint32_t nm = vksift_ext_getMatchesNumberBatch(inst, k);
+      if (k == 0)
+        g_t[5] += now_s() - t, t = now_s(); /* the wait for the matching */
+      if (nm)
         vksift_ext_downloadMatchesBatch(inst, k, match_buf);
+    }
+  g_t[6] += now_s() - t;
 }
 
 double proto_serial(vksift_Instance inst, const uint8_t *const *images, uint32_t n, uint32_t w, uint32_t h, int do_match, uint32_t steps,
@@ -71,8 +91,10 @@ static void run_pipelined(vksift_Instance inst, const uint8_t *const *images, ui
   for (uint32_t it = 0; it < iters; it++)
   {
     const uint32_t cur = it & 1u, nxt = cur ^ 1u;
+    const double t = now_s();
     if (it + 1 < iters)
       vksift_ext_detectFeaturesBatch(inst, images, n, w, h, nxt * n); /* queued behind the matching of `cur`; staged while the GPU works */
+    g_t[0] += now_s() - t;
     collect(inst, cur * n, n, do_match, feat_buf, match_buf);
     if (it + 1 < iters && do_match)
       vksift_ext_matchFeaturesBatch(inst, n, nxt ? ids1 : ids0, nxt ? ids1 : ids0); /* the match slots are free again once `cur`'s records are out */
@@ -90,6 +112,11 @@ double proto_pipelined(vksift_Instance inst, const uint8_t *const *images, uint3
   const double t0 = now_s();
   run_pipelined(inst, images, n, w, h, do_match, steps, ids0, ids1, feat_buf, match_buf);
   const double dt = now_s() - t0;
+  if (getenv("PROTO_TRACE") && atoi(getenv("PROTO_TRACE")))
+    fprintf(stderr, "PROTO_TRACE ms per iteration (2 warm-up iterations included in the sums): detect call %.2f | wait detection %.2f | first download %.2f | "
+                    "second %.2f | other %u downloads %.2f | wait matching %.2f | match downloads %.2f | measured period %.2f\n",
+            g_t[0] * 1e3 / (steps + 2), g_t[1] * 1e3 / (steps + 2), g_t[2] * 1e3 / (steps + 2), g_t[3] * 1e3 / (steps + 2), n - 2, g_t[4] * 1e3 / (steps + 2),
+            g_t[5] * 1e3 / (steps + 2), g_t[6] * 1e3 / (steps + 2), dt * 1e3 / steps);
   free(ids0);
   free(ids1);
   return dt;
