@@ -73,6 +73,8 @@ extern "C"
   int vksift_hip_memcpy_d2h(void *dst, const void *src, size_t n, vksift_hip_stream s);
   int vksift_hip_memcpy_d2d(void *dst, const void *src, size_t n, vksift_hip_stream s);
   int vksift_hip_memcpy2d_d2h(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t height, vksift_hip_stream s);
+  /* kernel store of n_words into a vksift_hip_host_malloc allocation (see runtime.hip: keeps dependent read-backs off the copy engine) */
+  int vksift_hip_post_words(uint32_t *host_mapped_dst, const uint32_t *src, size_t n_words, vksift_hip_stream s);
   int vksift_hip_memset(void *dst, int value, size_t n, vksift_hip_stream s);
   const char *vksift_hip_error_string(int err);
   void vksift_hip_range_push(const char *name);       /* roctx marker == VK_EXT_debug_marker region */

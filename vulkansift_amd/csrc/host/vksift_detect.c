@@ -475,8 +475,8 @@ static int enqueue_detection(DetectCtx *c)
     inst->last_scan_bytes += (uint64_t)L->w[o] * L->h[o] * pyr_texel_bytes(inst) * (inst->S + 2) * c->count;
 
   /* recCopySIFTCountCmds (sift_detector.c:1261-1291) */
-  TRY(vksift_hip_memcpy_d2h(inst->h_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES,
-                            sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, st),
+  TRY(vksift_hip_post_words(inst->h_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES,
+                            (size_t)VKSIFT_MAX_OCTAVES * c->count, st),
       "count read-back");
   return 0;
 }

@@ -126,7 +126,7 @@ uint32_t vksift_ext_exportDescriptorsDevice(vksift_Instance instance, uint32_t g
   {
     /* the matcher's cache entry of the buffer holds exactly these rows (filled now if the buffer changed since its last matching) */
     HIP_CHECK(refresh_match_cache(inst, &gpu_buffer_id, 1), "descriptor gather");
-    HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n + 2, inst->d_cache_n + gpu_buffer_id, sizeof(uint32_t), inst->stream), "descriptor gather");
+    HIP_CHECK(vksift_hip_post_words(inst->h_match_n + 2, inst->d_cache_n + gpu_buffer_id, 1, inst->stream), "descriptor gather");
     HIP_CHECK(vksift_hip_stream_sync(inst->stream), "descriptor gather");
     n = inst->h_match_n[2];
     HIP_CHECK(vksift_hip_memcpy_d2d(d_descriptors, inst->d_cache_desc + (uint64_t)gpu_buffer_id * inst->desc_slot_stride, (size_t)n * 128u, inst->stream),

@@ -174,7 +174,7 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
   /* one launch sequence serves up to VKSIFT_HIP_MATCH_SLOTS pairs; a longer list goes in runs of that many, run r into the slots from r on */
   for (uint32_t r = 0; r < count; r += VKSIFT_HIP_MATCH_SLOTS)
     HIP_CHECK(match_slots(inst, &fwd, ids_a + r, ids_b + r, count - r < VKSIFT_HIP_MATCH_SLOTS ? count - r : VKSIFT_HIP_MATCH_SLOTS, r), "2-NN matching");
-  HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_match_n, inst->d_match_n, sizeof(uint32_t) * 4 * count, inst->stream), "match count read-back");
+  HIP_CHECK(vksift_hip_post_words(inst->h_match_n, inst->d_match_n, (size_t)4 * count, inst->stream), "match count read-back");
   inst->filtered_slots_used = 0;
   inst->md_valid = false, inst->md_hits = 0;
   if (filter)
@@ -196,7 +196,7 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
                                           inst->filtered_slot_stride, inst->d_filtered_n + r, inst->stream),
                 "match filtering");
     }
-    HIP_CHECK(vksift_hip_memcpy_d2h(inst->h_filtered_n, inst->d_filtered_n, sizeof(uint32_t) * count, inst->stream), "filtered count read-back");
+    HIP_CHECK(vksift_hip_post_words(inst->h_filtered_n, inst->d_filtered_n, count, inst->stream), "filtered count read-back");
     inst->filtered_slots_used = count;
   }
   vksift_hip_range_pop();
