@@ -374,6 +374,8 @@ def protocol_client(api):
             for f in (L.proto_serial, L.proto_pipelined):
                 f.restype = C.c_double
                 f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+            L.proto_single.restype = C.c_double
+            L.proto_single.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
             _PROTO = L
         except Exception:  # noqa: BLE001
             _PROTO = False
@@ -471,7 +473,10 @@ def single_image_latency(api, dev_index, img, runs=100, warm=10):
     with api.Instance(cfg) as inst:
         feat_buf = np.zeros(cfg.max_nb_sift_per_buffer, api.FEATURE_DTYPE)
         match_buf = np.zeros(cfg.max_nb_sift_per_buffer, api.MATCH_DTYPE)
+        pc = protocol_client(api)
+        img = np.ascontiguousarray(img)
         for with_match in (False, True):
+            key = "detect_match_ms" if with_match else "detect_ms"
             ts = []
             for i in range(warm + runs):
                 t0 = time.perf_counter()
@@ -483,8 +488,14 @@ def single_image_latency(api, dev_index, img, runs=100, warm=10):
                     lib.vksift_downloadMatches(inst._h, match_buf.ctypes.data)
                 if i >= warm:
                     ts.append(time.perf_counter() - t0)
-            out["detect_match_ms" if with_match else "detect_ms"] = float(np.mean(ts) * 1e3)
+            out[key + "_python_caller"] = float(np.mean(ts) * 1e3)
+            out[key] = out[key + "_python_caller"]
             out["features"] = int(n)
+            if pc is not None:
+                nf = C.c_uint32(0)
+                out[key] = 1e3 * pc.proto_single(inst._h, img.ctypes.data, w, h, int(with_match), warm, runs, feat_buf.ctypes.data, match_buf.ctypes.data, C.byref(nf))
+                out["features"] = int(nf.value)
+    out["caller"] = "C (tests/native/protocol_client.c: proto_single)" if pc is not None else "python (ctypes)"
     out["protocol"] = f"{warm} warm-up + {runs} timed runs, host image in, count + features (+ matches) downloaded, plain vksift_detectFeatures/matchFeatures"
     return out
 

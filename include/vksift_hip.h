@@ -134,6 +134,14 @@ extern "C"
   /* vkCmdBlitImage(NEAREST) of sift_detector.c:1003-1034: dst(x,y) = src(floor((x+.5)*sw/dw), ...). */
   int vksift_hip_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, uint32_t batch, vksift_hip_stream s);
 
+  /* The scale-space of n_oct consecutive (trailing) octaves in ONE launch, one workgroup per image, planes held in LDS:
+   * layers[o * n_layers + l] = layer l of octave o; layer 0 of octave 0 of the run is the input (already in memory), every other plane is
+   * written: layer l = blur(layer l - 1, taps[l]) (sift_detector.c:927-1001), layer 0 of the next octave = nearest 2:1 of layer S
+   * (:1003-1034). taps: n_layers rows of VKSIFT_HIP_MAX_TAPS. Bit-identical to the vksift_hip_blur / vksift_hip_downsample sequence.
+   * Returns -1 without launching anything when the planes are not covered (fp16, width not a multiple of 4, too large for the LDS). */
+  int vksift_hip_octave_chain(const vksift_hip_Plane *layers, uint32_t n_oct, uint32_t n_layers, uint32_t S, const float *taps, const uint32_t *ntaps,
+                              uint32_t batch, vksift_hip_stream s);
+
   /* DifferenceOfGaussian.comp:13-17 for one layer of one image: out (dense w x h, fp32) = hi - lo (rounded to binary16 for an
    * fp16 pyramid); hi == NULL: the layer lo itself, widened. Only the debug downloads use it — the detection path never
    * materialises a DoG plane. */
@@ -176,6 +184,8 @@ extern "C"
     uint32_t desc_fp_tab_len;
     uint32_t scan_reverse;    /* dispatch-order hint of the streaming extrema scan, like vksift_hip_Plane::reverse: set when the last
                                * blur launch of the octave ran forward, so that the scan starts on the planes written last */
+    uint32_t masks_cleared;   /* the caller has cleared seg_mask for this launch itself (vksift_hip_clear_segment_masks, e.g. on another
+                               * stream, off the critical path): vksift_hip_extract_keypoints_multi skips its own fill */
   } vksift_hip_OctaveJob;
 
   /* ExtractKeypoints.comp (sift_detector.c:1106-1189) as a deterministic, atomic-free pipeline: streaming
@@ -194,6 +204,8 @@ extern "C"
    * fills the gaps of the large one's instead of trickling through launches of their own. jobs[0..n_jobs): same S, same texel
    * type, same batch; results are identical to calling the single-octave form once per job. scan_done as above (all octaves). */
   int vksift_hip_extract_keypoints_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s, vksift_hip_event scan_done);
+  /* the clear of the candidate-ballot masks that vksift_hip_extract_keypoints_multi starts with, on its own (see masks_cleared) */
+  int vksift_hip_clear_segment_masks(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s);
   int vksift_hip_orientations_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s);
   int vksift_hip_descriptors_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s);
 
@@ -238,10 +250,11 @@ extern "C"
   /* Download packing for a batch of up to 64 SIFT buffers that share one section table (the buffers of one batched detection):
    * slot i copies the stored records of buffer buf_ids[i] — sections in order, min(found, capacity) each, the order
    * vksift_downloadFeatures returns (sift_memory.c:957-1047, 1160-1196) — as dense 164-byte records to out + out_rows[i] * 164.
-   * The host then reads every buffer of the detection with one device-to-host copy instead of one per section and buffer. */
+   * The host then reads every buffer of the detection with one device-to-host copy instead of one per section and buffer.
+   * found_post (or NULL): a host-mapped mirror of found_base; the counters of the packed buffers are stored there as well. */
   int vksift_hip_pack_features(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, const uint32_t *out_rows, uint32_t nslots, uint32_t nsec,
                                const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *found_base, uint32_t found_buf_stride, uint8_t *out,
-                               uint32_t max_rows, vksift_hip_stream s);
+                               uint32_t max_rows, uint32_t *found_post, vksift_hip_stream s);
   int vksift_hip_gather_sections(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, uint32_t nslots, uint32_t nsec,
                                  const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *fixed_counts, const uint32_t *found_base,
                                  uint32_t found_buf_stride, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint64_t desc_stride,

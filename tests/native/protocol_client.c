@@ -6,6 +6,7 @@
  * proto_serial     src/perf/wrappers/vulkansift_wrapper.cpp:30-33 per frame = detect(host image) + getFeaturesNumber +
  *                  downloadFeatures; here per batch of n frames, then the self-match of every frame and the download of its
  *                  records. Strictly serial: nothing is queued while the host waits or copies.
+ * proto_single     one image per call, everything downloaded (BASELINE config 2 read literally)
  * proto_pipelined  the same inputs and outputs with two sets of n SIFT buffers: the detection of the next batch is queued before the
  *                  results of the current one are fetched (vulkansift.h:43-47: detection and matching calls are asynchronous). */
 #include <stdint.h>
@@ -79,6 +80,34 @@ double proto_serial(vksift_Instance inst, const uint8_t *const *images, uint32_t
   }
   const double dt = now_s() - t0;
   free(ids);
+  return dt;
+}
+
+/* BASELINE config 2 literally (src/perf/perf_runtime.cpp:63-81 through vulkansift_wrapper.cpp:30-33): ONE host image per call,
+ * vksift_detectFeatures + vksift_getFeaturesNumber + vksift_downloadFeatures (+ vksift_matchFeatures(0, 0) + vksift_getMatchesNumber +
+ * vksift_downloadMatches), `warm` untimed runs, then the mean of `runs`. Returns seconds per run. */
+double proto_single(vksift_Instance inst, const uint8_t *image, uint32_t w, uint32_t h, int do_match, uint32_t warm, uint32_t runs, vksift_Feature *feat_buf,
+                    vksift_Match_2NN *match_buf, uint32_t *nb_feats)
+{
+  double t0 = 0.0;
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < warm + runs; i++)
+  {
+    if (i == warm)
+      t0 = now_s();
+    vksift_detectFeatures(inst, image, w, h, 0u);
+    n = vksift_getFeaturesNumber(inst, 0u);
+    vksift_downloadFeatures(inst, feat_buf, 0u);
+    if (do_match)
+    {
+      vksift_matchFeatures(inst, 0u, 0u);
+      if (vksift_getMatchesNumber(inst))
+        vksift_downloadMatches(inst, match_buf);
+    }
+  }
+  const double dt = (now_s() - t0) / (double)runs;
+  if (nb_feats)
+    *nb_feats = n;
   return dt;
 }
 

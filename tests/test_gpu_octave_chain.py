@@ -1,0 +1,57 @@
+"""vksift_hip_octave_chain (the trailing octaves that fit the LDS, built by one launch): every plane it writes equals the oracle's
+(blur_plane + nearest 2:1, oracle/sift_oracle.c) and the per-scale launches' (VKSIFT_LDS_CHAIN=0), and so do the features."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    (640, 480, {}),                                   # 1280x960 -> chain = 160x120, 80x60
+    (640, 480, {"use_input_upsampling": False}),      # chain = 160x120, 80x60, 40x30
+    (1280, 720, {}),                                  # 160x90, 80x45
+    (320, 240, {}),                                   # 160x120 is octave 2
+    (160, 120, {"use_input_upsampling": False}),      # octave 0 itself fits: the chain starts at octave 1
+    (200, 136, {}),                                   # 400x272 -> 200x136 (too large), 100x68, 50x34 (not a multiple of 4: no chain)
+    (512, 512, {"nb_scales_per_octave": 4}),          # 7 layers
+    (512, 384, {"nb_scales_per_octave": 2, "seed_scale_sigma": 1.2}),  # other tap counts (the generic passes)
+]
+
+
+@pytest.mark.parametrize("w,h,kw", SHAPES)
+def test_chain_planes_and_features_equal_oracle_and_per_scale_launches(vk, oracle, monkeypatch, w, h, kw):
+    img = vk.gen_synthetic_image_family(9000 + w + h, w, h, (w // 8) % 3)
+    okw = {k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()}
+    pyr = oracle.Pyramid(oracle.default_config(math_mode=1, **okw), img)
+    S = kw.get("nb_scales_per_octave", 3)
+    out = {}
+    for chain in ("0", "1"):
+        monkeypatch.setenv("VKSIFT_LDS_CHAIN", chain)
+        monkeypatch.setenv("VKSIFT_LDS_CHAIN_MAX", "19200")
+        with vk.Instance(vk.default_config(input_image_max_size=w * h, **kw)) as inst:
+            for rep in range(2):  # the second run replays the captured sequence where there is one
+                inst.detectFeatures(img, 0)
+                feats = inst.downloadFeatures(0)
+            assert inst.getScaleSpaceNbOctaves() == pyr.nb_octaves
+            planes = [[inst.downloadScaleSpaceImage(o, s) for s in range(S + 3)] for o in range(pyr.nb_octaves)]
+        out[chain] = (feats, planes)
+    for o in range(pyr.nb_octaves):
+        for s in range(S + 3):
+            ref = pyr.gauss(o, s)
+            assert np.array_equal(out["1"][1][o][s].view(np.uint32), ref.view(np.uint32)), (o, s)
+            assert np.array_equal(out["0"][1][o][s].view(np.uint32), ref.view(np.uint32)), (o, s)
+    assert out["0"][0].tobytes() == out["1"][0].tobytes()
+    ref_feats, _ = pyr.detect()
+    assert out["1"][0].tobytes() == ref_feats.tobytes()
+
+
+def test_chain_in_a_batch_equals_single_detections(vk, monkeypatch):
+    w, h = 640, 480
+    imgs = [vk.gen_synthetic_image_family(77 + i, w, h, i % 3) for i in range(12)]
+    res = {}
+    for chain in ("0", "1"):
+        monkeypatch.setenv("VKSIFT_LDS_CHAIN", chain)
+        monkeypatch.setenv("VKSIFT_LDS_CHAIN_MAX", "19200")
+        with vk.Instance(vk.default_config(sift_buffer_count=12, input_image_max_size=w * h), batch_capacity=12) as inst:
+            inst.detectFeaturesBatch(imgs, 0)
+            res[chain] = [inst.downloadFeatures(i).tobytes() for i in range(12)]
+    assert res["0"] == res["1"] and all(len(r) > 0 for r in res["1"])

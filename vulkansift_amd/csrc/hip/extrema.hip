@@ -969,6 +969,23 @@ static int make_extrema_args(const vksift_hip_OctaveJob *job, ExtremaArgs *out)
   return 0;
 }
 
+/* one fill per run of octaves whose mask regions follow each other (the instance's layout) */
+static int clear_masks(const ExtremaArgs *args, uint32_t n, uint32_t batch, hipStream_t hs)
+{
+  for (uint32_t i = 0; i < n;)
+  {
+    uint32_t j = i + 1;
+    size_t bytes = sizeof(uint64_t) * (size_t)args[i].nsegs * batch;
+    while (j < n && (const uint8_t *)args[j].seg_mask == (const uint8_t *)args[i].seg_mask + bytes)
+      bytes += sizeof(uint64_t) * (size_t)args[j].nsegs * batch, j++;
+    const hipError_t me = hipMemsetAsync(args[i].seg_mask, 0, bytes, hs);
+    if (me != hipSuccess)
+      return (int)me;
+    i = j;
+  }
+  return 0;
+}
+
 /* the launches of one run of at most MULTI_MAX octaves (same S, same texel type) */
 static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t batch, hipStream_t hs, hipEvent_t scan_done)
 {
@@ -984,16 +1001,14 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
 
   /* 1. candidate ballots: only non-empty 64-pixel segments are stored (scattered 8-byte stores were the bottleneck of this
    * pass), so the mask arrays are cleared first: one fill when the octaves' regions follow each other (the instance's layout) */
-  for (uint32_t i = 0; i < n;)
+  bool cleared = true;
+  for (uint32_t i = 0; i < n; i++)
+    cleared = cleared && jobs[i].masks_cleared != 0;
+  if (!cleared)
   {
-    uint32_t j = i + 1;
-    size_t bytes = sizeof(uint64_t) * (size_t)args[i].nsegs * batch;
-    while (j < n && (const uint8_t *)args[j].seg_mask == (const uint8_t *)args[i].seg_mask + bytes)
-      bytes += sizeof(uint64_t) * (size_t)args[j].nsegs * batch, j++;
-    const hipError_t me = hipMemsetAsync(args[i].seg_mask, 0, bytes, hs);
-    if (me != hipSuccess)
-      return (int)me;
-    i = j;
+    const int me = clear_masks(args, n, batch, hs);
+    if (me)
+      return me;
   }
   static int lean_env = -1;
   if (lean_env < 0)
@@ -1114,6 +1129,22 @@ extern "C" int vksift_hip_extract_keypoints_multi(const vksift_hip_OctaveJob *jo
     i0 = i1;
   }
   return 0;
+}
+
+extern "C" int vksift_hip_clear_segment_masks(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s)
+{
+  if (n_jobs == 0 || batch == 0)
+    return 0;
+  if (n_jobs > 16)
+    return (int)hipErrorInvalidValue;
+  ExtremaArgs args[16];
+  for (uint32_t i = 0; i < n_jobs; i++)
+  {
+    const int e = make_extrema_args(&jobs[i], &args[i]);
+    if (e)
+      return e;
+  }
+  return clear_masks(args, n_jobs, batch, (hipStream_t)s);
 }
 
 extern "C" int vksift_hip_extract_keypoints(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s, vksift_hip_event scan_done)

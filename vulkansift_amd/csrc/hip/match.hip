@@ -160,12 +160,15 @@ struct PackOffsets
 };
 __global__ void __launch_bounds__(256) k_pack_features(const uint8_t *__restrict__ feats_base, uint64_t buf_stride, SlotMap map, SectionTable tab,
                                                        const uint32_t *__restrict__ found_base, uint32_t found_buf_stride, uint32_t *__restrict__ out,
-                                                       PackOffsets offs)
+                                                       PackOffsets offs, uint32_t *__restrict__ found_post)
 {
   const uint32_t slot = blockIdx.y;
   const uint32_t bufi = map.buf[slot];
   const uint32_t *feats = (const uint32_t *)(feats_base + (size_t)bufi * buf_stride);
   const uint32_t *found = found_base + (size_t)bufi * found_buf_stride;
+  // feature posting: the buffer's counters go to the host mirror with the records (same layout as found_base, mapped pinned memory)
+  if (found_post && blockIdx.x == 0 && threadIdx.x < found_buf_stride)
+    found_post[(size_t)bufi * found_buf_stride + threadIdx.x] = found[threadIdx.x];
   uint32_t cnt[16];
   uint32_t total = 0;
 #pragma unroll
@@ -2155,9 +2158,9 @@ extern "C"
 
   int vksift_hip_pack_features(const uint8_t *feats_base, uint64_t buf_stride, const uint32_t *buf_ids, const uint32_t *out_rows, uint32_t nslots, uint32_t nsec,
                                const uint32_t *sec_off, const uint32_t *sec_cap, const uint32_t *found_base, uint32_t found_buf_stride, uint8_t *out,
-                               uint32_t max_rows, vksift_hip_stream s)
+                               uint32_t max_rows, uint32_t *found_post, vksift_hip_stream s)
   {
-    if (nslots < 1 || nslots > 64 || nsec > 16)
+    if (nslots < 1 || nslots > 64 || nsec > 16 || (found_post && found_buf_stride > 256u))
       return (int)hipErrorInvalidValue;
     SectionTable t;
     t.nsec = nsec;
@@ -2174,7 +2177,7 @@ extern "C"
     uint32_t blocks = (uint32_t)(((uint64_t)max_rows * 41u + 1023u) / 1024u); /* four dwords per thread */
     blocks = blocks < 1u ? 1u : (blocks > 128u ? 128u : blocks);
     hipLaunchKernelGGL(k_pack_features, dim3(blocks, nslots), dim3(256), 0, (hipStream_t)s, feats_base, buf_stride, m, t, found_base, found_buf_stride,
-                       (uint32_t *)out, po);
+                       (uint32_t *)out, po, found_post);
     return (int)hipGetLastError();
   }
 

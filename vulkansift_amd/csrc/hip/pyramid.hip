@@ -928,6 +928,249 @@ __global__ void __launch_bounds__(64) k_blur_pair(PairArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_octave_chain — the WHOLE scale-space of the trailing octaves whose planes fit the LDS, one workgroup per image.
+//
+// A coarse octave (160x120 and below for a 640x480 input) is a few thousand texels: each of its blur launches costs the
+// launch-to-launch latency (~10 us of a single-image detection, 5 launches per octave) to move 77 KB. Here one 1024-thread
+// workgroup keeps the current scale (A) and the horizontal-pass temporary (B) of the octave in LDS and walks
+// scale 1 .. S+2 of every octave of the run: H pass A -> B, V pass B -> A and to the layer in memory; after scale S every
+// thread takes its share of the nearest-neighbour seed of the next octave into registers (dst(x, y) = src(floor((x + .5) * sw / dw), ..):
+// k_downsample's rule) and plants it in A when the octave is done. Per texel and pass exactly blur_plane's operations
+// (oracle/sift_oracle.c, GaussianBlur*.comp:32-44): acc = c * k0; acc = fma(t(+i) + t(-i), k[i], acc), i ascending, mirrored-repeat
+// borders — bit-identical to the per-scale launches.
+//   H pass: a thread takes 4 consecutive texels of a row: its 4 + 2 RA inputs are ds_read_b128 in the interior (7 reads per 4
+//           outputs at R = 12 instead of 25 per output), mirrored scalar reads in the border groups
+//   V pass: a thread takes CH_RUN consecutive rows of one column: CH_RUN + 2 R reads per CH_RUN outputs, lanes on consecutive columns
+// fp32 pyramids only; w % 4 == 0; 2 * w * h floats <= the LDS budget; the seed of the next octave <= CH_SEED texels per thread.
+// ---------------------------------------------------------------------------------------------
+constexpr int CH_MAX_OCT = 4, CH_MAX_LAYERS = 8, CH_THREADS = 1024, CH_RUN = 5, CH_SEED = 5;
+constexpr int CH_LDS_FLOATS = 19200 * 2; // 150 KiB of the CU's 160
+struct ChainOct
+{
+  float *layer[CH_MAX_LAYERS]; // image 0
+  int w, h, pitch;
+  unsigned long long img_stride; // texels
+};
+struct ChainArgs
+{
+  ChainOct o[CH_MAX_OCT];
+  int n_oct, n_layers, S;
+  int nt[CH_MAX_LAYERS];
+  float k[CH_MAX_LAYERS][VKSIFT_HIP_MAX_TAPS];
+};
+
+// one reflection of the mirrored-repeat addressing: all a run needs when every filter radius is below the plane's sides (checked by the launcher)
+__device__ __forceinline__ int mirror1(int i, int n) { return i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i); }
+// it / d for 0 <= it < 2^20 and 1 <= d <= 2^10 without an integer division: (it + 0.5) / d is at least 0.5 / d away from an integer
+__device__ __forceinline__ int div_small(int it, float inv_d) { return (int)(((float)it + 0.5f) * inv_d); }
+
+template <int NT>
+__device__ __forceinline__ void chain_h(const float *__restrict__ A, float *__restrict__ B, int w, int h, const float *__restrict__ k)
+{
+  constexpr int R = NT - 1, RA = (R + 3) & ~3, NV = 4 + 2 * RA, NB = RA / 4; // NB groups at each end of a row need mirrored inputs
+  const int groups = w >> 2;
+  const int gi = groups > 2 * NB ? groups - 2 * NB : 0; // interior groups per row
+  auto finish = [&](const float *v, int row, int x0) {
+    v4f out;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      float acc = v[RA + j] * k[0];
+#pragma unroll
+      for (int i = 1; i <= R; i++)
+        acc = fmaf(v[RA + j + i] + v[RA + j - i], k[i], acc);
+      out[j] = acc;
+    }
+    *(v4f *)(B + row * w + x0) = out;
+  };
+  // interior groups and border groups are separate index spaces: a wave never runs both input paths
+  if (gi > 0)
+  {
+    const float inv = 1.f / (float)gi;
+    for (int it = threadIdx.x; it < gi * h; it += CH_THREADS)
+    {
+      const int row = div_small(it, inv), x0 = (NB + it - row * gi) * 4;
+      const float *p = A + row * w + x0 - RA;
+      float v[NV];
+#pragma unroll
+      for (int q = 0; q < NV / 4; q++)
+      {
+        const v4f t = *(const v4f *)(p + 4 * q);
+        v[4 * q] = t.x, v[4 * q + 1] = t.y, v[4 * q + 2] = t.z, v[4 * q + 3] = t.w;
+      }
+      finish(v, row, x0);
+    }
+  }
+  {
+    const int nb = groups - gi;
+    const float inv = 1.f / (float)nb;
+    for (int it = threadIdx.x; it < nb * h; it += CH_THREADS)
+    {
+      const int row = div_small(it, inv), b = it - row * nb;
+      const int x0 = (gi > 0 && b >= NB ? gi + b : b) * 4;
+      const float *p = A + row * w;
+      float v[NV];
+#pragma unroll
+      for (int q = RA - R; q < NV - (RA - R); q++)
+        v[q] = p[mirror1(x0 - RA + q, w)];
+      finish(v, row, x0);
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void chain_v(const float *__restrict__ B, float *__restrict__ A, float *__restrict__ out, int pitch, int w, int h,
+                                        const float *__restrict__ k)
+{
+  constexpr int R = NT - 1, NV = CH_RUN + 2 * R;
+  const int runs = (h + CH_RUN - 1) / CH_RUN, items = runs * w;
+  const float inv = 1.f / (float)w;
+  for (int it = threadIdx.x; it < items; it += CH_THREADS)
+  {
+    const int run = div_small(it, inv), x = it - run * w, r0 = run * CH_RUN;
+    float v[NV];
+    if (r0 - R >= 0 && r0 + CH_RUN + R <= h) // (a wave spans at most two runs)
+    {
+#pragma unroll
+      for (int q = 0; q < NV; q++)
+        v[q] = B[(r0 - R + q) * w + x];
+    }
+    else
+    {
+#pragma unroll
+      for (int q = 0; q < NV; q++)
+        v[q] = B[mirror1(min(r0 - R + q, h - 1 + R), h) * w + x]; // rows past h + R - 1 feed only outputs past the last row
+    }
+#pragma unroll
+    for (int j = 0; j < CH_RUN; j++)
+    {
+      float acc = v[R + j] * k[0];
+#pragma unroll
+      for (int i = 1; i <= R; i++)
+        acc = fmaf(v[R + j + i] + v[R + j - i], k[i], acc);
+      if (r0 + j < h)
+      {
+        A[(r0 + j) * w + x] = acc;
+        out[(size_t)(r0 + j) * pitch + x] = acc;
+      }
+    }
+  }
+}
+
+// any tap count: straight from LDS, one texel per step (configurations whose kernels are not instantiated below)
+__device__ __forceinline__ void chain_h_any(const float *__restrict__ A, float *__restrict__ B, int w, int h, const float *__restrict__ k, int nt)
+{
+  for (int it = threadIdx.x; it < w * h; it += CH_THREADS)
+  {
+    const int row = it / w, x = it - row * w;
+    const float *p = A + row * w;
+    float acc = p[x] * k[0];
+    for (int i = 1; i < nt; i++)
+      acc = fmaf(p[mirror_idx(x + i, w)] + p[mirror_idx(x - i, w)], k[i], acc);
+    B[it] = acc;
+  }
+}
+__device__ __forceinline__ void chain_v_any(const float *__restrict__ B, float *__restrict__ A, float *__restrict__ out, int pitch, int w, int h,
+                                            const float *__restrict__ k, int nt)
+{
+  for (int it = threadIdx.x; it < w * h; it += CH_THREADS)
+  {
+    const int row = it / w, x = it - row * w;
+    float acc = B[it] * k[0];
+    for (int i = 1; i < nt; i++)
+      acc = fmaf(B[mirror_idx(row + i, h) * w + x] + B[mirror_idx(row - i, h) * w + x], k[i], acc);
+    A[it] = acc;
+    out[(size_t)row * pitch + x] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(CH_THREADS) k_octave_chain(ChainArgs a)
+{
+  extern __shared__ float lds[];
+  float *A = lds, *B = lds + a.o[0].w * a.o[0].h;
+  const int tid = threadIdx.x;
+  float seed[CH_SEED];
+  {
+    // scale 0 of the first octave of the run is in memory (written by the launch that blurred scale S of the octave before it)
+    const ChainOct &o = a.o[0];
+    const float *src = o.layer[0] + (size_t)blockIdx.x * o.img_stride;
+    const int groups = o.w >> 2;
+    for (int it = tid; it < groups * o.h; it += CH_THREADS)
+    {
+      const int row = it / groups, x0 = (it - row * groups) * 4;
+      *(v4f *)(A + row * o.w + x0) = *(const v4f *)(src + (size_t)row * o.pitch + x0);
+    }
+  }
+  for (int oi = 0; oi < a.n_oct; oi++)
+  {
+    const ChainOct &o = a.o[oi];
+    const int w = o.w, h = o.h;
+    if (oi > 0)
+    {
+      // plant the seed taken at scale S of the octave above (and store it: the keypoint stages read layer 0 too)
+      float *l0 = o.layer[0] + (size_t)blockIdx.x * o.img_stride;
+#pragma unroll
+      for (int q = 0; q < CH_SEED; q++)
+      {
+        const int idx = tid + q * CH_THREADS;
+        if (idx < w * h)
+        {
+          const int y = idx / w, x = idx - y * w;
+          A[idx] = seed[q];
+          l0[(size_t)y * o.pitch + x] = seed[q];
+        }
+      }
+    }
+    __syncthreads();
+    for (int s = 1; s < a.n_layers; s++)
+    {
+      const float *k = a.k[s];
+      float *out = o.layer[s] + (size_t)blockIdx.x * o.img_stride;
+      const int nt = a.nt[s];
+      switch (nt)
+      {
+      case 5: chain_h<5>(A, B, w, h, k); break;
+      case 7: chain_h<7>(A, B, w, h, k); break;
+      case 9: chain_h<9>(A, B, w, h, k); break;
+      case 11: chain_h<11>(A, B, w, h, k); break;
+      case 13: chain_h<13>(A, B, w, h, k); break;
+      default: chain_h_any(A, B, w, h, k, nt); break;
+      }
+      __syncthreads();
+      switch (nt)
+      {
+      case 5: chain_v<5>(B, A, out, o.pitch, w, h, k); break;
+      case 7: chain_v<7>(B, A, out, o.pitch, w, h, k); break;
+      case 9: chain_v<9>(B, A, out, o.pitch, w, h, k); break;
+      case 11: chain_v<11>(B, A, out, o.pitch, w, h, k); break;
+      case 13: chain_v<13>(B, A, out, o.pitch, w, h, k); break;
+      default: chain_v_any(B, A, out, o.pitch, w, h, k, nt); break;
+      }
+      __syncthreads();
+      if (s == a.S && oi + 1 < a.n_oct)
+      {
+        const int dw = a.o[oi + 1].w, dh = a.o[oi + 1].h;
+        const float sx = (float)w / (float)dw, sy = (float)h / (float)dh;
+#pragma unroll
+        for (int q = 0; q < CH_SEED; q++)
+        {
+          const int idx = tid + q * CH_THREADS;
+          seed[q] = 0.f;
+          if (idx < dw * dh)
+          {
+            const int y = idx / dw, x = idx - y * dw;
+            const int yy = clampi((int)floorf(((float)y + 0.5f) * sy), 0, h - 1);
+            const int xx = clampi((int)floorf(((float)x + 0.5f) * sx), 0, w - 1);
+            seed[q] = A[yy * w + xx];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Nearest-neighbour resample (2:1 -> odd source texels), one thread per destination pixel.
 // ---------------------------------------------------------------------------------------------
 template <bool F16>
@@ -1238,6 +1481,63 @@ extern "C"
     else
       hipLaunchKernelGGL(k_downsample<false>, grid, dim3(256), 0, (hipStream_t)s, src.base, src.img_stride, (int)src.w, (int)src.h, (int)src.pitch, dst.base,
                          dst.img_stride, (int)dst.w, (int)dst.h, (int)dst.pitch);
+    return (int)hipGetLastError();
+  }
+
+  int vksift_hip_octave_chain(const vksift_hip_Plane *layers, uint32_t n_oct, uint32_t n_layers, uint32_t S, const float *taps, const uint32_t *ntaps,
+                              uint32_t batch, vksift_hip_stream s)
+  {
+    if (n_oct < 1 || n_oct > (uint32_t)CH_MAX_OCT || n_layers < 2 || n_layers > (uint32_t)CH_MAX_LAYERS || S >= n_layers || batch < 1)
+      return -1;
+    ChainArgs a;
+    a.n_oct = (int)n_oct, a.n_layers = (int)n_layers, a.S = (int)S;
+    for (uint32_t o = 0; o < n_oct; o++)
+    {
+      const vksift_hip_Plane &p0 = layers[o * n_layers];
+      if (p0.fp16 || (p0.w & 3u) || (p0.pitch & 3u) || p0.w < 8u || p0.h < 8u || (uint64_t)p0.w * p0.h * 2u > (uint64_t)CH_LDS_FLOATS)
+        return -1;
+      if (o > 0 && ((uint64_t)p0.w * p0.h > (uint64_t)CH_SEED * CH_THREADS || p0.w > layers[(o - 1) * n_layers].w || p0.h > layers[(o - 1) * n_layers].h))
+        return -1;
+      a.o[o].w = (int)p0.w, a.o[o].h = (int)p0.h, a.o[o].pitch = (int)p0.pitch, a.o[o].img_stride = p0.img_stride;
+      for (uint32_t l = 0; l < n_layers; l++)
+      {
+        const vksift_hip_Plane &p = layers[o * n_layers + l];
+        if (p.w != p0.w || p.h != p0.h || p.pitch != p0.pitch || p.img_stride != p0.img_stride || p.fp16 || ((uintptr_t)p.base & 15u))
+          return -1;
+        a.o[o].layer[l] = p.base;
+      }
+    }
+    uint32_t min_side = 0xFFFFFFFFu;
+    for (uint32_t o = 0; o < n_oct; o++)
+    {
+      min_side = a.o[o].w < (int)min_side ? (uint32_t)a.o[o].w : min_side;
+      min_side = a.o[o].h < (int)min_side ? (uint32_t)a.o[o].h : min_side;
+    }
+    for (uint32_t l = 0; l < n_layers; l++)
+    {
+      if (ntaps[l] < 1 || ntaps[l] > VKSIFT_HIP_MAX_TAPS || (l > 0 && ntaps[l] > min_side))
+        return -1; /* (a radius that reaches past one reflection: the per-scale launches handle it) */
+      a.nt[l] = (int)ntaps[l];
+      {
+        static int pad = -1;
+        if (pad < 0)
+          pad = getenv("VKSIFT_CHAIN_PAD") ? atoi(getenv("VKSIFT_CHAIN_PAD")) : 0;
+        if (pad && l > 0 && a.nt[l] <= pad)
+          a.nt[l] = pad;
+      }
+      for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
+        a.k[l][i] = i < ntaps[l] ? taps[l * VKSIFT_HIP_MAX_TAPS + i] : 0.f;
+    }
+    static bool lds_attr_set = false;
+    if (!lds_attr_set)
+    {
+      const hipError_t ae = hipFuncSetAttribute((const void *)k_octave_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CH_LDS_FLOATS * sizeof(float)));
+      if (ae != hipSuccess)
+        return (int)ae;
+      lds_attr_set = true;
+    }
+    const size_t lds_bytes = sizeof(float) * 2u * (size_t)a.o[0].w * a.o[0].h;
+    hipLaunchKernelGGL(k_octave_chain, dim3(batch), dim3(CH_THREADS), lds_bytes, (hipStream_t)s, a);
     return (int)hipGetLastError();
   }
 

@@ -128,7 +128,7 @@ static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr,
       for (uint32_t k = 0; k < n; k++)
         ids[k] = first + i0 + k;
       if (vksift_hip_pack_features(inst->d_feats, inst->buf_stride, ids, inst->dl_row + i0, n, b->nb_sections, b->sec_off, b->sec_cap, inst->d_found,
-                                   VKSIFT_MAX_OCTAVES, inst->d_dl, max_rows, inst->dl_stream) != 0)
+                                   VKSIFT_MAX_OCTAVES, inst->d_dl, max_rows, NULL, inst->dl_stream) != 0)
         return false;
     }
     /* the copy goes in a few pieces with an event each: a caller that walks the buffers in order copies buffer i out of pinned
@@ -168,6 +168,20 @@ static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr,
   return true;
 }
 
+/* Posted features (vksift_internal.h: h_post): the detection itself left the dense records of this buffer in pinned memory */
+static bool download_posted(vksift_Instance inst, vksift_Feature *feats_ptr, uint32_t buf)
+{
+  const uint32_t slot = buf & 1u;
+  const BufferInfo *b = &inst->bufs[buf];
+  if (inst->post_seq[slot] == 0 || inst->post_seq[slot] != b->seq || inst->post_buf[slot] != buf)
+    return false;
+  const uint32_t n = buffer_counts(inst, buf, NULL, false);
+  memcpy(feats_ptr, inst->h_post[slot], (size_t)n * FEAT_BYTES);
+  inst->post_fetched[slot] = true;
+  inst->post_idle = 0;
+  return true;
+}
+
 /* One sectioned buffer (a single detection): the sections are packed on the device into the pinned staging pair and fetched with ONE
  * copy, then copied out — instead of one device-to-pageable-host copy per octave section, each of which the runtime stages and
  * synchronises on its own (five copies of a 640x480 detection: ~90 us of the 0.5 ms single-image latency; this path: ~45 us).
@@ -203,11 +217,13 @@ static bool download_one_packed(vksift_Instance inst, vksift_Feature *feats_ptr,
   inst->dl_valid = false;
   const uint32_t zero = 0;
   if (vksift_hip_pack_features(inst->d_feats, inst->buf_stride, &buf, &zero, 1, b->nb_sections, b->sec_off, b->sec_cap, inst->d_found, VKSIFT_MAX_OCTAVES,
-                               inst->d_dl, n, inst->dl_stream) != 0)
+                               inst->d_dl, n, NULL, inst->dl_stream) != 0)
     return false;
   if (vksift_hip_memcpy_d2h(inst->h_dl, inst->d_dl, bytes, inst->dl_stream) != 0 || vksift_hip_stream_sync(inst->dl_stream) != 0)
     return false;
   memcpy(feats_ptr, inst->h_dl, bytes);
+  if (inst->post_enabled && !inst->post_on)
+    inst->post_on = true, inst->post_idle = 0; /* the caller does fetch single detections: post the next ones */
   return true;
 }
 
@@ -221,7 +237,7 @@ void vksift_downloadFeatures(vksift_Instance instance, vksift_Feature *feats_ptr
   }
   vksift_Instance inst = instance;
   wait_for_buffer(inst, gpu_buffer_id);
-  if (download_from_batch(inst, feats_ptr, gpu_buffer_id))
+  if (download_posted(inst, feats_ptr, gpu_buffer_id) || download_from_batch(inst, feats_ptr, gpu_buffer_id))
     return;
   const BufferInfo *b = &inst->bufs[gpu_buffer_id];
   const uint8_t *base = inst->d_feats + (uint64_t)gpu_buffer_id * inst->buf_stride;

@@ -180,6 +180,8 @@ typedef struct
   bool overlap;   /* scale-space on its own stream and buffer (ping-pong), see detect_impl */
   bool upload;    /* host images were staged in h_input and have to be copied to d_input */
   bool capturing; /* the sequence is being captured into a hipGraph: no host-visible events inside */
+  bool post;      /* feature posting at the end of the sequence (vksift_internal.h: h_post) */
+  bool fork;      /* scales S+1.. of every octave on the side stream (vksift_internal.h: ev_fork) */
   const uint8_t *const *images; /* upload: the caller's images, staged chunk by chunk while the sequence is enqueued */
   const uint8_t *d_src;
   uint32_t w, h, count, first_buf;
@@ -229,6 +231,7 @@ static void build_jobs(DetectCtx *c)
     j->use_vlfeat = inst->cfg.descriptor_format == VKSIFT_DESCRIPTOR_FORMAT_VLFEAT ? 1u : 0u;
     j->desc_fp_tab = inst->d_desc_fp;
     j->desc_fp_tab_len = inst->desc_fp_len;
+    j->masks_cleared = 0;
     j->scan_reverse = 0; /* set by enqueue_pyramid: the direction opposite to the octave's last blur launch */
   }
 }
@@ -244,7 +247,7 @@ static vksift_hip_Plane plane_sub(vksift_Instance inst, vksift_hip_Plane p, uint
   return p;
 }
 
-enum { PYR_FIRST_GROUP = 1, PYR_LAST_GROUP = 2 };
+enum { PYR_FIRST_GROUP = 1, PYR_LAST_GROUP = 2, PYR_TRUNK = 4, PYR_BRANCH = 8 };
 static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint32_t first, uint32_t count, int group_flags, bool *g0_done)
 {
   vksift_Instance inst = c->inst;
@@ -252,7 +255,9 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint3
   uint32_t nb_o = 0;
 #define PL(oct, layer) plane_sub(inst, plane_at(inst, (oct), L->gauss_off[(oct)], (layer)), first)
   vksift_hip_range_push("Scale space construction");
-  if (o == 0)
+  if (group_flags & PYR_BRANCH)
+    ; /* the octave's seed and its scales up to S were queued by the trunk pass */
+  else if (o == 0)
   {
     if (c->prof && (group_flags & PYR_FIRST_GROUP))
       vksift_hip_event_record(c->PS->ev_pt[0], sp);
@@ -288,13 +293,29 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint3
   }
   else if (!*g0_done)
     TRY(vksift_hip_downsample(PL(o - 1, inst->S), PL(o, 0), count, sp), "downsample");
-  *g0_done = false;
+  if (!(group_flags & PYR_BRANCH))
+    *g0_done = false;
   /* consecutive launches of the chain walk the batch in opposite directions: a launch starts on the planes its predecessor wrote
    * last, which are still in the Infinity Cache (a whole-batch plane is 2.5x the cache: in the same direction every read misses);
    * the extrema scan continues the alternation */
   uint32_t li = 0;
   for (uint32_t s = 1; s < inst->S + 3; s++)
   {
+    /* forked detections (DetectCtx::fork): the launches up to scale S — the path to the next octave — are queued for ALL octaves
+     * first (PYR_TRUNK), the ones behind scale S afterwards on the side stream (PYR_BRANCH, sp is that stream then): the host
+     * queues a launch every ~5 us, and a branch launch queued in between would delay the trunk by as much */
+    if ((group_flags & PYR_BRANCH) && s <= inst->S)
+    {
+      li++;
+      continue;
+    }
+    if ((group_flags & PYR_TRUNK) && s == inst->S + 1u)
+    {
+      TRY(vksift_hip_event_record(inst->ev_fork[o], sp), "event record");
+      break;
+    }
+    if ((group_flags & PYR_BRANCH) && s == inst->S + 1u)
+      TRY(vksift_hip_stream_wait_event(sp, inst->ev_fork[o]), "scale fork");
     const vksift_hip_Plane srcp = PL(o, s - 1);
     vksift_hip_Plane dstp = PL(o, s);
     li++;
@@ -411,11 +432,80 @@ static int enqueue_detection(DetectCtx *c)
   if (c->prof)
     vksift_hip_event_record(c->PS->ev_t[1], st);
 
-  /* recClearBufferDataCmds (sift_detector.c:1081-1104) */
-  TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, st), "counter reset");
+  /* recClearBufferDataCmds (sift_detector.c:1081-1104); a forked detection clears on a side stream, off the path of the trunk */
+  if (!c->fork)
+    TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, st), "counter reset");
 
+  /* The trailing octaves whose planes fit the LDS are built by ONE launch (vksift_hip_octave_chain: a workgroup per image walks all
+   * their scales): from the first octave >= 1 behind which every octave qualifies. */
+  uint32_t chain_from = L->n_oct;
+  /* (forked = small detections only: in a batch the per-scale launches are faster — one workgroup per image keeps 16 waves on a CU for
+   * 80 us where the launches spread an octave over the chip: 512 x 640x480 23.3 k frames/s with the chain, 23.6 k without) */
+  if (inst->lds_chain && c->fork && !inst->fp16 && inst->S + 3u <= 8u)
+  {
+    while (chain_from > 1u && (L->w[chain_from - 1u] & 3u) == 0u && (uint64_t)L->w[chain_from - 1u] * L->h[chain_from - 1u] <= inst->lds_chain_max &&
+           L->w[chain_from - 1u] >= 8u && L->h[chain_from - 1u] >= 8u && L->n_oct - (chain_from - 1u) <= 4u)
+      chain_from--;
+  }
   for (uint32_t o = oct0_done ? 1u : 0u; o < L->n_oct; o++)
-    TRY(enqueue_pyramid(c, o, sp, 0, c->count, PYR_FIRST_GROUP | PYR_LAST_GROUP, &g0_done), "scale space construction");
+  {
+    if (o == chain_from)
+    {
+      vksift_hip_Plane layers[4 * 8];
+      const uint32_t nl = inst->S + 3u, no = L->n_oct - o;
+      for (uint32_t q = 0; q < no; q++)
+        for (uint32_t l = 0; l < nl; l++)
+          layers[q * nl + l] = plane_at(inst, o + q, L->gauss_off[o + q], l);
+      if (!g0_done)
+        TRY(vksift_hip_downsample(plane_at(inst, o - 1u, L->gauss_off[o - 1u], inst->S), layers[0], c->count, sp), "downsample");
+      const int ce = vksift_hip_octave_chain(layers, no, nl, inst->S, inst->taps, inst->ntaps, c->count, sp);
+      if (ce > 0)
+        TRY(ce, "coarse-octave chain");
+      if (ce == 0)
+      {
+        for (uint32_t q = o; q < L->n_oct; q++)
+          c->jobs[q].scan_reverse = 0u;
+        break;
+      }
+      g0_done = true; /* not covered after all: the octave's seed is in place, the per-scale launches follow */
+    }
+    TRY(enqueue_pyramid(c, o, sp, 0, c->count, PYR_FIRST_GROUP | PYR_LAST_GROUP | (c->fork ? PYR_TRUNK : 0), &g0_done), "scale space construction");
+  }
+  if (c->fork)
+  {
+    /* Branches: octave o on side stream o & 1 (two, so that a branch does not queue behind the previous octave's). The first one
+     * also takes the two clears: its stream is ordered behind everything queued on the trunk stream up to scale S of the first
+     * octave — in particular behind the previous detection's readers of the counters and masks. */
+    vksift_hip_stream side[2] = {inst->pyr_stream, inst->fork_streams > 1 ? inst->side_stream : inst->pyr_stream};
+    bool used[2] = {false, false};
+    const uint32_t o0 = oct0_done ? 1u : 0u;
+    const bool has_branch = o0 < chain_from && o0 < L->n_oct;
+    if (has_branch)
+    {
+      TRY(vksift_hip_stream_wait_event(side[o0 & 1u], inst->ev_fork[o0]), "scale fork");
+      TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, side[o0 & 1u]),
+          "counter reset");
+      if (vksift_hip_clear_segment_masks(c->jobs, L->n_oct, c->count, side[o0 & 1u]) == 0)
+        for (uint32_t o = 0; o < L->n_oct; o++)
+          c->jobs[o].masks_cleared = 1u;
+      used[o0 & 1u] = true;
+    }
+    else
+      TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, sp), "counter reset");
+    for (uint32_t o = o0; o < chain_from && o < L->n_oct; o++)
+    {
+      TRY(enqueue_pyramid(c, o, side[o & 1u], 0, c->count, PYR_BRANCH, &g0_done), "scale space construction");
+      used[o & 1u] = true;
+    }
+    if (side[1] == side[0])
+      used[0] = used[0] || used[1], used[1] = false;
+    for (int k = 0; k < 2; k++)
+      if (used[k])
+      {
+        TRY(vksift_hip_event_record(inst->ev_join[k], side[k]), "event record");
+        TRY(vksift_hip_stream_wait_event(sp, inst->ev_join[k]), "scale join");
+      }
+  }
   if (c->overlap)
   {
     TRY(vksift_hip_event_record(inst->ev_pyr_done, sp), "event record");
@@ -474,6 +564,17 @@ static int enqueue_detection(DetectCtx *c)
   for (uint32_t o = 0; o < L->n_oct; o++)
     inst->last_scan_bytes += (uint64_t)L->w[o] * L->h[o] * pyr_texel_bytes(inst) * (inst->S + 2) * c->count;
 
+  if (c->post)
+  {
+    /* the grid is sized for one keypoint per 128 pixels; the kernel strides over the device-side count */
+    const BufferInfo *b = &inst->bufs[c->first_buf];
+    const uint32_t zero = 0, id = c->first_buf;
+    const uint64_t est = (uint64_t)c->w * c->h / 128u + 64u;
+    TRY(vksift_hip_pack_features(inst->d_feats, inst->buf_stride, &id, &zero, 1, b->nb_sections, b->sec_off, b->sec_cap, inst->d_found, VKSIFT_MAX_OCTAVES,
+                                 inst->h_post[c->first_buf & 1u], est > 0xFFFFFFu ? 0xFFFFFFu : (uint32_t)est, inst->h_found, st),
+        "feature posting");
+    return 0; /* the counters went with the records */
+  }
   /* recCopySIFTCountCmds (sift_detector.c:1261-1291) */
   TRY(vksift_hip_post_words(inst->h_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES,
                             (size_t)VKSIFT_MAX_OCTAVES * c->count, st),
@@ -490,7 +591,7 @@ static DetectGraph *graph_lookup(vksift_Instance inst, const DetectCtx *c)
   for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
   {
     DetectGraph *g = &inst->graphs[i];
-    if (g->exec && g->w == c->w && g->h == c->h && g->count == c->count && g->first_buf == c->first_buf && g->d_src == c->d_src)
+    if (g->exec && g->w == c->w && g->h == c->h && g->count == c->count && g->first_buf == c->first_buf && g->d_src == c->d_src && g->post == c->post)
       return g;
     if (g->stamp < victim->stamp)
       victim = g;
@@ -585,6 +686,37 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   c.img_bytes = (size_t)w * h;
   c.nblur = 0;
   c.capturing = false;
+  c.fork = inst->fork_scales && !c.overlap && !c.prof && (uint64_t)count * w * h <= inst->fork_max_pixels;
+  /* feature posting for single-image detections whose records fit the slot (every section is capacity-bounded) */
+  c.post = false;
+  if (count == 1 && inst->post_enabled && inst->post_on && c.L->n_oct > 0 && inst->bufs[first_buf].nb_sections > 0 && inst->bufs[first_buf].nb_sections <= 16)
+  {
+    if (!inst->h_post[0])
+    {
+      const size_t cap = (size_t)inst->cfg.max_nb_sift_per_buffer * FEAT_BYTES + 4096u;
+      inst->h_post[0] = (uint8_t *)vksift_hip_host_malloc(cap);
+      inst->h_post[1] = (uint8_t *)vksift_hip_host_malloc(cap);
+      inst->post_cap = (inst->h_post[0] && inst->h_post[1]) ? cap : 0;
+      if (!inst->post_cap)
+      {
+        vksift_hip_host_free(inst->h_post[0]);
+        vksift_hip_host_free(inst->h_post[1]);
+        inst->h_post[0] = inst->h_post[1] = NULL;
+        inst->post_enabled = false;
+      }
+    }
+    uint64_t rows = 0;
+    for (uint32_t o = 0; o < inst->bufs[first_buf].nb_sections; o++)
+      rows += inst->bufs[first_buf].sec_cap[o];
+    c.post = inst->post_cap != 0 && rows * FEAT_BYTES <= inst->post_cap;
+    if (c.post)
+    {
+      const uint32_t slot = first_buf & 1u;
+      if (inst->post_seq[slot] != 0 && !inst->post_fetched[slot] && ++inst->post_idle >= VKSIFT_POST_IDLE)
+        inst->post_on = false, c.post = false; /* posted and overwritten without ever being fetched, too many times in a row */
+      inst->post_seq[slot] = 0; /* the slot is about to be rewritten: valid again once this detection is queued */
+    }
+  }
   PS->overlap = true; /* the scale-space interval is the one between ev_pt[0] and ev_pt[1] (octave 0) */
   if (c.prof)
     vksift_hip_event_record(PS->ev_t[0], st);
@@ -639,7 +771,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
       vksift_hip_graph exec = NULL;
       HIP_CHECK(vksift_hip_capture_end(st, &exec), "detection graph capture");
       dg->exec = exec;
-      dg->w = w, dg->h = h, dg->count = count, dg->first_buf = first_buf, dg->d_src = c.d_src;
+      dg->w = w, dg->h = h, dg->count = count, dg->first_buf = first_buf, dg->d_src = c.d_src, dg->post = c.post;
       HIP_CHECK(vksift_hip_graph_launch(dg->exec, st), "detection graph launch");
     }
   }
@@ -664,6 +796,8 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   {
     DetectSlot *d = &inst->det_ring[seq % VKSIFT_DETECT_RING];
     d->seq = seq, d->first = first_buf, d->count = count;
+    if (c.post)
+      inst->post_seq[first_buf & 1u] = seq, inst->post_buf[first_buf & 1u] = first_buf, inst->post_fetched[first_buf & 1u] = false;
     inst->det_seq = seq; /* from here on the buffers are "pending" even if the record below fails (wait_detect_seq then syncs a stale event: harmless) */
     HIP_CHECK(vksift_hip_event_record(d->ev, st), "event record");
   }
@@ -685,6 +819,8 @@ gpu_error:
     (void)vksift_hip_stream_sync(st);
     if (inst->pyr_stream)
       (void)vksift_hip_stream_sync(inst->pyr_stream);
+    if (inst->side_stream)
+      (void)vksift_hip_stream_sync(inst->side_stream);
     for (uint32_t i = 0; i < count; i++)
     {
       inst->bufs[first_buf + i].seq = 0;

@@ -193,6 +193,25 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   {
     const char *e = getenv("VKSIFT_PYR_ALTERNATE");
     inst->alt_order = !(e && e[0] == '0');
+    e = getenv("VKSIFT_FORK_SCALES");
+    inst->fork_scales = !(e && e[0] == '0');
+    e = getenv("VKSIFT_FORK_STREAMS");
+    inst->fork_streams = (e && e[0] == '2') ? 2 : 1; /* two measured no faster in stream order and 10 % slower in a replayed graph */
+    e = getenv("VKSIFT_FORK_MAX_PIXELS");
+    inst->fork_max_pixels = e ? strtoull(e, NULL, 10) : (uint64_t)16 << 20;
+    for (int i = 0; i < VKSIFT_MAX_OCTAVES; i++)
+      inst->ev_fork[i] = vksift_hip_event_create();
+    inst->ev_join[0] = vksift_hip_event_create();
+    inst->ev_join[1] = vksift_hip_event_create();
+    inst->side_stream = vksift_hip_stream_create();
+    if (!inst->side_stream || !inst->ev_join[0] || !inst->ev_join[1])
+      inst->fork_scales = false;
+    e = getenv("VKSIFT_LDS_CHAIN");
+    inst->lds_chain = !(e && e[0] == '0');
+    e = getenv("VKSIFT_LDS_CHAIN_MAX");
+    inst->lds_chain_max = e ? (uint32_t)strtoul(e, NULL, 10) : 4800u;
+    if (inst->lds_chain_max > 19200u)
+      inst->lds_chain_max = 19200u;
     /* hipGraph capture + replay of the detection launch sequence. Measured on MI355X / ROCm 7.2: 10 % faster for one
      * 640x480 image (0.58 vs 0.65 ms), 12 % slower from 1536x1024 up (the graph runs the per-octave branches less
      * concurrently than the streams do) -> by default only small workloads are replayed (graph_max_pixels).
@@ -200,6 +219,8 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     e = getenv("VKSIFT_GRAPH");
     inst->use_graphs = !(e && e[0] == '0');
     inst->graph_max_pixels = (e && e[0] == '1') ? ~(uint64_t)0 : (uint64_t)640 * 480;
+    e = getenv("VKSIFT_POST_FEATURES");
+    inst->post_enabled = inst->post_on = !(e && e[0] == '0');
   }
   for (int i = 0; i < VKSIFT_DETECT_RING; i++)
     inst->det_ring[i].ev = vksift_hip_event_create();
@@ -265,6 +286,8 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_set_device(inst->device);
   if (inst->pyr_stream)
     vksift_hip_stream_sync(inst->pyr_stream);
+  if (inst->side_stream)
+    vksift_hip_stream_sync(inst->side_stream);
   if (inst->dl_stream)
     vksift_hip_stream_sync(inst->dl_stream);
   if (inst->up_stream)
@@ -296,6 +319,8 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_free(inst->d_match_partial);
   vksift_hip_free(inst->d_dl);
   vksift_hip_host_free(inst->h_dl);
+  vksift_hip_host_free(inst->h_post[0]);
+  vksift_hip_host_free(inst->h_post[1]);
   free(inst->dl_row);
   for (uint32_t k = 0; k < VKSIFT_DL_CHUNKS; k++)
     vksift_hip_event_destroy(inst->dl_ev[k]);
@@ -324,6 +349,15 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   }
   vksift_hip_event_destroy(inst->ev_m[0]);
   vksift_hip_event_destroy(inst->ev_m[1]);
+  for (int i = 0; i < VKSIFT_MAX_OCTAVES; i++)
+    vksift_hip_event_destroy(inst->ev_fork[i]);
+  vksift_hip_event_destroy(inst->ev_join[0]);
+  vksift_hip_event_destroy(inst->ev_join[1]);
+  if (inst->side_stream)
+  {
+    vksift_hip_stream_sync(inst->side_stream);
+    vksift_hip_stream_destroy(inst->side_stream);
+  }
   vksift_hip_stream_destroy(inst->pyr_stream);
   vksift_hip_stream_destroy(inst->dl_stream);
   vksift_hip_stream_destroy(inst->up_stream);
@@ -397,6 +431,8 @@ int grow_image_scratch(vksift_Instance inst, const PyrLayout *L)
     return -1;
   if (inst->pyr_stream)
     vksift_hip_stream_sync(inst->pyr_stream);
+  if (inst->side_stream)
+    vksift_hip_stream_sync(inst->side_stream);
   for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
   {
     vksift_hip_graph_destroy(inst->graphs[i].exec);

@@ -67,11 +67,13 @@ typedef struct
 /* HIP-event stage timings of one detection (vksift_ext_setProfiling) */
 /* A captured detection launch sequence (hipGraph), valid for one (resolution, batch, first buffer, input pointer) */
 #define VKSIFT_GRAPH_CACHE 8
+#define VKSIFT_POST_IDLE 16u
 typedef struct
 {
   vksift_hip_graph exec;
   uint32_t w, h, count, first_buf;
   const uint8_t *d_src;
+  bool post; /* the sequence ends with the feature posting (see h_post) */
   uint64_t stamp;
 } DetectGraph;
 
@@ -173,6 +175,15 @@ struct vksift_Instance_T
   bool desc_start_valid;
   vksift_hip_event ev_input_free;  /* the last reader of d_input (seed pass of the most recent detection) has run */
   bool input_free_valid;
+  /* small detections (one image): the scales behind scale S of an octave are off the path to the next octave; they run on the
+   * (otherwise idle) scale-space stream beside the octaves below — forked per octave, joined in front of the keypoint stages */
+  vksift_hip_event ev_fork[VKSIFT_MAX_OCTAVES], ev_join[2];
+  vksift_hip_stream side_stream; /* second branch stream (the first is pyr_stream) */
+  int fork_streams;              /* VKSIFT_FORK_STREAMS: 1 or 2 branch streams */
+  bool fork_scales; /* VKSIFT_FORK_SCALES (default 1) */
+  uint64_t fork_max_pixels; /* ... for detections of at most this many input pixels (VKSIFT_FORK_MAX_PIXELS) */
+  uint32_t lds_chain_max; /* largest plane (texels) an octave of the chain may have: VKSIFT_LDS_CHAIN_MAX, at most 19200 (the LDS) */
+  bool lds_chain; /* VKSIFT_LDS_CHAIN (default 1): the trailing octaves that fit the LDS are built by one launch (vksift_hip_octave_chain) */
   bool alt_order; /* VKSIFT_PYR_ALTERNATE (default 1): launches of a blur chain alternate their dispatch direction (vksift_hip_Plane::reverse) */
   vksift_hip_event ev_match;
   bool match_pending;
@@ -190,6 +201,18 @@ struct vksift_Instance_T
   size_t dl_chunk_end[VKSIFT_DL_CHUNKS];
   uint32_t dl_chunks, dl_chunks_done;
   uint64_t dl_seq;      /* the detection the packed copy belongs to */
+  /* Feature posting: a single-image detection ends with the pack kernel storing the dense records of its buffer straight into
+   * mapped pinned memory (slot = buffer index & 1), so that vksift_getFeaturesNumber + vksift_downloadFeatures cost ONE host wait
+   * and a host copy — instead of wait, pack launch, device-to-host copy, second wait (~60 us of a 0.45 ms detection).
+   * Costs bus time when nobody downloads: switched off after VKSIFT_POST_IDLE posted detections in a row that were never
+   * fetched, on again by the next download of a single detection. VKSIFT_POST_FEATURES=0 disables. */
+  uint8_t *h_post[2];
+  size_t post_cap;        /* bytes of each */
+  uint64_t post_seq[2];   /* detection whose records the slot holds (0: none) */
+  uint32_t post_buf[2];
+  bool post_fetched[2];   /* the slot's records were downloaded at least once */
+  bool post_enabled, post_on;
+  uint32_t post_idle;
   uint64_t dl_hits_seq; /* the detection dl_hits counts for */
   uint32_t dl_hits; /* vksift_downloadFeatures calls on buffers of that detection, before its packed copy exists */
   /* packed download of the records of a batched matching (h_matches: pinned) */
