@@ -365,7 +365,9 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint3
 
 /* Everything a detection puts on the GPU, from the image upload to the count read-back: the part a hipGraph captures.
  *
- * Two streams at most. The scale-space of all octaves is built on one (octave o+1 is seeded by scale S of octave o anyway);
+ * Two streams at most for a batch. The scale-space of all octaves is built on one (octave o+1 is seeded by scale S of octave o anyway;
+ * small detections fork the scales behind S onto a side stream, see DetectCtx::fork: there the launch-to-launch latency is the cost,
+ * not the bandwidth);
  * then every keypoint stage — ExtractKeypoints, ComputeOrientation, ComputeDescriptors — is ONE chain of launches for all
  * octaves on the instance stream (vksift_hip_*_multi), like the reference records the dispatches of all octaves of a stage into
  * one command buffer (sift_detector.c:1106-1259). With two pyramid buffers the scale-space has a stream of its own, ordered
