@@ -180,6 +180,7 @@ typedef struct
   bool overlap;   /* scale-space on its own stream and buffer (ping-pong), see detect_impl */
   bool upload;    /* host images were staged in h_input and have to be copied to d_input */
   bool capturing; /* the sequence is being captured into a hipGraph: no host-visible events inside */
+  bool gpu_busy;  /* an earlier detection was still running when this one was queued */
   bool post;      /* feature posting at the end of the sequence (vksift_internal.h: h_post) */
   bool fork;      /* scales S+1.. of every octave on the side stream (vksift_internal.h: ev_fork) */
   const uint8_t *const *images; /* upload: the caller's images, staged chunk by chunk while the sequence is enqueued */
@@ -403,7 +404,10 @@ static int enqueue_detection(DetectCtx *c)
       per = (c->count + VKSIFT_UP_GROUPS - 1u) / VKSIFT_UP_GROUPS;
     if (per < 32u)
       per = 32u;
-    const bool grouped = !c->capturing && L->n_oct > 0 && c->count >= 2u * per;
+    /* ... when the GPU would otherwise wait for the bus. With the previous detection still running (a caller that queues the next
+     * batch before fetching the current one) the copies are hidden anyway, and whole-batch launches are the better launches:
+     * 512 frames, pipelined protocol, 21.45 -> 21.85 k frames/s */
+    const bool grouped = !c->capturing && L->n_oct > 0 && c->count >= 2u * per && !c->gpu_busy;
     if (!grouped)
       per = c->count;
     for (uint32_t i0 = 0, g = 0; i0 < c->count; g++)
@@ -688,6 +692,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   c.img_bytes = (size_t)w * h;
   c.nblur = 0;
   c.capturing = false;
+  c.gpu_busy = detect_running(inst);
   c.fork = inst->fork_scales && !c.overlap && !c.prof && (uint64_t)count * w * h <= inst->fork_max_pixels;
   /* feature posting for single-image detections whose records fit the slot (every section is capacity-bounded) */
   c.post = false;
