@@ -55,3 +55,21 @@ def test_chain_in_a_batch_equals_single_detections(vk, monkeypatch):
             inst.detectFeaturesBatch(imgs, 0)
             res[chain] = [inst.downloadFeatures(i).tobytes() for i in range(12)]
     assert res["0"] == res["1"] and all(len(r) > 0 for r in res["1"])
+
+
+def test_forked_batch_with_grouped_upload_equals_single_detections(vk, monkeypatch):
+    """a batch small enough to fork (<= 16 Mi pixels) on a single-pyramid instance, large enough for the grouped upload: octave 0 is
+    built group by group on the trunk stream, the rest forked, the coarsest octaves chained"""
+    w, h, n = 160, 120, 70
+    imgs = [vk.gen_synthetic_image_family(400 + i, w, h, i % 3) for i in range(n)]
+    monkeypatch.setenv("VKSIFT_PYR_PINGPONG", "0")
+    with vk.Instance(vk.default_config(sift_buffer_count=n, input_image_max_size=w * h), batch_capacity=n) as inst:
+        for rep in range(2):
+            inst.detectFeaturesBatch(imgs, 0)
+            batch = [inst.downloadFeatures(i).tobytes() for i in range(n)]
+    monkeypatch.setenv("VKSIFT_FORK_SCALES", "0")
+    monkeypatch.setenv("VKSIFT_LDS_CHAIN", "0")
+    with vk.Instance(vk.default_config(input_image_max_size=w * h)) as inst:
+        for i in (0, 1, 33, 69):
+            inst.detectFeatures(imgs[i], 0)
+            assert inst.downloadFeatures(0).tobytes() == batch[i] and len(batch[i]) > 0
