@@ -145,16 +145,18 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(w, h, batch):
+def pmc_traffic(w, h, batch, fp16=False):
     """HBM bytes per step of the octave-0 blur + scan launches from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
-    gfx950 FETCH_SIZE correction applied, see profiles/README.md). A file measured on other kernel sources is refused."""
+    gfx950 FETCH_SIZE correction applied, see profiles/README.md). A file measured on other kernel sources — or in the other
+    pyramid precision mode: binary16 planes move half the bytes — is refused."""
     sha = kernel_source_sha()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        if (d.get("width"), d.get("height"), d.get("batch")) == (w, h, batch) and d.get("kernel_source_sha") == sha:
+        if (d.get("width"), d.get("height"), d.get("batch")) == (w, h, batch) and d.get("kernel_source_sha") == sha \
+                and bool(d.get("fp16", False)) == bool(fp16):
             d["_path"] = os.path.join("profiles", os.path.basename(path))
             return d
     return None
@@ -717,7 +719,7 @@ def main():
     out = None
     if rank == 0:
         frames_total = B * NSUB * world * args.steps
-        pmc = pmc_traffic(W, H, B)
+        pmc = pmc_traffic(W, H, B, fp16=args.fp16)
         out = {
             "metric": "SIFT detect+match frames/sec (640x480, ~2k kp)" if do_match else "SIFT detect frames/sec",
             "value": frames_total / elapsed,
