@@ -89,23 +89,32 @@ double proto_serial(vksift_Instance inst, const uint8_t *const *images, uint32_t
 double proto_single(vksift_Instance inst, const uint8_t *image, uint32_t w, uint32_t h, int do_match, uint32_t warm, uint32_t runs, vksift_Feature *feat_buf,
                     vksift_Match_2NN *match_buf, uint32_t *nb_feats)
 {
-  double t0 = 0.0;
+  double t0 = 0.0, ph[4] = {0.0, 0.0, 0.0, 0.0};
   uint32_t n = 0;
   for (uint32_t i = 0; i < warm + runs; i++)
   {
     if (i == warm)
       t0 = now_s();
+    const double ta = now_s();
     vksift_detectFeatures(inst, image, w, h, 0u);
+    const double tb = now_s();
     n = vksift_getFeaturesNumber(inst, 0u);
+    const double tc = now_s();
     vksift_downloadFeatures(inst, feat_buf, 0u);
+    const double td = now_s();
     if (do_match)
     {
       vksift_matchFeatures(inst, 0u, 0u);
       if (vksift_getMatchesNumber(inst))
         vksift_downloadMatches(inst, match_buf);
     }
+    if (i >= warm)
+      ph[0] += tb - ta, ph[1] += tc - tb, ph[2] += td - tc, ph[3] += now_s() - td;
   }
   const double dt = (now_s() - t0) / (double)runs;
+  if (getenv("PROTO_TRACE") && atoi(getenv("PROTO_TRACE")))
+    fprintf(stderr, "PROTO_TRACE single image, us per run: detect call %.1f | wait (getFeaturesNumber) %.1f | downloadFeatures %.1f | match + download %.1f | period %.1f\n",
+            1e6 * ph[0] / runs, 1e6 * ph[1] / runs, 1e6 * ph[2] / runs, 1e6 * ph[3] / runs, 1e6 * dt);
   if (nb_feats)
     *nb_feats = n;
   return dt;

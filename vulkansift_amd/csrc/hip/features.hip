@@ -75,6 +75,7 @@ struct FeatArgs
   uint32_t use_vlfeat;
   const float *desc_fp_tab;
   uint32_t desc_fp_tab_len;
+  uint32_t *tickets; // vksift_hip_OctaveJob::tickets, kind 2 (k_orientation), or NULL
 };
 
 // ComputeDescriptors.comp:160-171 / ComputeOrientation.comp:100-104 wrap an angle with "if (t < 0) t += 2 pi; else if
@@ -90,7 +91,12 @@ __device__ __forceinline__ float wrap_2pi(float t)
 // -------------------------------------------------------------------------------------------------
 // Orientation histogram (ComputeOrientation.comp:52-186). grid = (blocks, batch); 4 keypoints/block.
 // -------------------------------------------------------------------------------------------------
-template <bool IMG_FAST, bool F16>
+template <int NT>
+__device__ __forceinline__ void orientation_finalize_body(const FeatArgs &a, const int b);
+
+// FUSE (small batches): the last workgroup of an image to finish its keypoints also does k_orientation_finalize's work for that
+// image (a ticket per image behind a device-wide fence; the word is left at zero) — one dependent launch less.
+template <bool IMG_FAST, bool F16, bool FUSE>
 __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
 {
   const VBlock vb = vblock(m); // virtual grid (images, blocks) when IMG_FAST, (blocks, images) otherwise
@@ -249,19 +255,37 @@ __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (FUSE)
+  {
+    __shared__ uint32_t s_last;
+    __threadfence(); // this thread's angles and counts, device-wide
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      uint32_t *ticket = a.tickets + b;
+      const uint32_t t = atomicAdd(ticket, 1u);
+      s_last = t + 1u == nbk ? 1u : 0u;
+      if (s_last)
+        atomicExch(ticket, 0u);
+    }
+    __syncthreads();
+    if (s_last != 0u)
+    {
+      __threadfence(); // the other workgroups' stores
+      orientation_finalize_body<256>(a, b);
+    }
+  }
 }
 
 // -------------------------------------------------------------------------------------------------
 // Write main orientations in place and append the extra-orientation copies in (keypoint, bin) order
 // (ComputeOrientation.comp:170-183, made deterministic). One 1024-thread block per image.
 // -------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_orientation_finalize(Multi<FeatArgs> m)
+template <int NT>
+__device__ __forceinline__ void orientation_finalize_body(const FeatArgs &a, const int b)
 {
-  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t wave_tot[NT / 64];
   __shared__ uint32_t carry_s;
-  const VBlock vb = vblock(m); // virtual grid (images)
-  const FeatArgs &a = m.oct[vb.o];
-  const int b = (int)vb.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t found = a.found[(size_t)b * a.found_img_stride];
   const uint32_t n0 = found < a.cap ? found : a.cap;
@@ -271,7 +295,7 @@ __global__ void __launch_bounds__(1024) k_orientation_finalize(Multi<FeatArgs> m
   if (threadIdx.x == 0)
     carry_s = 0;
   __syncthreads();
-  for (uint32_t base = 0; base < n0; base += 1024)
+  for (uint32_t base = 0; base < n0; base += NT)
   {
     uint32_t k = base + threadIdx.x;
     uint32_t c = k < n0 ? cnt[k] : 0u;
@@ -310,12 +334,18 @@ __global__ void __launch_bounds__(1024) k_orientation_finalize(Multi<FeatArgs> m
       }
     }
     __syncthreads();
-    if (threadIdx.x == 1023)
+    if (threadIdx.x == NT - 1)
       carry_s = carry + wave_base + incl;
     __syncthreads();
   }
   if (threadIdx.x == 0)
     a.found[(size_t)b * a.found_img_stride] = found + carry_s;
+}
+
+__global__ void __launch_bounds__(1024) k_orientation_finalize(Multi<FeatArgs> m)
+{
+  const VBlock vb = vblock(m); // virtual grid (images)
+  orientation_finalize_body<1024>(m.oct[vb.o], (int)vb.x);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -405,14 +435,28 @@ __device__ __forceinline__ DescSample desc_sample(const DescCtx &c, int cdx, int
 // pairs (1,2)(3,4)(5,6)(7,0) — so each of the four cells takes ONE ds_add_u64 instead of two ds_add_u32 (the sums stay below
 // 2^32 by construction of the fixed-point scale, so the low half never carries into the high half). Cell = 64 bytes:
 // [A: 4 pairs][B: 4 pairs]. The epilogue adds the two copies.
-constexpr int DESC_HIST_WORDS = 16 * 16;              // 16 cells x (8 + 8) words
-constexpr int DESC_WORK_WORDS = DESC_HIST_WORDS + 128; // + one 8-byte dummy slot per lane for the out-of-grid cells
+// The 4x4 grid sits inside a 6x8 array of cells (grid cell (cx, cy) = array cell (cx + 1, cy + 1)), so the 2x2 cells of a
+// sample share ONE address register — the other three are immediate offsets of the ds_add_u64, and the lower corner of a sample
+// one cell outside the grid still gives a non-negative address. Cells outside the grid (ComputeDescriptors.comp:189 drops
+// them: 36 % of all cell updates, the enumerated footprint is 5x5 cells) are not executed at all: the add sits under the
+// exec mask of its in-grid test. (Round 3's form redirected them to a per-lane dummy slot — four selects and three more
+// address computations per sample, and an LDS atomic for every dropped cell. Letting them land in the border cells of
+// the array instead, without any test, was measured 1.3 % SLOWER despite 6 % fewer instructions: the dropped updates then collide
+// on 20 border cells like the kept ones do on the grid, and the kernel is as sensitive to same-address LDS atomics as to
+// VALU issue.) Only the 16 grid cells are ever touched.
+constexpr int DESC_PAD = 1, DESC_ROW_CELLS = 8; // rows of 8 cells: a grid column keeps the LDS banks it had in the dense 4x4 layout
+constexpr int DESC_HIST_WORDS = (4 + 2 * DESC_PAD) * DESC_ROW_CELLS * 16; // 6 rows x 8 cells x (8 + 8) words = 3 KiB
+constexpr int DESC_WORK_WORDS = DESC_HIST_WORDS;
+__device__ __forceinline__ int desc_cell_word(int cell) // first word of grid cell cy * 4 + cx
+{
+  return (((cell >> 2) + DESC_PAD) * DESC_ROW_CELLS + (cell & 3) + DESC_PAD) * 16;
+}
 __device__ __forceinline__ uint32_t desc_hist_read(const uint32_t *s_work, int t) // descriptor element t = cell * 8 + bin
 {
-  const int cell = t >> 3, bin = t & 7;
-  const uint32_t a = s_work[cell * 16 + bin];                                  // copy A: pair bin / 2, half bin & 1
-  const int pb = ((bin + 7) & 7) >> 1;                                         // copy B: the pair that starts at the odd bin below
-  const uint32_t bq = s_work[cell * 16 + 8 + pb * 2 + ((bin & 1) ? 0 : 1)];    // odd bins are the low half there
+  const int cw = desc_cell_word(t >> 3), bin = t & 7;
+  const uint32_t a = s_work[cw + bin];                                  // copy A: pair bin / 2, half bin & 1
+  const int pb = ((bin + 7) & 7) >> 1;                                  // copy B: the pair that starts at the odd bin below
+  const uint32_t bq = s_work[cw + 8 + pb * 2 + ((bin & 1) ? 0 : 1)];    // odd bins are the low half there
   return a + bq;
 }
 
@@ -423,28 +467,28 @@ __device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample 
   const float flx = floorf(fhx - 0.5f), fly = floorf(fhy - 0.5f), flb = floorf(fbin);
   int hx = (int)flx, hy = (int)fly, hb = (int)flb;
   float rhx = fhx - (flx + 0.5f), rhy = fhy - (fly + 0.5f), rb = fbin - flb;
-  // The 2x2 spatial cells that fall outside the 4x4 grid (ComputeDescriptors.comp:189 drops them) are redirected to a
-  // per-lane dummy slot behind the histogram instead of being branched around: no exec-mask juggling in the hot loop.
-  // (Packed v_pk_mul_f32 for the weight products was measured 9 % slower despite 6 % fewer instructions.)
-  const unsigned dummy = (unsigned)DESC_HIST_WORDS * 4u + (threadIdx.x & 63u) * 8u;
   // ((w * wb) * mag) * fp == (w * wb) * (mag * fp) bit for bit: fp is a power of two (2^0 .. 2^31), so mag * fp is exact and
   // scaling by it commutes with the rounding of the product — except where (w * wb) * mag is subnormal, and there both
   // forms are far below 1 and convert to 0. One multiply per sample instead of one per bin value (8).
+  // (Packed v_pk_mul_f32 for the weight products was measured 9 % slower despite 6 % fewer instructions.)
   const float magfp = r.mag * c.fp;
   const unsigned b0 = (unsigned)smod8(hb);
   const unsigned pair = ((b0 & 1u) ? 32u : 0u) + (b0 >> 1) * 8u; // byte offset of the (hb, hb+1) pair inside a cell
-  char *base = (char *)s_work;
+  // in-grid tests of the two columns and the two rows (a dead sample — a lane whose run has ended — fails all of them);
+  // the address of a lane that fails is never used
+  const bool okx[2] = {live && (unsigned)hx < 4u, live && (unsigned)(hx + 1) < 4u};
+  const bool oky[2] = {(unsigned)hy < 4u, (unsigned)(hy + 1) < 4u};
+  char *base = (char *)s_work + ((unsigned)((hy + DESC_PAD) * (DESC_ROW_CELLS * 64) + (hx + DESC_PAD) * 64) + pair);
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
     {
-      const bool in_grid = live && (unsigned)(i + hx) < 4u && (unsigned)(j + hy) < 4u;
-      const unsigned cell = (unsigned)((j + hy) * 256 + (i + hx) * 64);
       const float w = fabsf(1.f - (float)i - rhx) * fabsf(1.f - (float)j - rhy);
       const uint32_t v0 = (uint32_t)((w * fabsf(1.f - 0.f - rb)) * magfp);
       const uint32_t v1 = (uint32_t)((w * fabsf(1.f - 1.f - rb)) * magfp);
-      atomicAdd((unsigned long long *)(base + (in_grid ? (cell | pair) : dummy)), ((unsigned long long)v1 << 32) | v0);
+      if (okx[i] && oky[j])
+        atomicAdd((unsigned long long *)(base + (j * DESC_ROW_CELLS * 64 + i * 64)), ((unsigned long long)v1 << 32) | v0);
     }
 }
 
@@ -492,8 +536,8 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(Multi<FeatArgs> m)
   for (uint32_t k = IMG_FAST ? vb.y : vb.x; k < n1; k += IMG_FAST ? vb.gy : vb.gx)
   {
     __syncthreads(); // the previous keypoint's epilogue has read the histogram
-    for (int i = tid; i < DESC_HIST_WORDS; i += NT_)
-      s_work[i] = 0; // made visible by the barrier behind the row-span pass below
+    for (int i = tid; i < 256; i += NT_)
+      s_work[desc_cell_word(i >> 4) + (i & 15)] = 0; // the 16 grid cells; made visible by the barrier behind the row-span pass below
 
     const float *rec = (const float *)(feats + (size_t)k * 164);
     const uint32_t scale_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const uint32_t *)rec)[4]); // uniform: keeps the resource in SGPRs
@@ -618,7 +662,7 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(Multi<FeatArgs> m)
       // Two samples per iteration: their (straight-line) contribution code is independent, so the scheduler interleaves
       // the two dependency chains instead of padding every compare -> select and transcendental with wait states. A lane
       // whose run has ended carries a dead sample: the taps go through the buffer resource (any offset is safe) and
-      // every contribution is redirected to the lane's dummy slot.
+      // no contribution is executed.
       auto next_sample = [&](int &sx, int &sy, bool &live) {
         live = sidx < send;
         if (live && sidx >= row_end)
@@ -648,7 +692,7 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(Multi<FeatArgs> m)
         }
         else
         {
-          // (a dead second sample takes whatever the pair load returns: its contribution goes to the dummy slot; the loads go
+          // (a dead second sample takes whatever the pair load returns: it contributes nothing; the loads go
           // through the buffer resource, so the texels past a row end are harmless too)
           desc_taps_pair(c, v0, t0, t1);
           if (live[1] && !(sy[1] == sy[0] && sx[1] == sx[0] + 1))
@@ -722,6 +766,7 @@ FeatArgs make_args(const vksift_hip_OctaveJob *job)
   a.max_keep = mk > VKSIFT_HIP_MAX_ORI ? VKSIFT_HIP_MAX_ORI : mk;
   a.use_vlfeat = job->use_vlfeat;
   a.desc_fp_tab = job->desc_fp_tab, a.desc_fp_tab_len = job->desc_fp_tab_len;
+  a.tickets = job->tickets ? job->tickets + 2 * job->ticket_stride : nullptr;
   return a;
 }
 
@@ -786,21 +831,40 @@ static int orientation_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_
   }
   const bool f16 = mo.oct[0].fp16 != 0;
   const dim3 grid(mo.start[mo.n]);
-  if (f)
+  static int fuse_env = -1;
+  if (fuse_env < 0)
   {
-    if (f16)
-      hipLaunchKernelGGL((k_orientation<true, true>), grid, dim3(256), 0, hs, mo);
-    else
-      hipLaunchKernelGGL((k_orientation<true, false>), grid, dim3(256), 0, hs, mo);
+    const char *e = getenv("VKSIFT_FUSE_TAILS"); /* 0: k_orientation_finalize as a launch of its own whatever the batch */
+    fuse_env = e ? atoi(e) : 1;
+  }
+  bool fuse = fuse_env != 0 && batch <= VKSIFT_HIP_FUSE_MAX_BATCH;
+  for (uint32_t i = 0; i < n; i++)
+    fuse = fuse && jobs[i].tickets != nullptr;
+#define VKSIFT_ORI(FU)                                                                       \
+  if (f)                                                                                     \
+  {                                                                                          \
+    if (f16)                                                                                 \
+      hipLaunchKernelGGL((k_orientation<true, true, FU>), grid, dim3(256), 0, hs, mo);       \
+    else                                                                                     \
+      hipLaunchKernelGGL((k_orientation<true, false, FU>), grid, dim3(256), 0, hs, mo);      \
+  }                                                                                          \
+  else                                                                                       \
+  {                                                                                          \
+    if (f16)                                                                                 \
+      hipLaunchKernelGGL((k_orientation<false, true, FU>), grid, dim3(256), 0, hs, mo);      \
+    else                                                                                     \
+      hipLaunchKernelGGL((k_orientation<false, false, FU>), grid, dim3(256), 0, hs, mo);     \
+  }
+  if (fuse)
+  {
+    VKSIFT_ORI(true)
   }
   else
   {
-    if (f16)
-      hipLaunchKernelGGL((k_orientation<false, true>), grid, dim3(256), 0, hs, mo);
-    else
-      hipLaunchKernelGGL((k_orientation<false, false>), grid, dim3(256), 0, hs, mo);
+    VKSIFT_ORI(false)
+    hipLaunchKernelGGL(k_orientation_finalize, dim3(mf.start[mf.n]), dim3(1024), 0, hs, mf);
   }
-  hipLaunchKernelGGL(k_orientation_finalize, dim3(mf.start[mf.n]), dim3(1024), 0, hs, mf);
+#undef VKSIFT_ORI
   return (int)hipGetLastError();
 }
 
