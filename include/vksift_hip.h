@@ -148,7 +148,6 @@ extern "C"
   int vksift_hip_dog_plane(const float *lo, const float *hi, uint32_t w, uint32_t h, uint32_t pitch, uint32_t fp16, float *out_dense, vksift_hip_stream s);
 
   /* ------------------------------------------------------------------ keypoints */
-#define VKSIFT_HIP_FUSE_MAX_BATCH 8u /* batches up to this size use vksift_hip_OctaveJob::tickets (see there) */
   typedef struct
   {
     float *gauss;        /* Gaussian layer 0 of image 0 of this octave (S+3 layers; DoG layer s = layer s+1 - layer s) */
@@ -185,10 +184,6 @@ extern "C"
     uint32_t desc_fp_tab_len;
     uint32_t scan_reverse;    /* dispatch-order hint of the streaming extrema scan, like vksift_hip_Plane::reverse: set when the last
                                * blur launch of the octave ran forward, so that the scan starts on the planes written last */
-    uint32_t *tickets;        /* NULL, or 3 arrays of `batch` zero-initialised words, ticket_stride apart, that belong to this octave: the
-                               * stage kernels of small batches then finish with the work of the one-workgroup-per-image kernel that
-                               * would follow them (the last workgroup of an image to arrive does it; the words are left at zero) */
-    uint64_t ticket_stride;
     uint32_t masks_cleared;   /* the caller has cleared seg_mask for this launch itself (vksift_hip_clear_segment_masks, e.g. on another
                                * stream, off the critical path): vksift_hip_extract_keypoints_multi skips its own fill */
   } vksift_hip_OctaveJob;

@@ -270,8 +270,6 @@ struct ExtremaArgs
   uint32_t nsegs;  // S * h * nseg: mask segments of one image
   uint32_t nchunks; // ceil(nsegs / SEG_CHUNK)
   int scan_rev; // the streaming scan walks every XCD's share of the work space back to front (vksift_hip_OctaveJob::scan_reverse)
-  uint32_t *tickets; // vksift_hip_OctaveJob::tickets (kind 0: k_segment_scan, kind 1: k_refine_flags)
-  uint64_t ticket_stride;
 };
 
 // Streaming detection pass: one wave owns a 64-column segment and marches down a band of
@@ -701,11 +699,6 @@ __global__ void __launch_bounds__(256, 4) k_extrema_lean(Multi<ExtremaArgs> m, i
 // consumer (k_cand_list) adds base + local offset.
 constexpr uint32_t SEG_CHUNK = 4096;
 
-template <bool ACCEPTED, int NT>
-__device__ __forceinline__ void chunk_offsets_body(const ExtremaArgs &a, const int b);
-__device__ __forceinline__ bool last_workgroup_of(uint32_t *ticket, uint32_t expected);
-
-template <bool FUSE>
 __global__ void __launch_bounds__(1024) k_segment_scan(Multi<ExtremaArgs> m)
 {
   __shared__ uint32_t wave_tot[16];
@@ -752,8 +745,6 @@ __global__ void __launch_bounds__(1024) k_segment_scan(Multi<ExtremaArgs> m)
   }
   if (threadIdx.x == 0)
     chunk_tot[(size_t)b * chunk_img_stride + vb.x] = total;
-  if (FUSE && last_workgroup_of(a.tickets + b, a.nchunks))
-    chunk_offsets_body<false, 1024>(a, b); // = k_chunk_offsets<false>
 }
 
 // In-place exclusive scan of the per-chunk totals of one image (one workgroup per image, the list is short: n / chunk
@@ -761,11 +752,14 @@ __global__ void __launch_bounds__(1024) k_segment_scan(Multi<ExtremaArgs> m)
 // ceil(min(count_in[b], count_cap) / per_chunk) (device-side candidate count), else n_entries.
 // ACCEPTED = false: the candidate-chunk totals of k_segment_scan (in the flag array) -> chunk bases, grand total -> cand_n[b];
 // ACCEPTED = true: the per-256-candidate accept counts of k_refine_flags (in the segment-offset array) -> bases, total -> found[b].
-template <bool ACCEPTED, int NT>
-__device__ __forceinline__ void chunk_offsets_body(const ExtremaArgs &a, const int b)
+template <bool ACCEPTED>
+__global__ void __launch_bounds__(1024) k_chunk_offsets(Multi<ExtremaArgs> m)
 {
-  __shared__ uint32_t wave_tot[NT / 64];
+  __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
+  const VBlock vb = vblock(m); // virtual grid (images)
+  const ExtremaArgs &a = m.oct[vb.o];
+  const int b = (int)vb.x;
   uint32_t *__restrict__ tot = ACCEPTED ? a.seg_off + (size_t)b * a.seg_img_stride : a.cand_flag + (size_t)b * a.cand_img_stride;
   uint32_t *__restrict__ total_out = ACCEPTED ? a.found : a.cand_n;
   const uint32_t total_stride = ACCEPTED ? a.found_img_stride : 1u;
@@ -780,7 +774,7 @@ __device__ __forceinline__ void chunk_offsets_body(const ExtremaArgs &a, const i
   if (threadIdx.x == 0)
     carry_s = 0;
   __syncthreads();
-  for (uint32_t base = 0; base < n; base += NT)
+  for (uint32_t base = 0; base < n; base += 1024)
   {
     const uint32_t i = base + threadIdx.x;
     const uint32_t v = i < n ? tot[i] : 0u;
@@ -802,41 +796,12 @@ __device__ __forceinline__ void chunk_offsets_body(const ExtremaArgs &a, const i
     if (i < n)
       tot[i] = carry + wave_base + incl - v;
     __syncthreads();
-    if (threadIdx.x == NT - 1)
+    if (threadIdx.x == 1023)
       carry_s = carry + wave_base + incl;
     __syncthreads();
   }
   if (threadIdx.x == 0)
     total_out[(size_t)b * total_stride] = carry_s;
-}
-
-template <bool ACCEPTED>
-__global__ void __launch_bounds__(1024) k_chunk_offsets(Multi<ExtremaArgs> m)
-{
-  const VBlock vb = vblock(m); // virtual grid (images)
-  chunk_offsets_body<ACCEPTED, 1024>(m.oct[vb.o], (int)vb.x);
-}
-
-// Small batches (FUSE instantiations): the one-workgroup-per-image kernel that follows a stage kernel costs a dependent launch for
-// 1-5 us of work. The workgroups of an image take a ticket when their stores are out; the last one to arrive does that kernel's
-// work itself, behind a fence, and leaves the ticket word at zero for the next detection.
-__device__ __forceinline__ bool last_workgroup_of(uint32_t *ticket, uint32_t expected)
-{
-  __shared__ uint32_t s_last;
-  __threadfence(); // this thread's stores, device-wide
-  __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    const uint32_t t = atomicAdd(ticket, 1u);
-    s_last = t + 1u == expected ? 1u : 0u;
-    if (s_last)
-      atomicExch(ticket, 0u);
-  }
-  __syncthreads();
-  const bool last = s_last != 0u;
-  if (last)
-    __threadfence(); // the other workgroups' stores
-  return last;
 }
 
 // One thread per 64-pixel segment: expand its candidate ballot into packed coordinates at offset + rank.
@@ -870,7 +835,7 @@ __global__ void __launch_bounds__(256) k_cand_list(Multi<ExtremaArgs> mu)
 // Dense refinement: thread t of a 256-candidate chunk refines candidate chunk*256 + t (count read from HBM, workgroups
 // stride over the chunks). Besides the accept flags every chunk publishes its number of accepted candidates (into the
 // segment-offset array, free again after k_cand_list) for the two-level scan of k_chunk_offsets / k_cand_emit.
-template <bool F16, bool BUF, bool FUSE>
+template <bool F16, bool BUF>
 __global__ void __launch_bounds__(256) k_refine_flags(Multi<ExtremaArgs> m)
 {
   __shared__ uint32_t s_cnt[4];
@@ -908,8 +873,6 @@ __global__ void __launch_bounds__(256) k_refine_flags(Multi<ExtremaArgs> m)
       chunk_sum[chunk] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     __syncthreads();
   }
-  if (FUSE && last_workgroup_of(a.tickets + a.ticket_stride + b, vb.gy))
-    chunk_offsets_body<true, 256>(a, b); // = k_chunk_offsets<true>
 }
 
 // Accepted candidates recompute their record (bit-identical) and store it at chunk base + rank inside the chunk (raster
@@ -994,7 +957,6 @@ static int make_extrema_args(const vksift_hip_OctaveJob *job, ExtremaArgs *out)
   a.cand_xy = job->cand_xy, a.cand_flag = job->cand_flag, a.cand_n = job->cand_n;
   a.cand_img_stride = job->cand_img_stride, a.cand_cap = job->cand_cap;
   a.scan_rev = (int)job->scan_reverse;
-  a.tickets = job->tickets, a.ticket_stride = job->ticket_stride;
   /* 32 rows per wave on the large octaves (3 % halo rows); 16 on the small ones, whose share of a launch is latency bound and
    * gains more from twice the waves */
   a.band = job->h > 256u ? 32 : 16;
@@ -1048,16 +1010,6 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
     if (me)
       return me;
   }
-  /* small batches: the two one-workgroup-per-image scans ride on the kernels in front of them (last_workgroup_of) */
-  static int fuse_env = -1;
-  if (fuse_env < 0)
-  {
-    const char *e = getenv("VKSIFT_FUSE_TAILS"); /* 0: separate launches whatever the batch (A/B runs) */
-    fuse_env = e ? atoi(e) : 1;
-  }
-  bool fuse = fuse_env != 0 && batch <= VKSIFT_HIP_FUSE_MAX_BATCH;
-  for (uint32_t i = 0; i < n; i++)
-    fuse = fuse && jobs[i].tickets != nullptr;
   static int lean_env = -1;
   if (lean_env < 0)
   {
@@ -1110,14 +1062,10 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
    * the start of the flag array until the refinement overwrites it */
   {
     VKSIFT_MULTI(m2, a.nchunks, batch, 1u)
-    if (fuse)
-      hipLaunchKernelGGL(k_segment_scan<true>, dim3(m2.start[m2.n]), dim3(1024), 0, hs, m2);
-    else
-      hipLaunchKernelGGL(k_segment_scan<false>, dim3(m2.start[m2.n]), dim3(1024), 0, hs, m2);
+    hipLaunchKernelGGL(k_segment_scan, dim3(m2.start[m2.n]), dim3(1024), 0, hs, m2);
   }
   VKSIFT_MULTI(mi, batch, 1u, 1u) /* one workgroup per image */
-  if (!fuse)
-    hipLaunchKernelGGL(k_chunk_offsets<false>, dim3(mi.start[mi.n]), dim3(1024), 0, hs, mi);
+  hipLaunchKernelGGL(k_chunk_offsets<false>, dim3(mi.start[mi.n]), dim3(1024), 0, hs, mi);
   /* 3. compact list, 4. dense refinement (+ per-chunk accept counts), 5. scan of those counts, 6. accepted -> records */
   {
     VKSIFT_MULTI(m3, (a.nsegs + 255u) / 256u, batch, 1u)
@@ -1143,25 +1091,15 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
   bool buf = buf_env != 0;
   for (uint32_t i = 0; i < n; i++)
     buf = buf && (uint64_t)(args[i].S + 3) * args[i].plane_stride * (f16 ? 2u : 4u) < 0x7FFF0000ull;
-#define VKSIFT_REFINE(FU)                                                                  \
-  if (f16 && buf)                                                                          \
-    hipLaunchKernelGGL((k_refine_flags<true, true, FU>), rgrid, dim3(256), 0, hs, mr);     \
-  else if (f16)                                                                            \
-    hipLaunchKernelGGL((k_refine_flags<true, false, FU>), rgrid, dim3(256), 0, hs, mr);    \
-  else if (buf)                                                                            \
-    hipLaunchKernelGGL((k_refine_flags<false, true, FU>), rgrid, dim3(256), 0, hs, mr);    \
-  else                                                                                     \
-    hipLaunchKernelGGL((k_refine_flags<false, false, FU>), rgrid, dim3(256), 0, hs, mr);
-  if (fuse)
-  {
-    VKSIFT_REFINE(true)
-  }
+  if (f16 && buf)
+    hipLaunchKernelGGL((k_refine_flags<true, true>), rgrid, dim3(256), 0, hs, mr);
+  else if (f16)
+    hipLaunchKernelGGL((k_refine_flags<true, false>), rgrid, dim3(256), 0, hs, mr);
+  else if (buf)
+    hipLaunchKernelGGL((k_refine_flags<false, true>), rgrid, dim3(256), 0, hs, mr);
   else
-  {
-    VKSIFT_REFINE(false)
-    hipLaunchKernelGGL(k_chunk_offsets<true>, dim3(mi.start[mi.n]), dim3(1024), 0, hs, mi);
-  }
-#undef VKSIFT_REFINE
+    hipLaunchKernelGGL((k_refine_flags<false, false>), rgrid, dim3(256), 0, hs, mr);
+  hipLaunchKernelGGL(k_chunk_offsets<true>, dim3(mi.start[mi.n]), dim3(1024), 0, hs, mi);
   if (f16 && buf)
     hipLaunchKernelGGL((k_cand_emit<true, true>), rgrid, dim3(256), 0, hs, mr);
   else if (f16)

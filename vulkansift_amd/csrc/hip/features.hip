@@ -75,7 +75,6 @@ struct FeatArgs
   uint32_t use_vlfeat;
   const float *desc_fp_tab;
   uint32_t desc_fp_tab_len;
-  uint32_t *tickets; // vksift_hip_OctaveJob::tickets, kind 2 (k_orientation), or NULL
 };
 
 // ComputeDescriptors.comp:160-171 / ComputeOrientation.comp:100-104 wrap an angle with "if (t < 0) t += 2 pi; else if
@@ -91,12 +90,7 @@ __device__ __forceinline__ float wrap_2pi(float t)
 // -------------------------------------------------------------------------------------------------
 // Orientation histogram (ComputeOrientation.comp:52-186). grid = (blocks, batch); 4 keypoints/block.
 // -------------------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void orientation_finalize_body(const FeatArgs &a, const int b);
-
-// FUSE (small batches): the last workgroup of an image to finish its keypoints also does k_orientation_finalize's work for that
-// image (a ticket per image behind a device-wide fence; the word is left at zero) — one dependent launch less.
-template <bool IMG_FAST, bool F16, bool FUSE>
+template <bool IMG_FAST, bool F16>
 __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
 {
   const VBlock vb = vblock(m); // virtual grid (images, blocks) when IMG_FAST, (blocks, images) otherwise
@@ -255,37 +249,19 @@ __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (FUSE)
-  {
-    __shared__ uint32_t s_last;
-    __threadfence(); // this thread's angles and counts, device-wide
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-      uint32_t *ticket = a.tickets + b;
-      const uint32_t t = atomicAdd(ticket, 1u);
-      s_last = t + 1u == nbk ? 1u : 0u;
-      if (s_last)
-        atomicExch(ticket, 0u);
-    }
-    __syncthreads();
-    if (s_last != 0u)
-    {
-      __threadfence(); // the other workgroups' stores
-      orientation_finalize_body<256>(a, b);
-    }
-  }
 }
 
 // -------------------------------------------------------------------------------------------------
 // Write main orientations in place and append the extra-orientation copies in (keypoint, bin) order
 // (ComputeOrientation.comp:170-183, made deterministic). One 1024-thread block per image.
 // -------------------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void orientation_finalize_body(const FeatArgs &a, const int b)
+__global__ void __launch_bounds__(1024) k_orientation_finalize(Multi<FeatArgs> m)
 {
-  __shared__ uint32_t wave_tot[NT / 64];
+  __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
+  const VBlock vb = vblock(m); // virtual grid (images)
+  const FeatArgs &a = m.oct[vb.o];
+  const int b = (int)vb.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t found = a.found[(size_t)b * a.found_img_stride];
   const uint32_t n0 = found < a.cap ? found : a.cap;
@@ -295,7 +271,7 @@ __device__ __forceinline__ void orientation_finalize_body(const FeatArgs &a, con
   if (threadIdx.x == 0)
     carry_s = 0;
   __syncthreads();
-  for (uint32_t base = 0; base < n0; base += NT)
+  for (uint32_t base = 0; base < n0; base += 1024)
   {
     uint32_t k = base + threadIdx.x;
     uint32_t c = k < n0 ? cnt[k] : 0u;
@@ -334,18 +310,12 @@ __device__ __forceinline__ void orientation_finalize_body(const FeatArgs &a, con
       }
     }
     __syncthreads();
-    if (threadIdx.x == NT - 1)
+    if (threadIdx.x == 1023)
       carry_s = carry + wave_base + incl;
     __syncthreads();
   }
   if (threadIdx.x == 0)
     a.found[(size_t)b * a.found_img_stride] = found + carry_s;
-}
-
-__global__ void __launch_bounds__(1024) k_orientation_finalize(Multi<FeatArgs> m)
-{
-  const VBlock vb = vblock(m); // virtual grid (images)
-  orientation_finalize_body<1024>(m.oct[vb.o], (int)vb.x);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -766,7 +736,6 @@ FeatArgs make_args(const vksift_hip_OctaveJob *job)
   a.max_keep = mk > VKSIFT_HIP_MAX_ORI ? VKSIFT_HIP_MAX_ORI : mk;
   a.use_vlfeat = job->use_vlfeat;
   a.desc_fp_tab = job->desc_fp_tab, a.desc_fp_tab_len = job->desc_fp_tab_len;
-  a.tickets = job->tickets ? job->tickets + 2 * job->ticket_stride : nullptr;
   return a;
 }
 
@@ -831,40 +800,21 @@ static int orientation_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_
   }
   const bool f16 = mo.oct[0].fp16 != 0;
   const dim3 grid(mo.start[mo.n]);
-  static int fuse_env = -1;
-  if (fuse_env < 0)
+  if (f)
   {
-    const char *e = getenv("VKSIFT_FUSE_TAILS"); /* 0: k_orientation_finalize as a launch of its own whatever the batch */
-    fuse_env = e ? atoi(e) : 1;
-  }
-  bool fuse = fuse_env != 0 && batch <= VKSIFT_HIP_FUSE_MAX_BATCH;
-  for (uint32_t i = 0; i < n; i++)
-    fuse = fuse && jobs[i].tickets != nullptr;
-#define VKSIFT_ORI(FU)                                                                       \
-  if (f)                                                                                     \
-  {                                                                                          \
-    if (f16)                                                                                 \
-      hipLaunchKernelGGL((k_orientation<true, true, FU>), grid, dim3(256), 0, hs, mo);       \
-    else                                                                                     \
-      hipLaunchKernelGGL((k_orientation<true, false, FU>), grid, dim3(256), 0, hs, mo);      \
-  }                                                                                          \
-  else                                                                                       \
-  {                                                                                          \
-    if (f16)                                                                                 \
-      hipLaunchKernelGGL((k_orientation<false, true, FU>), grid, dim3(256), 0, hs, mo);      \
-    else                                                                                     \
-      hipLaunchKernelGGL((k_orientation<false, false, FU>), grid, dim3(256), 0, hs, mo);     \
-  }
-  if (fuse)
-  {
-    VKSIFT_ORI(true)
+    if (f16)
+      hipLaunchKernelGGL((k_orientation<true, true>), grid, dim3(256), 0, hs, mo);
+    else
+      hipLaunchKernelGGL((k_orientation<true, false>), grid, dim3(256), 0, hs, mo);
   }
   else
   {
-    VKSIFT_ORI(false)
-    hipLaunchKernelGGL(k_orientation_finalize, dim3(mf.start[mf.n]), dim3(1024), 0, hs, mf);
+    if (f16)
+      hipLaunchKernelGGL((k_orientation<false, true>), grid, dim3(256), 0, hs, mo);
+    else
+      hipLaunchKernelGGL((k_orientation<false, false>), grid, dim3(256), 0, hs, mo);
   }
-#undef VKSIFT_ORI
+  hipLaunchKernelGGL(k_orientation_finalize, dim3(mf.start[mf.n]), dim3(1024), 0, hs, mf);
   return (int)hipGetLastError();
 }
 

@@ -223,8 +223,6 @@ static void build_jobs(DetectCtx *c)
     j->cand_xy = inst->d_cand_xy + L->cand_off[o];
     j->cand_flag = inst->d_cand_flag + L->cand_off[o];
     j->cand_n = inst->d_cand_n + (size_t)o * inst->batch_cap;
-    j->tickets = inst->d_tickets + (size_t)o * inst->batch_cap;
-    j->ticket_stride = (uint64_t)inst->batch_cap * VKSIFT_MAX_OCTAVES;
     j->cand_img_stride = inst->cand_cap;
     j->cand_cap = (uint32_t)L->cand_cap[o];
     j->ori_ang = inst->d_ori_ang + (size_t)b0->sec_off[o] * VKSIFT_HIP_MAX_ORI;

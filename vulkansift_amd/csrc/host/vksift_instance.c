@@ -2,8 +2,6 @@
  * vksift_instance.c — instance creation / destruction, scale-space layout, synchronisation helpers (vulkansift.c:165-313, sift_memory.c:15-87,133-360)
  */
 #include "vksift_internal.h"
-#include <stdlib.h>
-#include <time.h>
 
 /* ------------------------------------------------------------------------------------------------ */
 /* layout helpers                                                                                   */
@@ -159,8 +157,6 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   ALLOC_D(inst->d_cand_xy, sizeof(uint32_t) * inst->cand_cap * batch_cap);
   ALLOC_D(inst->d_cand_flag, sizeof(uint32_t) * inst->cand_cap * batch_cap);
   ALLOC_D(inst->d_cand_n, sizeof(uint32_t) * batch_cap * VKSIFT_MAX_OCTAVES);
-  /* tickets of the fused stage tails (vksift_hip_OctaveJob::tickets): [3 kinds][octave][image], zero between detections */
-  ALLOC_D(inst->d_tickets, sizeof(uint32_t) * 3u * batch_cap * VKSIFT_MAX_OCTAVES);
   ALLOC_D(inst->d_ori_ang, sizeof(float) * VKSIFT_HIP_MAX_ORI * inst->ori_cap * batch_cap);
   ALLOC_D(inst->d_ori_cnt, sizeof(uint32_t) * inst->ori_cap * batch_cap);
   ALLOC_D(inst->d_desc_fp, sizeof(float) * DESC_FP_TAB_MAX);
@@ -256,7 +252,6 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   memset(inst->h_found, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
   memset(inst->h_match_n, 0, sizeof(uint32_t) * 4 * batch_cap);
   if (vksift_hip_memset(inst->d_found, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count, inst->stream) != 0 ||
-      vksift_hip_memset(inst->d_tickets, 0, sizeof(uint32_t) * 3u * batch_cap * VKSIFT_MAX_OCTAVES, inst->stream) != 0 ||
       vksift_hip_memcpy_h2d(inst->d_desc_fp, fp_tab, sizeof(float) * inst->desc_fp_len, inst->stream) != 0 || vksift_hip_stream_sync(inst->stream) != 0)
   {
     logError(LOG_TAG, "vksift_createInstance() failure: device initialisation failed");
@@ -311,7 +306,6 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_free(inst->d_cand_xy);
   vksift_hip_free(inst->d_cand_flag);
   vksift_hip_free(inst->d_cand_n);
-  vksift_hip_free(inst->d_tickets);
   vksift_hip_free(inst->d_ori_ang);
   vksift_hip_free(inst->d_ori_cnt);
   vksift_hip_free(inst->d_desc_fp);
@@ -411,26 +405,6 @@ int wait_detect_seq(vksift_Instance inst, uint64_t seq)
   if (seq <= inst->det_done)
     return 0;
   const DetectSlot *d = &inst->det_ring[seq % VKSIFT_DETECT_RING];
-  /* VKSIFT_SPIN_WAIT_US=n: poll the event for up to n microseconds before blocking in hipEventSynchronize (experiment) */
-  static int spin_us = -1;
-  if (spin_us < 0)
-  {
-    const char *ev = getenv("VKSIFT_SPIN_WAIT_US");
-    spin_us = ev ? atoi(ev) : 0;
-  }
-  if (spin_us > 0)
-  {
-    struct timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (;;)
-    {
-      if (vksift_hip_event_busy(d->ev) != 1)
-        break;
-      clock_gettime(CLOCK_MONOTONIC, &t1);
-      if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000L > spin_us)
-        break;
-    }
-  }
   const int e = vksift_hip_event_sync(d->ev);
   if (d->seq > inst->det_done)
     inst->det_done = d->seq;

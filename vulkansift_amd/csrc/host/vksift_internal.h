@@ -127,7 +127,7 @@ struct vksift_Instance_T
   uint64_t *d_seg_mask;
   uint32_t *d_seg_off;
   uint64_t seg_cap; /* elements reserved per image */
-  uint32_t *d_cand_xy, *d_cand_flag, *d_cand_n, *d_tickets;
+  uint32_t *d_cand_xy, *d_cand_flag, *d_cand_n;
   uint64_t cand_cap; /* candidates reserved per image */
   float *d_ori_ang;
   uint32_t *d_ori_cnt;
