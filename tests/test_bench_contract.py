@@ -26,6 +26,8 @@ def test_stale_pmc_capture_is_refused(monkeypatch):
     assert got is not None and got["hbm_bytes_per_call"] == newest["hbm_bytes_per_call"]
     # ... and for the workload it was taken on
     assert b.pmc_traffic(newest["width"] + 2, newest["height"], newest["batch"]) is None
+    # ... and in the pyramid precision mode it was taken in: binary16 planes move half the bytes, an fp32 capture must not price them
+    assert b.pmc_traffic(newest["width"], newest["height"], newest["batch"], fp16=not newest.get("fp16", False)) is None
     # any other kernel source hash: no traffic figure rather than a stale one
     monkeypatch.setattr(b, "kernel_source_sha", lambda: "0" * 16)
     assert b.pmc_traffic(newest["width"], newest["height"], newest["batch"]) is None
