@@ -34,6 +34,7 @@ extern "C"
 /* u32 words of scratch vksift_hip_match_2nn_desc needs for na query rows against nb reference rows (norms of A and B, row flags /
  * row list, per-row partial lists of the decomposed kernels: 16 words per piece for the cell scan of large reference sets) */
 #define VKSIFT_HIP_MATCH_SCRATCH_U32(na, nb) (2u * (size_t)(na) + (size_t)(nb) + 72u + (size_t)(na) * 16u * VKSIFT_HIP_MATCH_CHUNKS)
+#define VKSIFT_HIP_ABI_VERSION 5u      /* bumped whenever a signature or a scratch contract of this header changes (vksift_hip_abi_version) */
 #define VKSIFT_HIP_MATCH_SLOTS 256u    /* pairs one vksift_hip_match_2nn_async launch sequence serves */
 #define VKSIFT_HIP_MATCH_PK_NB 32768u  /* reference sets of at most this many rows take the branch-free packed-key kernel (k_match_pk) */
 #define VKSIFT_HIP_MAX_ORI 18  /* a 36-bin circular histogram has at most 18 strict local maxima */
@@ -44,6 +45,7 @@ extern "C"
 
   /* ------------------------------------------------------------------ runtime (replaces the vkenv directory) */
   int vksift_hip_init(void);                          /* vulkan_device.c:17 vkenv_createInstance */
+  uint32_t vksift_hip_abi_version(void);              /* VKSIFT_HIP_ABI_VERSION the library was built with */
   int vksift_hip_device_count(void);                  /* vulkan_device.c: vkenv_getPhysicalDevicesProperties */
   int vksift_hip_device_name(int idx, char *out256);
   int vksift_hip_set_device(int idx);
@@ -215,18 +217,21 @@ extern "C"
   int vksift_hip_gather_descriptors(const uint8_t *feats, uint32_t n, uint8_t *desc, vksift_hip_stream s);
   /* Get2NearestNeighbors.comp (sift_matcher.c:246-279) on dense descriptor matrices in HBM, as an exact int8
    * MFMA contraction with a fused top-2 epilogue. desc_a: na rows, desc_b: nb >= 2 rows (callers pad, quirk Q6).
-   * norm_scratch: VKSIFT_HIP_MATCH_SCRATCH_U32(na, nb) u32 of scratch (2*na + nb suffice when na <= VKSIFT_HIP_MATCH_SMALL_NA and
-   * nb <= VKSIFT_HIP_MATCH_SMALL_NB). matches: na records of 20 B {idx_a = a_index_base + row, idx_b1,
+   * norm_scratch: scratch_u32 words of scratch, at least vksift_hip_match_scratch_u32(na, nb) (= the macro
+   * VKSIFT_HIP_MATCH_SCRATCH_U32; the call returns hipErrorInvalidValue WITHOUT launching anything when it is given less: the
+   * requirement grew between ABI versions 4 and 5, and a buffer sized by an old formula must fail loudly, not be overrun).
+   * matches: na records of 20 B {idx_a = a_index_base + row, idx_b1,
    * idx_b2, dist1, dist2}; B rows are scanned in index order, so sharding A rows over GPUs (a_index_base =
    * shard offset) gives bit-identical results to a single call. */
+  size_t vksift_hip_match_scratch_u32(uint32_t na, uint32_t nb);
   int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
-                                uint8_t *matches, vksift_hip_stream s);
+                                size_t scratch_u32, uint8_t *matches, vksift_hip_stream s);
   /* The two halves of vksift_hip_match_2nn_desc, for callers that overlap the pre-pass of A with the arrival of B (the sharded
    * matcher: RCCL all-gather of B): norms[i] = sum over the 128 bytes of (byte - 128)^2; scratch:
-   * VKSIFT_HIP_MATCH_SCRATCH_U32(na, nb) - 2*na - nb u32 (na of them suffice when na <= VKSIFT_HIP_MATCH_SMALL_NA and nb <= VKSIFT_HIP_MATCH_SMALL_NB). */
+   * scratch_u32 >= vksift_hip_match_scratch_u32(na, nb) - 2*na - nb words (checked like above). */
   int vksift_hip_shifted_norms(const uint8_t *desc, uint32_t n, uint32_t *norms, vksift_hip_stream s);
   int vksift_hip_match_2nn_prenormed(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b,
-                                     const uint32_t *norm_b, uint32_t nb, uint32_t *scratch, uint8_t *matches, vksift_hip_stream s);
+                                     const uint32_t *norm_b, uint32_t nb, uint32_t *scratch, size_t scratch_u32, uint8_t *matches, vksift_hip_stream s);
 
   /* Cross-check + Lowe ratio over forward (A->B) and optional reverse (B->A, rev != NULL) 2-NN records, the CPU loop of
    * src/examples/test_sift_match.cpp:90-107 / src/perf/perf_common.cpp:123-169: keep record i iff d1/d2 < ratio and (with

@@ -213,6 +213,30 @@ def test_match_device_pointer_api_chunked(vk, oracle):
     assert got["idx_b1"][7] == 3 and got["idx_b2"][7] == 700
 
 
+def test_match_device_pointer_api_refuses_an_undersized_scratch(vk):
+    """the scratch requirement of vksift_hip_match_2nn_desc grew with the cell scan (ABI version 5): a buffer sized by the old
+    formula (2 na + nb + 5 * 32 na words) is refused with hipErrorInvalidValue and NOTHING is launched — the record buffer keeps
+    its fill pattern; the library's own figure is accepted"""
+    import torch
+    L = vk.lib()
+    assert L.vksift_hip_abi_version() >= 5
+    na = nb = 40000
+    a = torch.from_numpy(vk.gen_synthetic_descriptors(71, na)).cuda()
+    b = torch.from_numpy(vk.gen_synthetic_descriptors(72, nb)).cuda()
+    out = torch.full((na, 5), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    need = int(L.vksift_hip_match_scratch_u32(na, nb))
+    old = 2 * na + nb + 5 * na * 32
+    assert old < need
+    scratch = torch.empty(need, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    err = L.vksift_hip_match_2nn_desc(a.data_ptr(), na, 0, b.data_ptr(), nb, scratch.data_ptr(), old, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert err == 1 and bool((out == 0x5A5A5A5A).all())
+    err = L.vksift_hip_match_2nn_desc(a.data_ptr(), na, 0, b.data_ptr(), nb, scratch.data_ptr(), need, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert err == 0 and bool((out[:, 0].cpu() == torch.arange(na, dtype=torch.int32)).all())
+
+
 @pytest.mark.parametrize("na,nb,via_ptr", [(9000, 300, False), (33000, 520, True)])
 def test_match_float_collisions_all_regimes(vk, oracle, na, nb, via_ptr):
     """d2 >= 2^22 candidates in the 16-rows-per-wave and the B-chunked kernels: flagged rows are replayed by the exact

@@ -137,6 +137,29 @@ def test_filtered_matching_of_128_pairs_in_one_call(vk, oracle):
         assert np.array_equal(got[k]["idx_a"], ra) and np.array_equal(got[k]["idx_b"], rb), k
 
 
+def test_256_distinct_pairs_over_512_buffers_in_one_call(vk, oracle):
+    """one launch sequence of VKSIFT_HIP_MATCH_SLOTS = 256 pairs whose two sides name 256 DISTINCT not-yet-cached buffers each
+    (even against odd, 512 buffers): the matcher cache of every one of them has to be gathered before the kernels read it
+    (vksift_match.c: refresh_match_cache walks the ids in passes of 128; round 4 stopped after the first 128 and matched slots
+    128..255 against stale cache entries). Small frames so that the oracle checks EVERY pair."""
+    B, W, H = 512, 128, 96
+    frames = np.stack([vk.gen_synthetic_image(0xC0FFEE + i, W, H) for i in range(B)])
+    cfg = vk.default_config(sift_buffer_count=B, input_image_max_size=W * H, max_nb_sift_per_buffer=4096)
+    a = list(range(0, B, 2))
+    b = list(range(1, B, 2))
+    with vk.Instance(cfg, batch_capacity=B) as inst:
+        inst.detectFeaturesBatch(list(frames), 0)
+        inst.matchFeaturesBatch(a, b)                      # nothing cached yet on either side
+        fwd = [inst.downloadMatchesBatch(k) for k in range(len(a))]
+        inst.matchFeaturesBatch(b, a)                      # everything cached now: the reverse direction
+        rev = [inst.downloadMatchesBatch(k) for k in range(len(a))]
+        feats = [inst.downloadFeatures(i) for i in range(B)]
+    assert min(len(f) for f in feats) >= 2
+    for k in range(len(a)):
+        assert fwd[k].tobytes() == oracle.match_2nn(feats[a[k]], feats[b[k]]).tobytes(), k
+        assert rev[k].tobytes() == oracle.match_2nn(feats[b[k]], feats[a[k]]).tobytes(), k
+
+
 def test_pipelined_two_buffer_sets_like_the_bench_leg(vk, oracle):
     """bench.py's value_host_input_pipelined: 2 x 128 buffers, detection of the next batch queued before the results of the current
     one are fetched. Accessors must wait for the detection that filled THEIR buffer (sequence-numbered completion events), results

@@ -157,7 +157,11 @@ def lib():
         getattr(L, name).restype = C.c_int
     L.vksift_hip_stream_sync.argtypes = [C.c_void_p]
     L.vksift_hip_stream_sync.restype = C.c_int
-    L.vksift_hip_match_2nn_desc.argtypes = [C.c_void_p, u32, u32, C.c_void_p, u32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vksift_hip_match_2nn_desc.argtypes = [C.c_void_p, u32, u32, C.c_void_p, u32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.vksift_hip_match_scratch_u32.argtypes = [u32, u32]
+    L.vksift_hip_match_scratch_u32.restype = C.c_size_t
+    L.vksift_hip_abi_version.argtypes = []
+    L.vksift_hip_abi_version.restype = u32
     L.vksift_hip_match_2nn_desc.restype = C.c_int
     L.vksift_hip_gather_descriptors.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p]
     L.vksift_hip_gather_descriptors.restype = C.c_int

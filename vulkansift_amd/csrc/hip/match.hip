@@ -2032,12 +2032,14 @@ extern "C"
   }
 
   int vksift_hip_match_2nn_prenormed(const uint8_t *desc_a, const uint32_t *norm_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b,
-                                     const uint32_t *norm_b, uint32_t nb, uint32_t *scratch, uint8_t *matches, vksift_hip_stream s)
+                                     const uint32_t *norm_b, uint32_t nb, uint32_t *scratch, size_t scratch_u32, uint8_t *matches, vksift_hip_stream s)
   {
     if (na == 0)
       return 0;
     if (nb < 2)
       return (int)hipErrorInvalidValue; /* callers pad B to two rows (quirk Q6) */
+    if (scratch == nullptr || scratch_u32 < vksift_hip_match_scratch_u32(na, nb) - 2u * (size_t)na - (size_t)nb)
+      return (int)hipErrorInvalidValue; /* a buffer sized by an older formula: nothing is launched */
     hipStream_t hs = (hipStream_t)s;
     uint32_t *redo = scratch;
     const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
@@ -2117,19 +2119,23 @@ extern "C"
     return (int)hipGetLastError();
   }
 
+  size_t vksift_hip_match_scratch_u32(uint32_t na, uint32_t nb) { return VKSIFT_HIP_MATCH_SCRATCH_U32(na, nb); }
+
   int vksift_hip_match_2nn_desc(const uint8_t *desc_a, uint32_t na, uint32_t a_index_base, const uint8_t *desc_b, uint32_t nb, uint32_t *norm_scratch,
-                                uint8_t *matches, vksift_hip_stream s)
+                                size_t scratch_u32, uint8_t *matches, vksift_hip_stream s)
   {
     if (na == 0)
       return 0;
     if (nb < 2)
       return (int)hipErrorInvalidValue; /* callers pad B to two rows (quirk Q6) */
+    if (norm_scratch == nullptr || scratch_u32 < vksift_hip_match_scratch_u32(na, nb))
+      return (int)hipErrorInvalidValue;
     uint32_t *norm_a = norm_scratch, *norm_b = norm_scratch + na;
     int e = vksift_hip_shifted_norms(desc_a, na, norm_a, s);
     if (e == 0)
       e = vksift_hip_shifted_norms(desc_b, nb, norm_b, s);
     if (e == 0)
-      e = vksift_hip_match_2nn_prenormed(desc_a, norm_a, na, a_index_base, desc_b, norm_b, nb, norm_scratch + na + nb, matches, s);
+      e = vksift_hip_match_2nn_prenormed(desc_a, norm_a, na, a_index_base, desc_b, norm_b, nb, norm_scratch + na + nb, scratch_u32 - na - nb, matches, s);
     return e;
   }
 

@@ -674,6 +674,209 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_blur_wide — the strip march of k_blur_lean with FOUR output texels per lane (256-column strips), fp32 plane -> fp32 plane.
+//
+// Why: the horizontal pass of k_blur_lean reads a (2R + 2)-float window per lane for 2 texels through ds_read2_b64 — the slow LDS
+// read form (128 B/clk/CU) and 5-14x read amplification; at 11 and 13 taps the LDS array is busy as long as the VALUs are
+// (8 waves x 7 ds_read2_b64 x 8 rows against 2 waves x ~900 VALU per SIMD and group), and the two do not hide behind each other
+// with two waves per SIMD. Here a lane owns texels 4L .. 4L+3 of the strip and reads the 16-byte-aligned window
+// [4L, 4L + 2 RA + 4) of the staged row with RA/2 + 1 ds_read_b128 (256 B/clk/CU): a quarter of the LDS-array cycles per texel.
+// The strip's horizontal halo (2 RA columns) is shared by 256 columns instead of 128, rows are stored 16 bytes per lane
+// (half the store instructions), every lane stages (64 + RA/2 float4 per row: the RA/2 beyond the 64 lanes of all 8 rows of a
+// group are ONE load + ONE LDS write of up to 48 lanes). The price is the register window: 4 floats x (2R + 8) rows.
+// Same operations per texel in the same order as k_blur_lean / blur_plane of the oracle: bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(64) k_blur_wide(StreamArgs a)
+{
+  constexpr int NR = 8;
+  constexpr int R = NT - 1;
+  constexpr int RA = (R + 3) & ~3;
+  constexpr int TW = 256;
+  constexpr int SW = TW + 2 * RA;
+  constexpr int NX = RA / 2;   // float4 columns of a staged row beyond the 64 that the lanes stage themselves
+  constexpr int NXT = NX * NR; // ... of a whole group: lane e < NXT stages float4 column 64 + e % NX of row e / NX
+  constexpr int NQ = RA / 2 + 1; // ds_read_b128 per row in the horizontal pass
+  constexpr int NWIN = 2 * R + NR;
+  static_assert(NXT <= 64, "the extra float4 columns of a group are staged by one instruction");
+  __shared__ __attribute__((aligned(16))) float s_grp[NR * SW];
+
+  const int lane = threadIdx.x;
+  const int W = a.w, H = a.h;
+  uint32_t bs = blockIdx.x, bseg = blockIdx.y, bimg = blockIdx.z;
+  {
+    // XCD-aware work mapping, as k_blur_lean
+    const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
+    const uint32_t b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    uint32_t wi = b;
+    if ((total & 7u) == 0)
+    {
+      const uint32_t per = total >> 3, k = b >> 3;
+      wi = (b & 7u) * per + (a.rev ? per - 1u - k : k);
+    }
+    else if (a.rev)
+      wi = total - 1u - b;
+    if ((total & 7u) == 0 || a.rev)
+    {
+      bs = wi % gridDim.x;
+      const uint32_t r = wi / gridDim.x;
+      bseg = r % gridDim.y;
+      bimg = r / gridDim.y;
+    }
+  }
+  const int x0 = bs * TW;
+  const int y0 = bseg * a.seg;
+  const int y1 = min(y0 + a.seg, H);
+  const __amdgpu_buffer_rsrc_t rs = plane_rsrc<false>(a.src, (size_t)bimg * a.src_img_stride, a.spitch, H);
+  const __amdgpu_buffer_rsrc_t rd = plane_rsrc<false>(a.dst, (size_t)bimg * a.dst_img_stride, a.dpitch, H);
+  const bool has_ds = a.ds != nullptr;
+  const __amdgpu_buffer_rsrc_t rds =
+      plane_rsrc<false>(has_ds ? a.ds : a.dst, has_ds ? (size_t)bimg * a.ds_img_stride : 0, has_ds ? a.ds_pitch : a.dpitch, has_ds ? H / 2 : H);
+  const int spitch4 = a.spitch * 4, dpitch4 = a.dpitch * 4, dspitch4 = a.ds_pitch * 4;
+
+  // ---- lane constants: the float4 column this lane stages in every row ...
+  auto col_off = [&](int gx4, bool &rv) -> unsigned {
+    if (gx4 >= 0 && gx4 + 3 < W)
+      return (unsigned)gx4 * 4u;
+    rv = true;
+    return (unsigned)mirror_idx(gx4 + 3, W) * 4u; // the four virtual columns map to m3+3, m3+2, m3+1, m3
+  };
+  bool rev = false, rev_x = false;
+  const unsigned ld_off = col_off(x0 - RA + 4 * lane, rev);
+  // ... and the (row, column) beyond the 64th float4 it stages once per group
+  const int xr = lane / NX, xq = 64 + lane % NX;
+  unsigned ldx_col = BUF_OOB;
+  if (lane < NXT)
+    ldx_col = col_off(x0 - RA + 4 * xq, rev_x);
+  const unsigned ldx_off = lane < NXT ? ldx_col + (unsigned)(xr * spitch4) : BUF_OOB;
+  float *const sx = s_grp + xr * SW + 4 * xq;
+  const int px = x0 + 4 * lane;
+  const unsigned st_off = px + 3 < W ? (unsigned)px * 4u : BUF_OOB;
+  const unsigned st_off_ds = px + 3 < W ? (unsigned)(px >> 1) * 4u : BUF_OOB; // columns px+1, px+3 -> px/2, px/2+1 of the half-size plane
+  const float k0 = a.taps.k[0];
+
+  u32x4 pf[NR], pfx;
+  auto prefetch = [&](int r0) {
+    if (r0 >= 0 && r0 + NR <= H)
+    {
+      int so = r0 * spitch4;
+      pfx = __builtin_amdgcn_raw_buffer_load_b128(rs, ldx_off, so, 0);
+#pragma unroll
+      for (int j = 0; j < NR; j++, so += spitch4)
+        pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, so, 0);
+    }
+    else
+    {
+      // a group that crosses the top or bottom edge: every row mirrored on its own (the extra column's row is a lane value)
+      const unsigned ox = lane < NXT ? ldx_col + (unsigned)(mirror_idx(r0 + xr, H) * spitch4) : BUF_OOB;
+      pfx = __builtin_amdgcn_raw_buffer_load_b128(rs, ox, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+        pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, mirror_idx(r0 + j, H) * spitch4, 0);
+    }
+  };
+
+  int rg = y0 - R; // first virtual row of the current group
+  prefetch(rg);
+
+  v4f wv[NWIN];
+#pragma unroll
+  for (int k = 0; k < NWIN; k++)
+    wv[k] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  for (; rg - R < y1; rg += NR)
+  {
+    // ---- stage the prefetched group, then prefetch the next one
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NR; j++)
+    {
+      u32x4 v = pf[j];
+      if (rev)
+        v = u32x4{v.w, v.z, v.y, v.x};
+      *(u32x4 *)(s_grp + j * SW + 4 * lane) = v;
+    }
+    if (lane < NXT)
+    {
+      u32x4 v = pfx;
+      if (rev_x)
+        v = u32x4{v.w, v.z, v.y, v.x};
+      *(u32x4 *)sx = v;
+    }
+    prefetch(rg + NR);
+    __syncthreads();
+
+    // ---- horizontal pass of the new rows, into the top of the register window: four independent accumulator chains per row
+    {
+      const v4f *hb = (const v4f *)(s_grp + 4 * lane);
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+      {
+        float va[4 * NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+        {
+          const v4f t = hb[j * (SW / 4) + q];
+          va[4 * q] = t.x, va[4 * q + 1] = t.y, va[4 * q + 2] = t.z, va[4 * q + 3] = t.w;
+        }
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          o[k] = va[RA + k] * k0;
+#pragma unroll
+        for (int i = 1; i < NT; i++)
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            o[k] = fmaf(va[RA + k + i] + va[RA + k - i], a.taps.k[i], o[k]);
+        wv[2 * R + j] = v4f{o[0], o[1], o[2], o[3]};
+      }
+    }
+
+    // ---- vertical pass: output rows yb .. yb+NR-1
+    const int yb = rg - R;
+    if (yb + NR > y0)
+    {
+      auto vrow = [&](int j, int so_d) {
+        v4f acc = wv[R + j] * k0;
+#pragma unroll
+        for (int i = 1; i < NT; i++)
+        {
+          const v4f sm = wv[R + j + i] + wv[R + j - i];
+          acc.x = fmaf(sm.x, a.taps.k[i], acc.x);
+          acc.y = fmaf(sm.y, a.taps.k[i], acc.y);
+          acc.z = fmaf(sm.z, a.taps.k[i], acc.z);
+          acc.w = fmaf(sm.w, a.taps.k[i], acc.w);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)}, rd, st_off,
+                                               so_d, ST_STREAM);
+        // vkCmdBlitImage(NEAREST) into the next octave, exact 2:1: destination (x, y) takes source (2x+1, 2y+1); yb is even
+        if (has_ds && (j & 1))
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc.y), __float_as_uint(acc.w)}, rds, st_off_ds, ((yb + j) >> 1) * dspitch4, ST_STREAM);
+      };
+      if (yb >= y0 && yb + NR <= y1)
+      {
+        int so_d = yb * dpitch4;
+#pragma unroll
+        for (int j = 0; j < NR; j++, so_d += dpitch4)
+          vrow(j, so_d);
+      }
+      else
+      {
+        int so_d = yb * dpitch4;
+#pragma unroll
+        for (int j = 0; j < NR; j++, so_d += dpitch4)
+          if (yb + j >= y0 && yb + j < y1)
+            vrow(j, so_d);
+      }
+    }
+    // ---- slide the window
+#pragma unroll
+    for (int k = 0; k < 2 * R; k++)
+      wv[k] = wv[k + NR];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_blur_pair — TWO consecutive scales in one launch: reads plane s-1 once, writes planes s and s+1 (12 B per texel instead
 // of 16 for the two launches of k_blur_lean; the chain of an octave is memory bound in its narrow-tap launches).
 //
@@ -1270,9 +1473,9 @@ extern "C"
   /* Row segments of the streaming kernel: enough workgroups to give every CU ~40 waves over the launch (2560 long-lived waves
    * left the slowest CU to set the time), but segments long enough that the 2R-row warm-up stays a small fraction; launches
    * that cannot fill the GPU anyway (small octaves, small batches) are latency bound and take shorter marches. */
-  static dim3 stream_grid(uint32_t w, uint32_t h, uint32_t batch, uint32_t wg_target, int *seg_out)
+  static dim3 stream_grid(uint32_t w, uint32_t h, uint32_t batch, uint32_t wg_target, int *seg_out, uint32_t strip_w = 128u)
   {
-    const uint32_t strips = (w + 127u) / 128u;
+    const uint32_t strips = (w + strip_w - 1u) / strip_w;
     uint32_t nseg = (wg_target + strips * batch - 1u) / (strips * batch);
     const uint32_t waves64 = strips * batch * ((h + 63u) / 64u);
     const uint32_t seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u);
@@ -1286,6 +1489,8 @@ extern "C"
     *seg_out = (int)seg;
     return dim3(strips, nseg, batch);
   }
+
+  constexpr int WIDE_DEFAULT_MASK = (1 << 9) | (1 << 11) | (1 << 13);
 
   static int blur_impl(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane ds, const float *taps, uint32_t ntaps, uint32_t batch, vksift_hip_stream s)
   {
@@ -1314,8 +1519,32 @@ extern "C"
     a.w = (int)src.w, a.h = (int)src.h;
     a.rev = (int)dst.reverse;
     a.taps = t;
-    const dim3 grid = stream_grid(src.w, src.h, batch, 10240u, &a.seg);
     hipStream_t hs = (hipStream_t)s;
+    /* four texels per lane on 256-column strips (k_blur_wide): fp32 planes whose width wastes little of the last strip */
+    static int wide_mask = -1;
+    if (wide_mask < 0)
+    {
+      const char *e = getenv("VKSIFT_BLUR_WIDE"); /* bit mask over the tap counts (bit n = n taps); 0: never (A/B runs) */
+      wide_mask = e ? (int)strtol(e, NULL, 0) : WIDE_DEFAULT_MASK;
+    }
+    const uint32_t wstrips = (src.w + 255u) / 256u;
+    if (!src.fp16 && !dst.fp16 && ((wide_mask >> ntaps) & 1) && (src.w % 4u) == 0 && ra <= src.w && wstrips * 256u + ra <= 2u * src.w &&
+        wstrips * 256u - src.w <= 64u && ((src.pitch | dst.pitch) & 3u) == 0)
+    {
+      const dim3 wgrid = stream_grid(src.w, src.h, batch, 10240u, &a.seg, 256u);
+      switch (ntaps)
+      {
+#define VKSIFT_CASE(N)                                              \
+  case N:                                                           \
+    hipLaunchKernelGGL((k_blur_wide<N>), wgrid, dim3(64), 0, hs, a); \
+    return (int)hipGetLastError();
+        VKSIFT_CASE(5) VKSIFT_CASE(7) VKSIFT_CASE(9) VKSIFT_CASE(11) VKSIFT_CASE(13)
+#undef VKSIFT_CASE
+      default:
+        break;
+      }
+    }
+    const dim3 grid = stream_grid(src.w, src.h, batch, 10240u, &a.seg);
     switch (ntaps)
     {
 #define VKSIFT_CASE(N)                                                        \

@@ -19,6 +19,8 @@ __global__ void k_post_words(uint32_t *__restrict__ dst, const uint32_t *__restr
 extern "C"
 {
 
+  uint32_t vksift_hip_abi_version(void) { return VKSIFT_HIP_ABI_VERSION; }
+
   int vksift_hip_init(void)
   {
     hipError_t e = hipInit(0);

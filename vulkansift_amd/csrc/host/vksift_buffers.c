@@ -222,8 +222,14 @@ static bool download_one_packed(vksift_Instance inst, vksift_Feature *feats_ptr,
   if (vksift_hip_memcpy_d2h(inst->h_dl, inst->d_dl, bytes, inst->dl_stream) != 0 || vksift_hip_stream_sync(inst->dl_stream) != 0)
     return false;
   memcpy(feats_ptr, inst->h_dl, bytes);
-  if (inst->post_enabled && !inst->post_on)
-    inst->post_on = true, inst->post_idle = 0; /* the caller does fetch single detections: post the next ones */
+  {
+    /* the caller does fetch single detections: post the next ones. (Not when this buffer came out of a batched detection — the first
+     * download of a batch lands here too, and says nothing about single-image use.) */
+    const DetectSlot *det = &inst->det_ring[b->seq % VKSIFT_DETECT_RING];
+    const bool single = b->seq != 0 && det->seq == b->seq && det->count == 1u;
+    if (single && inst->post_enabled && !inst->post_on)
+      inst->post_on = true, inst->post_idle = 0;
+  }
   return true;
 }
 

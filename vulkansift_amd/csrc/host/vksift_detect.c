@@ -464,7 +464,8 @@ static int enqueue_detection(DetectCtx *c)
           layers[q * nl + l] = plane_at(inst, o + q, L->gauss_off[o + q], l);
       if (!g0_done)
         TRY(vksift_hip_downsample(plane_at(inst, o - 1u, L->gauss_off[o - 1u], inst->S), layers[0], c->count, sp), "downsample");
-      const int ce = vksift_hip_octave_chain(layers, no, nl, inst->S, inst->taps, inst->ntaps, c->count, sp);
+      /* (lds_chain_refuse: test hook — S = nl is outside the shim's domain, so it declines exactly like a shape it does not cover) */
+      const int ce = vksift_hip_octave_chain(layers, no, nl, inst->lds_chain_refuse ? nl : inst->S, inst->taps, inst->ntaps, c->count, sp);
       if (ce > 0)
         TRY(ce, "coarse-octave chain");
       if (ce == 0)
@@ -473,7 +474,10 @@ static int enqueue_detection(DetectCtx *c)
           c->jobs[q].scan_reverse = 0u;
         break;
       }
-      g0_done = true; /* not covered after all: the octave's seed is in place, the per-scale launches follow */
+      /* not covered after all: the octave's seed is in place, the per-scale launches follow — for a forked detection trunk AND
+       * branch, so the branch loop below has to reach these octaves too (it stops at chain_from) */
+      g0_done = true;
+      chain_from = L->n_oct;
     }
     TRY(enqueue_pyramid(c, o, sp, 0, c->count, PYR_FIRST_GROUP | PYR_LAST_GROUP | (c->fork ? PYR_TRUNK : 0), &g0_done), "scale space construction");
   }
@@ -693,7 +697,9 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   c.nblur = 0;
   c.capturing = false;
   c.gpu_busy = detect_running(inst);
-  c.fork = inst->fork_scales && !c.overlap && !c.prof && (uint64_t)count * w * h <= inst->fork_max_pixels;
+  /* forked scale-space + LDS chain are latency measures for ONE image (or a handful): a batch on a single-buffer instance
+   * (batch_cap < 8 or VKSIFT_PYR_PINGPONG=0) fills the chip with its per-scale launches and takes those */
+  c.fork = inst->fork_scales && !c.overlap && !c.prof && count <= VKSIFT_FORK_MAX_COUNT && (uint64_t)count * w * h <= inst->fork_max_pixels;
   /* feature posting for single-image detections whose records fit the slot (every section is capacity-bounded) */
   c.post = false;
   if (count == 1 && inst->post_enabled && inst->post_on && c.L->n_oct > 0 && inst->bufs[first_buf].nb_sections > 0 && inst->bufs[first_buf].nb_sections <= 16)

@@ -206,8 +206,12 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     inst->side_stream = vksift_hip_stream_create();
     if (!inst->side_stream || !inst->ev_join[0] || !inst->ev_join[1])
       inst->fork_scales = false;
+    for (int i = 0; i < VKSIFT_MAX_OCTAVES; i++)
+      if (!inst->ev_fork[i])
+        inst->fork_scales = false;
     e = getenv("VKSIFT_LDS_CHAIN");
     inst->lds_chain = !(e && e[0] == '0');
+    inst->lds_chain_refuse = e && e[0] == 'r'; /* "refuse": the chain is attempted and declines (tests of the fallback) */
     e = getenv("VKSIFT_LDS_CHAIN_MAX");
     inst->lds_chain_max = e ? (uint32_t)strtoul(e, NULL, 10) : 4800u;
     if (inst->lds_chain_max > 19200u)

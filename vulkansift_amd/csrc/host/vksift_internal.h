@@ -25,6 +25,7 @@
 #define VKSIFT_DL_BATCH_MIN 8u
 #define VKSIFT_DL_CHUNKS 8u
 #define VKSIFT_UP_GROUPS 8u
+#define VKSIFT_FORK_MAX_COUNT 4u /* forked scale-space (and the LDS chain): detections of at most this many images */
 #define FEAT_BYTES 164u
 #define MATCH_BYTES 20u
 #define PITCH_ALIGN 64u
@@ -183,6 +184,7 @@ struct vksift_Instance_T
   bool fork_scales; /* VKSIFT_FORK_SCALES (default 1) */
   uint64_t fork_max_pixels; /* ... for detections of at most this many input pixels (VKSIFT_FORK_MAX_PIXELS) */
   uint32_t lds_chain_max; /* largest plane (texels) an octave of the chain may have: VKSIFT_LDS_CHAIN_MAX, at most 19200 (the LDS) */
+  bool lds_chain_refuse; /* VKSIFT_LDS_CHAIN=refuse: test hook, the chain launch declines and the per-scale launches take over */
   bool lds_chain; /* VKSIFT_LDS_CHAIN (default 1): the trailing octaves that fit the LDS are built by one launch (vksift_hip_octave_chain) */
   bool alt_order; /* VKSIFT_PYR_ALTERNATE (default 1): launches of a blur chain alternate their dispatch direction (vksift_hip_Plane::reverse) */
   vksift_hip_event ev_match;

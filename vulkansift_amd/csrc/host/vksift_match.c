@@ -67,46 +67,59 @@ int refresh_match_cache(vksift_Instance inst, const uint32_t *ids, uint32_t coun
   if (ce)
     return ce;
   (void)detect_running(inst); /* polls the detections in flight: counts_valid() is up to date */
-  uint32_t todo[128];
-  uint32_t n = 0;
-  for (uint32_t i = 0; i < count && n < 128; i++)
+  /* Passes of at most 128 not-yet-cached buffers until none is left: a run of VKSIFT_HIP_MATCH_SLOTS (256) pairs may name that many
+   * distinct buffers per side, and every one of them must be gathered before the matching kernels read its cache entry. */
+  for (;;)
   {
-    bool seen = inst->cache_valid[ids[i]];
-    for (uint32_t k = 0; k < n && !seen; k++)
-      seen = todo[k] == ids[i];
-    if (!seen)
+    uint32_t todo[128];
+    uint32_t n = 0;
+    bool more = false;
+    for (uint32_t i = 0; i < count; i++)
+    {
+      bool seen = inst->cache_valid[ids[i]];
+      for (uint32_t k = 0; k < n && !seen; k++)
+        seen = todo[k] == ids[i];
+      if (seen)
+        continue;
+      if (n == 128)
+      {
+        more = true; /* taken by the next pass */
+        break;
+      }
       todo[n++] = ids[i];
-  }
-  uint32_t i0 = 0;
-  while (i0 < n)
-  {
-    /* one launch per run of buffers that share a section layout (always all of them after a batched detection) */
-    const BufferInfo *b = &inst->bufs[todo[i0]];
-    uint32_t i1 = i0 + 1, max_rows = rows_bound(inst, todo[i0]);
-    while (i1 < n && i1 - i0 < 64 && same_layout(b, &inst->bufs[todo[i1]]))
-    {
-      const uint32_t r = rows_bound(inst, todo[i1]);
-      max_rows = r > max_rows ? r : max_rows;
-      i1++;
     }
-    int e;
-    if (b->nb_sections == 0)
+    uint32_t i0 = 0;
+    while (i0 < n)
     {
-      uint32_t zero_off = 0, cap1 = b->nb_stored, fixed1 = b->nb_stored;
-      e = vksift_hip_gather_sections(inst->d_feats, inst->buf_stride, todo + i0, i1 - i0, 1, &zero_off, &cap1, &fixed1, NULL, 0, max_rows, 2u, inst->d_cache_desc,
-                                     inst->desc_slot_stride, inst->d_cache_norm, inst->cache_norm_stride, inst->d_cache_n, 1, inst->stream);
+      /* one launch per run of buffers that share a section layout (always all of them after a batched detection) */
+      const BufferInfo *b = &inst->bufs[todo[i0]];
+      uint32_t i1 = i0 + 1, max_rows = rows_bound(inst, todo[i0]);
+      while (i1 < n && i1 - i0 < 64 && same_layout(b, &inst->bufs[todo[i1]]))
+      {
+        const uint32_t r = rows_bound(inst, todo[i1]);
+        max_rows = r > max_rows ? r : max_rows;
+        i1++;
+      }
+      int e;
+      if (b->nb_sections == 0)
+      {
+        uint32_t zero_off = 0, cap1 = b->nb_stored, fixed1 = b->nb_stored;
+        e = vksift_hip_gather_sections(inst->d_feats, inst->buf_stride, todo + i0, i1 - i0, 1, &zero_off, &cap1, &fixed1, NULL, 0, max_rows, 2u,
+                                       inst->d_cache_desc, inst->desc_slot_stride, inst->d_cache_norm, inst->cache_norm_stride, inst->d_cache_n, 1, inst->stream);
+      }
+      else
+        e = vksift_hip_gather_sections(inst->d_feats, inst->buf_stride, todo + i0, i1 - i0, b->nb_sections, b->sec_off, b->sec_cap, NULL, inst->d_found,
+                                       VKSIFT_MAX_OCTAVES, max_rows, 2u, inst->d_cache_desc, inst->desc_slot_stride, inst->d_cache_norm, inst->cache_norm_stride,
+                                       inst->d_cache_n, 1, inst->stream);
+      if (e)
+        return e;
+      for (uint32_t k = i0; k < i1; k++)
+        inst->cache_valid[todo[k]] = true;
+      i0 = i1;
     }
-    else
-      e = vksift_hip_gather_sections(inst->d_feats, inst->buf_stride, todo + i0, i1 - i0, b->nb_sections, b->sec_off, b->sec_cap, NULL, inst->d_found,
-                                     VKSIFT_MAX_OCTAVES, max_rows, 2u, inst->d_cache_desc, inst->desc_slot_stride, inst->d_cache_norm, inst->cache_norm_stride,
-                                     inst->d_cache_n, 1, inst->stream);
-    if (e)
-      return e;
-    for (uint32_t k = i0; k < i1; k++)
-      inst->cache_valid[todo[k]] = true;
-    i0 = i1;
+    if (!more)
+      return 0;
   }
-  return 0;
 }
 
 MatchScratch fwd_scratch(vksift_Instance inst)

@@ -238,7 +238,7 @@ static int shard_reserve(vksift_ext_ShardGroup g, uint32_t na, size_t nb_rows)
 {
   const size_t b_bytes = nb_rows * 128u;
   /* norms of A, norms of B (padded rows included), redo flags, partial lists of the stream-decomposed kernel */
-  const size_t scratch = VKSIFT_HIP_MATCH_SCRATCH_U32(na, nb_rows);
+  const size_t scratch = vksift_hip_match_scratch_u32(na, (uint32_t)nb_rows);
   if (b_bytes <= g->b_cap && scratch <= g->scratch_cap)
     return 0;
   vksift_hip_stream_sync(g->comm_stream);
@@ -325,7 +325,8 @@ vksift_Result vksift_ext_matchSharded(vksift_ext_ShardGroup g, const uint8_t *d_
   if (e == 0 && compute)
     e = vksift_hip_shifted_norms(g->d_b_full, nb_total, norm_b, g->stream);
   if (e == 0 && compute)
-    e = vksift_hip_match_2nn_prenormed(d_a_rows, norm_a, na, a_index_base, g->d_b_full, norm_b, nb_total, rest, d_matches, g->stream);
+    e = vksift_hip_match_2nn_prenormed(d_a_rows, norm_a, na, a_index_base, g->d_b_full, norm_b, nb_total, rest,
+                                       g->scratch_cap - na - (size_t)nb_shard * g->world, d_matches, g->stream);
   if (e == 0)
     e = vksift_hip_event_record(g->ev_t1, g->stream);
   vksift_hip_range_pop();

@@ -57,10 +57,11 @@ def hip_match_fn(desc_a, a_index_base, desc_b):
     assert desc_a.is_cuda and desc_b.is_cuda and desc_a.dtype == torch.uint8 and desc_b.dtype == torch.uint8
     assert desc_a.is_contiguous() and desc_b.is_contiguous() and nb >= 2
     out = torch.empty((na, 5), dtype=torch.int32, device=desc_a.device)
-    # VKSIFT_HIP_MATCH_SCRATCH_U32(na, nb) of include/vksift_hip.h: norms, row list, per-row lists of the decomposed kernels
-    scratch = torch.empty(2 * na + nb + 72 + na * 16 * 32, dtype=torch.int32, device=desc_a.device)
+    # the library's own figure (norms, row list, per-row lists of the decomposed kernels): never a formula restated here
+    n_words = int(api.lib().vksift_hip_match_scratch_u32(na, nb))
+    scratch = torch.empty(n_words, dtype=torch.int32, device=desc_a.device)
     stream = torch.cuda.current_stream(desc_a.device).cuda_stream
-    err = api.lib().vksift_hip_match_2nn_desc(desc_a.data_ptr(), na, a_index_base, desc_b.data_ptr(), nb, scratch.data_ptr(), out.data_ptr(), stream)
+    err = api.lib().vksift_hip_match_2nn_desc(desc_a.data_ptr(), na, a_index_base, desc_b.data_ptr(), nb, scratch.data_ptr(), n_words, out.data_ptr(), stream)
     if err != 0:
         raise RuntimeError(f"vksift_hip_match_2nn_desc failed with HIP error {err}")
     return out
