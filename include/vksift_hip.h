@@ -82,6 +82,16 @@ extern "C"
   void vksift_hip_range_push(const char *name);       /* roctx marker == VK_EXT_debug_marker region */
   void vksift_hip_range_pop(void);
 
+  /* Development knobs of the launch shims (A/B tools only; nothing in the library or the tests of its results depends on them:
+   * every setting produces identical planes). */
+  enum
+  {
+    VKSIFT_TUNE_WG_TARGET = 0, /* waves per strip-march launch aimed at (0 = built-in) */
+    VKSIFT_TUNE_WIDE_MASK = 1, /* bit n: n-tap launches take the four-texels-per-lane form (-1 = built-in) */
+    VKSIFT_TUNE_COUNT = 8
+  };
+  int vksift_hip_tune(int knob, int value);
+
   /* ------------------------------------------------------------------ pyramid */
   /* A batch of same-sized planes. */
   typedef struct

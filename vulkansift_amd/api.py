@@ -127,6 +127,8 @@ def lib():
     L.vksift_ext_getDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings)]
     L.vksift_ext_getAccumulatedDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.POINTER(u32), C.c_bool]
     L.vksift_ext_getDetectTimingsSized.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.c_size_t]
+    L.vksift_ext_getScaleSpacePlacement.argtypes = [inst, C.POINTER(C.c_float), C.POINTER(u32)]
+    L.vksift_ext_getScaleSpacePlacement.restype = u32
     L.vksift_ext_getAccumulatedDetectTimingsSized.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.c_size_t, C.POINTER(u32), C.c_bool]
     L.vksift_ext_getMatchTime.argtypes = [inst]
     L.vksift_ext_getMatchTime.restype = C.c_float
@@ -435,6 +437,13 @@ class Instance:
         d = {f[0]: getattr(t, f[0]) for f in t._fields_}
         d["nb_calls"] = n.value
         return d
+
+    def getScaleSpacePlacement(self):
+        """candidate memory ranges timed at allocation: {"gbps": [...], "chosen": [...]} (empty lists: plain allocation)"""
+        g = (C.c_float * 8)()
+        ch = (C.c_uint32 * 2)()
+        n = lib().vksift_ext_getScaleSpacePlacement(self._h, g, ch)
+        return {"gbps": [round(float(g[i]), 1) for i in range(n)], "chosen": [int(ch[0]), int(ch[1])] if n else []}
 
     def getMatchTime(self):
         return lib().vksift_ext_getMatchTime(self._h)

@@ -286,10 +286,26 @@ struct StreamArgs
 // XCD until its reader (the next launch) comes by, and written the ordinary way it evicts the source rows the neighbouring strips
 // and segments are about to re-read (halo columns, warm-up rows). Measured, same box: octave 0's launches 5.95 -> 5.59 ms per 512
 // frames, +1.6 % frames/s; `sc0` (the other candidate) changes nothing.
-constexpr int ST_STREAM = 2; // the `nt` bit of a gfx950 buffer instruction
+#ifndef VKSIFT_ST_POLICY
+#define VKSIFT_ST_POLICY 2
+#endif
+constexpr int ST_STREAM = VKSIFT_ST_POLICY; // 2 = the `nt` bit of a gfx950 buffer instruction
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned BUF_OOB = 0x80000000u; // byte offset beyond any plane: loads return 0, stores are dropped
+
+// A 16-byte buffer store whose data registers the NEXT instruction may overwrite. gfx950 reads the store data of a wave over several
+// cycles after issue; hipcc (ROCm 7.2) inserts the wait state this needs only when the store has NO scalar offset register
+// (GCNHazardRecognizer: "this hazard only exists if the instruction is not using a register in the soffset field"), yet with
+// `buffer_store_dwordx4 v[36:39], v88, s[12:15], s68 offen nt` directly followed by `v_pk_mul_f32 v[38:39], ...` the LAST dword of
+// lanes 12-15 of every 16 arrived in memory with the next row's value (found by the first bit-comparison of k_blur_wide against
+// k_blur_lean, whose stores are 8 bytes wide and have no such hazard). Two wait states behind the store, fenced against the scheduler.
+__device__ __forceinline__ void store_b128_stream(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, ST_STREAM);
+  asm volatile("s_nop 1");
+  __builtin_amdgcn_sched_barrier(0);
+}
 
 template <bool F16>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base, size_t texel_off, int pitch, int h)
@@ -684,7 +700,9 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 // The strip's horizontal halo (2 RA columns) is shared by 256 columns instead of 128, rows are stored 16 bytes per lane
 // (half the store instructions), every lane stages (64 + RA/2 float4 per row: the RA/2 beyond the 64 lanes of all 8 rows of a
 // group are ONE load + ONE LDS write of up to 48 lanes). The price is the register window: 4 floats x (2R + 8) rows.
-// Same operations per texel in the same order as k_blur_lean / blur_plane of the oracle: bit-identical.
+// Same operations per texel in the same order as k_blur_lean / blur_plane of the oracle: bit-identical. (The fused up-sampling + seed
+// launch was built in this form too, bit-identical at the first run and no faster — 542 vs 530 us per 512 frames: that launch issues
+// ~930 VALU instructions per 2048 texels in either form, conversion and interpolation of the u8 source among them — and is not kept.)
 // ---------------------------------------------------------------------------------------------
 template <int NT>
 __global__ void __launch_bounds__(64) k_blur_wide(StreamArgs a)
@@ -732,7 +750,7 @@ __global__ void __launch_bounds__(64) k_blur_wide(StreamArgs a)
   const bool has_ds = a.ds != nullptr;
   const __amdgpu_buffer_rsrc_t rds =
       plane_rsrc<false>(has_ds ? a.ds : a.dst, has_ds ? (size_t)bimg * a.ds_img_stride : 0, has_ds ? a.ds_pitch : a.dpitch, has_ds ? H / 2 : H);
-  const int spitch4 = a.spitch * 4, dpitch4 = a.dpitch * 4, dspitch4 = a.ds_pitch * 4;
+  const int spitch4 = a.spitch * 4, dpitch4 = a.dpitch * 4, dspitch4 = a.ds_pitch * 4; // row pitches in bytes
 
   // ---- lane constants: the float4 column this lane stages in every row ...
   auto col_off = [&](int gx4, bool &rv) -> unsigned {
@@ -847,8 +865,7 @@ __global__ void __launch_bounds__(64) k_blur_wide(StreamArgs a)
           acc.z = fmaf(sm.z, a.taps.k[i], acc.z);
           acc.w = fmaf(sm.w, a.taps.k[i], acc.w);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)}, rd, st_off,
-                                               so_d, ST_STREAM);
+        store_b128_stream(u32x4{__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)}, rd, st_off, so_d);
         // vkCmdBlitImage(NEAREST) into the next octave, exact 2:1: destination (x, y) takes source (2x+1, 2y+1); yb is even
         if (has_ds && (j & 1))
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc.y), __float_as_uint(acc.w)}, rds, st_off_ds, ((yb + j) >> 1) * dspitch4, ST_STREAM);
@@ -1470,12 +1487,25 @@ extern "C"
     return (int)hipGetLastError();
   }
 
+  /* development knobs set through vksift_hip_tune() by the A/B tools (tools/blur_ab.py): -1 / 0 = the built-in choice */
+  static int g_tune[VKSIFT_TUNE_COUNT] = {0, -1, 0, 0, 0, 0, 0, 0};
+
+  int vksift_hip_tune(int knob, int value)
+  {
+    if (knob < 0 || knob >= VKSIFT_TUNE_COUNT)
+      return -1;
+    g_tune[knob] = value;
+    return 0;
+  }
+
   /* Row segments of the streaming kernel: enough workgroups to give every CU ~40 waves over the launch (2560 long-lived waves
    * left the slowest CU to set the time), but segments long enough that the 2R-row warm-up stays a small fraction; launches
    * that cannot fill the GPU anyway (small octaves, small batches) are latency bound and take shorter marches. */
   static dim3 stream_grid(uint32_t w, uint32_t h, uint32_t batch, uint32_t wg_target, int *seg_out, uint32_t strip_w = 128u)
   {
     const uint32_t strips = (w + strip_w - 1u) / strip_w;
+    if (g_tune[VKSIFT_TUNE_WG_TARGET] > 0)
+      wg_target = (uint32_t)g_tune[VKSIFT_TUNE_WG_TARGET];
     uint32_t nseg = (wg_target + strips * batch - 1u) / (strips * batch);
     const uint32_t waves64 = strips * batch * ((h + 63u) / 64u);
     const uint32_t seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u);
@@ -1491,7 +1521,6 @@ extern "C"
   }
 
   constexpr int WIDE_DEFAULT_MASK = (1 << 9) | (1 << 11) | (1 << 13);
-
   static int blur_impl(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane ds, const float *taps, uint32_t ntaps, uint32_t batch, vksift_hip_stream s)
   {
     if (ntaps < 1 || ntaps > VKSIFT_HIP_MAX_TAPS || src.base == dst.base || dst.base == NULL)
@@ -1521,12 +1550,13 @@ extern "C"
     a.taps = t;
     hipStream_t hs = (hipStream_t)s;
     /* four texels per lane on 256-column strips (k_blur_wide): fp32 planes whose width wastes little of the last strip */
-    static int wide_mask = -1;
-    if (wide_mask < 0)
+    static int wide_env = -2;
+    if (wide_env == -2)
     {
       const char *e = getenv("VKSIFT_BLUR_WIDE"); /* bit mask over the tap counts (bit n = n taps); 0: never (A/B runs) */
-      wide_mask = e ? (int)strtol(e, NULL, 0) : WIDE_DEFAULT_MASK;
+      wide_env = e ? (int)strtol(e, NULL, 0) : -1;
     }
+    const int wide_mask = g_tune[VKSIFT_TUNE_WIDE_MASK] >= 0 ? g_tune[VKSIFT_TUNE_WIDE_MASK] : (wide_env >= 0 ? wide_env : WIDE_DEFAULT_MASK);
     const uint32_t wstrips = (src.w + 255u) / 256u;
     if (!src.fp16 && !dst.fp16 && ((wide_mask >> ntaps) & 1) && (src.w % 4u) == 0 && ra <= src.w && wstrips * 256u + ra <= 2u * src.w &&
         wstrips * 256u - src.w <= 64u && ((src.pitch | dst.pitch) & 3u) == 0)

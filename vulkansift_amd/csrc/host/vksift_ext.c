@@ -69,6 +69,14 @@ void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext
   vksift_ext_getAccumulatedDetectTimingsSized(instance, sum, VKSIFT_EXT_DETECT_TIMINGS_V1_BYTES, nb_calls, reset);
 }
 
+uint32_t vksift_ext_getScaleSpacePlacement(vksift_Instance instance, float gbps[8], uint32_t chosen[2])
+{
+  for (uint32_t i = 0; i < 8u; i++)
+    gbps[i] = i < instance->place_n ? instance->place_gbps[i] : 0.f;
+  chosen[0] = instance->place_chosen[0], chosen[1] = instance->place_chosen[1];
+  return instance->place_n;
+}
+
 static void last_timings(vksift_Instance instance, vksift_ext_DetectTimings *out)
 {
   memset(out, 0, sizeof(*out));

@@ -36,6 +36,8 @@ void compute_layout(vksift_Instance inst, uint32_t w, uint32_t h, PyrLayout *L)
   L->cand_total = co;
 }
 
+static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t img_stride, const PyrLayout *L, uint32_t need, float **out);
+
 void set_buffer_sections(vksift_Instance inst, uint32_t buf, uint32_t n_oct, uint32_t w, uint32_t h)
 {
   BufferInfo *b = &inst->bufs[buf];
@@ -143,10 +145,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     const char *e = getenv("VKSIFT_PYR_PINGPONG");
     inst->pyr_pingpong = e ? (e[0] == '1') : (batch_cap >= 8u);
   }
-  ALLOC_D(inst->d_pyr_buf[0], pyr_texel_bytes(inst) * inst->pyr_img_stride * batch_cap);
-  if (inst->pyr_pingpong)
-    ALLOC_D(inst->d_pyr_buf[1], pyr_texel_bytes(inst) * inst->pyr_img_stride * batch_cap);
-  inst->d_pyr = inst->d_pyr_buf[0];
+  /* (the scale-space buffers themselves: below, once the stream exists — they are placed by measurement, place_pyramid_buffers) */
   ALLOC_D(inst->d_input, (size_t)inst->max_image_size * batch_cap);
   ALLOC_H(inst->h_input, (size_t)inst->max_image_size * batch_cap);
   ALLOC_D(inst->d_feats, inst->buf_stride * config->sift_buffer_count);
@@ -182,6 +181,13 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   /* All streams at the default priority: a high-priority instance stream with low-priority octave streams was measured
    * 20 % slower on MI355X (11.3k vs 14.1k frames/s). */
   inst->stream = vksift_hip_stream_create();
+  if (ok)
+  {
+    /* first of the large blocks after the stream: candidates need room, and everything allocated before stays where it is */
+    ok = place_pyramid_buffers(inst, pyr_texel_bytes(inst) * inst->pyr_img_stride * batch_cap, inst->pyr_img_stride, &L, inst->pyr_pingpong ? 2u : 1u,
+                               inst->d_pyr_buf);
+    inst->d_pyr = inst->d_pyr_buf[0];
+  }
   inst->pyr_stream = vksift_hip_stream_create();
   inst->dl_stream = vksift_hip_stream_create();
   inst->up_stream = vksift_hip_stream_create();
@@ -425,6 +431,133 @@ bool match_running(vksift_Instance inst)
   memset(inst->match_busy, 0, sizeof(bool) * inst->cfg.sift_buffer_count);
   return false;
 }
+/* ------------------------------------------------------------------------------------------------ */
+/* Where in HBM the scale-space lives (round 5; DESIGN.md §8, tools/microbench/stream_patterns.hip)    */
+/* ------------------------------------------------------------------------------------------------ */
+/* The strip-march launches of pyramid.hip and the extrema scan — thousands of waves each streaming its own row segment — run at
+ * 4.9-5.0 TB/s on some ranges of the device's memory and at 5.9-6.1 TB/s on others, for the SAME kernel, sizes and strides: measured
+ * with a pure copy in that access pattern sliding over a 240 GiB allocation of an idle MI355X, the first ~40 GB of a fresh process's
+ * memory and a few later windows are the slow ones, ~75-170 GB the fast plateau; a linear copy runs at 6.2 TB/s everywhere. A fresh
+ * process gets the low range first, so an instance that simply allocates its scale-space takes the slow memory. The two
+ * scale-space buffers of a batch instance are therefore chosen by measurement: allocate a candidate, time one whole-batch blur
+ * launch of octave 0 on it (the pattern that matters, 1 warm-up + 3 runs of ~1 ms), keep it, allocate the next — rejected candidates
+ * stay allocated while the search runs, so that the allocator has to hand out new ranges — until `need` candidates run within
+ * VKSIFT_PLACE_SPREAD of the best AND a slower range has been seen (the fast mode is identified), or everything looks alike, or the
+ * candidate / memory budget is used up; then every candidate but the best `need` is freed. Nothing depends on it but speed.
+ * VKSIFT_PYR_PLACEMENT=<max candidates> (default 7; 0 or 1: plain allocation). */
+#define VKSIFT_PLACE_MAX 8
+#define VKSIFT_PLACE_SPREAD 1.04f
+static float placement_probe_ms(vksift_Instance inst, void *buf, uint64_t img_stride, const PyrLayout *L, vksift_hip_event e0, vksift_hip_event e1)
+{
+  vksift_hip_Plane src, dst;
+  src.base = (float *)((uint8_t *)buf + L->gauss_off[0] * pyr_texel_bytes(inst));
+  src.fp16 = inst->fp16 ? 1u : 0u, src.reverse = 0;
+  /* (a width the strip-march kernels take — the reservation's square layout may have one they leave to the generic tile kernel) */
+  src.w = L->w[0] >= 512u ? (L->w[0] & ~255u) : (L->w[0] & ~3u);
+  src.h = L->h[0], src.pitch = L->pitch[0], src.img_stride = img_stride;
+  dst = src;
+  dst.base = (float *)((uint8_t *)buf + (L->gauss_off[0] + L->plane_stride[0]) * pyr_texel_bytes(inst));
+  float best = -1.f;
+  for (int r = 0; r < 4; r++)
+  {
+    dst.reverse = (uint32_t)(r & 1);
+    if (vksift_hip_event_record(e0, inst->stream) != 0 ||
+        vksift_hip_blur(src, dst, &inst->taps[1 * VKSIFT_MAX_TAPS], inst->ntaps[1], inst->batch_cap, inst->stream) != 0 ||
+        vksift_hip_event_record(e1, inst->stream) != 0 || vksift_hip_event_sync(e1) != 0)
+      return -1.f;
+    const float ms = vksift_hip_event_elapsed_ms(e0, e1);
+    if (r > 0 && ms > 0.f && (best < 0.f || ms < best))
+      best = ms;
+  }
+  return best;
+}
+
+/* out[0 .. need): device blocks of `bytes` each for a scale-space of layout L (octave 0 is what gets timed); false: out of memory
+ * (nothing is left allocated). */
+static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t img_stride, const PyrLayout *L, uint32_t need, float **out)
+{
+  int max_cand = 7;
+  {
+    const char *e = getenv("VKSIFT_PYR_PLACEMENT");
+    if (e)
+      max_cand = atoi(e);
+    if (max_cand > VKSIFT_PLACE_MAX)
+      max_cand = VKSIFT_PLACE_MAX;
+  }
+  inst->place_n = 0;
+  vksift_hip_event e0 = NULL, e1 = NULL;
+  const bool search = max_cand > (int)need && inst->batch_cap >= 8u && bytes >= ((size_t)256 << 20) && L->n_oct > 0 && inst->stream != NULL &&
+                      (e0 = vksift_hip_event_create()) != NULL && (e1 = vksift_hip_event_create()) != NULL;
+  void *cand[VKSIFT_PLACE_MAX] = {NULL};
+  float ms[VKSIFT_PLACE_MAX];
+  uint32_t n = 0;
+  bool ok = true;
+  while (n < need || (search && n < (uint32_t)max_cand))
+  {
+    if (n >= need)
+    {
+      /* another candidate only while the device still has room for it and the rest of an instance */
+      if (vksift_hip_device_free_mem() < bytes + ((size_t)24 << 30))
+        break;
+      /* stop rules (sorted view of what has been timed) */
+      float lo = ms[0], hi = ms[0];
+      uint32_t near_best = 0;
+      for (uint32_t i = 0; i < n; i++)
+        lo = ms[i] < lo ? ms[i] : lo, hi = ms[i] > hi ? ms[i] : hi;
+      for (uint32_t i = 0; i < n; i++)
+        near_best += ms[i] <= lo * VKSIFT_PLACE_SPREAD ? 1u : 0u;
+      if (near_best >= need && hi > lo * 1.08f)
+        break; /* the fast mode has been seen `need` times, and a slow one beside it */
+      if (n >= need + 2u && hi <= lo * VKSIFT_PLACE_SPREAD)
+        break; /* this memory is all alike */
+    }
+    void *p = vksift_hip_malloc(bytes);
+    if (!p)
+    {
+      ok = n >= need;
+      break;
+    }
+    cand[n] = p;
+    ms[n] = search ? placement_probe_ms(inst, p, img_stride, L, e0, e1) : 0.f;
+    if (search && ms[n] <= 0.f)
+      ms[n] = 1e9f; /* the probe failed: last choice */
+    n++;
+  }
+  if (ok && n >= need)
+  {
+    /* the `need` fastest, the rest goes back */
+    for (uint32_t k = 0; k < need; k++)
+    {
+      uint32_t b = 0;
+      for (uint32_t i = 0; i < n; i++)
+        if (cand[i] && (!cand[b] || ms[i] < ms[b]))
+          b = i;
+      out[k] = (float *)cand[b];
+      inst->place_chosen[k] = b;
+      cand[b] = NULL;
+    }
+    for (uint32_t i = 0; i < n; i++)
+    {
+      const double px = (double)(L->w[0] >= 512u ? (L->w[0] & ~255u) : (L->w[0] & ~3u)) * L->h[0] * inst->batch_cap * 2.0 * (double)pyr_texel_bytes(inst);
+      inst->place_gbps[i] = (search && ms[i] < 1e8f) ? (float)(px / (ms[i] * 1e-3) / 1e9) : 0.f;
+    }
+    inst->place_n = search ? n : 0;
+    if (search)
+      logInfo(LOG_TAG, "scale-space placement: %u candidate range(s) of %.1f GB timed, fastest %.0f GB/s, slowest %.0f GB/s", n, bytes / 1e9,
+              inst->place_gbps[inst->place_chosen[0]], inst->place_gbps[0]);
+  }
+  else
+    ok = false;
+  for (uint32_t i = 0; i < n; i++)
+    vksift_hip_free(cand[i]); /* NULL for the chosen ones */
+  vksift_hip_event_destroy(e0);
+  vksift_hip_event_destroy(e1);
+  if (!ok)
+    for (uint32_t k = 0; k < need; k++)
+      out[k] = NULL;
+  return ok;
+}
+
 /* The reservation made at creation covers a square image of input_image_max_size pixels plus 25 %. A narrow image of the
  * same area can need more (every row is padded to 64 floats on every octave: 139x356 needs 1.5x). The reference re-creates
  * its images for every new input resolution (sift_memory.c:362-452); here the per-image scratch grows, once, to what the
@@ -453,10 +586,8 @@ int grow_image_scratch(vksift_Instance inst, const PyrLayout *L)
   vksift_hip_free(inst->d_seg_off);
   vksift_hip_free(inst->d_cand_xy);
   vksift_hip_free(inst->d_cand_flag);
-  inst->d_pyr_buf[1] = NULL;
-  inst->d_pyr_buf[0] = vksift_hip_malloc(pyr_texel_bytes(inst) * new_pyr * n);
-  if (inst->pyr_pingpong)
-    inst->d_pyr_buf[1] = vksift_hip_malloc(pyr_texel_bytes(inst) * new_pyr * n);
+  inst->d_pyr_buf[0] = inst->d_pyr_buf[1] = NULL;
+  (void)place_pyramid_buffers(inst, pyr_texel_bytes(inst) * new_pyr * n, new_pyr, L, inst->pyr_pingpong ? 2u : 1u, inst->d_pyr_buf);
   inst->d_seg_mask = vksift_hip_malloc(sizeof(uint64_t) * new_seg * n);
   inst->d_seg_off = vksift_hip_malloc(sizeof(uint32_t) * new_seg * n);
   inst->d_cand_xy = vksift_hip_malloc(sizeof(uint32_t) * new_cand * n);

@@ -116,6 +116,9 @@ struct vksift_Instance_T
 
   /* device memory */
   float *d_pyr;            /* pyramid storage of the current detection (= d_pyr_buf[pyr_cur]); texel offsets scale with pyr_texel_bytes() */
+  uint32_t place_n;        /* candidate ranges timed by place_pyramid_buffers (0: plain allocation), their rates, the chosen ones */
+  float place_gbps[8];
+  uint32_t place_chosen[2];
   float *d_pyr_buf[2];     /* ping-pong: detection N+1 builds its pyramid while detection N still reads its own */
   int pyr_cur;
   bool pyr_pingpong;
