@@ -465,7 +465,7 @@ def pipelined_protocol(api, dev_index, frames, W, H, B, do_match, steps):
     return B * steps / dt
 
 
-def single_image_latency(api, dev_index, img, runs=100, warm=10):
+def single_image_latency(api, dev_index, img, runs=100, warm=10, detect_only=False):
     """perf_runtime.cpp:63-81: warm-up, then the mean over `runs` of detect + count + download of ONE host image (and of the
     same followed by matchFeatures(0, 0) + downloadMatches = BASELINE config 2)."""
     lib = api.lib()
@@ -477,7 +477,7 @@ def single_image_latency(api, dev_index, img, runs=100, warm=10):
         match_buf = np.zeros(cfg.max_nb_sift_per_buffer, api.MATCH_DTYPE)
         pc = protocol_client(api)
         img = np.ascontiguousarray(img)
-        for with_match in (False, True):
+        for with_match in ((False,) if detect_only else (False, True)):
             key = "detect_match_ms" if with_match else "detect_ms"
             ts = []
             for i in range(warm + runs):
@@ -610,6 +610,11 @@ def sharded_match(api, torch, dist, dev, rank, world, rows):
     return ms, crc
 
 
+def multigpu_mod():
+    from vulkansift_amd import multigpu
+    return multigpu
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -705,10 +710,14 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
+    rank_elapsed = [elapsed]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own time of the same K steps (between the same two barriers): the line carries them all, value uses the maximum
+        te = torch.zeros(world, dtype=torch.float64, device=dev)
+        te[rank] = elapsed
+        dist.all_reduce(te, op=dist.ReduceOp.SUM)
+        rank_elapsed = [float(x) for x in te.tolist()]
+        elapsed = max(rank_elapsed)
 
     acc = inst.getAccumulatedDetectTimings()
     placement = inst.getScaleSpacePlacement()
@@ -726,6 +735,9 @@ def main():
             "value": frames_total / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
+            # frames/s of every rank alone (its frames / its own time between the two barriers); value = all frames / the slowest rank's time
+            "per_rank_value": [B * NSUB * args.steps / max(e, 1e-9) for e in rank_elapsed],
+            "torch_distributed_world": dist.get_world_size() if use_dist else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -743,10 +755,11 @@ def main():
                 "mean_features_per_frame": float(np.mean(nfeat)),
                 "parallelism": f"batch split x{world}, no collectives",
                 "input": "host images, upload inside the timed region" if args.host_input else "resident in HBM",
-                "protocols": "value: batched detection on HBM-resident frames, nothing downloaded (kernel-side figure, the bench contract's "
-                             "definition). value_host_input: the REFERENCE's own protocol (src/perf/wrappers/vulkansift_wrapper.cpp:30-33: host "
-                             "image in, count + features + matches downloaded, strictly serial) — the figure to compare with the reference's "
-                             "published runtimes. value_host_input_pipelined: the same inputs and outputs with the asynchronous API (both legs run "
+                "protocols": "value_host_input: the REFERENCE's own protocol and SURVEY.md 8(d)'s definition of the metric "
+                             "(src/perf/wrappers/vulkansift_wrapper.cpp:30-33: host image in, count + features + matches downloaded, strictly "
+                             "serial) — the figure to compare with the reference's published runtimes. value: batched detection on HBM-resident "
+                             "frames, nothing downloaded (kernel-side figure, the bench contract's definition of `value`: inputs resident when the "
+                             "timed region starts). value_host_input_pipelined: the same inputs and outputs with the asynchronous API (both legs run "
                              "in C: tests/native/protocol_client.c, public API only). "
                              "single_image_ms: BASELINE config 2 literally (one image per call)",
             },
@@ -805,6 +818,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             extras["roofline_c3"] = {"error": repr(e)[:300]}
         extras["single_image_ms"] = single_image_latency(api, dev.index, frames[0])
+        # the sizes the reference publishes single-image detection times for (docs/Performances.md:26-35: 1536x1024 and 3456x2304, RTX 2060 /
+        # GTX 1050 class GPUs, real photographs) on the same synthetic image family: detection only, same protocol
+        for (pw, ph) in ((1536, 1024), (3456, 2304)):
+            try:
+                r = single_image_latency(api, dev.index, api.gen_synthetic_image(0x5EED0000, pw, ph), runs=30, warm=5, detect_only=True)
+                extras["single_image_ms"][f"{pw}x{ph}"] = {"detect_ms": r["detect_ms"], "features": r["features"]}
+            except Exception as e:  # noqa: BLE001
+                extras["single_image_ms"][f"{pw}x{ph}"] = {"error": repr(e)[:200]}
         # the same workload in the FP16 pyramid mode (binary16 scale-space storage, fp32 arithmetic: DESIGN.md 2.3), fresh process;
         # its roofline is priced with the same per-pixel counts at 2 bytes per pyramid texel
         try:
@@ -833,7 +854,11 @@ def main():
             ops = 2.0 * args.match_rows * args.match_rows * 128
             extras["sharded_match"] = {"workload": f"BASELINE config 4: 2-NN {args.match_rows} x {args.match_rows} x 128-D, query rows sharded x{world}, one RCCL all-gather of B",
                                        "ms": ms, "tops_int8": ops / (ms * 1e-3) / 1e12, "frac_of_int8_peak": ops / (ms * 1e-3) / 1e12 / INT8_PEAK_TOPS / world,
-                                       "records_crc32": crc}
+                                       "records_crc32": crc,
+                                       # ncclCommCount / ncclCommUserRank of the library's OWN communicator on rank 0 (vksift_ext_shardGroupInfo):
+                                       # how many ranks RCCL itself saw in the all-gather
+                                       "rccl_ranks": (getattr(multigpu_mod().sharded_match_timed, "last_info", None) or {}).get("rccl_ranks"),
+                                       "group": getattr(multigpu_mod().sharded_match_timed, "last_info", None)}
         except Exception as e:  # noqa: BLE001
             extras["sharded_match"] = {"error": repr(e)[:300]}
 

@@ -135,6 +135,10 @@ extern "C"
   /* The block layout of the reference set that vksift_ext_matchSharded all-gathers: block_rows = ceil(n_total / world) (= nb_shard),
    * rank `rank` holds rows [first_row, first_row + nb_rows) of B (nb_rows <= block_rows; the rest of its block is padding). Pure
    * arithmetic (no GPU needed); callers that shard the query rows the same way use first_row as a_index_base. */
+  /* What the group runs on: (world, rank) as created, and ncclCommCount / ncclCommUserRank of its RCCL communicator — 0 / 0 for a group
+   * over the application's transport. A creation whose communicator disagrees with (world, rank) fails; a caller that prints
+   * rccl_ranks proves how many ranks RCCL itself saw (bench.py does). */
+  VKSIFT_EXPORT void vksift_ext_shardGroupInfo(vksift_ext_ShardGroup group, uint32_t *world, uint32_t *rank, uint32_t *rccl_ranks, uint32_t *rccl_rank);
   VKSIFT_EXPORT void vksift_ext_shardGroupLayout(uint32_t n_total, uint32_t world, uint32_t rank, uint32_t *block_rows, uint32_t *first_row,
                                                  uint32_t *nb_rows);
   VKSIFT_EXPORT void vksift_ext_shardGroupDestroy(vksift_ext_ShardGroup *group_ptr);

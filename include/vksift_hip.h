@@ -35,6 +35,7 @@ extern "C"
  * row list, per-row partial lists of the decomposed kernels: 16 words per piece for the cell scan of large reference sets) */
 #define VKSIFT_HIP_MATCH_SCRATCH_U32(na, nb) (2u * (size_t)(na) + (size_t)(nb) + 72u + (size_t)(na) * 16u * VKSIFT_HIP_MATCH_CHUNKS)
 #define VKSIFT_HIP_ABI_VERSION 5u      /* bumped whenever a signature or a scratch contract of this header changes (vksift_hip_abi_version) */
+#define VKSIFT_HIP_GATHER_SLOTS 512u   /* SIFT buffers one vksift_hip_gather_sections launch serves */
 #define VKSIFT_HIP_MATCH_SLOTS 256u    /* pairs one vksift_hip_match_2nn_async launch sequence serves */
 #define VKSIFT_HIP_MATCH_PK_NB 32768u  /* reference sets of at most this many rows take the branch-free packed-key kernel (k_match_pk) */
 #define VKSIFT_HIP_MAX_ORI 18  /* a 36-bin circular histogram has at most 18 strict local maxima */
@@ -82,15 +83,19 @@ extern "C"
   void vksift_hip_range_push(const char *name);       /* roctx marker == VK_EXT_debug_marker region */
   void vksift_hip_range_pop(void);
 
-  /* Development knobs of the launch shims (A/B tools only; nothing in the library or the tests of its results depends on them:
-   * every setting produces identical planes). */
+  /* Development / test knobs of the launch shims (A/B tools, tests of fallback paths). Every setting produces identical results. */
   enum
   {
-    VKSIFT_TUNE_WG_TARGET = 0, /* waves per strip-march launch aimed at (0 = built-in) */
-    VKSIFT_TUNE_WIDE_MASK = 1, /* bit n: n-tap launches take the four-texels-per-lane form (-1 = built-in) */
+    VKSIFT_TUNE_WG_TARGET = 0,  /* waves per strip-march launch aimed at (0 = built-in) */
+    VKSIFT_TUNE_WIDE_MASK = 1,  /* bit n: n-tap launches take the four-texels-per-lane form (-1 = built-in) */
+    VKSIFT_TUNE_MULTI_MAX = 2,  /* octaves per multi-octave launch, 1..8 (0 = built-in 8): the cutting of longer octave lists into runs is
+                                 * otherwise only reached by images of 4097 pixels and more on the shortest side */
+    VKSIFT_TUNE_REFINE_PTR = 3, /* 1: the refinement kernels address the scale-space through pointers everywhere (the form octaves beyond
+                                 * 2 GiB take) instead of one buffer resource per image and octave */
     VKSIFT_TUNE_COUNT = 8
   };
   int vksift_hip_tune(int knob, int value);
+  int vksift_hip_tune_get(int knob);
 
   /* ------------------------------------------------------------------ pyramid */
   /* A batch of same-sized planes. */
@@ -253,7 +258,7 @@ extern "C"
 
   /* Asynchronous (and batched) matching pipeline used by vksift_matchFeatures / vksift_ext_matchFeaturesBatch — no
    * host round trip for the feature counts.
-   * gather_sections: fills the matcher's per-buffer cache entries of the SIFT buffers buf_ids[0..nslots) (feats_base +
+   * gather_sections: fills the matcher's per-buffer cache entries of the SIFT buffers buf_ids[0..nslots), nslots <= VKSIFT_HIP_GATHER_SLOTS (feats_base +
    * id*buf_stride, counters found_base + id*found_buf_stride; all buffers of one call share the section table): walks up
    * to 16 sections whose stored counts are min(found[o], sec_cap[o]) (or fixed_counts[o] when found_base is NULL), writes
    * the dense descriptor rows in download order to desc + id*desc_stride, their shifted norms to norms + id*norm_stride and

@@ -103,3 +103,54 @@ def test_single_scaling_exp_for_non_positive_arguments(oracle):
     a = _vec(L.orc_dm_expf, x)
     b = _vec(L.orc_dm_expf_nb_nonpos, x)
     assert a.view(np.uint32).tolist() == b.view(np.uint32).tolist()
+
+
+def test_kernel_argument_ranges_against_float64(oracle):
+    """The functions on the EXACT argument ranges the kernels feed them (features.hip / extrema.hip), against float64, with the bound
+    DESIGN.md section 2.2 claims (<= 2 ulp):
+      exp    descriptor weights exp(-0.125 (ox^2 + oy^2)) with |ox|, |oy| <= 2.5 sqrt(2): arguments in [-3.2, 0]; orientation weights
+             exp(-d^2 / (2 (1.5 sigma)^2)) over the 3-lambda square window: [-9, 0] -> every float of [-4.5, 0] in steps + a dense sample to -9.5
+      atan2  image gradients: any sign combination, +-0 components, denormal magnitudes (flat image regions), all eight octants and the
+             axes; compared as angles (absolute error against the float32 spacing at pi), since the bin index is floor(angle * n / 2 pi)
+      sincos keypoint orientations: [0, 2 pi], the half-bin grid (k + 0.5) pi / 36 the orientation stage emits, and 2 pi itself
+      exp2   sigma = seed * 2^((s + ds) / S): arguments in [-0.5, 2.5]"""
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    # exp: a regular grid of 180 001 points over [-4.5, 0] (every 2.5e-5) + random floats down to -9.5 + the exact products the kernels form
+    x = np.concatenate([np.linspace(-4.5, 0.0, 180001), -rng.uniform(0, 9.5, 60000), -0.125 * rng.uniform(0, 25.0, 20000), [-0.0, 0.0, -1e-38, -1e-45]]).astype(np.float32)
+    for fn in (L.orc_dm_expf, L.orc_dm_expf_nb_nonpos):
+        got = _vec(fn, x)
+        assert _ulp(got, np.exp(x.astype(np.float64))).max() <= 2.0
+    # atan2: octants x magnitudes from denormal to 1e3, and the axes with signed zeros
+    mags = np.array([1e-45, 3e-42, 1e-39, 1.2e-38, 1e-30, 1e-12, 1e-6, 3e-3, 0.04, 0.5, 1.0, 7.0, 255.0, 1e3], dtype=np.float32)
+    ys, xs = [], []
+    for my in mags:
+        for mx in mags:
+            for sy in (1.0, -1.0):
+                for sx in (1.0, -1.0):
+                    ys.append(sy * my)
+                    xs.append(sx * mx)
+    for z in (0.0, -0.0):
+        for m in mags:
+            for s in (1.0, -1.0):
+                ys += [z, s * m]
+                xs += [s * m, z]
+    ry, rx = rng.normal(0, 0.05, 60000), rng.normal(0, 0.05, 60000)          # gradient-sized values: half differences of texels in [0, 1]
+    y = np.concatenate([np.array(ys), ry]).astype(np.float32)
+    xx = np.concatenate([np.array(xs), rx]).astype(np.float32)
+    got = _vec(L.orc_dm_atan2f, y, xx)
+    ref = np.arctan2(y.astype(np.float64), xx.astype(np.float64))
+    # +-0 and denormal inputs: the reference's own convention for atan2(+-0, -x) = +-pi is kept in magnitude; the sign of a zero
+    # y is not (both ends of the branch cut land in the same histogram bin after the [0, 2 pi) wrap): compare modulo 2 pi
+    d = np.abs(((got.astype(np.float64) - ref + np.pi) % (2 * np.pi)) - np.pi)
+    assert d.max() <= 2.0 * np.spacing(np.float32(np.pi)), float(d.max())
+    assert np.all(np.isfinite(got)) and np.all(np.abs(got) <= np.float32(np.pi) + np.spacing(np.float32(np.pi)))
+    # sincos on [0, 2 pi] and on the emitted orientation grid
+    t = np.concatenate([rng.uniform(0.0, 2 * np.pi, 60000), (np.arange(0, 72) + 0.5) * np.pi / 36, [0.0, 2 * np.pi, np.pi, np.pi / 2]]).astype(np.float32)
+    s = _vec(L.orc_dm_sinf, t)
+    c = _vec(L.orc_dm_cosf, t)
+    # 2 ulp of values near 1: absolute 2.4e-7 (relative ulps are meaningless at the zeros of sin / cos, where the argument's own rounding decides)
+    assert np.abs(s - np.sin(t.astype(np.float64))).max() <= 2.4e-7 and np.abs(c - np.cos(t.astype(np.float64))).max() <= 2.4e-7
+    # exp2
+    e = np.concatenate([np.linspace(-0.5, 2.5, 60001), rng.uniform(-0.5, 2.5, 20000)]).astype(np.float32)
+    assert _ulp(_vec(L.orc_dm_exp2f, e), np.exp2(e.astype(np.float64))).max() <= 2.0

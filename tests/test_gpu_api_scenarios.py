@@ -383,6 +383,10 @@ import numpy as np
 sys.path.insert(0, %r)
 from vulkansift_amd import api as vk
 vk.lib().vksift_setLogLevel(vk.VKSIFT_LOG_ERROR)
+import os
+for kv in os.environ.get("PROBE_TUNE", "").split(","):      # "knob=value,...": the test knobs of vksift_hip_tune (include/vksift_hip.h)
+    if kv:
+        vk.lib().vksift_hip_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
 imgs = [vk.gen_synthetic_image(400 + i, 352, 264) for i in range(2)]
 h = hashlib.sha256()
 with vk.Instance(vk.default_config(sift_buffer_count=2), batch_capacity=2) as inst:
@@ -409,9 +413,11 @@ def test_every_runtime_switch_is_bit_identical(vk):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # PROBE_TUNE: knob 1 = wide-blur mask (0: two texels per lane everywhere), 2 = octaves per multi-octave launch, 3 = pointer form of the refinement
     variants = [{}, {"VKSIFT_BLUR_KERNEL": "tile"}, {"VKSIFT_PYR_PINGPONG": "1"}, {"VKSIFT_PYR_PINGPONG": "0"},
-                {"VKSIFT_GRAPH": "1"}, {"VKSIFT_GRAPH": "0"}, {"VKSIFT_DESC_WAVES": "1"}, {"VKSIFT_DESC_WAVES": "2"}, {"VKSIFT_DESC_WAVES": "8"},
-                {"VKSIFT_EXTREMA_LEAN": "0"}, {"VKSIFT_PYR_ALTERNATE": "0"}, {"VKSIFT_MULTI_MAX": "2"}, {"VKSIFT_MULTI_MAX": "1"}, {"VKSIFT_REFINE_BUF": "0"}, {"VKSIFT_BLUR_PAIR": "0"}, {"VKSIFT_PYR_PINGPONG": "1", "VKSIFT_EXTREMA_LEAN": "0", "VKSIFT_PYR_ALTERNATE": "0"}]
+                {"VKSIFT_GRAPH": "1"}, {"VKSIFT_GRAPH": "0"}, {"PROBE_TUNE": "2=2"}, {"PROBE_TUNE": "2=1"}, {"PROBE_TUNE": "3=1"}, {"PROBE_TUNE": "1=0"},
+                {"PROBE_TUNE": "1=1048575"}, {"VKSIFT_BLUR_PAIR": "0"}, {"VKSIFT_FORK_SCALES": "0"}, {"VKSIFT_LDS_CHAIN": "0"}, {"VKSIFT_POST_FEATURES": "0"},
+                {"VKSIFT_PYR_PLACEMENT": "0"}, {"VKSIFT_MATCH_PK": "0"}, {"VKSIFT_PYR_PINGPONG": "1", "PROBE_TUNE": "2=2,3=1", "VKSIFT_BLUR_PAIR": "0"}]
     digests = {}
     for v in variants:
         env = dict(os.environ)

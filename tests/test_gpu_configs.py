@@ -23,36 +23,58 @@ def _key(f):
 
 
 LIBM_CASES = [
-    ("default_640x480", 640, 480, {}, {}),
-    ("vlfeat_unlimited", 480, 360, {"descriptor_format": 1, "max_nb_orientation_per_keypoint": 0}, {"use_vlfeat_format": 1, "max_nb_orientation_per_keypoint": 0}),
-    ("no_upsampling", 640, 480, {"use_input_upsampling": False}, {"use_input_upsampling": 0}),
-    ("two_scales", 400, 300, {"nb_scales_per_octave": 2}, {"nb_scales_per_octave": 2}),
-    ("five_scales", 400, 300, {"nb_scales_per_octave": 5}, {"nb_scales_per_octave": 5}),
-    ("direct_taps", 400, 300, {"use_hardware_interpolated_blur": False}, {"use_hardware_interpolated_blur": 0}),
-    ("1080p", 1920, 1080, {"input_image_max_size": 1920 * 1080}, {}),
+    # (name, w, h, vksift config overrides, oracle config overrides, image: None = blob family seeded by the name, 1 / 2 = edge / 1-f
+    #  family (vksift_synth.c), "c3" = frame 0 of BASELINE config 3)
+    ("default_640x480", 640, 480, {}, {}, None),
+    ("vlfeat_unlimited", 480, 360, {"descriptor_format": 1, "max_nb_orientation_per_keypoint": 0}, {"use_vlfeat_format": 1, "max_nb_orientation_per_keypoint": 0}, None),
+    ("no_upsampling", 640, 480, {"use_input_upsampling": False}, {"use_input_upsampling": 0}, None),
+    ("two_scales", 400, 300, {"nb_scales_per_octave": 2}, {"nb_scales_per_octave": 2}, None),
+    ("five_scales", 400, 300, {"nb_scales_per_octave": 5}, {"nb_scales_per_octave": 5}, None),
+    ("direct_taps", 400, 300, {"use_hardware_interpolated_blur": False}, {"use_hardware_interpolated_blur": 0}, None),
+    ("1080p", 1920, 1080, {"input_image_max_size": 1920 * 1080}, {}, None),
+    ("edges_640x480", 640, 480, {}, {}, 1),
+    ("noise_640x480", 640, 480, {}, {}, 2),
+    ("edges_1080p", 1920, 1080, {"input_image_max_size": 1920 * 1080}, {}, 1),
+    ("c3_frame0", 1920, 1080, {"input_image_max_size": 1920 * 1080}, {}, "c3"),
 ]
 
 
-@pytest.mark.parametrize("name,w,h,vkw,okw", LIBM_CASES, ids=[c[0] for c in LIBM_CASES])
-def test_libm_oracle_within_tolerance_configs(vk, oracle, name, w, h, vkw, okw):
-    """stated tolerance: same keypoint set (>= 99.5 % keyed hits), |dx|+|dy| < 1e-4 px, |dsigma|/sigma < 1e-5,
-    |dtheta| < 1e-4 rad, descriptor RMS / 512 < 1e-3 at the 99th percentile (median < 1e-4)"""
-    img = vk.gen_synthetic_image(900 + len(name), w, h)
+@pytest.mark.parametrize("name,w,h,vkw,okw,family", LIBM_CASES, ids=[c[0] for c in LIBM_CASES])
+def test_libm_oracle_within_tolerance_configs(vk, oracle, name, w, h, vkw, okw, family):
+    """The one comparison in which kernels and oracle do NOT share csrc/detmath.h: the oracle computes exp / atan2 / sin / cos / pow with
+    glibc. Stated tolerance (north_star: descriptors within 1e-3 RMS): the SAME keypoint set, key by key; |dx| + |dy| < 1e-4 px;
+    |dsigma| / sigma < 1e-5; |dtheta| < 1e-4 rad; descriptor RMS / 512 — MAXIMUM over all descriptors — < 6e-4, no descriptor byte off by
+    more than 1, at most 2 % of the descriptors touched at all.
+    Measured (CPU, oracle det mode == the kernels bit for bit, against its libm mode, tools/libm_gap.py, all eleven cases): identical
+    keypoint sets, positions and orientations identical to the bit, sigma within 1 ulp (powf), descriptor bytes identical except for
+    single bytes off by one in 0.1-0.6 % of the descriptors; largest RMS 4.57e-4 (7 of 128 bytes off by one, 1080p frames). The
+    histograms are fixed-point sums of rounded weights, so a last-bit difference of exp or atan2 moves a byte only when it flips a
+    floor() in the final quantisation."""
+    if family == "c3":
+        img = vk.gen_synthetic_image(0x5EED0000, w, h)
+    elif family is None:
+        img = vk.gen_synthetic_image(900 + len(name), w, h)
+    else:
+        img = vk.gen_synthetic_image_family(900 + len(name), w, h, family)
     with vk.Instance(vk.default_config(**vkw)) as inst:
         inst.detectFeatures(img, 0)
         got = inst.downloadFeatures(0)
     ref, _ = oracle.detect(oracle.default_config(math_mode=0, **okw), img)
     assert len(ref) > 300
-    assert abs(len(got) - len(ref)) <= max(2, len(ref) // 200)
+    assert len(got) == len(ref)
     rmap = {_key(f): f for f in ref}
     hit = [(g, rmap[_key(g)]) for g in got if _key(g) in rmap]
-    assert len(hit) >= 0.995 * len(ref)
+    assert len(hit) == len(ref)
     g = np.array([h_[0] for h_ in hit])
     r = np.array([h_[1] for h_ in hit])
     assert (np.abs(g["x"] - r["x"]) + np.abs(g["y"] - r["y"])).max() < 1e-4
     assert np.abs(g["sigma"] / r["sigma"] - 1).max() < 1e-5
     assert np.abs(g["orientation"] - r["orientation"]).max() < 1e-4
-    rms = np.sqrt(((g["descriptor"].astype(float) - r["descriptor"].astype(float)) ** 2).mean(axis=1)) / 512.0
+    diff = g["descriptor"].astype(int) - r["descriptor"].astype(int)
+    rms = np.sqrt((diff.astype(float) ** 2).mean(axis=1)) / 512.0
+    assert rms.max() < 6e-4, float(rms.max())
+    assert np.abs(diff).max() <= 1
+    assert (rms > 0).mean() < 0.02
     assert np.median(rms) < 1e-4 and np.percentile(rms, 99) < 1e-3
 
 

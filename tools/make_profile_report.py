@@ -55,7 +55,7 @@ def main():
             f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
             for name, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
                 f.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (name, len(v), sum(v), sum(v) / len(v), 100.0 * sum(v) / tot, min(v), max(v)))
-    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(src, "trace"), KERNEL + ",k_blur_pair," + SCAN + ",k_descriptor,k_orientation<"],
+    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(src, "trace"), KERNEL + ",k_blur_wide,k_blur_pair," + SCAN + ",k_descriptor,k_orientation<"],
                           capture_output=True, text=True).stdout if have_trace else ""
     if have_trace:
         open(os.path.join(dst, f"{tag}_kernel_summary.txt"), "w").write(summ)
@@ -68,6 +68,10 @@ def main():
         wr = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", gridx)
         f.update(pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", gridx_pair, "k_blur_pair"))
         wr.update(pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", gridx_pair, "k_blur_pair"))
+        # k_blur_wide (round 5): four texels per lane, 256-column strips
+        gridx_wide = ((2 * w + 255) // 256) * 64
+        f.update(pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", gridx_wide, "k_blur_wide"))
+        wr.update(pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", gridx_wide, "k_blur_wide"))
         # the streaming extrema scan: ONE launch per detection over all octaves (flat grid) since round 3 — every dispatch of the kernel
         sf = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", None, SCAN)
         sw_ = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", None, SCAN)
@@ -94,7 +98,7 @@ def main():
                 is_scan = name in sf
                 fk = (sf if is_scan else f)[name]
                 wk = (sw_ if is_scan else wr).get(name, {"avg": 0.0})
-                gx = None if is_scan else (gridx_pair if "k_blur_pair" in name else gridx)
+                gx = None if is_scan else (gridx_pair if "k_blur_pair" in name else (gridx_wide if "k_blur_wide" in name else gridx))
                 dd = [v for (n, g), vs in durs.items() if n == name and (gx is None or g == gx) for v in vs]
                 if not dd:
                     continue
@@ -102,7 +106,7 @@ def main():
                 avg_us, min_us = sum(dd) / len(dd) / 1e3, min(dd) / 1e3
                 per_launch_rows.append({"kernel": name.replace("void (anonymous namespace)::", "").split("(")[0], "hbm_bytes": hbm, "avg_us": avg_us, "min_us": min_us,
                                         "frac_of_8TBps": hbm / (avg_us * 1e-6) / 8e12, "frac_at_min_duration": hbm / (min_us * 1e-6) / 8e12, "launches_in_trace": len(dd)})
-        rec = {"per_launch": per_launch_rows, "width": w, "height": h, "batch": batch, "kernel": KERNEL + " / k_blur_pair (octave-0 launches) + " + SCAN + " (one launch over all octaves)", "kernel_source_sha": kernel_source_sha(),
+        rec = {"per_launch": per_launch_rows, "width": w, "height": h, "batch": batch, "kernel": KERNEL + " / k_blur_wide / k_blur_pair (octave-0 launches) + " + SCAN + " (one launch over all octaves)", "kernel_source_sha": kernel_source_sha(),
                "launches_fetch_pass": calls, "launches_write_pass": wcalls, "scan_launches": scalls,
                "FETCH_SIZE_KiB_sum": fetch_kb, "WRITE_SIZE_KiB_sum": write_kb, "fetch_correction": 2.0,
                "hbm_bytes_per_blur_launch": per_launch, "hbm_bytes_per_scan_launch": scan_launch,

@@ -151,6 +151,8 @@ def lib():
     L.vksift_ext_shardGroupSynchronize.restype = C.c_int
     L.vksift_ext_shardGroupCreateWithTransport.argtypes = [C.POINTER(C.c_void_p), C.c_int, u32, u32, C.c_void_p, C.c_void_p]
     L.vksift_ext_shardGroupCreateWithTransport.restype = C.c_int
+    L.vksift_ext_shardGroupInfo.argtypes = [C.c_void_p, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.vksift_ext_shardGroupInfo.restype = None
     L.vksift_ext_shardGroupLayout.argtypes = [u32, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.vksift_ext_shardGroupLayout.restype = None
     # kernel-layer C-ABI (include/vksift_hip.h) entry points used directly by bench.py / tests

@@ -7,7 +7,7 @@
 // Replaces ExtractKeypoints.comp (dispatch: sift_detector.c:1106-1189). The reference appends
 // keypoints with a global atomicAdd (ExtractKeypoints.comp:208), which makes their order
 // non-deterministic. Here the append is an atomic-free pipeline whose output order is raster (scale, y, x):
-//   k_extrema_stream : streaming 26-neighbour test; one u64 candidate ballot per 64-pixel row segment
+//   k_extrema_lean   : streaming 26-neighbour test; one u64 candidate ballot per 64-pixel row segment
 //   k_segment_scan   : exclusive prefix sum of popcount(mask) over segments in (scale, y, x) order
 //   k_cand_list      : one thread per segment writes its candidates' packed (x, y, s) at offset + rank
 //   k_refine_flags   : one thread per CANDIDATE (dense waves: no lane idles while a neighbour refines) -> accept flag
@@ -328,154 +328,9 @@ __device__ __forceinline__ unsigned long long spread32(unsigned long long x)
   return x;
 }
 
-template <int S>
-__global__ void __launch_bounds__(256) k_extrema_stream(Multi<ExtremaArgs> m)
-{
-  const VBlock vb = vblock(m);
-  const ExtremaArgs &a = m.oct[vb.o];
-  const int band = a.band;
-  // Each lane owns two adjacent columns (x, x+1): one 8-byte load per layer and row, and only one lane-crossing
-  // operation per pixel pair and side. A wave covers 128 columns = two 64-pixel mask segments.
-  constexpr int NL = S + 2;
-  const int lane = threadIdx.x & 63;
-  const int b = vb.z;
-  const int y0 = (vb.y * 4 + (threadIdx.x >> 6)) * band; // 4 independent waves per block, one row band each
-  if (y0 >= a.h)
-    return;
-  const int y1 = min(y0 + band, a.h);
-  const int x0 = vb.x * 128, x = x0 + 2 * lane;
-  DogView d{(const float *)((const uint8_t *)a.gauss + (size_t)b * a.img_stride * (a.fp16 ? 2u : 4u)), a.w, a.h, a.pitch, (size_t)a.plane_stride, a.S, a.fp16};
-  const bool in0 = x < a.w, in1 = x + 1 < a.w;
-  const int hx = lane == 0 ? x0 - 1 : x0 + 128;
-  const bool hok = (lane == 0 || lane == 63) && hx >= 0 && hx < a.w;
-  const float pre = a.dog_threshold * 0.8f;
-  const int seg0 = vb.x * 2;
-  const bool has_seg1 = seg0 + 1 < a.nseg;
-
-  // per layer, rows (y-1, y, y+1): horizontal 3-max / 3-min of both columns; rows (y, y+1): centre and max/min(left,right)
-  float hmxA[NL][3], hmnA[NL][3], hmxB[NL][3], hmnB[NL][3];
-  float cA[NL][2], cB[NL][2], lxA[NL][2], lnA[NL][2], lxB[NL][2], lnB[NL][2];
-#pragma unroll
-  for (int l = 0; l < NL; l++)
-  {
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-      hmxA[l][k] = hmnA[l][k] = hmxB[l][k] = hmnB[l][k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 2; k++)
-      cA[l][k] = cB[l][k] = lxA[l][k] = lnA[l][k] = lxB[l][k] = lnB[l][k] = 0.f;
-  }
-
-  // Software prefetch: the loads of row r+1 are issued before row r is processed (a wave otherwise serialises one HBM
-  // round trip per row). Measured: a two-row look-ahead is slower (register pressure), one row is the sweet spot.
-  struct RowRegs
-  {
-    float va[NL], vb[NL], hv[NL];
-  };
-  auto fetch_row = [&](int r, RowRegs &p) {
-#pragma unroll
-    for (int l = 0; l < NL; l++)
-    {
-      p.va[l] = p.vb[l] = p.hv[l] = 0.f;
-      if (r >= 0 && r < a.h && r <= y1)
-      {
-        // Gaussian layer l; layer l+1 one plane further
-        auto dog = [&](int xx) { return d.fp16 ? ld<true>(d, l, xx, r) : ld<false>(d, l, xx, r); };
-        if (in1)
-          p.va[l] = dog(x), p.vb[l] = dog(x + 1);
-        else if (in0)
-          p.va[l] = dog(x);
-        if (hok)
-          p.hv[l] = dog(hx);
-      }
-    }
-  };
-
-  auto process_row = [&](int r, const RowRegs &c) {
-#pragma unroll
-    for (int l = 0; l < NL; l++)
-    {
-      hmxA[l][0] = hmxA[l][1], hmxA[l][1] = hmxA[l][2], hmnA[l][0] = hmnA[l][1], hmnA[l][1] = hmnA[l][2];
-      hmxB[l][0] = hmxB[l][1], hmxB[l][1] = hmxB[l][2], hmnB[l][0] = hmnB[l][1], hmnB[l][1] = hmnB[l][2];
-      cA[l][0] = cA[l][1], cB[l][0] = cB[l][1];
-      lxA[l][0] = lxA[l][1], lnA[l][0] = lnA[l][1], lxB[l][0] = lxB[l][1], lnB[l][0] = lnB[l][1];
-    }
-#pragma unroll
-    for (int l = 0; l < NL; l++)
-    {
-      const float va = c.va[l], vb = c.vb[l], hv = c.hv[l];
-      const float la = wave_shr1(vb, hv); // left neighbour of column x   = previous lane's column x+1
-      const float rb = wave_shl1(va, hv); // right neighbour of column x+1 = next lane's column x
-      const float mxa = fmax2(la, vb), mna = fmin2(la, vb);
-      const float mxb = fmax2(va, rb), mnb = fmin2(va, rb);
-      cA[l][1] = va, cB[l][1] = vb;
-      lxA[l][1] = mxa, lnA[l][1] = mna, lxB[l][1] = mxb, lnB[l][1] = mnb;
-      hmxA[l][2] = fmax2(mxa, va), hmnA[l][2] = fmin2(mna, va);
-      hmxB[l][2] = fmax2(mxb, vb), hmnB[l][2] = fmin2(mnb, vb);
-    }
-    const int y = r - 1;
-    if (y < y0 || y >= y1)
-      return;
-    const bool yin = y >= 1 && y < a.h - 1;
-    const bool intA = yin && x >= 1 && x < a.w - 1;
-    const bool intB = yin && x + 1 < a.w - 1;
-#pragma unroll
-    for (int sz = 0; sz < S; sz++)
-    {
-      const int l = sz + 1;
-      // column x
-      const float ca = cA[l][0];
-      bool candA = intA && fabsf(ca) > pre;
-      {
-        float nmx = fmax3(lxA[l][0], hmxA[l][0], hmxA[l][2]);
-        float nmn = fmin3(lnA[l][0], hmnA[l][0], hmnA[l][2]);
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-        {
-          nmx = fmax3(nmx, hmxA[l - 1][k], hmxA[l + 1][k]);
-          nmn = fmin3(nmn, hmnA[l - 1][k], hmnA[l + 1][k]);
-        }
-        candA = candA && ((ca > nmx) || (ca < nmn));
-      }
-      // column x+1
-      const float cb = cB[l][0];
-      bool candB = intB && fabsf(cb) > pre;
-      {
-        float nmx = fmax3(lxB[l][0], hmxB[l][0], hmxB[l][2]);
-        float nmn = fmin3(lnB[l][0], hmnB[l][0], hmnB[l][2]);
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-        {
-          nmx = fmax3(nmx, hmxB[l - 1][k], hmxB[l + 1][k]);
-          nmn = fmin3(nmn, hmnB[l - 1][k], hmnB[l + 1][k]);
-        }
-        candB = candB && ((cb > nmx) || (cb < nmn));
-      }
-      const unsigned long long ma = __ballot(candA), mb = __ballot(candB);
-      if (lane == 0 && (ma | mb) != 0ull) // the mask array was zeroed by a memset: only non-empty ballots are written
-      {
-        // pixel 2i of the wave comes from ma bit i, pixel 2i+1 from mb bit i
-        const size_t base = ((size_t)sz * a.h + y) * a.nseg + (size_t)b * a.seg_img_stride;
-        a.seg_mask[base + seg0] = spread32(ma) | (spread32(mb) << 1);
-        if (has_seg1)
-          a.seg_mask[base + seg0 + 1] = spread32(ma >> 32) | (spread32(mb >> 32) << 1);
-      }
-    }
-  };
-
-  RowRegs p0;
-  fetch_row(y0 - 1, p0);
-  for (int r = y0 - 1; r <= y1; r++)
-  {
-    const RowRegs c0 = p0;
-    fetch_row(r + 1, p0);
-    process_row(r, c0);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// k_extrema_lean — the production form of the streaming pass above (same mapping, same masks, same results), rebuilt
-// around what bounds it. The pass is a pure stream (20 B per octave pixel at S = 3, no reuse beyond a 3-row window), so
+// k_extrema_lean — the streaming 26-neighbour test (a generic form of it, k_extrema_stream, was the fallback until round 5: planes
+// stay below 2 GiB — sides of 16384 and more are refused — so nothing ever took it), built around what bounds it. The pass is a pure stream (20 B per octave pixel at S = 3, no reuse beyond a 3-row window), so
 // its speed is the number of bytes a CU keeps in flight: the generic kernel holds the horizontal 3-max AND 3-min of three
 // rows per layer and column (~100 live registers of window state, one row of loads in flight, and ~700 issued
 // instructions per row — 64-bit per-lane address arithmetic, exec-mask branches around every load, window moves).
@@ -1010,20 +865,14 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
     if (me)
       return me;
   }
-  static int lean_env = -1;
-  if (lean_env < 0)
-  {
-    const char *e = getenv("VKSIFT_EXTREMA_LEAN"); /* 0: the generic streaming kernel (A/B runs) */
-    lean_env = e ? atoi(e) : 1;
-  }
   /* bit 0: the 4 waves of a block take adjacent strips (-5 % against adjacent bands), bit 1: XCD-contiguous block order (-3 %) */
   const int sm = 3;
   /* window slots: fp32 texels 4 (one row of loads in flight; two rows spill registers since the slots receive S+3 Gaussian
    * texels), binary16 texels 5 (a row in flight costs half the registers) */
-  /* the lean kernel addresses a plane with 32-bit byte offsets */
-  bool lean = lean_env != 0;
+  /* the kernel addresses a plane with 32-bit byte offsets: planes stay below 2 GiB (sides of 16384 and more are refused above) */
   for (uint32_t i = 0; i < n; i++)
-    lean = lean && (uint64_t)jobs[i].pitch * jobs[i].h * (f16 ? 2u : 4u) < 0x80000000ull;
+    if ((uint64_t)jobs[i].pitch * jobs[i].h * (f16 ? 2u : 4u) >= 0x80000000ull)
+      return (int)hipErrorInvalidValue;
 
 #define VKSIFT_MULTI(M, GX, GY, GZ)                              \
   Multi<ExtremaArgs> M;                                           \
@@ -1042,12 +891,10 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
     {
 #define VKSIFT_CASE(N)                                                                \
   case N:                                                                             \
-    if (lean && f16)                                                                  \
+    if (f16)                                                                          \
       hipLaunchKernelGGL((k_extrema_lean<N, 5, true>), sgrid, dim3(256), 0, hs, ms, sm);  \
-    else if (lean)                                                                    \
-      hipLaunchKernelGGL((k_extrema_lean<N, 4, false>), sgrid, dim3(256), 0, hs, ms, sm); \
     else                                                                              \
-      hipLaunchKernelGGL(k_extrema_stream<N>, sgrid, dim3(256), 0, hs, ms);           \
+      hipLaunchKernelGGL((k_extrema_lean<N, 4, false>), sgrid, dim3(256), 0, hs, ms, sm); \
     break;
       VKSIFT_CASE(1) VKSIFT_CASE(2) VKSIFT_CASE(3) VKSIFT_CASE(4) VKSIFT_CASE(5) VKSIFT_CASE(6) VKSIFT_CASE(7) VKSIFT_CASE(8) VKSIFT_CASE(9)
       VKSIFT_CASE(10) VKSIFT_CASE(11) VKSIFT_CASE(12) VKSIFT_CASE(13)
@@ -1082,13 +929,7 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
   const dim3 rgrid(mr.start[mr.n]);
   /* the refinement addresses an image's octave through one buffer resource with 32-bit offsets where it fits (always, short of
    * 4096 x 4096 octaves with many scales); the pointer form serves the rest */
-  static int buf_env = -1;
-  if (buf_env < 0)
-  {
-    const char *e = getenv("VKSIFT_REFINE_BUF"); /* 0: the pointer form everywhere (A/B runs, tests of the fallback) */
-    buf_env = e ? atoi(e) : 1;
-  }
-  bool buf = buf_env != 0;
+  bool buf = vksift_hip_tune_get(VKSIFT_TUNE_REFINE_PTR) == 0;
   for (uint32_t i = 0; i < n; i++)
     buf = buf && (uint64_t)(args[i].S + 3) * args[i].plane_stride * (f16 ? 2u : 4u) < 0x7FFF0000ull;
   if (f16 && buf)

@@ -837,13 +837,8 @@ static int descriptor_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t
   }
   /* waves per keypoint: 4 keep the critical path of a single image short; a batch has keypoints to spare and runs
    * 3-4 % faster with 2 (less redundant per-keypoint work, measured under the overlapped batch schedule) */
-  static int nwv_env = -1;
-  if (nwv_env < 0)
-  {
-    const char *e = getenv("VKSIFT_DESC_WAVES"); /* 1, 2, 4 or 8 (A/B runs) */
-    nwv_env = e ? atoi(e) : 0;
-  }
-  const int nwv = nwv_env ? nwv_env : (batch >= 8u ? 2 : 4);
+  /* waves per keypoint: 4 for single images (latency), 2 for batches (1 wave: 55 % slower, 8: no faster than 4; measured round 2) */
+  const int nwv = batch >= 8u ? 2 : 4;
   const bool f16 = md.oct[0].fp16 != 0;
   const dim3 grid(md.start[md.n]);
 #define VKSIFT_DESC(N)                                                                  \
@@ -864,12 +859,8 @@ static int descriptor_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t
         hipLaunchKernelGGL((k_descriptor<N, false, false>), grid, dim3(64 * N), 0, hs, md); \
     }                                                                                   \
   } while (0)
-  if (nwv == 1)
-    VKSIFT_DESC(1);
-  else if (nwv == 2)
+  if (nwv == 2)
     VKSIFT_DESC(2);
-  else if (nwv == 8)
-    VKSIFT_DESC(8);
   else
     VKSIFT_DESC(4);
 #undef VKSIFT_DESC

@@ -89,7 +89,14 @@ struct SlotMap
   uint32_t buf[64]; // SIFT buffer index handled by slot blockIdx.y
 };
 
-__global__ void __launch_bounds__(256) k_gather_sections(const uint8_t *__restrict__ feats_base, uint64_t buf_stride, SlotMap map, SectionTable tab,
+// (all buffers of a batched detection in ONE launch: 512 buffers = 8 launches of 64 slots x 256 blocks until round 5 — 25 us each alone,
+// 330 us each queued behind the next detection's blur launches, 16 384 mostly idle workgroups per launch)
+struct GatherMap
+{
+  uint32_t buf[VKSIFT_HIP_GATHER_SLOTS]; // SIFT buffer index handled by slot blockIdx.y
+};
+
+__global__ void __launch_bounds__(256) k_gather_sections(const uint8_t *__restrict__ feats_base, uint64_t buf_stride, GatherMap map, SectionTable tab,
                                                          const uint32_t *__restrict__ found_base, uint32_t found_buf_stride, uint32_t *__restrict__ desc,
                                                          uint64_t desc_slot_stride, uint32_t *__restrict__ norms, uint64_t norm_slot_stride,
                                                          uint32_t *__restrict__ n_out, uint32_t n_slot_stride, uint32_t pad_rows_to)
@@ -211,6 +218,7 @@ struct SlotStrides
   uint32_t slot_fast;      // k_match_mfma: blockIdx.x is the slot, blockIdx.y the row block
   uint32_t use_ids;        // descriptor / norm strides address the per-buffer cache: entry = SlotIds::a/b[slot] instead of the slot
   uint32_t pk_nb_max;      // slots with N_B <= this are matched by k_match_pk: the pruning kernels of the same launch sequence skip them
+  uint32_t nslots_loop;    // k_match_mfma: != 0: slots of the call; the grid's slot dimension is smaller and every workgroup walks it
 };
 
 // SIFT buffer (= cache entry) matched by each slot of a batched launch
@@ -255,18 +263,6 @@ uint32_t device_cus()
     cached = (uint32_t)n, cached_dev = dev;
   }
   return cached;
-}
-
-// VKSIFT_MATCH_MFMA=32 selects k_match32 (v_mfma_i32_32x32x32_i8) instead of the round-2 kernels (16x16x64, k_match_mfma): A/B switch, same results
-bool match_use32()
-{
-  static int cached = -1;
-  if (cached < 0)
-  {
-    const char *e = getenv("VKSIFT_MATCH_MFMA");
-    cached = (e && atoi(e) == 32) ? 1 : 0;
-  }
-  return cached == 1;
 }
 
 // VKSIFT_MATCH_SCAN=0: single pairs with large reference sets take the stream-decomposed pruning kernel instead of the cell scan
@@ -374,22 +370,30 @@ __global__ void __launch_bounds__(64 * NW) k_match_mfma(const uint32_t *__restri
   const uint32_t nchunks = stream ? (uint32_t)VKSIFT_HIP_MATCH_CHUNKS : gridDim.z;
   uint32_t chunk = blockIdx.z;
   // ss.slot_fast: grid = (slots, row blocks) — see the batched launch
-  const uint32_t slot = ss.slot_fast ? blockIdx.x : blockIdx.y;
   const uint32_t rb0 = ss.slot_fast ? blockIdx.y : blockIdx.x, rb_step = ss.slot_fast ? gridDim.y : gridDim.x;
-  const uint32_t ea = ss.use_ids ? ids.a[slot] : slot, eb = ss.use_ids ? ids.b[slot] : slot;
-  desc_a += (size_t)ea * ss.desc_a, desc_b += (size_t)eb * ss.desc_b;
-  norm_a += (size_t)ea * ss.norm_a, norm_b += (size_t)eb * ss.norm_b;
-  matches += (size_t)slot * ss.matches;
-  redo += (size_t)slot * ss.redo;
-  if (n_dev)
+  // ss.nslots_loop != 0 (the size regimes of a batch that the packed-key kernel does not take): the grid covers only SOME slot
+  // positions; a workgroup walks the slots slot0, slot0 + step, ... and works on those whose device-side counts fall in ITS regime —
+  // for a batch of small sets every workgroup reads a few counts and ends (a grid sized for the capacity put thousands of
+  // idle workgroups in front of the next detection's launches)
+  const uint32_t slot0 = ss.slot_fast ? blockIdx.x : blockIdx.y, slot_step = ss.slot_fast ? gridDim.x : gridDim.y;
+  const uint32_t *const desc_a_0 = desc_a, *const desc_b_0 = desc_b, *const norm_a_0 = norm_a, *const norm_b_0 = norm_b, *const n_dev_0 = n_dev;
+  uint32_t *const matches_0 = matches, *const redo_0 = redo;
+  for (uint32_t slot = slot0; slot == slot0 || slot < ss.nslots_loop; slot += slot_step)
   {
-    n_dev += (size_t)slot * ss.n;
+  const uint32_t ea = ss.use_ids ? ids.a[slot] : slot, eb = ss.use_ids ? ids.b[slot] : slot;
+  desc_a = desc_a_0 + (size_t)ea * ss.desc_a, desc_b = desc_b_0 + (size_t)eb * ss.desc_b;
+  norm_a = norm_a_0 + (size_t)ea * ss.norm_a, norm_b = norm_b_0 + (size_t)eb * ss.norm_b;
+  matches = matches_0 + (size_t)slot * ss.matches;
+  redo = redo_0 + (size_t)slot * ss.redo;
+  if (n_dev_0)
+  {
+    n_dev = n_dev_0 + (size_t)slot * ss.n;
     // asynchronous path: the row counts were produced on the device by k_gather_sections; this instantiation only
-    // serves na in (na_lo, na_hi] (the host launches one kernel per regime, the others exit here)
+    // serves na in (na_lo, na_hi] (the host launches one kernel per regime, the others skip the slot here)
     na = n_dev[0];
     nb = n_dev[1] < 2u ? 2u : n_dev[1];
     if (na <= na_lo || na > na_hi || nb <= ss.pk_nb_max)
-      return;
+      continue;
   }
   // Operand roles are swapped with respect to the textbook A x B^T: the B descriptors are the MFMA's A operand and the query
   // rows its B operand, so the 16x16 result block is indexed [B column][A row] and lane (col = lane & 15, grp = lane >> 4)
@@ -649,316 +653,17 @@ __global__ void __launch_bounds__(64 * NW) k_match_mfma(const uint32_t *__restri
       }
     }
   } // row-block loop
+  } // slot loop
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// k_match32: the same scan on v_mfma_i32_32x32x32_i8 (round 4). Same contract, arguments, work decomposition and partial-list
-// format as k_match_mfma; a workgroup covers 32 * AT * NW query rows.
-//
-// Why another shape. Counters of k_match_mfma<2,8,128> at 50k x 50k (profiles/r04_sq_counters_match.json): the matrix pipe is busy
-// 30 % of the time, a wave spends 52 % of its cycles parked (s_waitcnt / barrier) and issues 6.8 VALU + 3.5 SALU instructions per
-// MFMA, although the pruning test itself is 3 VALU per two MFMAs: the rest is the candidate path, entered by the WHOLE wave
-// whenever one of its 256 accumulators beats its lane's bound (~130 instructions per entry). A 16x16 tile gives a lane 4
-// accumulators per 32 matrix-pipe cycles; a 32x32 tile gives it 16 per 128 cycles:
-//   * operand roles swapped as before (B descriptors = the MFMA's A operand): lane (j = lane & 31, h = lane >> 5) holds query row j
-//     of its tile against the B columns 8b + 4h + r (accumulator element 4b + r) of a 32-column sub-block — ONE query row per lane
-//     and tile, its running bound a lane-private scalar, the accumulator initialised with -(|b'|^2 >> 1) through the C operand;
-//   * the test is a max-tree over 16 accumulators kept as four group maxima (b = 0..3): 10 v_max3/v_max + 1 compare per 4 MFMAs
-//     (128 pipe cycles) instead of 12 VALU for the same columns with 16x16 tiles; AT tiles share one branch;
-//   * the candidate path visits only the groups whose maximum passes (one, as a rule), four columns each in increasing index
-//     order (in-lane insertion stays "strict <, earlier index wins"), and tightens the bound at once; the two lanes of a row
-//     (h = 0, 1) exchange their bounds whenever one of them inserted, so a row's bound is its true running second best — the
-//     expected number of entries per row falls from ~2 ln(N/4) per lane x 4 lanes to ~2 ln N per row;
-//   * the B tile sits in LDS without padding, 16-byte chunks XOR-swizzled by ((row >> 1) & 7): the four 16-lane groups of a
-//     ds_read_b128 hit 16 distinct bank quads (the 144-byte pitch of k_match_mfma: 33 % conflict cycles, SQ_LDS_BANK_CONFLICT).
-// Bit-exactness argument: unchanged (integers only, d2 < 2^22 or the row is replayed by k_match_redo; Q7 by the swap flag).
+// shared by the v_mfma_i32_32x32x32_i8 kernels below (k_match_scan32, k_match_pk)
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-// position of 16-byte chunk c of staged row r inside the row (LDS swizzle)
+// position of 16-byte chunk c of staged row r inside the row (LDS swizzle): B tiles sit in LDS without padding, 16-byte chunks
+// XOR-swizzled by ((row >> 1) & 7), so the four 16-lane groups of a ds_read_b128 hit 16 distinct bank quads (the 144-byte pitch
+// of k_match_mfma: 33 % conflict cycles, SQ_LDS_BANK_CONFLICT)
 __device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 1) & 7); }
-
-template <int AT, int NW, int BTT>
-__global__ void __launch_bounds__(64 * NW) k_match32(const uint32_t *__restrict__ desc_a, const uint32_t *__restrict__ norm_a, uint32_t na,
-                                                 uint32_t a_index_base, const uint32_t *__restrict__ desc_b, const uint32_t *__restrict__ norm_b,
-                                                 uint32_t nb, uint32_t *__restrict__ matches, uint32_t *__restrict__ redo,
-                                                 const uint32_t *__restrict__ n_dev, uint32_t na_lo, uint32_t na_hi, SlotStrides ss,
-                                                 uint32_t *__restrict__ partial, SlotIds ids, uint32_t stream)
-{
-  static_assert(BTT % 64 == 0, "the parity words are built per wave of staging threads");
-  constexpr uint32_t ROWS = 32u * AT * NW; // query rows per workgroup
-  const uint32_t nchunks = stream ? (uint32_t)VKSIFT_HIP_MATCH_CHUNKS : gridDim.z;
-  uint32_t chunk = blockIdx.z;
-  const uint32_t slot = ss.slot_fast ? blockIdx.x : blockIdx.y;
-  const uint32_t rb0 = ss.slot_fast ? blockIdx.y : blockIdx.x, rb_step = ss.slot_fast ? gridDim.y : gridDim.x;
-  const uint32_t ea = ss.use_ids ? ids.a[slot] : slot, eb = ss.use_ids ? ids.b[slot] : slot;
-  desc_a += (size_t)ea * ss.desc_a, desc_b += (size_t)eb * ss.desc_b;
-  norm_a += (size_t)ea * ss.norm_a, norm_b += (size_t)eb * ss.norm_b;
-  matches += (size_t)slot * ss.matches;
-  redo += (size_t)slot * ss.redo;
-  if (n_dev)
-  {
-    n_dev += (size_t)slot * ss.n;
-    na = n_dev[0];
-    nb = n_dev[1] < 2u ? 2u : n_dev[1];
-    if (na <= na_lo || na > na_hi || nb <= ss.pk_nb_max)
-      return;
-  }
-  __shared__ __attribute__((aligned(16))) uint8_t s_b2[2][BTT * 128];
-  __shared__ __attribute__((aligned(16))) int s_nbh2[2][BTT]; // -(bn >> 1), ACC_DEAD for rows beyond B: the MFMA's C operand
-  __shared__ uint32_t s_par2[2][BTT / 32];                    // bit c of word w: parity of the norm of column 32 w + c
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 31, h = lane >> 5;
-  const uint32_t tiles = (nb + BTT - 1) / BTT, tiles_per_chunk = (tiles + gridDim.z - 1) / gridDim.z;
-  uint32_t tb = chunk * tiles_per_chunk * BTT;
-  uint32_t te = min(nb, tb + tiles_per_chunk * BTT);
-  const uint32_t nblocks = (na + ROWS - 1u) / ROWS;
-  const uint32_t span = stream ? stream_span(nblocks, tiles, gridDim.x) : 0u;
-  uint32_t pos = blockIdx.x * span;
-  const uint32_t pos_end = min(pos + span, nblocks * tiles);
-
-  for (uint32_t rb = rb0;; rb += rb_step)
-  {
-    if (span)
-    {
-      if (pos >= pos_end)
-        break;
-      rb = pos / tiles;
-      const uint32_t t_first = pos - rb * tiles, t_cnt = min(tiles - t_first, pos_end - pos);
-      tb = t_first * BTT, te = min(nb, (t_first + t_cnt) * BTT);
-      chunk = blockIdx.x - (rb * tiles) / span;
-      pos += t_cnt;
-    }
-    else if (rb * ROWS >= na)
-      break;
-    const uint32_t row_base = (rb * NW + wave) * (32 * AT);
-
-    // query fragments: K step s of the 32x32x32 MFMA takes bytes 32 s + 16 h .. + 16 of row j (the staged B rows are sliced the
-    // same way, so the K permutation cancels in the dot product)
-    v4i afrag[AT][4];
-    uint32_t an[AT];
-#pragma unroll
-    for (int t = 0; t < AT; t++)
-    {
-      uint32_t r = row_base + t * 32 + j;
-      if (r >= na)
-        r = na - 1;
-      const uint4 *p = (const uint4 *)(desc_a + (size_t)r * 32);
-#pragma unroll
-      for (int s = 0; s < 4; s++)
-      {
-        const uint4 v = p[2 * s + h];
-        afrag[t][s] = v4i{(int)(v.x ^ 0x80808080u), (int)(v.y ^ 0x80808080u), (int)(v.z ^ 0x80808080u), (int)(v.w ^ 0x80808080u)};
-      }
-      an[t] = norm_a[r];
-    }
-
-    Top2 st[AT];
-    uint32_t eff[AT];
-    int thr[AT];
-#pragma unroll
-    for (int t = 0; t < AT; t++)
-    {
-      st[t] = Top2{QMAX, QMAX, QMAX, QMAX};
-      eff[t] = QMAX;
-      thr[t] = ACC_PASS;
-    }
-    uint32_t swap_bits = 0, risky_bits = 0;
-
-    constexpr int NTH = 64 * NW, NLD = (BTT * 8 + NTH - 1) / NTH;
-    struct TileRegs
-    {
-      uint4 d[NLD];
-      uint32_t n;
-    };
-    TileRegs pf0;
-    auto fetch_tile = [&](uint32_t t0, TileRegs &pf) {
-#pragma unroll
-      for (int q = 0; q < NLD; q++)
-      {
-        const int i = threadIdx.x + q * NTH;
-        const int r = i >> 3, c = i & 7;
-        pf.d[q] = make_uint4(0, 0, 0, 0);
-        if (i < BTT * 8 && t0 + r < nb)
-          pf.d[q] = ((const uint4 *)(desc_b + (size_t)(t0 + r) * 32))[c];
-      }
-      pf.n = (threadIdx.x < BTT && t0 + threadIdx.x < nb) ? norm_b[t0 + threadIdx.x] : 0u;
-    };
-    auto stage_tile = [&](uint32_t t0, int bufi, const TileRegs &pf) {
-#pragma unroll
-      for (int q = 0; q < NLD; q++)
-      {
-        const int i = threadIdx.x + q * NTH;
-        const int r = i >> 3, c = i & 7;
-        uint4 v = pf.d[q];
-        v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
-        if (i < BTT * 8)
-          *(uint4 *)(s_b2[bufi] + r * 128 + swz(r, c) * 16) = v;
-      }
-      if ((int)threadIdx.x < BTT) // whole waves (BTT % 64 == 0)
-      {
-        s_nbh2[bufi][threadIdx.x] = t0 + threadIdx.x < nb ? -(int)(pf.n >> 1) : ACC_DEAD;
-        const unsigned long long odd = __ballot(pf.n & 1u);
-        if (lane == 0)
-        {
-          s_par2[bufi][2 * wave] = (uint32_t)odd;
-          s_par2[bufi][2 * wave + 1] = (uint32_t)(odd >> 32);
-        }
-      }
-    };
-    __syncthreads(); // the previous row block has finished reading both buffers
-    fetch_tile(tb, pf0);
-    stage_tile(tb, 0, pf0);
-    __syncthreads();
-
-    int buf = 0;
-    for (uint32_t t0 = tb; t0 < te; t0 += BTT, buf ^= 1)
-    {
-      const bool more = t0 + BTT < te;
-      if (more)
-        fetch_tile(t0 + BTT, pf0); // in flight during this tile's MFMAs
-      const uint8_t *s_b = s_b2[buf];
-      const int *s_nbh = s_nbh2[buf];
-      uint32_t par[BTT / 32];
-#pragma unroll
-      for (int w = 0; w < BTT / 32; w++)
-        par[w] = s_par2[buf][w];
-
-      // the MFMAs of sub-block s+1 are issued before the tests of sub-block s
-      auto issue = [&](int sub, v16i *acc) {
-        const uint8_t *prow = s_b + (sub * 32 + j) * 128;
-        v4i bf[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-          bf[s] = *(const v4i *)(prow + swz(j, 2 * s + h) * 16); // (sub * 32 + j) >> 1 & 7 == j >> 1 & 7
-        v16i cinit;
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-        {
-          const v4i c4 = *(const v4i *)(s_nbh + sub * 32 + 8 * b + 4 * h);
-          cinit[4 * b + 0] = c4[0], cinit[4 * b + 1] = c4[1], cinit[4 * b + 2] = c4[2], cinit[4 * b + 3] = c4[3];
-        }
-#pragma unroll
-        for (int t = 0; t < AT; t++)
-          acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[0], afrag[t][0], cinit, 0, 0, 0);
-#pragma unroll
-        for (int s = 1; s < 4; s++)
-#pragma unroll
-          for (int t = 0; t < AT; t++)
-            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[s], afrag[t][s], acc[t], 0, 0, 0);
-      };
-      v16i accp[2][AT];
-      issue(0, accp[0]);
-#pragma unroll
-      for (int sub = 0; sub < BTT / 32; sub++)
-      {
-        if (sub + 1 < BTT / 32)
-          issue(sub + 1, accp[(sub + 1) & 1]);
-        const v16i *acc = accp[sub & 1];
-        const bool first = (sub == 0 && t0 == 0);
-        // group maxima and the wave-wide test: one branch for all tiles
-        int g[AT][4];
-        bool any = first;
-#pragma unroll
-        for (int t = 0; t < AT; t++)
-        {
-#pragma unroll
-          for (int b = 0; b < 4; b++)
-            g[t][b] = max(max(acc[t][4 * b], acc[t][4 * b + 1]), max(acc[t][4 * b + 2], acc[t][4 * b + 3]));
-          const int m = max(max(g[t][0], g[t][1]), max(g[t][2], g[t][3]));
-          any = any || (m > thr[t]);
-        }
-        if (!__any(any))
-          continue;
-        const uint32_t cb = t0 + sub * 32 + 4 * h; // column of accumulator element 4 b + r: cb + 8 b + r
-#pragma unroll
-        for (int t = 0; t < AT; t++)
-        {
-          bool inserted = false;
-#pragma unroll
-          for (int b = 0; b < 4; b++)
-          {
-            if (!__any(g[t][b] > thr[t]))
-              continue;
-            if (first && b == 0)
-            {
-              // quirk Q7: d2(b0) == d2(b1) (both in the h = 0 lane of the row): index 1 becomes the best
-              const uint32_t q0 = an[t] + (par[0] & 1u) - 2u * (uint32_t)acc[t][0], q1 = an[t] + ((par[0] >> 1) & 1u) - 2u * (uint32_t)acc[t][1];
-              if (h == 0 && q0 == q1)
-                swap_bits |= 1u << t;
-              if (h == 0 && (q0 >= Q_EXACT || q1 >= Q_EXACT))
-                risky_bits |= 1u << t; // the tie test itself needs the float comparison
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-            {
-              // columns beyond B carry ACC_DEAD accumulators (below every bound, ACC_PASS included)
-              const int a = acc[t][4 * b + r];
-              if (!(a > thr[t]))
-                continue;
-              const uint32_t pbit = (par[sub] >> (8 * b + 4 * h + r)) & 1u;
-              const uint32_t q = an[t] + pbit - 2u * (uint32_t)a;
-              if (q < eff[t])
-              {
-                if (q >= Q_EXACT)
-                  risky_bits |= 1u << t;
-                insert_seq(st[t], q, cb + 8u * b + (uint32_t)r);
-                eff[t] = min(eff[t], st[t].q2);
-                thr[t] = acc_threshold(an[t], eff[t]);
-                inserted = true;
-              }
-            }
-          }
-          // the two lanes of a row exchange their lists' heads whenever one of them changed: the row's bound is the second
-          // smallest d2 of the union (exact pruning: two candidates with smaller-or-equal d2 and smaller index are already held)
-          if (__any(inserted))
-          {
-            const uint32_t o1 = __shfl_xor(st[t].q1, 32, 64), o2 = __shfl_xor(st[t].q2, 32, 64);
-            const uint32_t second = min(max(st[t].q1, o1), min(st[t].q2, o2));
-            eff[t] = min(eff[t], second);
-            thr[t] = acc_threshold(an[t], eff[t]);
-          }
-        }
-      }
-      if (more)
-        stage_tile(t0 + BTT, buf ^ 1, pf0); // nobody reads that buffer any more (barrier at the end of the previous tile)
-      __syncthreads();
-    }
-
-    // merge the 2 lanes that share a query row, then the h = 0 lane writes
-    risky_bits |= __shfl_xor(risky_bits, 32, 64);
-    swap_bits |= __shfl_xor(swap_bits, 32, 64);
-#pragma unroll
-    for (int t = 0; t < AT; t++)
-    {
-      Top2 s = st[t], o;
-      o.q1 = __shfl_xor(s.q1, 32, 64), o.k1 = __shfl_xor(s.k1, 32, 64);
-      o.q2 = __shfl_xor(s.q2, 32, 64), o.k2 = __shfl_xor(s.k2, 32, 64);
-      s = merge2(s, o);
-      const uint32_t r = row_base + t * 32 + j;
-      const uint32_t sw = (swap_bits >> t) & 1u, rk = (risky_bits >> t) & 1u;
-      if (h == 0 && r < na)
-      {
-        if (nchunks > 1)
-        {
-          uint32_t *pp = partial + ((size_t)r * nchunks + chunk) * 4;
-          pp[0] = s.q1, pp[1] = s.k1, pp[2] = s.q2, pp[3] = s.k2;
-          partial[(size_t)na * nchunks * 4 + (size_t)r * nchunks + chunk] = sw | (rk << 1);
-        }
-        else
-        {
-          uint32_t *m = matches + (size_t)r * 5;
-          m[0] = a_index_base + r;
-          m[1] = (sw && s.k1 < 2) ? (s.k1 ^ 1u) : s.k1;
-          m[2] = (sw && s.k2 < 2) ? (s.k2 ^ 1u) : s.k2;
-          m[3] = __float_as_uint(sqrtf((float)s.q1));
-          m[4] = __float_as_uint(sqrtf((float)s.q2));
-          redo[r] = rk;
-        }
-      }
-    }
-  } // row-block loop
-}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_match_scan32 + k_match_fix + k_match_redo_rows: the matcher for LARGE reference sets (beyond VKSIFT_HIP_MATCH_PK_NB rows).
@@ -2043,7 +1748,7 @@ extern "C"
     hipStream_t hs = (hipStream_t)s;
     uint32_t *redo = scratch;
     const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
-    const SlotStrides z{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const SlotStrides z{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const SlotIds noids{};
     /* A small problem (a few hundred thousand distances): 16 A rows per workgroup with B split over its waves, one launch.
      * Everything else: the stream decomposition (see k_match_mfma) — 8 waves x 32 rows per workgroup, 128-row B tiles, two
@@ -2104,12 +1809,8 @@ extern "C"
     {
       uint32_t *partial = redo + na;
       const uint32_t G = 2u * device_cus();
-      if (match_use32())
-        hipLaunchKernelGGL((k_match32<2, 4, 128>), dim3(G), dim3(256), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
-                           (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids, 1u);
-      else
-        hipLaunchKernelGGL((k_match_mfma<2, 8, 128>), dim3(G), dim3(512), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
-                           (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids, 1u);
+      hipLaunchKernelGGL((k_match_mfma<2, 8, 128>), dim3(G), dim3(512), 0, hs, da, norm_a, na, a_index_base, db, norm_b, nb, (uint32_t *)matches, redo,
+                         (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, z, partial, noids, 1u);
       hipLaunchKernelGGL(k_match_merge, dim3((na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial, na, (uint32_t)VKSIFT_HIP_MATCH_CHUNKS, a_index_base,
                          (uint32_t *)matches, redo, (const uint32_t *)nullptr, 0u, 0xFFFFFFFFu, G, nb, 128u, 256u);
     }
@@ -2144,7 +1845,7 @@ extern "C"
                                  uint32_t found_buf_stride, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint64_t desc_slot_stride,
                                  uint32_t *norms, uint64_t norm_slot_stride, uint32_t *n_out_dev, uint32_t n_slot_stride, vksift_hip_stream s)
   {
-    if (nsec > 16 || nslots < 1 || nslots > 64)
+    if (nsec > 16 || nslots < 1 || nslots > VKSIFT_HIP_GATHER_SLOTS)
       return (int)hipErrorInvalidValue;
     SectionTable t;
     t.nsec = nsec;
@@ -2154,14 +1855,17 @@ extern "C"
       t.cap[o] = o < nsec ? sec_cap[o] : 0u;
       t.fixed[o] = (o < nsec && fixed_counts) ? fixed_counts[o] : 0u;
     }
-    SlotMap m;
-    for (uint32_t i = 0; i < 64; i++)
+    GatherMap m;
+    for (uint32_t i = 0; i < VKSIFT_HIP_GATHER_SLOTS; i++)
       m.buf[i] = i < nslots ? buf_ids[i] : 0u;
     if (max_rows < pad_rows_to)
       max_rows = pad_rows_to;
-    uint32_t blocks = (max_rows + 7u) / 8u;
-    if (blocks > 256u)
-      blocks = 256u; /* grid-stride over the rows that actually exist (count read on the device) */
+    /* grid-stride over the rows that actually exist (count read on the device): ~4096 workgroups per launch whatever the batch — a
+     * buffer alone gets up to 256 blocks of 8 rows, 512 buffers 8 each (30 rounds over 1900 rows) */
+    uint32_t blocks = (max_rows + 7u) / 8u, cap_blocks = 4096u / nslots;
+    cap_blocks = cap_blocks < 8u ? 8u : (cap_blocks > 256u ? 256u : cap_blocks);
+    if (blocks > cap_blocks)
+      blocks = cap_blocks;
     if (blocks == 0)
       blocks = 1;
     hipLaunchKernelGGL(k_gather_sections, dim3(blocks, nslots), dim3(256), 0, (hipStream_t)s, feats_base, buf_stride, m, t, found_base, found_buf_stride,
@@ -2218,6 +1922,7 @@ extern "C"
     ss.slot_fast = 0;
     ss.use_ids = 1;
     ss.pk_nb_max = 0;
+    ss.nslots_loop = 0;
     hipStream_t hs = (hipStream_t)s;
     const uint32_t *da = (const uint32_t *)desc_a, *db = (const uint32_t *)desc_b;
     if (nslots == 1 && partial_scratch)
@@ -2231,12 +1936,8 @@ extern "C"
       if (max_na > SS)
       {
         const uint32_t G = 2u * device_cus();
-        if (match_use32())
-          hipLaunchKernelGGL((k_match32<2, 4, 128>), dim3(G), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev, SS,
-                             0xFFFFFFFFu, ss, partial_scratch, ids, 1u);
-        else
-          hipLaunchKernelGGL((k_match_mfma<2, 8, 128>), dim3(G), dim3(512), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev, SS,
-                             0xFFFFFFFFu, ss, partial_scratch, ids, 1u);
+        hipLaunchKernelGGL((k_match_mfma<2, 8, 128>), dim3(G), dim3(512), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev, SS,
+                           0xFFFFFFFFu, ss, partial_scratch, ids, 1u);
         hipLaunchKernelGGL(k_match_merge, dim3((max_na + 255u) / 256u), dim3(256), 0, hs, (const uint32_t *)partial_scratch, 0u,
                            (uint32_t)VKSIFT_HIP_MATCH_CHUNKS, 0u, (uint32_t *)matches, redo, n_dev, SS, 0xFFFFFFFFu, G, 0u, 128u, 256u);
       }
@@ -2280,27 +1981,29 @@ extern "C"
       if (n1 > 0)
         hipLaunchKernelGGL(k_match_mfma_split, dim3((n1 + 15u) / 16u, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u, (uint32_t *)matches, redo, n_dev,
                            0u, S1, ss, ids);
+      /* What the packed-key kernel leaves (reference sets beyond 32 768 rows) and, without it, everything above S1: two size regimes
+       * of the pruning kernel, (S1, 32768] with 16 rows per wave and above with 32 (B fragment reuse). With the packed-key kernel these
+       * are the odd slots of a batch, usually none: at most 16 slot positions x 16 row-block positions = 256 workgroups per regime, every
+       * one walking the slots of the call (ss.nslots_loop) and the row blocks of a slot that is its own. Without it they carry the
+       * whole batch: one workgroup column per slot, slot index fastest so that the busy workgroups are contiguous in dispatch order. */
+      SlotStrides s2 = ss;
+      s2.slot_fast = nslots > 1 ? 1u : 0u;
+      uint32_t gs = nslots;
+      if (pk && nslots > 16u)
+        gs = 16u, s2.nslots_loop = nslots;
       if (max_na > S1)
       {
         const uint32_t n2 = max_na < S2 ? max_na : S2;
-        /* slot index fastest, so that the busy workgroups (row block < N_A / 64, unknown here) are contiguous in dispatch
-         * order instead of a short run at the start of every slot's row (see features.hip: img_fast) */
-        SlotStrides s2 = ss;
-        s2.slot_fast = nslots > 1 ? 1u : 0u;
         const uint32_t gb = bounded((n2 + 63u) / 64u);
-        if (match_use32())
-          hipLaunchKernelGGL((k_match32<1, 2, 64>), s2.slot_fast ? dim3(nslots, gb) : dim3(gb, nslots), dim3(128), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
-                             (uint32_t *)matches, redo, n_dev, S1, S2, s2, (uint32_t *)nullptr, ids, 0u);
-        else
-          hipLaunchKernelGGL(k_match_mfma<1>, s2.slot_fast ? dim3(nslots, gb) : dim3(gb, nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
-                             (uint32_t *)matches, redo, n_dev, S1, S2, s2, (uint32_t *)nullptr, ids, 0u);
+        hipLaunchKernelGGL(k_match_mfma<1>, s2.slot_fast ? dim3(gs, gb) : dim3(gb, gs), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+                           (uint32_t *)matches, redo, n_dev, S1, S2, s2, (uint32_t *)nullptr, ids, 0u);
       }
-      if (max_na > S2 && match_use32())
-        hipLaunchKernelGGL((k_match32<2, 2, 64>), dim3(bounded((max_na + 127u) / 128u), nslots), dim3(128), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
-                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, (uint32_t *)nullptr, ids, 0u);
-      else if (max_na > S2)
-        hipLaunchKernelGGL(k_match_mfma<2>, dim3(bounded((max_na + 127u) / 128u), nslots), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
-                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, ss, (uint32_t *)nullptr, ids, 0u);
+      if (max_na > S2)
+      {
+        const uint32_t gb = bounded((max_na + 127u) / 128u);
+        hipLaunchKernelGGL(k_match_mfma<2>, s2.slot_fast ? dim3(gs, gb) : dim3(gb, gs), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
+                           (uint32_t *)matches, redo, n_dev, S2, 0xFFFFFFFFu, s2, (uint32_t *)nullptr, ids, 0u);
+      }
     }
     uint32_t rblocks = (max_na + 63u) / 64u;
     const uint32_t rlim = nslots > 64u ? 16u : 64u; /* grid-stride over the rows: the flags are all zero for real descriptors */

@@ -11,6 +11,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "vksift_hip.h"
+
 constexpr int MULTI_MAX = 8; // octaves per launch (a 1920x1080 frame with up-sampling has 7); longer lists are cut in runs
 
 template <typename A>
@@ -50,18 +52,11 @@ __device__ __forceinline__ VBlock vblock(const Multi<A> &m)
   return v;
 }
 
-// host side: octaves per launch. VKSIFT_MULTI_MAX=1..8 lowers it (tests: the cutting of longer octave lists into runs is otherwise
-// only reached by images of 4097 pixels and more on the shortest side)
+// host side: octaves per launch (vksift_hip_tune(VKSIFT_TUNE_MULTI_MAX, 1..8) lowers it: tests of the cutting of longer octave lists)
 static inline uint32_t multi_run_max()
 {
-  static int v = -1;
-  if (v < 0)
-  {
-    const char *e = getenv("VKSIFT_MULTI_MAX");
-    const int n = e ? atoi(e) : MULTI_MAX;
-    v = n >= 1 && n <= MULTI_MAX ? n : MULTI_MAX;
-  }
-  return (uint32_t)v;
+  const int n = vksift_hip_tune_get(VKSIFT_TUNE_MULTI_MAX);
+  return (uint32_t)(n >= 1 && n <= MULTI_MAX ? n : MULTI_MAX);
 }
 
 // host side: append entry i with its virtual grid; returns false if the flat grid would overflow 2^31 workgroups

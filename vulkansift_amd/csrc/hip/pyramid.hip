@@ -1487,25 +1487,14 @@ extern "C"
     return (int)hipGetLastError();
   }
 
-  /* development knobs set through vksift_hip_tune() by the A/B tools (tools/blur_ab.py): -1 / 0 = the built-in choice */
-  static int g_tune[VKSIFT_TUNE_COUNT] = {0, -1, 0, 0, 0, 0, 0, 0};
-
-  int vksift_hip_tune(int knob, int value)
-  {
-    if (knob < 0 || knob >= VKSIFT_TUNE_COUNT)
-      return -1;
-    g_tune[knob] = value;
-    return 0;
-  }
-
   /* Row segments of the streaming kernel: enough workgroups to give every CU ~40 waves over the launch (2560 long-lived waves
    * left the slowest CU to set the time), but segments long enough that the 2R-row warm-up stays a small fraction; launches
    * that cannot fill the GPU anyway (small octaves, small batches) are latency bound and take shorter marches. */
   static dim3 stream_grid(uint32_t w, uint32_t h, uint32_t batch, uint32_t wg_target, int *seg_out, uint32_t strip_w = 128u)
   {
     const uint32_t strips = (w + strip_w - 1u) / strip_w;
-    if (g_tune[VKSIFT_TUNE_WG_TARGET] > 0)
-      wg_target = (uint32_t)g_tune[VKSIFT_TUNE_WG_TARGET];
+    if (vksift_hip_tune_get(VKSIFT_TUNE_WG_TARGET) > 0)
+      wg_target = (uint32_t)vksift_hip_tune_get(VKSIFT_TUNE_WG_TARGET);
     uint32_t nseg = (wg_target + strips * batch - 1u) / (strips * batch);
     const uint32_t waves64 = strips * batch * ((h + 63u) / 64u);
     const uint32_t seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u);
@@ -1550,15 +1539,12 @@ extern "C"
     a.taps = t;
     hipStream_t hs = (hipStream_t)s;
     /* four texels per lane on 256-column strips (k_blur_wide): fp32 planes whose width wastes little of the last strip */
-    static int wide_env = -2;
-    if (wide_env == -2)
-    {
-      const char *e = getenv("VKSIFT_BLUR_WIDE"); /* bit mask over the tap counts (bit n = n taps); 0: never (A/B runs) */
-      wide_env = e ? (int)strtol(e, NULL, 0) : -1;
-    }
-    const int wide_mask = g_tune[VKSIFT_TUNE_WIDE_MASK] >= 0 ? g_tune[VKSIFT_TUNE_WIDE_MASK] : (wide_env >= 0 ? wide_env : WIDE_DEFAULT_MASK);
+    const int wide_mask = vksift_hip_tune_get(VKSIFT_TUNE_WIDE_MASK) >= 0 ? vksift_hip_tune_get(VKSIFT_TUNE_WIDE_MASK) : WIDE_DEFAULT_MASK;
     const uint32_t wstrips = (src.w + 255u) / 256u;
-    if (!src.fp16 && !dst.fp16 && ((wide_mask >> ntaps) & 1) && (src.w % 4u) == 0 && ra <= src.w && wstrips * 256u + ra <= 2u * src.w &&
+    /* (launches that cannot fill the chip — a single image, the coarse octaves of a small batch — are latency bound and want the larger
+     * number of shorter-lived waves the 128-column strips give them: one 640x480 image 0.355 -> 0.378 ms with wide strips everywhere) */
+    const bool fills = (uint64_t)wstrips * batch * ((src.h + 63u) / 64u) >= 2048u || vksift_hip_tune_get(VKSIFT_TUNE_WIDE_MASK) >= 0;
+    if (fills && !src.fp16 && !dst.fp16 && ((wide_mask >> ntaps) & 1) && (src.w % 4u) == 0 && ra <= src.w && wstrips * 256u + ra <= 2u * src.w &&
         wstrips * 256u - src.w <= 64u && ((src.pitch | dst.pitch) & 3u) == 0)
     {
       const dim3 wgrid = stream_grid(src.w, src.h, batch, 10240u, &a.seg, 256u);
@@ -1782,13 +1768,6 @@ extern "C"
       if (ntaps[l] < 1 || ntaps[l] > VKSIFT_HIP_MAX_TAPS || (l > 0 && ntaps[l] > min_side))
         return -1; /* (a radius that reaches past one reflection: the per-scale launches handle it) */
       a.nt[l] = (int)ntaps[l];
-      {
-        static int pad = -1;
-        if (pad < 0)
-          pad = getenv("VKSIFT_CHAIN_PAD") ? atoi(getenv("VKSIFT_CHAIN_PAD")) : 0;
-        if (pad && l > 0 && a.nt[l] <= pad)
-          a.nt[l] = pad;
-      }
       for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
         a.k[l][i] = i < ntaps[l] ? taps[l * VKSIFT_HIP_MAX_TAPS + i] : 0.f;
     }

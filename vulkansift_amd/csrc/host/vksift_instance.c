@@ -169,7 +169,8 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
    * users never pay for them */
   ALLOC_D(inst->d_cache_n, sizeof(uint32_t) * config->sift_buffer_count);
   inst->cache_valid = (bool *)calloc(config->sift_buffer_count, sizeof(bool));
-  ok = ok && inst->cache_valid != NULL;
+  inst->cache_queued = (bool *)calloc(config->sift_buffer_count, sizeof(bool));
+  ok = ok && inst->cache_valid != NULL && inst->cache_queued != NULL;
   ALLOC_D(inst->d_matches, inst->match_slot_stride * batch_cap);
   ALLOC_D(inst->d_redo, sizeof(uint32_t) * inst->redo_slot_stride * batch_cap);
   ALLOC_D(inst->d_match_n, sizeof(uint32_t) * 4 * batch_cap);
@@ -197,14 +198,11 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   for (int i = 0; i < 2; i++)
     inst->ev_pyr_free[i] = vksift_hip_event_create();
   {
-    const char *e = getenv("VKSIFT_PYR_ALTERNATE");
-    inst->alt_order = !(e && e[0] == '0');
-    e = getenv("VKSIFT_FORK_SCALES");
+    inst->alt_order = true; /* consecutive launches of a chain walk the batch in opposite directions (+9 % on the chain, round 3) */
+    const char *e = getenv("VKSIFT_FORK_SCALES");
     inst->fork_scales = !(e && e[0] == '0');
-    e = getenv("VKSIFT_FORK_STREAMS");
-    inst->fork_streams = (e && e[0] == '2') ? 2 : 1; /* two measured no faster in stream order and 10 % slower in a replayed graph */
-    e = getenv("VKSIFT_FORK_MAX_PIXELS");
-    inst->fork_max_pixels = e ? strtoull(e, NULL, 10) : (uint64_t)16 << 20;
+    inst->fork_streams = 1; /* two branch streams measured no faster in stream order and 10 % slower in a replayed graph */
+    inst->fork_max_pixels = (uint64_t)16 << 20;
     for (int i = 0; i < VKSIFT_MAX_OCTAVES; i++)
       inst->ev_fork[i] = vksift_hip_event_create();
     inst->ev_join[0] = vksift_hip_event_create();
@@ -323,6 +321,7 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   vksift_hip_free(inst->d_cache_norm);
   vksift_hip_free(inst->d_cache_n);
   free(inst->cache_valid);
+  free(inst->cache_queued);
   vksift_hip_free(inst->d_matches);
   vksift_hip_free(inst->d_redo);
   vksift_hip_free(inst->d_match_n);

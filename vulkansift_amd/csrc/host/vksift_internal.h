@@ -146,6 +146,7 @@ struct vksift_Instance_T
   uint32_t *d_cache_norm, *d_cache_n;
   uint64_t cache_norm_stride; /* u32 elements */
   bool *cache_valid;
+  bool *cache_queued;      /* scratch of refresh_match_cache: the buffer is already in the current gather pass */
   uint32_t *d_match_partial; /* partial top-2 lists of the stream-decomposed single-pair matcher (NULL when max_nb <= VKSIFT_HIP_MATCH_SMALL_NA) */
   uint32_t *d_match_n, *h_match_n; /* per match slot: {N_A, N_B, spare, spare} of the last matching pipeline */
   /* filtered matching (vksift_ext_matchFeaturesFiltered): scratch of the reverse (B->A) matching and the survivors; allocated on first use */

@@ -67,34 +67,34 @@ int refresh_match_cache(vksift_Instance inst, const uint32_t *ids, uint32_t coun
   if (ce)
     return ce;
   (void)detect_running(inst); /* polls the detections in flight: counts_valid() is up to date */
-  /* Passes of at most 128 not-yet-cached buffers until none is left: a run of VKSIFT_HIP_MATCH_SLOTS (256) pairs may name that many
-   * distinct buffers per side, and every one of them must be gathered before the matching kernels read its cache entry. */
+  /* Passes of at most VKSIFT_HIP_GATHER_SLOTS not-yet-cached buffers until none is left: a run of VKSIFT_HIP_MATCH_SLOTS (256) pairs may
+   * name that many distinct buffers per side, and every one of them must be gathered before the matching kernels read its cache entry. */
   for (;;)
   {
-    uint32_t todo[128];
+    uint32_t todo[VKSIFT_HIP_GATHER_SLOTS];
     uint32_t n = 0;
     bool more = false;
     for (uint32_t i = 0; i < count; i++)
     {
-      bool seen = inst->cache_valid[ids[i]];
-      for (uint32_t k = 0; k < n && !seen; k++)
-        seen = todo[k] == ids[i];
-      if (seen)
+      if (inst->cache_valid[ids[i]] || inst->cache_queued[ids[i]])
         continue;
-      if (n == 128)
+      if (n == VKSIFT_HIP_GATHER_SLOTS)
       {
         more = true; /* taken by the next pass */
         break;
       }
+      inst->cache_queued[ids[i]] = true;
       todo[n++] = ids[i];
     }
+    for (uint32_t k = 0; k < n; k++)
+      inst->cache_queued[todo[k]] = false;
     uint32_t i0 = 0;
     while (i0 < n)
     {
       /* one launch per run of buffers that share a section layout (always all of them after a batched detection) */
       const BufferInfo *b = &inst->bufs[todo[i0]];
       uint32_t i1 = i0 + 1, max_rows = rows_bound(inst, todo[i0]);
-      while (i1 < n && i1 - i0 < 64 && same_layout(b, &inst->bufs[todo[i1]]))
+      while (i1 < n && same_layout(b, &inst->bufs[todo[i1]]))
       {
         const uint32_t r = rows_bound(inst, todo[i1]);
         max_rows = r > max_rows ? r : max_rows;
@@ -184,6 +184,9 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
   vksift_hip_range_push("Matching");
   range_open = true;
   const MatchScratch fwd = fwd_scratch(inst);
+  /* the matcher's view of every buffer of the call first, in one gather launch per 512 buffers (each run below would gather its own) */
+  HIP_CHECK(refresh_match_cache(inst, ids_a, count), "descriptor gather");
+  HIP_CHECK(refresh_match_cache(inst, ids_b, count), "descriptor gather");
   /* one launch sequence serves up to VKSIFT_HIP_MATCH_SLOTS pairs; a longer list goes in runs of that many, run r into the slots from r on */
   for (uint32_t r = 0; r < count; r += VKSIFT_HIP_MATCH_SLOTS)
     HIP_CHECK(match_slots(inst, &fwd, ids_a + r, ids_b + r, count - r < VKSIFT_HIP_MATCH_SLOTS ? count - r : VKSIFT_HIP_MATCH_SLOTS, r), "2-NN matching");

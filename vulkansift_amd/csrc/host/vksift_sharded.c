@@ -35,6 +35,8 @@ static struct
   int (*CommDestroy)(rccl_Comm);
   int (*CommAbort)(rccl_Comm);
   int (*AllGather)(const void *, void *, size_t, int, rccl_Comm, void *);
+  int (*CommCount)(const rccl_Comm, int *);    /* optional: what the communicator itself says about its size ... */
+  int (*CommUserRank)(const rccl_Comm, int *); /* ... and this rank (vksift_ext_shardGroupInfo) */
   const char *(*GetErrorString)(int);
 } g_rccl;
 #define RTLD_DEFAULT_SENTINEL ((void *)&g_rccl) /* "bound through the global scope": nothing to dlclose */
@@ -47,6 +49,8 @@ static bool rccl_bind(void *so)
   *(void **)&g_rccl.CommAbort = dlsym(so, "ncclCommAbort");
   *(void **)&g_rccl.AllGather = dlsym(so, "ncclAllGather");
   *(void **)&g_rccl.GetErrorString = dlsym(so, "ncclGetErrorString");
+  *(void **)&g_rccl.CommCount = dlsym(so, "ncclCommCount");
+  *(void **)&g_rccl.CommUserRank = dlsym(so, "ncclCommUserRank");
   return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllGather;
 }
 
@@ -97,6 +101,7 @@ struct vksift_ext_ShardGroup_T
   uint8_t *d_b_full;
   uint32_t *d_scratch;
   size_t b_cap, scratch_cap; /* bytes / u32 elements */
+  uint32_t comm_ranks, comm_rank; /* ncclCommCount / ncclCommUserRank of the communicator (0 / 0: a transport group, or an RCCL without them) */
   bool timed;
   bool broken; /* the communicator was aborted after a local failure: every later call fails */
 };
@@ -142,6 +147,22 @@ static vksift_Result shard_group_create(vksift_ext_ShardGroup *out, int gpu_devi
       free(g);
       return VKSIFT_VULKAN_ERROR;
     }
+    /* the communicator's own view of the job: a group whose RCCL communicator disagrees with the (world, rank) it was created
+     * for would all-gather into the wrong slots — refused here, and reported to the caller through vksift_ext_shardGroupInfo */
+    int cn = 0, cr = 0;
+    if (g_rccl.CommCount && g_rccl.CommUserRank && g_rccl.CommCount(g->comm, &cn) == 0 && g_rccl.CommUserRank(g->comm, &cr) == 0)
+    {
+      g->comm_ranks = (uint32_t)cn, g->comm_rank = (uint32_t)cr;
+      if (g->comm_ranks != world || g->comm_rank != rank)
+      {
+        logError(LOG_TAG, "vksift_ext_shardGroupCreate() failure: the RCCL communicator reports rank %d of %d, the group was created as rank %u of %u", cr, cn,
+                 rank, world);
+        if (g_rccl.CommAbort)
+          g_rccl.CommAbort(g->comm);
+        free(g);
+        return VKSIFT_VULKAN_ERROR;
+      }
+    }
   }
   g->stream = vksift_hip_stream_create();
   g->comm_stream = vksift_hip_stream_create();
@@ -175,6 +196,18 @@ vksift_Result vksift_ext_shardGroupCreateWithTransport(vksift_ext_ShardGroup *ou
   if (!all_gather)
     return VKSIFT_INVALID_INPUT_ERROR;
   return shard_group_create(out, gpu_device_index, world, rank, NULL, all_gather, user);
+}
+
+void vksift_ext_shardGroupInfo(vksift_ext_ShardGroup g, uint32_t *world, uint32_t *rank, uint32_t *rccl_ranks, uint32_t *rccl_rank)
+{
+  if (world)
+    *world = g ? g->world : 0;
+  if (rank)
+    *rank = g ? g->rank : 0;
+  if (rccl_ranks)
+    *rccl_ranks = g ? g->comm_ranks : 0;
+  if (rccl_rank)
+    *rccl_rank = g ? g->comm_rank : 0;
 }
 
 void vksift_ext_shardGroupLayout(uint32_t n_total, uint32_t world, uint32_t rank, uint32_t *block_rows, uint32_t *first_row, uint32_t *nb_rows)

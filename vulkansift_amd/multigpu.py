@@ -136,6 +136,13 @@ class ShardGroup:
         if r != 0:
             raise RuntimeError(f"vksift_ext_shardGroupCreate failed ({r})")
 
+    def info(self):
+        """{"world", "rank", "rccl_ranks", "rccl_rank"}: the last two are ncclCommCount / ncclCommUserRank of the group's own communicator
+        (0 for a transport group)"""
+        v = [C.c_uint32(0) for _ in range(4)]
+        self._api.lib().vksift_ext_shardGroupInfo(self._h, *[C.byref(x) for x in v])
+        return dict(zip(("world", "rank", "rccl_ranks", "rccl_rank"), (int(x.value) for x in v)))
+
     def reserve(self, max_na, max_nb_total):
         """vksift_ext_shardGroupReserve: device scratch up front, so that match() within these sizes allocates nothing (a rank that
         runs out of memory inside a collective call cannot leave it without stranding its peers). Local; returns the result code —
@@ -193,6 +200,7 @@ def sharded_match_timed(d_a, a_index_base, d_b_block, nb_total, world, rank, rep
     try:
         d_b = pad_rows(d_b_block, blk)
         best, rec = None, None
+        sharded_match_timed.last_info = grp.info() if hasattr(grp, "info") else None
         for _ in range(repeats):
             if world > 1:
                 dist.barrier()
