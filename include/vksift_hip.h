@@ -92,6 +92,7 @@ extern "C"
                                  * otherwise only reached by images of 4097 pixels and more on the shortest side */
     VKSIFT_TUNE_REFINE_PTR = 3, /* 1: the refinement kernels address the scale-space through pointers everywhere (the form octaves beyond
                                  * 2 GiB take) instead of one buffer resource per image and octave */
+    VKSIFT_TUNE_SCAN_FORM = 4,  /* development: launch form of the cell-scan matcher (0 = built-in) */
     VKSIFT_TUNE_COUNT = 8
   };
   int vksift_hip_tune(int knob, int value);

@@ -705,11 +705,14 @@ __device__ __forceinline__ void cell_update(Cell3 &s, int m, uint32_t idx)
 }
 
 // Partial lists: 16 words per (row, piece): per lane h two uint4 [m1 i1 m2 i2][m3 i3 m4 -]. Work decomposition, staging and LDS layout of k_match32.
-template <int AT, int NW, int BTT>
+template <int AT, int NW, int BTT, int PIPE = 1>
 __global__ void __launch_bounds__(64 * NW) k_match_scan32(const uint32_t *__restrict__ desc_a, uint32_t na, const uint32_t *__restrict__ desc_b,
-                                                      const uint32_t *__restrict__ norm_b, uint32_t nb, uint32_t *__restrict__ partial)
+                                                      const uint32_t *__restrict__ norm_b, uint32_t nb, uint32_t *__restrict__ partial,
+                                                      uint32_t *__restrict__ redo_list)
 {
   constexpr uint32_t ROWS = 32u * AT * NW;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    redo_list[0] = 0u; // the replay list k_match_fix appends to (a launch of its own until round 5: 5 us of a 370 us call)
   constexpr uint32_t nchunks = VKSIFT_HIP_MATCH_CHUNKS;
   __shared__ __attribute__((aligned(16))) uint8_t s_b2[2][BTT * 128];
   __shared__ __attribute__((aligned(16))) int s_nbh2[2][BTT]; // -(bn >> 1), ACC_DEAD for rows beyond B: the MFMA's C operand
@@ -838,6 +841,23 @@ __global__ void __launch_bounds__(64 * NW) k_match_scan32(const uint32_t *__rest
             m = max(max(m, acc[t][i]), acc[t][i + 1]);
           m = max(m, acc[t][15]);
           cell_update(st[t], m, cell0 + (uint32_t)sub);
+        }
+        if (PIPE)
+        {
+          // Pin the software pipeline the source spells out: the 4 AT MFMAs of sub-block sub + 1 spread over the fold of sub-block sub.
+          // Left alone the compiler sinks all four folds of a tile behind the staging of the next tile and issues the tile's 32 MFMAs in
+          // one run: ~180 VALU instructions with nothing of this wave in the matrix pipe. The empty asm ties the fold's result to this
+          // point of the program (nothing sinks past it, and with the memory clobber no LDS read of a later sub-block rises above it);
+          // the group barriers order the instructions between two such points: one MFMA, its share of the fold's VALU, the next MFMA, ...
+#pragma unroll
+          for (int t = 0; t < AT; t++)
+            asm volatile("" : "+v"(st[t].m1), "+v"(st[t].m2), "+v"(st[t].m3), "+v"(st[t].m4), "+v"(st[t].i1), "+v"(st[t].i2), "+v"(st[t].i3)::"memory");
+#pragma unroll
+          for (int g = 0; g < 4 * AT; g++)
+          {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, (22 * AT + 4 * AT - 1) / (4 * AT), 0); // its share of the fold's VALU
+          }
         }
       }
       if (more)
@@ -1797,12 +1817,19 @@ extern "C"
        * Scratch: [row list: 1 + na][pad to 16 B][cell lists: 16 * na * VKSIFT_HIP_MATCH_CHUNKS] (VKSIFT_HIP_MATCH_SCRATCH_U32). */
       uint32_t *list = scratch;
       uint32_t *cells = (uint32_t *)(((uintptr_t)(scratch + na + 1u) + 15u) & ~(uintptr_t)15u); /* 16 words per (row, piece) */
-      const uint32_t G = 2u * device_cus();
-      (void)hipMemsetAsync(list, 0, sizeof(uint32_t), hs);
-      hipLaunchKernelGGL((k_match_scan32<2, 4, 128>), dim3(G), dim3(256), 0, hs, da, na, db, norm_b, nb, cells);
-      hipLaunchKernelGGL(k_match_fix, dim3((na + 31u) / 32u), dim3(256), 0, hs, (const uint32_t *)cells, da, norm_a, na, a_index_base, db, norm_b, nb, G, 128u, 256u,
+      /* Eight waves per workgroup, one workgroup per CU (the two waves of a SIMD share the staged tile: half the staging per MFMA of
+       * the 4-wave form), 256-row tiles of B (half the barriers and exposed pipeline ends per MFMA of 128-row tiles; 512 gives nothing
+       * more), MFMAs and folds interleaved as the source spells them (k_match_scan32: PIPE). 50 k x 50 k on one box, whole call:
+       * 0.430 ms (<2,4,128>, round 4) -> 0.413 (8 waves) -> 0.390 (pinned interleave) -> 0.370 (256-row tiles) */
+      const int form = vksift_hip_tune_get(VKSIFT_TUNE_SCAN_FORM);
+      const uint32_t Gs = form == 1 ? 2u * device_cus() : device_cus(), brows = form == 1 ? 256u : 512u, trows = form == 1 ? 128u : 256u;
+      if (form == 1)
+        hipLaunchKernelGGL((k_match_scan32<2, 4, 128, 0>), dim3(Gs), dim3(256), 0, hs, da, na, db, norm_b, nb, cells, list);
+      else
+        hipLaunchKernelGGL((k_match_scan32<2, 8, 256, 1>), dim3(Gs), dim3(512), 0, hs, da, na, db, norm_b, nb, cells, list);
+      hipLaunchKernelGGL(k_match_fix, dim3((na + 31u) / 32u), dim3(256), 0, hs, (const uint32_t *)cells, da, norm_a, na, a_index_base, db, norm_b, nb, Gs, trows, brows,
                          (uint32_t *)matches, list);
-      hipLaunchKernelGGL(k_match_redo_rows, dim3(2048), dim3(256), 0, hs, da, a_index_base, db, nb, (uint32_t *)matches, (const uint32_t *)list);
+      hipLaunchKernelGGL(k_match_redo_rows, dim3(512), dim3(256), 0, hs, da, a_index_base, db, nb, (uint32_t *)matches, (const uint32_t *)list);
       return (int)hipGetLastError();
     }
     else
@@ -1832,9 +1859,16 @@ extern "C"
     if (norm_scratch == nullptr || scratch_u32 < vksift_hip_match_scratch_u32(na, nb))
       return (int)hipErrorInvalidValue;
     uint32_t *norm_a = norm_scratch, *norm_b = norm_scratch + na;
-    int e = vksift_hip_shifted_norms(desc_a, na, norm_a, s);
-    if (e == 0)
-      e = vksift_hip_shifted_norms(desc_b, nb, norm_b, s);
+    /* both norm arrays in one launch (they are consecutive in the scratch and the rows are independent) when the descriptor sets are too */
+    int e = 0;
+    if (desc_b == desc_a + (size_t)na * 128u)
+      e = vksift_hip_shifted_norms(desc_a, na + nb, norm_a, s);
+    else
+    {
+      e = vksift_hip_shifted_norms(desc_a, na, norm_a, s);
+      if (e == 0)
+        e = vksift_hip_shifted_norms(desc_b, nb, norm_b, s);
+    }
     if (e == 0)
       e = vksift_hip_match_2nn_prenormed(desc_a, norm_a, na, a_index_base, desc_b, norm_b, nb, norm_scratch + na + nb, scratch_u32 - na - nb, matches, s);
     return e;
