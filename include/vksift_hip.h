@@ -55,6 +55,9 @@ extern "C"
   void vksift_hip_free(void *p);
   void *vksift_hip_host_malloc(size_t bytes);         /* pinned; replaces HOST_VISIBLE staging buffers */
   void vksift_hip_host_free(void *p);
+  int vksift_hip_host_register(void *p, size_t bytes); /* page-lock caller memory: copies into it become DMA transfers */
+  int vksift_hip_host_unregister(void *p);
+  int vksift_hip_is_pinned(const void *p);             /* 1: page-locked host memory (registered or vksift_hip_host_malloc) */
   vksift_hip_stream vksift_hip_stream_create(void);
   void vksift_hip_stream_destroy(vksift_hip_stream s);
   int vksift_hip_stream_sync(vksift_hip_stream s);    /* vkWaitForFences */

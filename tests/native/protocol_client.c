@@ -146,6 +146,14 @@ double proto_pipelined(vksift_Instance inst, const uint8_t *const *images, uint3
   uint32_t *ids0 = (uint32_t *)malloc(sizeof(uint32_t) * n), *ids1 = (uint32_t *)malloc(sizeof(uint32_t) * n);
   for (uint32_t i = 0; i < n; i++)
     ids0[i] = i, ids1[i] = n + i;
+  /* PROTO_PIN=1: page-locked result buffers (vksift_ext_pinHostMemory) — every download becomes a DMA transfer of its own out of device
+   * memory. Measured on MI355X with the next detection already queued: 77 us per transfer (the copy engine's ring behind a busy GPU,
+   * DESIGN.md section 4) against 7.5 us for the host copy out of the library's staged block: 6.9 k instead of 22.3 k frames/s. Off by
+   * default; the entry is for callers that fetch while the GPU is idle. */
+  const int pin = getenv("PROTO_PIN") && atoi(getenv("PROTO_PIN")) == 1;
+  const vksift_Config cfg_sz = vksift_getDefaultConfig();
+  const int pinned_f = pin && vksift_ext_pinHostMemory(feat_buf, (size_t)cfg_sz.max_nb_sift_per_buffer * sizeof(vksift_Feature)) == VKSIFT_SUCCESS;
+  const int pinned_m = pin && vksift_ext_pinHostMemory(match_buf, (size_t)cfg_sz.max_nb_sift_per_buffer * sizeof(vksift_Match_2NN)) == VKSIFT_SUCCESS;
   run_pipelined(inst, images, n, w, h, do_match, 2, ids0, ids1, feat_buf, match_buf);
   const double t0 = now_s();
   run_pipelined(inst, images, n, w, h, do_match, steps, ids0, ids1, feat_buf, match_buf);
@@ -155,6 +163,10 @@ double proto_pipelined(vksift_Instance inst, const uint8_t *const *images, uint3
                     "second %.2f | other %u downloads %.2f | wait matching %.2f | match downloads %.2f | measured period %.2f\n",
             g_t[0] * 1e3 / (steps + 2), g_t[1] * 1e3 / (steps + 2), g_t[2] * 1e3 / (steps + 2), g_t[3] * 1e3 / (steps + 2), n - 2, g_t[4] * 1e3 / (steps + 2),
             g_t[5] * 1e3 / (steps + 2), g_t[6] * 1e3 / (steps + 2), dt * 1e3 / steps);
+  if (pinned_f)
+    vksift_ext_unpinHostMemory(feat_buf);
+  if (pinned_m)
+    vksift_ext_unpinHostMemory(match_buf);
   free(ids0);
   free(ids1);
   return dt;

@@ -91,3 +91,45 @@ def test_scale_space_placement_is_measured_and_changes_no_result(vk, monkeypatch
     # a single-image instance never searches
     with vk.Instance(vk.default_config(input_image_max_size=w * h)) as inst:
         assert inst.getScaleSpacePlacement()["gbps"] == []
+
+
+def test_page_locked_destinations_receive_the_same_records(vk):
+    """vksift_ext_pinHostMemory: a page-locked destination gets the records of a batched detection / matching by DMA straight from the
+    packed device copy (no pinned staging, no host memcpy) — byte for byte what the pageable path returns, in any interleaving of pinned
+    and pageable downloads of the same detection"""
+    w, h, n = 320, 240, 16
+    imgs = [vk.gen_synthetic_image_family(610 + i, w, h, i % 3) for i in range(n)]
+    L = vk.lib()
+    cap = 20000
+    cfg = vk.default_config(sift_buffer_count=n, input_image_max_size=w * h, max_nb_sift_per_buffer=cap)
+    fbuf = np.zeros(cap, vk.FEATURE_DTYPE)
+    mbuf = np.zeros(cap, vk.MATCH_DTYPE)
+    assert L.vksift_ext_pinHostMemory(fbuf.ctypes.data, fbuf.nbytes) == 0 and L.vksift_ext_pinHostMemory(mbuf.ctypes.data, mbuf.nbytes) == 0
+    try:
+        with vk.Instance(cfg, batch_capacity=n) as inst:
+            ids = list(range(n))
+            for order in ("pinned_first", "pageable_first"):
+                inst.detectFeaturesBatch(imgs, 0)
+                inst.matchFeaturesBatch(ids, ids[::-1])
+                ref, got = {}, {}
+                seq = ids if order == "pinned_first" else []
+                if order == "pageable_first":
+                    for i in ids[:3]:
+                        ref[i] = inst.downloadFeatures(i)      # builds the staged copy: the pinned downloads below read it
+                for i in ids:
+                    cnt = inst.getFeaturesNumber(i)
+                    fbuf[:] = 0
+                    L.vksift_downloadFeatures(inst._h, fbuf.ctypes.data, i)
+                    got[i] = fbuf[:cnt].copy()
+                for i in ids:
+                    if i not in ref:
+                        ref[i] = inst.downloadFeatures(i)
+                for i in ids:
+                    assert len(got[i]) > 50 and got[i].tobytes() == ref[i].tobytes(), (order, i)
+                for k in ids:
+                    cnt = L.vksift_ext_getMatchesNumberBatch(inst._h, k)
+                    mbuf[:] = 0
+                    L.vksift_ext_downloadMatchesBatch(inst._h, k, mbuf.ctypes.data)
+                    assert mbuf[:cnt].tobytes() == inst.downloadMatchesBatch(k).tobytes(), (order, k)
+    finally:
+        assert L.vksift_ext_unpinHostMemory(fbuf.ctypes.data) == 0 and L.vksift_ext_unpinHostMemory(mbuf.ctypes.data) == 0

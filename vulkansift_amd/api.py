@@ -127,6 +127,10 @@ def lib():
     L.vksift_ext_getDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings)]
     L.vksift_ext_getAccumulatedDetectTimings.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.POINTER(u32), C.c_bool]
     L.vksift_ext_getDetectTimingsSized.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.c_size_t]
+    L.vksift_ext_pinHostMemory.argtypes = [C.c_void_p, C.c_size_t]
+    L.vksift_ext_pinHostMemory.restype = C.c_int
+    L.vksift_ext_unpinHostMemory.argtypes = [C.c_void_p]
+    L.vksift_ext_unpinHostMemory.restype = C.c_int
     L.vksift_ext_getScaleSpacePlacement.argtypes = [inst, C.POINTER(C.c_float), C.POINTER(u32)]
     L.vksift_ext_getScaleSpacePlacement.restype = u32
     L.vksift_ext_getAccumulatedDetectTimingsSized.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.c_size_t, C.POINTER(u32), C.c_bool]

@@ -1818,15 +1818,18 @@ extern "C"
       uint32_t *list = scratch;
       uint32_t *cells = (uint32_t *)(((uintptr_t)(scratch + na + 1u) + 15u) & ~(uintptr_t)15u); /* 16 words per (row, piece) */
       /* Eight waves per workgroup, one workgroup per CU (the two waves of a SIMD share the staged tile: half the staging per MFMA of
-       * the 4-wave form), 256-row tiles of B (half the barriers and exposed pipeline ends per MFMA of 128-row tiles; 512 gives nothing
-       * more), MFMAs and folds interleaved as the source spells them (k_match_scan32: PIPE). 50 k x 50 k on one box, whole call:
-       * 0.430 ms (<2,4,128>, round 4) -> 0.413 (8 waves) -> 0.390 (pinned interleave) -> 0.370 (256-row tiles) */
-      const int form = vksift_hip_tune_get(VKSIFT_TUNE_SCAN_FORM);
-      const uint32_t Gs = form == 1 ? 2u * device_cus() : device_cus(), brows = form == 1 ? 256u : 512u, trows = form == 1 ? 128u : 256u;
-      if (form == 1)
+       * round 4's 4-wave form), 96 query rows per wave (three MFMAs per B fragment read from LDS), 256-row tiles of B (half the
+       * barriers and exposed pipeline ends per MFMA of 128-row tiles; 512 gives nothing more), MFMAs and folds interleaved as the
+       * source spells them (k_match_scan32: PIPE). 50 k x 50 k on one box, whole call: 0.430 ms (<2,4,128>, round 4) -> 0.413 (8 waves)
+       * -> 0.390 (pinned interleave) -> 0.370 (256-row tiles) -> 0.354 (96 rows per wave; 12 waves x 64 rows: 0.358, 128 rows per
+       * wave: 0.360 at 256 VGPRs, 12 waves x 96 rows: 0.50); 100 k x 100 k 1.50 -> 1.18 ms = 55 % of the int8 peak.
+       * VKSIFT_TUNE_SCAN_FORM = 1: round 4's form (A/B). */
+      const bool r4 = vksift_hip_tune_get(VKSIFT_TUNE_SCAN_FORM) == 1;
+      const uint32_t Gs = r4 ? 2u * device_cus() : device_cus(), brows = r4 ? 256u : 768u, trows = r4 ? 128u : 256u;
+      if (r4)
         hipLaunchKernelGGL((k_match_scan32<2, 4, 128, 0>), dim3(Gs), dim3(256), 0, hs, da, na, db, norm_b, nb, cells, list);
       else
-        hipLaunchKernelGGL((k_match_scan32<2, 8, 256, 1>), dim3(Gs), dim3(512), 0, hs, da, na, db, norm_b, nb, cells, list);
+        hipLaunchKernelGGL((k_match_scan32<3, 8, 256, 1>), dim3(Gs), dim3(512), 0, hs, da, na, db, norm_b, nb, cells, list);
       hipLaunchKernelGGL(k_match_fix, dim3((na + 31u) / 32u), dim3(256), 0, hs, (const uint32_t *)cells, da, norm_a, na, a_index_base, db, norm_b, nb, Gs, trows, brows,
                          (uint32_t *)matches, list);
       hipLaunchKernelGGL(k_match_redo_rows, dim3(512), dim3(256), 0, hs, da, a_index_base, db, nb, (uint32_t *)matches, (const uint32_t *)list);

@@ -92,6 +92,20 @@ extern "C"
       return nullptr;
     return p;
   }
+  /* page-lock caller memory (hipHostRegister) so that device-to-host copies into it are real DMA transfers; 1 / 0 / <0 */
+  int vksift_hip_host_register(void *p, size_t bytes) { return (int)hipHostRegister(p, bytes, hipHostRegisterDefault); }
+  int vksift_hip_host_unregister(void *p) { return (int)hipHostUnregister(p); }
+  int vksift_hip_is_pinned(const void *p)
+  {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess)
+    {
+      (void)hipGetLastError(); /* plain pageable memory: the query fails, and the sticky error must not surface in a later launch check */
+      return 0;
+    }
+    return a.type == hipMemoryTypeHost ? 1 : 0;
+  }
+
   void vksift_hip_host_free(void *p)
   {
     if (p)

@@ -131,9 +131,22 @@ static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr,
                                    VKSIFT_MAX_OCTAVES, inst->d_dl, max_rows, NULL, inst->dl_stream) != 0)
         return false;
     }
+    /* A page-locked destination (vksift_ext_pinHostMemory, hipHostMalloc) takes its records by DMA straight out of the packed device
+     * copy: no transfer into the pinned staging block for this detection at all. (A later pageable destination of the same detection
+     * falls back to a plain copy out of the device block.) */
+    inst->dl_direct = vksift_hip_is_pinned(feats_ptr) == 1;
+    if (inst->dl_direct)
+    {
+      if (!inst->dl_ev[0])
+        inst->dl_ev[0] = vksift_hip_event_create();
+      if (!inst->dl_ev[0] || vksift_hip_event_record(inst->dl_ev[0], inst->dl_stream) != 0)
+        return false;
+      inst->dl_chunks = 0, inst->dl_chunks_done = 0;
+      inst->dl_first = first, inst->dl_count = count, inst->dl_seq = b->seq, inst->dl_valid = true;
+    }
     /* the copy goes in a few pieces with an event each: a caller that walks the buffers in order copies buffer i out of pinned
      * memory while the pieces behind it are still on the bus */
-    uint32_t nch = (uint32_t)(bytes / ((size_t)4 << 20)) + 1u;
+    uint32_t nch = inst->dl_direct ? 0u : (uint32_t)(bytes / ((size_t)4 << 20)) + 1u;
     if (nch > VKSIFT_DL_CHUNKS)
       nch = VKSIFT_DL_CHUNKS;
     for (uint32_t k = 0; k < nch; k++)
@@ -147,10 +160,27 @@ static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr,
         return false;
       inst->dl_chunk_end[k] = hi;
     }
-    inst->dl_chunks = nch, inst->dl_chunks_done = 0;
-    inst->dl_first = first, inst->dl_count = count, inst->dl_seq = b->seq, inst->dl_valid = true;
+    if (!inst->dl_direct)
+    {
+      inst->dl_chunks = nch, inst->dl_chunks_done = 0;
+      inst->dl_first = first, inst->dl_count = count, inst->dl_seq = b->seq, inst->dl_valid = true;
+    }
   }
   const uint32_t i = buf - first;
+  if (inst->dl_direct)
+  {
+    /* device block -> the caller's memory: one transfer on the download stream (behind the pack kernels), one wait */
+    const size_t n_bytes = (size_t)(inst->dl_row[i + 1] - inst->dl_row[i]) * FEAT_BYTES;
+    if (n_bytes == 0)
+      return true;
+    if (vksift_hip_memcpy_d2h(feats_ptr, inst->d_dl + (size_t)inst->dl_row[i] * FEAT_BYTES, n_bytes, inst->dl_stream) != 0 ||
+        vksift_hip_stream_sync(inst->dl_stream) != 0)
+    {
+      inst->dl_valid = false;
+      return false;
+    }
+    return true;
+  }
   {
     /* wait for the pieces that hold this buffer's records */
     const size_t need = (size_t)inst->dl_row[i + 1] * FEAT_BYTES;

@@ -69,6 +69,20 @@ void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext
   vksift_ext_getAccumulatedDetectTimingsSized(instance, sum, VKSIFT_EXT_DETECT_TIMINGS_V1_BYTES, nb_calls, reset);
 }
 
+vksift_Result vksift_ext_pinHostMemory(void *ptr, size_t bytes)
+{
+  if (!ptr || !bytes || !vksift_g_loaded)
+    return VKSIFT_VULKAN_ERROR;
+  return vksift_hip_host_register(ptr, bytes) == 0 ? VKSIFT_SUCCESS : VKSIFT_VULKAN_ERROR;
+}
+
+vksift_Result vksift_ext_unpinHostMemory(void *ptr)
+{
+  if (!ptr || !vksift_g_loaded)
+    return VKSIFT_VULKAN_ERROR;
+  return vksift_hip_host_unregister(ptr) == 0 ? VKSIFT_SUCCESS : VKSIFT_VULKAN_ERROR;
+}
+
 uint32_t vksift_ext_getScaleSpacePlacement(vksift_Instance instance, float gbps[8], uint32_t chosen[2])
 {
   for (uint32_t i = 0; i < 8u; i++)

@@ -203,6 +203,7 @@ struct vksift_Instance_T
   uint32_t *dl_row;    /* sift_buffer_count + 1 row offsets of the cached buffers */
   uint32_t dl_first, dl_count;
   bool dl_valid;
+  bool dl_direct;            /* the packed copy of the current detection is fetched by DMA into page-locked destinations: nothing went to h_dl */
   vksift_hip_event dl_ev[VKSIFT_DL_CHUNKS]; /* the packed copy arrives in pieces */
   size_t dl_chunk_end[VKSIFT_DL_CHUNKS];
   uint32_t dl_chunks, dl_chunks_done;

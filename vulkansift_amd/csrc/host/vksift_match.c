@@ -331,7 +331,9 @@ static void download_matches(vksift_Instance inst, uint32_t pair, vksift_Match_2
     /* A caller that walks the pairs of a batched matching gets them out of ONE strided copy into pinned memory instead of one
      * copy + synchronisation per pair (12 us each: 1.5 ms per 128 pairs). Like the packed feature download it starts with the
      * second download after a matching: a caller that samples one pair must not pay for all of them. */
-    if (inst->match_slots_used >= VKSIFT_DL_BATCH_MIN && (inst->md_valid || inst->md_hits++ > 0) && packed_match_download(inst, pair, matches, n))
+    /* (a page-locked destination takes the records by DMA straight from the slot: vksift_ext_pinHostMemory) */
+    if (inst->match_slots_used >= VKSIFT_DL_BATCH_MIN && vksift_hip_is_pinned(matches) != 1 && (inst->md_valid || inst->md_hits++ > 0) &&
+        packed_match_download(inst, pair, matches, n))
       return;
     HIP_CHECK(vksift_hip_memcpy_d2h(matches, inst->d_matches + (uint64_t)pair * inst->match_slot_stride, (size_t)n * MATCH_BYTES, inst->dl_stream),
               "match read-back");
