@@ -478,6 +478,8 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
 
   int rg = y0 - R; // first virtual row of the current group
   prefetch(rg);
+  float hrc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; // UPS: see the staging of a shared group
+  int hrc_from = -(1 << 30);                                      // ... the group they were left by
 
   float2 wv[NWIN];
 #pragma unroll
@@ -490,12 +492,15 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
     __syncthreads();
     if (UPS && ups_shared(rg))
     {
+      // the first UPS_NSRC - 4 source rows of this group are the last ones of the previous group (8 output rows = 4 source rows further
+      // down): their horizontally interpolated texels are carried over in registers instead of being converted and interpolated
+      // again — a third of this launch's conversion work, the same values
+      const bool carried = hrc_from == rg - NR;
+      hrc_from = rg;
       if (lane < NV4)
       {
         float hr[UPS_NSRC][4];
-#pragma unroll
-        for (int s = 0; s < UPS_NSRC; s++)
-        {
+        auto hrow = [&](int s) {
           const unsigned d = __builtin_amdgcn_perm(pf[s].x, pf[s].x, perm_sel);
           float t[4];
 #pragma unroll
@@ -508,7 +513,29 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
             const float aw = (k & 1) ? 0.25f : 0.75f;
             hr[s][k] = fmaf(aw, t[i0 + 1], (1.f - aw) * t[i0]);
           }
+        };
+        if (carried)
+        {
+#pragma unroll
+          for (int s = 0; s < UPS_NSRC - 4; s++)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              hr[s][k] = hrc[s][k];
         }
+        else
+        {
+#pragma unroll
+          for (int s = 0; s < UPS_NSRC - 4; s++)
+            hrow(s);
+        }
+#pragma unroll
+        for (int s = UPS_NSRC - 4; s < UPS_NSRC; s++)
+          hrow(s);
+#pragma unroll
+        for (int s = 0; s < UPS_NSRC - 4; s++)
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            hrc[s][k] = hr[4 + s][k];
 #pragma unroll
         for (int j = 0; j < NR; j++)
         {
@@ -797,13 +824,20 @@ __global__ void __launch_bounds__(64) k_blur_wide(StreamArgs a)
   int rg = y0 - R; // first virtual row of the current group
   prefetch(rg);
 
-  v4f wv[NWIN];
+  // The register window is a RING of NWP = NPH * NR rows: in phase P (the P-th group of a round) window row k lives in
+  // wv[(k + P * NR) % NWP], so the window slides by renaming — the march loop is unrolled over the NPH phases and every index is a
+  // compile-time constant. (The copy form, wv[k] = wv[k + NR] for the 2R rows that stay, was 96 of ~1550 VALU instructions per group at 13
+  // taps.) NWIN rounded up to whole groups: 4 spare rows at 11 taps.
+  constexpr int NPH = (NWIN + NR - 1) / NR, NWP = NPH * NR;
+  static_assert(NPH <= 4, "phases spelled out in the march loop");
+  v4f wv[NWP];
 #pragma unroll
-  for (int k = 0; k < NWIN; k++)
+  for (int k = 0; k < NWP; k++)
     wv[k] = v4f{0.f, 0.f, 0.f, 0.f};
 
-  for (; rg - R < y1; rg += NR)
-  {
+  auto group = [&](auto PH) {
+    constexpr int P = decltype(PH)::value;
+#define WV(k) wv[((k) + P * NR) % NWP]
     // ---- stage the prefetched group, then prefetch the next one
     __syncthreads();
 #pragma unroll
@@ -846,7 +880,7 @@ __global__ void __launch_bounds__(64) k_blur_wide(StreamArgs a)
 #pragma unroll
           for (int k = 0; k < 4; k++)
             o[k] = fmaf(va[RA + k + i] + va[RA + k - i], a.taps.k[i], o[k]);
-        wv[2 * R + j] = v4f{o[0], o[1], o[2], o[3]};
+        WV(2 * R + j) = v4f{o[0], o[1], o[2], o[3]};
       }
     }
 
@@ -854,12 +888,13 @@ __global__ void __launch_bounds__(64) k_blur_wide(StreamArgs a)
     const int yb = rg - R;
     if (yb + NR > y0)
     {
-      auto vrow = [&](int j, int so_d) {
-        v4f acc = wv[R + j] * k0;
+      auto vrow = [&](auto J, int so_d) {
+        constexpr int j = decltype(J)::value;
+        v4f acc = WV(R + j) * k0;
 #pragma unroll
         for (int i = 1; i < NT; i++)
         {
-          const v4f sm = wv[R + j + i] + wv[R + j - i];
+          const v4f sm = WV(R + j + i) + WV(R + j - i);
           acc.x = fmaf(sm.x, a.taps.k[i], acc.x);
           acc.y = fmaf(sm.y, a.taps.k[i], acc.y);
           acc.z = fmaf(sm.z, a.taps.k[i], acc.z);
@@ -870,26 +905,37 @@ __global__ void __launch_bounds__(64) k_blur_wide(StreamArgs a)
         if (has_ds && (j & 1))
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(acc.y), __float_as_uint(acc.w)}, rds, st_off_ds, ((yb + j) >> 1) * dspitch4, ST_STREAM);
       };
+      const int so_0 = yb * dpitch4;
+#define VROW(J) vrow(std::integral_constant<int, J>{}, so_0 + J * dpitch4);
+#define VROWC(J)                            \
+  if (yb + J >= y0 && yb + J < y1)          \
+    VROW(J)
       if (yb >= y0 && yb + NR <= y1)
       {
-        int so_d = yb * dpitch4;
-#pragma unroll
-        for (int j = 0; j < NR; j++, so_d += dpitch4)
-          vrow(j, so_d);
+        VROW(0) VROW(1) VROW(2) VROW(3) VROW(4) VROW(5) VROW(6) VROW(7)
       }
       else
       {
-        int so_d = yb * dpitch4;
-#pragma unroll
-        for (int j = 0; j < NR; j++, so_d += dpitch4)
-          if (yb + j >= y0 && yb + j < y1)
-            vrow(j, so_d);
+        VROWC(0) VROWC(1) VROWC(2) VROWC(3) VROWC(4) VROWC(5) VROWC(6) VROWC(7)
       }
+#undef VROWC
+#undef VROW
     }
-    // ---- slide the window
-#pragma unroll
-    for (int k = 0; k < 2 * R; k++)
-      wv[k] = wv[k + NR];
+#undef WV
+  };
+
+  for (;;)
+  {
+#define PHASE(P)                                      \
+  if (P < NPH)                                        \
+  {                                                   \
+    if (!(rg - R < y1))                               \
+      break;                                          \
+    group(std::integral_constant<int, (P < NPH ? P : 0)>{}); \
+    rg += NR;                                         \
+  }
+    PHASE(0) PHASE(1) PHASE(2) PHASE(3)
+#undef PHASE
   }
 }
 
