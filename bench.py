@@ -129,9 +129,25 @@ def dry_launch(args, rank, local_rank, world):
         t = torch.tensor([local_rank], dtype=torch.int64)
     got = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(got, t)
+    # with a GPU per rank: the library's OWN RCCL communicator comes up too (vksift_ext_shardGroupCreate: ncclCommInitRank on every rank)
+    # and says how many ranks it sees (ncclCommCount / ncclCommUserRank through vksift_ext_shardGroupInfo); without GPUs: null
+    rccl = None
+    if use_gpu:
+        try:
+            from vulkansift_amd import multigpu
+            grp = multigpu.ShardGroup(local_rank, world, rank, dist if world > 1 else None)
+            info = grp.info()
+            grp.close()
+            r = torch.tensor([info["rccl_ranks"], info["rccl_rank"]], dtype=torch.int64, device=t.device)
+            allr = [torch.zeros_like(r) for _ in range(world)]
+            dist.all_gather(allr, r)
+            rccl = {"rccl_ranks": [int(x[0].item()) for x in allr], "rccl_rank": [int(x[1].item()) for x in allr]}
+        except Exception as e:  # noqa: BLE001
+            rccl = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps({"dry_launch": True, "n_gpus": world, "backend": "nccl" if use_gpu else "gloo",
-                          "local_ranks": [int(x.item()) for x in got], "gpus_visible": torch.cuda.device_count() if torch.cuda.is_available() else 0}), flush=True)
+                          "local_ranks": [int(x.item()) for x in got], "gpus_visible": torch.cuda.device_count() if torch.cuda.is_available() else 0,
+                          "rccl_ranks": rccl}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     return 0

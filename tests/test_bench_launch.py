@@ -24,6 +24,7 @@ def test_gpus_2_dry_launch_brings_two_ranks_up():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["dry_launch"] is True and d["n_gpus"] == 2
+    assert "rccl_ranks" in d and d["rccl_ranks"] is None       # gloo here: no communicator of the library's own to ask
     assert sorted(d["local_ranks"]) == [0, 1]          # two processes, distinct LOCAL_RANKs
     assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
 
