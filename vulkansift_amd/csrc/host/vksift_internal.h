@@ -225,6 +225,7 @@ struct vksift_Instance_T
   /* packed download of the records of a batched matching (h_matches: pinned) */
   size_t md_cap, md_pitch;
   bool md_valid;
+  bool md_asked, md_direct;  /* (asked once per matching) the caller's destination of this matching's records is page-locked: per-pair DMA, no packed copy */
   uint32_t md_hits;
   bool *match_busy; /* per SIFT buffer: read by the matching pipeline in flight (all pairs of a batched call) */
   uint32_t curr_nb_matches;

@@ -192,7 +192,7 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
     HIP_CHECK(match_slots(inst, &fwd, ids_a + r, ids_b + r, count - r < VKSIFT_HIP_MATCH_SLOTS ? count - r : VKSIFT_HIP_MATCH_SLOTS, r), "2-NN matching");
   HIP_CHECK(vksift_hip_post_words(inst->h_match_n, inst->d_match_n, (size_t)4 * count, inst->stream), "match count read-back");
   inst->filtered_slots_used = 0;
-  inst->md_valid = false, inst->md_hits = 0;
+  inst->md_valid = false, inst->md_hits = 0, inst->md_direct = false, inst->md_asked = false;
   if (filter)
   {
     /* the reverse matching, then cross-check + ratio test on the device; only the survivors are read back */
@@ -332,7 +332,9 @@ static void download_matches(vksift_Instance inst, uint32_t pair, vksift_Match_2
      * copy + synchronisation per pair (12 us each: 1.5 ms per 128 pairs). Like the packed feature download it starts with the
      * second download after a matching: a caller that samples one pair must not pay for all of them. */
     /* (a page-locked destination takes the records by DMA straight from the slot: vksift_ext_pinHostMemory) */
-    if (inst->match_slots_used >= VKSIFT_DL_BATCH_MIN && vksift_hip_is_pinned(matches) != 1 && (inst->md_valid || inst->md_hits++ > 0) &&
+    if (inst->match_slots_used >= VKSIFT_DL_BATCH_MIN && !inst->md_asked)
+      inst->md_direct = vksift_hip_is_pinned(matches) == 1, inst->md_asked = true; /* once per matching: the query costs a microsecond */
+    if (inst->match_slots_used >= VKSIFT_DL_BATCH_MIN && !inst->md_direct && (inst->md_valid || inst->md_hits++ > 0) &&
         packed_match_download(inst, pair, matches, n))
       return;
     HIP_CHECK(vksift_hip_memcpy_d2h(matches, inst->d_matches + (uint64_t)pair * inst->match_slot_stride, (size_t)n * MATCH_BYTES, inst->dl_stream),
