@@ -96,6 +96,7 @@ extern "C"
     VKSIFT_TUNE_REFINE_PTR = 3, /* 1: the refinement kernels address the scale-space through pointers everywhere (the form octaves beyond
                                  * 2 GiB take) instead of one buffer resource per image and octave */
     VKSIFT_TUNE_SCAN_FORM = 4,  /* development: launch form of the cell-scan matcher (0 = built-in) */
+    VKSIFT_TUNE_PAIR_FORM = 5,  /* two-scale blur launch: 0 built-in, 1 two texels per lane, 2 four texels per lane */
     VKSIFT_TUNE_COUNT = 8
   };
   int vksift_hip_tune(int knob, int value);

@@ -68,6 +68,60 @@ def test_wide_blur_in_a_batch_with_both_march_directions(vk):
     assert res["wide"] == res["lean"] and all(len(r) > 164 * 100 for r in res["wide"])
 
 
+PAIR_SHAPES = [
+    (640, 480, {}),                                    # 1280 wide: 6 strips of 240 owned columns (the last one a third full); 640, 320 wide below
+    (960, 540, {}),                                    # 1920 = 8 strips exactly
+    (1000, 600, {}),                                   # 2000 wide: 9 strips, image edge 80 columns into the last one
+    (126, 250, {}),                                    # 252 wide: one strip, both image edges inside it; octave 1 falls to the two-texel form
+    (1920, 1080, {"use_input_upsampling": False}),
+]
+
+
+@pytest.mark.parametrize("w,h,kw", PAIR_SHAPES)
+def test_two_scale_launch_in_both_lane_widths(vk, oracle, w, h, kw):
+    """k_blur_pair_wide (four texels per lane) against k_blur_pair (two) through VKSIFT_TUNE_PAIR_FORM, and against the oracle"""
+    img = vk.gen_synthetic_image_family(5100 + w + h, w, h, (w // 64) % 3)
+    L = vk.lib()
+    out = {}
+    try:
+        for name, form in (("two", 1), ("four", 2)):
+            L.vksift_hip_tune(5, form)
+            with vk.Instance(vk.default_config(input_image_max_size=w * h, **kw)) as inst:
+                inst.detectFeatures(img, 0)
+                feats = inst.downloadFeatures(0)
+                n_oct = inst.getScaleSpaceNbOctaves()
+                planes = [[inst.downloadScaleSpaceImage(o, s) for s in range(6)] for o in range(n_oct)]
+            out[name] = (feats, planes)
+    finally:
+        L.vksift_hip_tune(5, 0)
+    assert len(out["four"][0]) > 20
+    for o, (pw, pl) in enumerate(zip(out["four"][1], out["two"][1])):
+        for s, (a, b) in enumerate(zip(pw, pl)):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (o, s)
+    assert out["four"][0].tobytes() == out["two"][0].tobytes()
+    okw = {k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()}
+    ref, _ = oracle.detect(oracle.default_config(math_mode=1, **okw), img)
+    assert out["four"][0].tobytes() == ref.tobytes()
+
+
+def test_two_scale_launch_widths_in_a_batch(vk):
+    """24 frames on a two-buffer instance (both march directions, XCD remap), both lane widths, against each other"""
+    w, h, n = 640, 480, 24
+    imgs = [vk.gen_synthetic_image_family(1880 + i, w, h, i % 3) for i in range(n)]
+    L = vk.lib()
+    res = {}
+    try:
+        for name, form in (("two", 1), ("four", 2)):
+            L.vksift_hip_tune(5, form)
+            with vk.Instance(vk.default_config(sift_buffer_count=n, input_image_max_size=w * h), batch_capacity=n) as inst:
+                for rep in range(2):
+                    inst.detectFeaturesBatch(imgs, 0)
+                res[name] = [inst.downloadFeatures(i).tobytes() for i in range(n)]
+    finally:
+        L.vksift_hip_tune(5, 0)
+    assert res["four"] == res["two"] and all(len(r) > 164 * 100 for r in res["four"])
+
+
 def test_scale_space_placement_is_measured_and_changes_no_result(vk, monkeypatch):
     """batch instances whose scale-space is large enough time candidate memory ranges and keep the fastest (vksift_ext_getScaleSpacePlacement
     reports the rates); VKSIFT_PYR_PLACEMENT=0 allocates plainly. Same features either way."""

@@ -1199,6 +1199,236 @@ __global__ void __launch_bounds__(64) k_blur_pair(PairArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_blur_pair_wide — k_blur_pair with four texels per lane on 256-column strips (round 5): the two window reads per row become
+// aligned ds_read_b128 (3 + 5 per row for 5 + 7 taps instead of 6 + 8 ds_read_b64 for half the texels), the scale-s rows go to the
+// second LDS buffer and to HBM 16 bytes per lane. A wave computes scale s on 256 columns and owns the inner 256 - 2 HC. Same
+// operations per texel in the same order: bit-identical to k_blur_pair and to two k_blur_lean launches.
+// ---------------------------------------------------------------------------------------------
+template <int NT1, int NT2>
+__global__ void __launch_bounds__(64) k_blur_pair_wide(PairArgs a)
+{
+  constexpr int NR = 8;
+  constexpr int R1 = NT1 - 1, R2 = NT2 - 1;
+  constexpr int RA1 = (R1 + 3) & ~3, RA2 = (R2 + 3) & ~3;
+  constexpr int HC = RA2;
+  constexpr int TW = 256, OW = TW - 2 * HC;
+  constexpr int SW = TW + 2 * RA1;
+  constexpr int NX = RA1 / 2, NXT = NX * NR;
+  constexpr int NQ1 = RA1 / 2 + 1, NQ2 = RA2 / 2 + 1;
+  constexpr int G1S = TW + 2 * RA2; // row stride of the scale-s rows in LDS: RA2 floats of padding on both sides
+  constexpr int NWIN1 = 2 * R1 + NR, NWIN2 = 2 * R2 + NR;
+  static_assert(NXT <= 64, "the extra float4 columns of a group are staged by one instruction");
+  __shared__ __attribute__((aligned(16))) float s_grp[NR * SW];
+  __shared__ __attribute__((aligned(16))) float s_g1[NR * G1S];
+
+  const int lane = threadIdx.x;
+  const int W = a.w, H = a.h;
+  uint32_t bs = blockIdx.x, bseg = blockIdx.y, bimg = blockIdx.z;
+  {
+    const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
+    const uint32_t b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    uint32_t wi = b;
+    if ((total & 7u) == 0)
+    {
+      const uint32_t per = total >> 3, k = b >> 3;
+      wi = (b & 7u) * per + (a.rev ? per - 1u - k : k);
+    }
+    else if (a.rev)
+      wi = total - 1u - b;
+    bs = wi % gridDim.x;
+    const uint32_t r = wi / gridDim.x;
+    bseg = r % gridDim.y;
+    bimg = r / gridDim.y;
+  }
+  const int x0 = (int)bs * OW - HC; // first computed column (virtual: negative on the first strip)
+  const int y0 = bseg * a.seg;
+  const int y1 = min(y0 + a.seg, H);
+  const __amdgpu_buffer_rsrc_t rs = plane_rsrc<false>(a.src, (size_t)bimg * a.src_img_stride, a.spitch, H);
+  const __amdgpu_buffer_rsrc_t rd1 = plane_rsrc<false>(a.dst1, (size_t)bimg * a.dst1_img_stride, a.d1pitch, H);
+  const __amdgpu_buffer_rsrc_t rd2 = plane_rsrc<false>(a.dst2, (size_t)bimg * a.dst2_img_stride, a.d2pitch, H);
+  const int spitch4 = a.spitch * 4, d1pitch4 = a.d1pitch * 4, d2pitch4 = a.d2pitch * 4;
+
+  auto col_off = [&](int gx4, bool &rv) -> unsigned {
+    if (gx4 >= 0 && gx4 + 3 < W)
+      return (unsigned)gx4 * 4u;
+    rv = true;
+    return (unsigned)mirror_idx(gx4 + 3, W) * 4u; // the four virtual columns map to m3+3, m3+2, m3+1, m3
+  };
+  bool rev = false, rev_x = false;
+  const unsigned ld_off = col_off(x0 - RA1 + 4 * lane, rev);
+  const int xr = lane / NX, xq = 64 + lane % NX;
+  unsigned ldx_col = BUF_OOB;
+  if (lane < NXT)
+    ldx_col = col_off(x0 - RA1 + 4 * xq, rev_x);
+  const unsigned ldx_off = lane < NXT ? ldx_col + (unsigned)(xr * spitch4) : BUF_OOB;
+  float *const sx = s_grp + xr * SW + 4 * xq;
+  const int px = x0 + 4 * lane;
+  const bool own = 4 * lane >= HC && 4 * lane + 3 < TW - HC;
+  const unsigned st_off = (own && px >= 0 && px + 3 < W) ? (unsigned)px * 4u : BUF_OOB;
+  const float k10 = a.t1.k[0], k20 = a.t2.k[0];
+
+  u32x4 pf[NR], pfx;
+  auto prefetch = [&](int r0) {
+    if (r0 >= 0 && r0 + NR <= H)
+    {
+      int so = r0 * spitch4;
+      pfx = __builtin_amdgcn_raw_buffer_load_b128(rs, ldx_off, so, 0);
+#pragma unroll
+      for (int j = 0; j < NR; j++, so += spitch4)
+        pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, so, 0);
+    }
+    else
+    {
+      const unsigned ox = lane < NXT ? ldx_col + (unsigned)(mirror_idx(r0 + xr, H) * spitch4) : BUF_OOB;
+      pfx = __builtin_amdgcn_raw_buffer_load_b128(rs, ox, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+        pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, mirror_idx(r0 + j, H) * spitch4, 0);
+    }
+  };
+
+  int rg = y0 - R1 - R2; // first virtual source row of the current group
+  prefetch(rg);
+
+  v4f wv1[NWIN1], wv2[NWIN2];
+#pragma unroll
+  for (int k = 0; k < NWIN1; k++)
+    wv1[k] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NWIN2; k++)
+    wv2[k] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  for (; rg - R1 - R2 < y1; rg += NR)
+  {
+    // ---- stage the prefetched group, then prefetch the next one
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NR; j++)
+    {
+      u32x4 v = pf[j];
+      if (rev)
+        v = u32x4{v.w, v.z, v.y, v.x};
+      *(u32x4 *)(s_grp + j * SW + 4 * lane) = v;
+    }
+    if (lane < NXT)
+    {
+      u32x4 v = pfx;
+      if (rev_x)
+        v = u32x4{v.w, v.z, v.y, v.x};
+      *(u32x4 *)sx = v;
+    }
+    prefetch(rg + NR);
+    __syncthreads();
+
+    // ---- first filter, horizontal: the new rows into the top of window 1
+    {
+      const v4f *hb = (const v4f *)(s_grp + 4 * lane);
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+      {
+        float va[4 * NQ1];
+#pragma unroll
+        for (int q = 0; q < NQ1; q++)
+        {
+          const v4f t = hb[j * (SW / 4) + q];
+          va[4 * q] = t.x, va[4 * q + 1] = t.y, va[4 * q + 2] = t.z, va[4 * q + 3] = t.w;
+        }
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          o[k] = va[RA1 + k] * k10;
+#pragma unroll
+        for (int i = 1; i < NT1; i++)
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            o[k] = fmaf(va[RA1 + k + i] + va[RA1 + k - i], a.t1.k[i], o[k]);
+        wv1[2 * R1 + j] = v4f{o[0], o[1], o[2], o[3]};
+      }
+    }
+    // ---- first filter, vertical: rows yb1 .. yb1+7 of scale s (all 256 columns: the second filter's horizontal halo included)
+    const int yb1 = rg - R1;
+    {
+      int so_d = yb1 * d1pitch4;
+#pragma unroll
+      for (int j = 0; j < NR; j++, so_d += d1pitch4)
+      {
+        v4f acc = wv1[R1 + j] * k10;
+#pragma unroll
+        for (int i = 1; i < NT1; i++)
+        {
+          const v4f sm = wv1[R1 + j + i] + wv1[R1 + j - i];
+          acc.x = fmaf(sm.x, a.t1.k[i], acc.x);
+          acc.y = fmaf(sm.y, a.t1.k[i], acc.y);
+          acc.z = fmaf(sm.z, a.t1.k[i], acc.z);
+          acc.w = fmaf(sm.w, a.t1.k[i], acc.w);
+        }
+        *(v4f *)(s_g1 + j * G1S + RA2 + 4 * lane) = acc;
+        // the segment's own rows of scale s (wave-uniform test)
+        if (yb1 + j >= y0 && yb1 + j < y1)
+          store_b128_stream(u32x4{__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)}, rd1, st_off, so_d);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * R1; k++)
+      wv1[k] = wv1[k + NR];
+    __syncthreads();
+
+    // ---- second filter, horizontal, from the rows of scale s just written to LDS (lanes outside the owned columns read into the
+    // padding: their results are never stored)
+    {
+      const v4f *hb = (const v4f *)(s_g1 + 4 * lane);
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+      {
+        float va[4 * NQ2];
+#pragma unroll
+        for (int q = 0; q < NQ2; q++)
+        {
+          const v4f t = hb[j * (G1S / 4) + q];
+          va[4 * q] = t.x, va[4 * q + 1] = t.y, va[4 * q + 2] = t.z, va[4 * q + 3] = t.w;
+        }
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          o[k] = va[RA2 + k] * k20;
+#pragma unroll
+        for (int i = 1; i < NT2; i++)
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            o[k] = fmaf(va[RA2 + k + i] + va[RA2 + k - i], a.t2.k[i], o[k]);
+        wv2[2 * R2 + j] = v4f{o[0], o[1], o[2], o[3]};
+      }
+    }
+    // ---- second filter, vertical: rows yb2 .. yb2+7 of scale s+1
+    const int yb2 = yb1 - R2;
+    if (yb2 + NR > y0)
+    {
+      int so_d = yb2 * d2pitch4;
+#pragma unroll
+      for (int j = 0; j < NR; j++, so_d += d2pitch4)
+      {
+        if (yb2 + j < y0 || yb2 + j >= y1)
+          continue;
+        v4f acc = wv2[R2 + j] * k20;
+#pragma unroll
+        for (int i = 1; i < NT2; i++)
+        {
+          const v4f sm = wv2[R2 + j + i] + wv2[R2 + j - i];
+          acc.x = fmaf(sm.x, a.t2.k[i], acc.x);
+          acc.y = fmaf(sm.y, a.t2.k[i], acc.y);
+          acc.z = fmaf(sm.z, a.t2.k[i], acc.z);
+          acc.w = fmaf(sm.w, a.t2.k[i], acc.w);
+        }
+        store_b128_stream(u32x4{__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)}, rd2, st_off, so_d);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * R2; k++)
+      wv2[k] = wv2[k + NR];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_octave_chain — the WHOLE scale-space of the trailing octaves whose planes fit the LDS, one workgroup per image.
 //
 // A coarse octave (160x120 and below for a 640x480 input) is a few thousand texels: each of its blur launches costs the
@@ -1644,6 +1874,31 @@ extern "C"
     /* one mirror reflection has to cover every staged column and every virtual row of a march */
     if ((W % 4u) != 0 || hc + ra1 > W || (strips - 1u) * ow + 128u + ra1 > 2u * W + hc || H < 64u || dst1.w != W || dst2.w != W || dst1.h != H || dst2.h != H)
       return -1;
+    {
+      /* four texels per lane on 256-column strips (k_blur_pair_wide) for launches that fill the chip */
+      const uint32_t hcw = (r2 + 3u) & ~3u, oww = 256u - 2u * hcw, wstrips = (W + oww - 1u) / oww;
+      const int pw = vksift_hip_tune_get(VKSIFT_TUNE_PAIR_FORM); /* 0: built-in, 1: two texels per lane, 2: four */
+      const bool fills = (uint64_t)wstrips * batch * ((H + 63u) / 64u) >= 2048u;
+      if (pw != 1 && (fills || pw == 2) && hcw + ra1 <= W && (wstrips - 1u) * oww + 256u + ra1 <= 2u * W + hcw && ((src.pitch | dst1.pitch | dst2.pitch) & 3u) == 0)
+      {
+        PairArgs aw;
+        aw.src = src.base, aw.dst1 = dst1.base, aw.dst2 = dst2.base;
+        aw.src_img_stride = src.img_stride, aw.dst1_img_stride = dst1.img_stride, aw.dst2_img_stride = dst2.img_stride;
+        aw.spitch = (int)src.pitch, aw.d1pitch = (int)dst1.pitch, aw.d2pitch = (int)dst2.pitch;
+        aw.w = (int)W, aw.h = (int)H;
+        aw.rev = (int)dst2.reverse;
+        for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
+          aw.t1.k[i] = i < ntaps1 ? taps1[i] : 0.f, aw.t2.k[i] = i < ntaps2 ? taps2[i] : 0.f;
+        uint32_t nsegw = (10240u + wstrips * batch - 1u) / (wstrips * batch);
+        const uint32_t max_segw = (H + 63u) / 64u;
+        nsegw = nsegw > max_segw ? max_segw : (nsegw < 1u ? 1u : nsegw);
+        const uint32_t segw = ((H + nsegw - 1u) / nsegw + 7u) & ~7u;
+        nsegw = (H + segw - 1u) / segw;
+        aw.seg = (int)segw;
+        hipLaunchKernelGGL((k_blur_pair_wide<5, 7>), dim3(wstrips, nsegw, batch), dim3(64), 0, (hipStream_t)s, aw);
+        return (int)hipGetLastError();
+      }
+    }
     PairArgs a;
     a.src = src.base, a.dst1 = dst1.base, a.dst2 = dst2.base;
     a.src_img_stride = src.img_stride, a.dst1_img_stride = dst1.img_stride, a.dst2_img_stride = dst2.img_stride;
