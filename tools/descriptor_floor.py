@@ -140,7 +140,7 @@ def kernel_isa():
     src = os.path.join(ROOT, "vulkansift_amd", "csrc", "hip", "features.hip")
     out = "/tmp/_features_floor.s"
     import vulkansift_amd.build as b  # the flags the shipped kernels are compiled with
-    cmd = [b.HIPCC] + [f for f in b.HIPFLAGS if f != "-fPIC"] + b._extra_flags("features.hip") + b.INCLUDES + ["-S", "--cuda-device-only", "-o", out, src]
+    cmd = [b.HIPCC] + [f for f in b.HIPFLAGS if f != "-fPIC"] + b._extra_flags("hip/features.hip") + b.INCLUDES + ["-S", "--cuda-device-only", "-o", out, src]
     subprocess.run(cmd, check=True, capture_output=True, cwd="/tmp")
     lines = open(out).read().split("\n")
     s = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
@@ -194,7 +194,15 @@ def regions(blocks):
     main = next(r for r in runs if sum(n_add[i] for i in r) == 8)
     # the slow path inside it: the block a s_cbranch_vccnz of the loop jumps to (inputs below 2^-96: never seen)
     targets = {t.split()[-1] for i in main for t in blocks[i][3] if t.startswith("s_cbranch_vccnz")}
-    slow = [i for i in main if blocks[i][0] in targets]
+    slow = []
+    for i in main:
+        if blocks[i][0] in targets:  # ... and the blocks behind it up to the unconditional branch back into the loop
+            j = i
+            while j in main:
+                slow.append(j)
+                if any(t.startswith("s_branch") for t in blocks[j][3]):
+                    break
+                j += 1
     after = main[-1] + 1
     epi = next(i for i in range(after, len(blocks)) if blocks[i][1] <= 1)
     tail = list(range(after, epi))
