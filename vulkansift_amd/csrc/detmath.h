@@ -146,15 +146,9 @@ DM_FN float dm_div_2pi(float x)
   return q;
 }
 
-/* atan2(y, x) in (-pi, pi]; atan2(0,0) = 0 (GLSL leaves it undefined, quirk Q13). <= ~2 ulp. */
-DM_FN float dm_atan2f(float y, float x)
+/* dm_atan2f behind its division: a = min(|x|, |y|) / max(|x|, |y|) (a = 0 for x = y = 0), ax = |x|, ay = |y| */
+DM_FN float dm_atan2f_ratio(float a, float ax, float ay, float x, float y)
 {
-  float ax = fabsf(x), ay = fabsf(y);
-  float mx = ax > ay ? ax : ay;
-  float mn = ax > ay ? ay : ax;
-  /* atan2(+-0, +-0) = +0: with the divisor replaced by 1 the straight-line path below yields exactly that
-   * (a = 0, t = +0, neither x < 0 nor y < 0 holds for a signed zero) — no early return, no branch in the kernels */
-  float a = mn / (mx == 0.f ? 1.f : mx); /* in [0,1] */
   float z = a * a;
   float p = -0x1.f76bccp-11f;
   p = fmaf(p, z, 0x1.9eb02ep-8f);
@@ -173,6 +167,18 @@ DM_FN float dm_atan2f(float y, float x)
   if (x < 0.f)
     t = 0x1.921fb6p+1f - t; /* pi - t */
   return y < 0.f ? -t : t;
+}
+
+/* atan2(y, x) in (-pi, pi]; atan2(0,0) = 0 (GLSL leaves it undefined, quirk Q13). <= ~2 ulp. */
+DM_FN float dm_atan2f(float y, float x)
+{
+  float ax = fabsf(x), ay = fabsf(y);
+  float mx = ax > ay ? ax : ay;
+  float mn = ax > ay ? ay : ax;
+  /* atan2(+-0, +-0) = +0: with the divisor replaced by 1 the straight-line path below yields exactly that
+   * (a = 0, t = +0, neither x < 0 nor y < 0 holds for a signed zero) — no early return, no branch in the kernels */
+  float a = mn / (mx == 0.f ? 1.f : mx); /* in [0,1] */
+  return dm_atan2f_ratio(a, ax, ay, x, y);
 }
 
 /* sin and cos of t for |t| <= ~16 (the pipeline passes orientations in [0, 2*pi]). <= ~1.5 ulp. */

@@ -87,6 +87,72 @@ __device__ __forceinline__ float wrap_2pi(float t)
   return t < 0 ? up : t;
 }
 
+// sqrtf(x) and a / b as hipcc expands them, minus the parts that only matter outside the range the caller has checked:
+// * sqrt_inrange: v_sqrt_f32 (<= 1 ulp), then one step down / up by the signs of two exact residuals — the compiler's own correctly rounded
+//   expansion without the 2^32 input scaling for x < 2^-96 and without the class test for 0 / inf behind it (x = 0: both residual tests fail
+//   on NaN / zero, the result is the 0 v_sqrt_f32 returned);
+// * div_inrange: v_rcp_f32, one Newton step, quotient, two remainder corrections — the compiler's expansion without v_div_scale (operands
+//   with exponents far apart or near the ends of the range), v_div_fmas' rescaling and v_div_fixup (zeros, infinities, NaN). With
+//   2^-64 <= a <= b <= 2^2 (or a = 0) no intermediate leaves the normal range, so every step computes what the scaled sequence computes.
+// Both return the bits of the IEEE operation (the descriptor parity tests run both paths against the oracle's sqrtf and '/').
+// 14 instead of 26 and 8 instead of 11 instructions; k_descriptor is bound by VALU issue (profiles/r05_descriptor_floor.md).
+__device__ __forceinline__ float sqrt_inrange(float x)
+{
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
+  float r = rd <= 0.f ? sd : s;
+  r = ru > 0.f ? su : r;
+  return r;
+}
+__device__ __forceinline__ float div_inrange(float a, float b)
+{
+  float r = __builtin_amdgcn_rcpf(b);
+  const float e = fmaf(-b, r, 1.f);
+  r = fmaf(e, r, r);
+  float q = a * r;
+  float m = fmaf(-b, q, a);
+  q = fmaf(m, r, q);
+  m = fmaf(-b, q, a);
+  return fmaf(m, r, q);
+}
+// v is 0 or at least 2^(E - 127) (v >= 0): one subtract, one unsigned compare
+template <uint32_t E>
+__device__ __forceinline__ bool below_range(float v) { return __float_as_uint(v) - 1u < (E << 23) - 1u; }
+
+// x / (2*pi): the 3-operation form of dm_div_2pi (detmath.h) without its tests. The caller checks the range (non-zero magnitudes below 2^-96
+// take the general form); a zero comes out as +0 whatever its sign, and floor and remainder of a zero bin coordinate are the same for both.
+__device__ __forceinline__ float div_2pi_inrange(float x)
+{
+  const float c2 = 2.f * PI_F, rc = 0x1.45f306p-3f;
+  const float q = x * rc;
+  return fmaf(fmaf(-q, c2, x), rc, q);
+}
+
+// Angle and length of a gradient for both per-keypoint kernels (ComputeOrientation.comp:102-106, ComputeDescriptors.comp:146-162): atan2 and
+// sqrt. INRANGE: the short forms; *odd is set where their range conditions do not hold (the caller then repeats the step with the general
+// forms: a wave-uniform branch that real images take in regions darker than ~2^-30, if at all; black synthetic backgrounds do, in the
+// tails of the blurs: tests/test_gpu_descriptor_ranges.py)
+template <bool INRANGE>
+__device__ __forceinline__ void grad_polar(float gradX, float gradY, float *ori, float *len, bool *odd)
+{
+  const float g2 = (gradX * gradX) + (gradY * gradY);
+  if (INRANGE)
+  {
+    const float ax = fabsf(gradX), ay = fabsf(gradY);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    *ori = dm_atan2f_ratio(div_inrange(mn, mx == 0.f ? 1.f : mx), ax, ay, gradX, gradY);
+    *len = sqrt_inrange(g2);
+    // g2 >= 2^-96 (then mx >= 2^-49) or 0; mn >= 2^-64 or 0
+    *odd = below_range<127 - 96>(g2) || below_range<127 - 64>(mn);
+  }
+  else
+  {
+    *ori = dm_atan2f(gradY, gradX);
+    *len = sqrtf(g2);
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // Orientation histogram (ComputeOrientation.comp:52-186). grid = (blocks, batch); 4 keypoints/block.
 // -------------------------------------------------------------------------------------------------
@@ -153,11 +219,23 @@ __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
       int py = lane / box, px = lane - py * box;
       // the contribution of one window texel given its gradient taps (ComputeOrientation.comp:102-121)
       auto accumulate = [&](float sdx2, float tr, float tl, float td, float tu) {
-        float gradX = 0.5f * (tr - tl);
-        float gradY = 0.5f * (td - tu);
-        float mag = dm_expf_nb_nonpos(sdx2 * es) /* d2 >= 0 > es */ * sqrtf((gradX * gradX) + (gradY * gradY));
-        float ori = wrap_2pi(dm_atan2f(gradY, gradX));
-        int bin = (int)(dm_div_2pi(ori * 36.f)); // == ori * 36 / (2 pi)
+        const float gradX = 0.5f * (tr - tl);
+        const float gradY = 0.5f * (td - tu);
+        const float e = dm_expf_nb_nonpos(sdx2 * es); /* d2 >= 0 > es */
+        float ori, len, fbin;
+        bool odd;
+        grad_polar<true>(gradX, gradY, &ori, &len, &odd);
+        float x36 = wrap_2pi(ori) * 36.f;
+        fbin = div_2pi_inrange(x36); // == ori * 36 / (2 pi)
+        odd |= below_range<127 - 96>(fabsf(x36));
+        if (__builtin_expect(__ballot(odd) != 0ull, 0))
+        {
+          grad_polar<false>(gradX, gradY, &ori, &len, nullptr);
+          x36 = wrap_2pi(ori) * 36.f;
+          fbin = dm_div_2pi(x36);
+        }
+        const float mag = e * len;
+        int bin = (int)fbin;
         if (bin < 0)
           bin += 36;
         else if (bin >= 36)
@@ -382,7 +460,9 @@ __device__ __forceinline__ void desc_taps_pair(const DescCtx &c, unsigned v0, De
   a.dn = __uint_as_float(dn.x), b.dn = __uint_as_float(dn.y);
 }
 
-__device__ __forceinline__ DescSample desc_sample(const DescCtx &c, int cdx, int cdy, const DescTaps &t)
+// INRANGE: see grad_polar
+template <bool INRANGE>
+__device__ __forceinline__ DescSample desc_sample(const DescCtx &c, int cdx, int cdy, const DescTaps &t, bool *odd)
 {
   const float es = -1.f / (2.f * 2 * 2);
   float sdx = (c.rsx + (float)cdx) - c.scale_x;
@@ -392,19 +472,20 @@ __device__ __forceinline__ DescSample desc_sample(const DescCtx &c, int cdx, int
   r.oy = c.kcos * sdy - c.ksin * sdx;
   float gradX = 0.5f * (t.rt - t.lf);
   float gradY = 0.5f * (t.dn - t.up);
-  float ori = wrap_2pi(dm_atan2f(gradY, gradX));
+  float ori, root;
+  grad_polar<INRANGE>(gradX, gradY, &ori, &root, odd);
+  ori = wrap_2pi(ori);
   ori = wrap_2pi(ori - c.kori);
   // |ox|, |oy| < 4 for every enumerated sample: the exponent is in [-4, 0], no range handling needed
-  r.mag = dm_expf_core_nonpos(es * ((r.ox * r.ox) + (r.oy * r.oy))) * sqrtf((gradX * gradX) + (gradY * gradY));
+  r.mag = dm_expf_core_nonpos(es * ((r.ox * r.ox) + (r.oy * r.oy))) * root;
   r.xb = ori * c.bin_scale; // +8 (VLFeat order) or -8: (-ori) * 8 == ori * (-8) exactly
   return r;
 }
 
-// Histogram layout for 64-bit atomics: the two orientation bins a sample touches, hb and hb + 1 (mod 8), are always one
-// aligned 8-byte pair of one of two interleaved copies of a cell — copy A holds the pairs (0,1)(2,3)(4,5)(6,7), copy B the
-// pairs (1,2)(3,4)(5,6)(7,0) — so each of the four cells takes ONE ds_add_u64 instead of two ds_add_u32 (the sums stay below
-// 2^32 by construction of the fixed-point scale, so the low half never carries into the high half). Cell = 64 bytes:
-// [A: 4 pairs][B: 4 pairs]. The epilogue adds the two copies.
+// Histogram layout for 64-bit atomics: a cell is eight 8-byte slots, slot b holding the sums for the bin pair (b, b + 1 mod 8). The two
+// orientation bins a sample touches are hb and hb + 1 (mod 8), so each of the four cells takes ONE ds_add_u64 into slot hb mod 8 instead of
+// two ds_add_u32 (the sums stay below 2^32 by construction of the fixed-point scale, so the low half never carries into the high half),
+// and the slot's byte offset is (hb & 7) * 8 — no parity split. Cell = 64 bytes. The epilogue adds the two halves that belong to a bin.
 // The 4x4 grid sits inside a 6x8 array of cells (grid cell (cx, cy) = array cell (cx + 1, cy + 1)), so the 2x2 cells of a
 // sample share ONE address register — the other three are immediate offsets of the ds_add_u64, and the lower corner of a sample
 // one cell outside the grid still gives a non-negative address. Cells outside the grid (ComputeDescriptors.comp:189 drops
@@ -424,10 +505,8 @@ __device__ __forceinline__ int desc_cell_word(int cell) // first word of grid ce
 __device__ __forceinline__ uint32_t desc_hist_read(const uint32_t *s_work, int t) // descriptor element t = cell * 8 + bin
 {
   const int cw = desc_cell_word(t >> 3), bin = t & 7;
-  const uint32_t a = s_work[cw + bin];                                  // copy A: pair bin / 2, half bin & 1
-  const int pb = ((bin + 7) & 7) >> 1;                                  // copy B: the pair that starts at the odd bin below
-  const uint32_t bq = s_work[cw + 8 + pb * 2 + ((bin & 1) ? 0 : 1)];    // odd bins are the low half there
-  return a + bq;
+  // slot b of a cell holds (bin b, bin b + 1 mod 8): bin = the low half of its own slot + the high half of the slot below
+  return s_work[cw + 2 * bin] + s_work[cw + 2 * ((bin + 7) & 7) + 1];
 }
 
 __device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample &r, float fbin, bool live, uint32_t *s_work)
@@ -443,7 +522,7 @@ __device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample 
   // (Packed v_pk_mul_f32 for the weight products was measured 9 % slower despite 6 % fewer instructions.)
   const float magfp = r.mag * c.fp;
   const unsigned b0 = (unsigned)smod8(hb);
-  const unsigned pair = ((b0 & 1u) ? 32u : 0u) + (b0 >> 1) * 8u; // byte offset of the (hb, hb+1) pair inside a cell
+  const unsigned pair = b0 * 8u; // byte offset of the (hb, hb + 1) slot inside a cell
   // in-grid tests of the two columns and the two rows (a dead sample — a lane whose run has ended — fails all of them);
   // the address of a lane that fails is never used
   const bool okx[2] = {live && (unsigned)hx < 4u, live && (unsigned)(hx + 1) < 4u};
@@ -462,23 +541,6 @@ __device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample 
     }
 }
 
-// x / (2*pi) for two samples: the 3-operation form of dm_div_2pi (detmath.h) unconditionally, and one wave-uniform test
-// for the inputs it does not cover (non-zero magnitudes below 2^-96: never seen, they take the IEEE division)
-__device__ __forceinline__ void desc_fbin2(float xa, float xb, float *fa, float *fb)
-{
-  const float c2 = 2.f * PI_F, rc = 0x1.45f306p-3f;
-  float qa = xa * rc, qb = xb * rc;
-  const float ra = fmaf(fmaf(-qa, c2, xa), rc, qa), rb = fmaf(fmaf(-qb, c2, xb), rc, qb);
-  const bool za = fabsf(xa) < 0x1p-96f, zb = fabsf(xb) < 0x1p-96f; // zeros keep x * rc (their sign survives)
-  qa = za ? qa : ra, qb = zb ? qb : rb;
-  if (__builtin_expect(__ballot((za && xa != 0.f) || (zb && xb != 0.f)) != 0ull, 0))
-  {
-    qa = (za && xa != 0.f) ? xa / c2 : qa;
-    qb = (zb && xb != 0.f) ? xb / c2 : qb;
-  }
-  *fa = qa, *fb = qb;
-}
-
 // One 256-thread workgroup per keypoint (the window of a coarse-scale keypoint has up to ~7.5k pixels; a single wave
 // would make it the critical path of the whole launch). About half of the window falls outside the rotated 4x4 grid:
 // the reference evaluates atan/exp for those pixels and then drops the contribution (ComputeDescriptors.comp:189);
@@ -487,7 +549,7 @@ __device__ __forceinline__ void desc_fbin2(float xa, float xb, float *fa, float 
 constexpr int DESC_MAX_ROWS = 256; // window rows handled per pass (R <= 127: every stock configuration); taller windows take several passes
 
 template <int NWV, bool IMG_FAST, bool F16>
-__global__ void __launch_bounds__(64 * NWV) k_descriptor(Multi<FeatArgs> m)
+__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV == 2 ? 8 : 6, 8))) k_descriptor(Multi<FeatArgs> m)
 {
   const VBlock vb = vblock(m); // virtual grid (images, blocks) when IMG_FAST, (blocks, images) otherwise
   const FeatArgs &a = m.oct[vb.o];
@@ -668,9 +730,16 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(Multi<FeatArgs> m)
           if (live[1] && !(sy[1] == sy[0] && sx[1] == sx[0] + 1))
             t1 = desc_taps<F16>(c, desc_tap_base(c, sx[1], sy[1])); // the run crossed into the next row span
         }
-        const DescSample s0 = desc_sample(c, sx[0], sy[0], t0), s1 = desc_sample(c, sx[1], sy[1], t1);
-        float f0, f1;
-        desc_fbin2(s0.xb, s1.xb, &f0, &f1);
+        bool o0, o1;
+        DescSample s0 = desc_sample<true>(c, sx[0], sy[0], t0, &o0), s1 = desc_sample<true>(c, sx[1], sy[1], t1, &o1);
+        float f0 = div_2pi_inrange(s0.xb), f1 = div_2pi_inrange(s1.xb);
+        o0 |= below_range<127 - 96>(fabsf(s0.xb)), o1 |= below_range<127 - 96>(fabsf(s1.xb));
+        if (__builtin_expect(__ballot(o0 || o1) != 0ull, 0))
+        {
+          // some lane holds a value outside the ranges of the short forms (see desc_sample): the general forms for this step
+          s0 = desc_sample<false>(c, sx[0], sy[0], t0, nullptr), s1 = desc_sample<false>(c, sx[1], sy[1], t1, nullptr);
+          f0 = dm_div_2pi(s0.xb), f1 = dm_div_2pi(s1.xb);
+        }
         desc_scatter(c, s0, f0, live[0], s_work);
         desc_scatter(c, s1, f1, live[1], s_work);
       }
@@ -679,7 +748,7 @@ __global__ void __launch_bounds__(64 * NWV) k_descriptor(Multi<FeatArgs> m)
         int sx, sy;
         bool live;
         next_sample(sx, sy, live);
-        const DescSample s0 = desc_sample(c, sx, sy, desc_taps<F16>(c, desc_tap_base(c, sx, sy)));
+        const DescSample s0 = desc_sample<false>(c, sx, sy, desc_taps<F16>(c, desc_tap_base(c, sx, sy)), nullptr);
         desc_scatter(c, s0, dm_div_2pi(s0.xb), live, s_work);
       }
     }
