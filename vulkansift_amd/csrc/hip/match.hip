@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) k_shifted_norms(const uint32_t *__restric
 
 // Gather the descriptors of a (sectioned or packed) SIFT buffer into dense rows in download order AND compute
 // their shifted norms, with the per-section feature counts read on the device (no host round trip):
-// row -> section by scanning the <= 16 section counts; one half-wave (32 lanes) per row, one dword per lane.
+// row -> section by scanning the <= 16 section counts; eight lanes per row, 16 bytes per lane.
 struct SectionTable
 {
   uint32_t nsec;
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_gather_sections(const uint8_t *__restri
   norms += (size_t)bufi * norm_slot_stride;
   n_out += (size_t)bufi * n_slot_stride;
 
-  const uint32_t j = threadIdx.x & 31u;
+  const uint32_t j = threadIdx.x & 7u; // 16 bytes of a row per lane: a wave moves 8 rows at a time, a workgroup 32
   // stored count of every section (uniform), then a grid-stride walk over the rows that exist
   uint32_t cnt[16];
   uint32_t total = 0;
@@ -129,9 +129,9 @@ __global__ void __launch_bounds__(256) k_gather_sections(const uint8_t *__restri
   if (blockIdx.x == 0 && threadIdx.x == 0)
     *n_out = total;
   const uint32_t nrows = total > pad_rows_to ? total : pad_rows_to;
-  for (uint32_t row = blockIdx.x * 8 + (threadIdx.x >> 5); row < nrows; row += gridDim.x * 8)
+  for (uint32_t row = blockIdx.x * 32 + (threadIdx.x >> 3); row < nrows; row += gridDim.x * 32)
   {
-    uint32_t v = 0u; // rows in [total, pad_rows_to): quirk Q6 padding, all-zero descriptors
+    uint4 v = uint4{0u, 0u, 0u, 0u}; // rows in [total, pad_rows_to): quirk Q6 padding, all-zero descriptors
     if (row < total)
     {
       uint32_t base = 0, src_row = 0;
@@ -142,13 +142,17 @@ __global__ void __launch_bounds__(256) k_gather_sections(const uint8_t *__restri
           src_row = tab.off[o] + (row - base);
         base += cnt[o];
       }
-      v = *(const uint32_t *)(feats + (size_t)src_row * 164 + 36 + 4 * j);
+      // (records are 164 bytes, the descriptor starts at byte 36: dword-aligned 16-byte loads)
+      const uint32_t *p = (const uint32_t *)(feats + (size_t)src_row * 164 + 36 + 16 * j);
+      v = uint4{p[0], p[1], p[2], p[3]};
     }
-    desc[(size_t)row * 32 + j] = v;
-    uint32_t s2 = __builtin_amdgcn_udot4(v, v, 0u, false);
-    uint32_t s1 = __builtin_amdgcn_udot4(v, 0x01010101u, 0u, false);
+    *(uint4 *)(desc + (size_t)row * 32 + 4 * j) = v;
+    uint32_t s2 = __builtin_amdgcn_udot4(v.x, v.x, 0u, false), s1 = __builtin_amdgcn_udot4(v.x, 0x01010101u, 0u, false);
+    s2 = __builtin_amdgcn_udot4(v.y, v.y, s2, false), s1 = __builtin_amdgcn_udot4(v.y, 0x01010101u, s1, false);
+    s2 = __builtin_amdgcn_udot4(v.z, v.z, s2, false), s1 = __builtin_amdgcn_udot4(v.z, 0x01010101u, s1, false);
+    s2 = __builtin_amdgcn_udot4(v.w, v.w, s2, false), s1 = __builtin_amdgcn_udot4(v.w, 0x01010101u, s1, false);
 #pragma unroll
-    for (int d = 16; d >= 1; d >>= 1)
+    for (int d = 4; d >= 1; d >>= 1)
     {
       s2 += __shfl_xor(s2, d, 64);
       s1 += __shfl_xor(s1, d, 64);
@@ -1898,8 +1902,8 @@ extern "C"
     if (max_rows < pad_rows_to)
       max_rows = pad_rows_to;
     /* grid-stride over the rows that actually exist (count read on the device): ~4096 workgroups per launch whatever the batch — a
-     * buffer alone gets up to 256 blocks of 8 rows, 512 buffers 8 each (30 rounds over 1900 rows) */
-    uint32_t blocks = (max_rows + 7u) / 8u, cap_blocks = 4096u / nslots;
+     * buffer alone gets up to 256 blocks of 32 rows, 512 buffers 8 each (8 rounds over 1900 rows) */
+    uint32_t blocks = (max_rows + 31u) / 32u, cap_blocks = 4096u / nslots;
     cap_blocks = cap_blocks < 8u ? 8u : (cap_blocks > 256u ? 256u : cap_blocks);
     if (blocks > cap_blocks)
       blocks = cap_blocks;
