@@ -20,7 +20,7 @@ cd $R
 python tools/make_profile_report.py gpurun_out/$TAG/c3 ${TAG}_c3 1920 1080 64 > $OUT/report_c3.log 2>&1
 # SQ counters of the VALU-bound kernels and of the seed / scan launches, detections one after the other (clean attribution)
 VKSIFT_PYR_PINGPONG=0 PMC_GROUPS="SQ_WAVES,SQ_BUSY_CU_CYCLES,SQ_WAVE_CYCLES,SQ_INSTS_VALU;SQ_ACTIVE_INST_VALU,SQ_WAIT_INST_ANY,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE;SQ_VMEM_TA_ADDR_FIFO_FULL,SQ_INSTS_VMEM,SQ_INSTS_LDS,SQ_INSTS_SALU" PMC_PASS_TIMEOUT=240 \
-  python tools/pmc_kernel.py "k_descriptor,k_orientation<,k_extrema_lean,k_blur_lean<5, 1,k_blur_pair,k_blur_wide<13>@$(( ((2 * W + 127) / 128) * 64 ))" -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras \
+  python tools/pmc_kernel.py "k_descriptor,k_orientation<,k_extrema_lean,k_blur_lean<5, 1,k_blur_pair_wide,k_blur_wide<13>@$(( ((2 * W + 127) / 128) * 64 ))" -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras \
   > profiles/${TAG}_sq_counters.json 2> $OUT/sq.log
 timeout 1200 python tools/capture_match_counters.py $TAG > $OUT/match_counters.log 2>&1
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err

@@ -72,6 +72,10 @@ def main():
         gridx_wide = ((2 * w + 255) // 256) * 64
         f.update(pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", gridx_wide, "k_blur_wide"))
         wr.update(pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", gridx_wide, "k_blur_wide"))
+        # k_blur_pair_wide (round 5): the two-scale launch with four texels per lane, 240 owned columns per strip
+        gridx_pw = ((2 * w + 239) // 240) * 64
+        f.update(pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", gridx_pw, "k_blur_pair_wide"))
+        wr.update(pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", gridx_pw, "k_blur_pair_wide"))
         # the streaming extrema scan: ONE launch per detection over all octaves (flat grid) since round 3 — every dispatch of the kernel
         sf = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", None, SCAN)
         sw_ = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", None, SCAN)
@@ -98,7 +102,7 @@ def main():
                 is_scan = name in sf
                 fk = (sf if is_scan else f)[name]
                 wk = (sw_ if is_scan else wr).get(name, {"avg": 0.0})
-                gx = None if is_scan else (gridx_pair if "k_blur_pair" in name else (gridx_wide if "k_blur_wide" in name else gridx))
+                gx = None if is_scan else (gridx_pw if "k_blur_pair_wide" in name else (gridx_pair if "k_blur_pair" in name else (gridx_wide if "k_blur_wide" in name else gridx)))
                 dd = [v for (n, g), vs in durs.items() if n == name and (gx is None or g == gx) for v in vs]
                 if not dd:
                     continue
