@@ -537,7 +537,7 @@ def c3_roofline(api, torch, dev, steps=5):
     dt = time.perf_counter() - t0
     acc = inst.getAccumulatedDetectTimings()
     inst.close()
-    r = roofline_from(acc, pmc_traffic(W, H, B), "k_blur_lean x6 on octave 0 (3840x2160 planes) + k_extrema_lean over all octaves, 64 x 1920x1080 frames")
+    r = roofline_from(acc, pmc_traffic(W, H, B), "the 5 blur launches of octave 0 (3840x2160 planes: seed, two-scale launch, 9 / 11 / 13 taps) + k_extrema_lean over all octaves, 64 x 1920x1080 frames")
     r.update({"workload": "BASELINE config 3: 64 x 1920x1080 uint8 frames, detect only, default vksift_Config, inputs resident in HBM",
               "steps": steps, "frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "mean_features_per_frame": nfeat,
               "stage_ms_per_step": {k: acc[k] / max(acc["nb_calls"], 1) for k in ("pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")}})
@@ -779,7 +779,7 @@ def main():
                              "in C: tests/native/protocol_client.c, public API only). "
                              "single_image_ms: BASELINE config 2 literally (one image per call)",
             },
-            "roofline": roofline_from(acc, pmc, "k_blur_lean x6 on octave 0 (1280x960 planes): scale-space construction, + k_extrema_lean over all octaves: the scan that forms the DoG values"),
+            "roofline": roofline_from(acc, pmc, "the 5 blur launches of octave 0 (1280x960 planes: k_blur_lean<5,1> seed, k_blur_pair_wide<5,7>, k_blur_wide<9/11/13>): scale-space construction, + k_extrema_lean over all octaves: the scan that forms the DoG values"),
             "stage_ms_per_call": {k: acc[k] / max(acc["nb_calls"], 1) for k in
                                   ("upload_ms", "pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")},
             "last_match_ms": match_ms,
