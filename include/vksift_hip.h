@@ -228,6 +228,10 @@ extern "C"
   int vksift_hip_extract_keypoints_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s, vksift_hip_event scan_done);
   /* the clear of the candidate-ballot masks that vksift_hip_extract_keypoints_multi starts with, on its own (see masks_cleared) */
   int vksift_hip_clear_segment_masks(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s);
+  /* test entry (tests/test_gpu_descriptor_ranges.py): the in-range forms of sqrtf, '/' and x / 2 pi that the orientation and descriptor kernels
+   * use (features.hip: sqrt_inrange, div_inrange, div_2pi_inrange) against the compiler's general forms on n pseudo-random operands
+   * inside their ranges, incl. the range ends; *d_mismatches (device memory, one word) = results that differ in any bit */
+  int vksift_hip_selftest_inrange(uint32_t n, uint32_t seed, uint32_t *d_mismatches, vksift_hip_stream s);
   int vksift_hip_orientations_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s);
   int vksift_hip_descriptors_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s);
 

@@ -55,3 +55,22 @@ def test_a_batch_of_dark_frames_matches_the_single_image_results(vk):
         inst.detectFeaturesBatch(imgs, 0)
         batch = [inst.downloadFeatures(i).tobytes() for i in range(n)]
     assert batch == single and sum(len(b) for b in batch) > 164 * 300
+
+
+def test_in_range_forms_equal_the_general_ones_on_the_device(vk):
+    """vksift_hip_selftest_inrange: sqrt_inrange / div_inrange / div_2pi_inrange (what the orientation and descriptor kernels evaluate when
+    their wave-uniform range check passes) against sqrtf, '/' and x / (2 pi) as the compiler expands them, on 64 M pseudo-random
+    operands per form, spread uniformly over the EXPONENTS of the guarded ranges (2^-96 .. 2^8 for the square root, divisors from 2^-49, dividends
+    from 2^-64 or zero) plus the range ends: no result may differ in any bit"""
+    import ctypes as C
+    import torch
+    L = vk.lib()
+    L.vksift_hip_selftest_inrange.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.vksift_hip_selftest_inrange.restype = C.c_int
+    bad = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    total = 0
+    for seed in (1, 0x9E3779B9, 0x51ED270B, 77777):
+        assert L.vksift_hip_selftest_inrange(1 << 24, seed, bad.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        total += int(bad.item())
+    assert total == 0

@@ -189,8 +189,8 @@ __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
       // planes stay below 2 GiB (vksift_hip_extract_keypoints refuses sides of 16384 and more)
       const __amdgpu_buffer_rsrc_t rs = layer_rsrc(a.gauss, (size_t)b * a.img_stride + (size_t)scale_idx * g.plane, g.pitch, g.h, F16);
 
-      float scale_factor = dm_pow2i(octave_idx);
-      float lambda = 1.5f * (sigma / scale_factor);
+      // sigma / 2^octave_idx as a product with 2^-octave_idx: the same real number, rounded once either way
+      float lambda = 1.5f * (sigma * dm_pow2i(-octave_idx));
       int r = (int)floorf(3 * lambda);
       float es = -1.f / (2.f * lambda * lambda);
 
@@ -215,8 +215,12 @@ __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
       int box = 2 * r + 1;
       int npix = box * box;
       // lane l visits window pixels l, l + 64, ...: (row, column) advance by (64 / box, 64 % box) with at most one carry
-      const int step_q = 64 / box, step_r = 64 - step_q * box;
-      int py = lane / box, px = lane - py * box;
+      // a / box for 0 <= a <= 64 as (int)((a + 0.5) * rcp(box)): (a + 0.5) / box stays 0.5 / box away from every integer — for box < 32768
+      // far more than the error of v_rcp_f32 and one product — 4 instructions instead of the ~25 of a 32-bit integer division
+      const float rbox = __builtin_amdgcn_rcpf((float)box);
+      const bool small_box = box < 32768;
+      const int step_q = small_box ? (int)(64.5f * rbox) : 64 / box, step_r = 64 - step_q * box;
+      int py = small_box ? (int)(((float)lane + 0.5f) * rbox) : lane / box, px = lane - py * box;
       // the contribution of one window texel given its gradient taps (ComputeOrientation.comp:102-121)
       auto accumulate = [&](float sdx2, float tr, float tl, float td, float tu) {
         const float gradX = 0.5f * (tr - tl);
@@ -952,8 +956,58 @@ static int for_runs(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, F run)
   return 0;
 }
 
+namespace
+{
+// test only (vksift_hip_selftest_inrange): the short forms against the compiler's general ones on pseudo-random operands inside their ranges
+__device__ __forceinline__ uint32_t st_hash(uint32_t x)
+{
+  x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
+  return x;
+}
+// 2^e * (1 + m / 2^23) with e uniform in [elo, ehi]
+__device__ __forceinline__ float st_float(uint32_t h, int elo, int ehi)
+{
+  const int e = elo + (int)((h >> 23) % (uint32_t)(ehi - elo + 1));
+  return __uint_as_float(((uint32_t)(e + 127) << 23) | (h & 0x7FFFFFu));
+}
+__global__ void __launch_bounds__(256) k_inrange_selftest(uint32_t n, uint32_t seed, uint32_t *bad)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n)
+    return;
+  const uint32_t h0 = st_hash(i * 3u + seed), h1 = st_hash(i * 3u + 1u + seed), h2 = st_hash(i * 3u + 2u + seed);
+  uint32_t miss = 0;
+  // sqrt: 0 and [2^-96, 2^8), the ends of the range in the first lanes
+  float x = i == 0 ? 0.f : (i == 1 ? 0x1p-96f : (i == 2 ? __uint_as_float(0x0F800001u) : st_float(h0, -96, 7)));
+  asm volatile("" : "+v"(x));
+  miss += __float_as_uint(sqrt_inrange(x)) != __float_as_uint(sqrtf(x));
+  // a / b: b in [2^-49, 4), a = 0 or in [2^-64, b]
+  float b = st_float(h1, -49, 1), a = st_float(h2, -64, 1);
+  a = (i & 15u) == 3u ? 0.f : (a > b ? b * __uint_as_float(0x3F000000u | (h2 & 0x7FFFFFu)) : a); // b * [0.5, 1) where the draw exceeds b
+  a = a < 0x1p-64f && a != 0.f ? 0x1p-64f : a;
+  asm volatile("" : "+v"(a), "+v"(b));
+  miss += __float_as_uint(div_inrange(a, b)) != __float_as_uint(a / b);
+  // x / 2 pi: +-[2^-96, 2^8)
+  float y = st_float(h0 ^ h1, -96, 7);
+  y = (h2 & 1u) ? -y : y;
+  asm volatile("" : "+v"(y));
+  miss += __float_as_uint(div_2pi_inrange(y)) != __float_as_uint(y / (2.f * PI_F));
+  if (miss)
+    atomicAdd(bad, miss);
+}
+} // namespace
+
 extern "C"
 {
+  int vksift_hip_selftest_inrange(uint32_t n, uint32_t seed, uint32_t *d_mismatches, vksift_hip_stream s)
+  {
+    hipError_t e = hipMemsetAsync(d_mismatches, 0, sizeof(uint32_t), (hipStream_t)s);
+    if (e != hipSuccess)
+      return (int)e;
+    hipLaunchKernelGGL(k_inrange_selftest, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)s, n, seed, d_mismatches);
+    return (int)hipGetLastError();
+  }
+
   int vksift_hip_orientations_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s)
   {
     if (batch == 0)
