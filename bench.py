@@ -77,6 +77,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip value_host_input / single_image_ms / roofline_c3 / sharded match")
     ap.add_argument("--host-input", action="store_true", help="time the PCIe-inclusive protocol as the main loop (not the headline value)")
+    ap.add_argument("--serialize-match", action="store_true",
+                    help="the next detection's scale-space starts BEHIND the matching queued before it instead of beside it "
+                         "(vksift_hip_tune VKSIFT_TUNE_PYR_GATE: stage times become kernel times; not the headline schedule)")
     ap.add_argument("--fp16", action="store_true", help="VKSIFT_PYRAMID_PRECISION_FLOAT16: binary16 scale-space storage (not the headline configuration)")
     ap.add_argument("--extras-timeout", type=float, default=300.0, help="seconds the legs after the timed region may take before the headline line is printed without them")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1: exercises every collective branch of the multi-GPU path on one GPU")
@@ -676,6 +679,8 @@ def main():
     api.lib().vksift_setLogLevel(api.VKSIFT_LOG_ERROR)
     W, H, B, NSUB = args.width, args.height, args.batch, max(1, args.sub_batches)
     do_match = not args.no_match
+    if args.serialize_match:
+        api.lib().vksift_hip_tune(6, 1)   # VKSIFT_TUNE_PYR_GATE
 
     # synthetic frames (seeded per global frame index), uploaded once: inputs are HBM-resident when timing starts.
     # Up to 128 generated frames per rank (85 ms of host time each) and, for longer batches, their three mirror images: B distinct
@@ -853,6 +858,19 @@ def main():
                                    "stage_ms_per_call": d16["stage_ms_per_call"]}
         except Exception as e:  # noqa: BLE001
             extras["fp16_mode"] = {"error": repr(e)[:300]}
+    if not args.no_extras and world == 1 and do_match:
+        # the same workload with the matching of a step serialised in front of the next detection's scale-space instead of running beside it
+        # (fresh process): what the blur launches and the scan reach when nothing shares the chip with them. The shipped schedule overlaps
+        # them because it is ~1 % faster in frames/s; its stage times — and the headline roofline.frac — therefore include the contention.
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--serialize-match", "--no-extras", "--no-cpu-baseline", "--steps", "5", "--warmup", "2",
+                                "--width", str(W), "--height", str(H), "--batch", str(B)], capture_output=True, text=True, timeout=300)
+            ds = json.loads(r.stdout.strip().splitlines()[-1])
+            extras["matching_serialised"] = {"value": ds["value"], "unit": ds["unit"], "roofline_frac": ds["roofline"]["frac"], "roofline_achieved": ds["roofline"]["achieved"],
+                                             "roofline_basis": ds["roofline"]["basis"], "stage_ms_per_call": ds["stage_ms_per_call"],
+                                             "note": "not the shipped schedule: scale-space behind the previous matching (VKSIFT_TUNE_PYR_GATE = 1)"}
+        except Exception as e:  # noqa: BLE001
+            extras["matching_serialised"] = {"error": repr(e)[:300]}
     if not args.no_extras:
         # BASELINE config 5 (north_star's multi-GPU workload): every rank, weak scaling; its collectives are timing barriers only
         try:

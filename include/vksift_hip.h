@@ -97,6 +97,7 @@ extern "C"
                                  * 2 GiB take) instead of one buffer resource per image and octave */
     VKSIFT_TUNE_SCAN_FORM = 4,  /* development: launch form of the cell-scan matcher (0 = built-in) */
     VKSIFT_TUNE_PAIR_FORM = 5,  /* two-scale blur launch: 0 built-in, 1 two texels per lane, 2 four texels per lane */
+    VKSIFT_TUNE_PYR_GATE = 6,   /* 1: the next detection's scale-space starts behind the matching queued before it (default: beside it) */
     VKSIFT_TUNE_COUNT = 8
   };
   int vksift_hip_tune(int knob, int value);

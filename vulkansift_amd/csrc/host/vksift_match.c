@@ -191,6 +191,8 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
   for (uint32_t r = 0; r < count; r += VKSIFT_HIP_MATCH_SLOTS)
     HIP_CHECK(match_slots(inst, &fwd, ids_a + r, ids_b + r, count - r < VKSIFT_HIP_MATCH_SLOTS ? count - r : VKSIFT_HIP_MATCH_SLOTS, r), "2-NN matching");
   HIP_CHECK(vksift_hip_post_words(inst->h_match_n, inst->d_match_n, (size_t)4 * count, inst->stream), "match count read-back");
+  if (inst->desc_start_valid && vksift_hip_tune_get(VKSIFT_TUNE_PYR_GATE) == 1)
+    vksift_hip_event_record(inst->ev_desc_start, inst->stream); /* experiment: the next scale-space behind this matching, not beside it */
   inst->filtered_slots_used = 0;
   inst->md_valid = false, inst->md_hits = 0, inst->md_direct = false, inst->md_asked = false;
   if (filter)
