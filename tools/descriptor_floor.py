@@ -70,6 +70,32 @@ def sample_counts(feats, w0, h0, upsampling=True):
     return out
 
 
+def orientation_counts(feats, w0, h0, upsampling=True):
+    """k_orientation's work for one image: it runs once per KEYPOINT (the records of one keypoint's orientations share position, scale and
+    sigma), one wave each, npix = (2 r + 1)^2 window texels in steps of 64; keypoints whose window touches the image border take the general loop.
+    -> (keypoints, steps of the interior loop, steps of the border loop, sum of r + 1 = iterations of the weight-sum loop)"""
+    import numpy as np
+    f32 = np.float32
+    if len(feats) == 0:
+        return 0, 0, 0, 0
+    key = np.stack([feats["scale_x"].view(np.uint32), feats["scale_y"].view(np.uint32), feats["sigma"].view(np.uint32),
+                    feats["scale_idx"].astype(np.uint32), feats["octave_idx"].astype(np.int64).astype(np.uint32)], axis=1)
+    _, first = np.unique(key, axis=0, return_index=True)
+    f = feats[np.sort(first)]
+    o = f["octave_idx"].astype(np.int64)
+    oi = o + 1 if upsampling else o
+    ow = (w0 * 2 if upsampling else w0) >> oi
+    oh = (h0 * 2 if upsampling else h0) >> oi
+    lam = f32(1.5) * (f["sigma"].astype(f32) / np.exp2(o.astype(f32)).astype(f32))
+    r = np.floor(f32(3.0) * lam).astype(np.int64)
+    npix = (2 * r + 1) ** 2
+    steps = (npix + 63) // 64
+    cx = np.floor(f["scale_x"].astype(f32) + f32(0.5)).astype(np.int64)
+    cy = np.floor(f["scale_y"].astype(f32) + f32(0.5)).astype(np.int64)
+    interior = (cx - r >= 1) & (cx + r <= ow - 2) & (cy - r >= 1) & (cy + r <= oh - 2)
+    return len(f), int(steps[interior].sum()), int(steps[~interior].sum()), int((r + 1).sum())
+
+
 def collect(args):
     import numpy as np
     import torch
@@ -93,12 +119,15 @@ def collect(args):
     inst.setProfiling(False)
     stage = {k: acc[k] / max(acc["nb_calls"], 1) for k in ("pyramid_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")}
     K = steps = samples = iters = odd = 0
+    ori = [0, 0, 0, 0]
     hist = collections.Counter()
     per_oct = collections.Counter()
     nfr = min(B, args.count_frames)
     for b in range(nfr):
         f = inst.downloadFeatures(b)
         n = sample_counts(f, W, H)
+        for k, v in enumerate(orientation_counts(f, W, H)):
+            ori[k] += v
         t = (n + 63) // 64
         # two waves per keypoint (batch >= 8): the first takes ceil(t / 2) steps, the second floor(t / 2); a wave's loop does two
         # steps per iteration and one odd step in the tail
@@ -125,6 +154,7 @@ def collect(args):
         "mean_samples_per_keypoint": samples / max(K, 1), "mean_steps_per_keypoint": steps / max(K, 1),
         "lane_fill": samples / max(steps * 64, 1),
         "keypoints_per_octave": dict(sorted(per_oct.items())),
+        "orientation": {"keypoints": ori[0] * (B / nfr), "interior_steps": ori[1] * (B / nfr), "border_steps": ori[2] * (B / nfr), "weight_sum_iterations": ori[3] * (B / nfr)},
         "costs_ps": costs,
     }
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
@@ -136,14 +166,18 @@ def collect(args):
 KERNEL = "_ZN12_GLOBAL__N_112k_descriptorILi2ELb1ELb0EEEv5MultiINS_8FeatArgsEE"
 
 
-def kernel_isa():
+ORI_KERNEL = "_ZN12_GLOBAL__N_113k_orientationILb1ELb0EEEv5MultiINS_8FeatArgsEE"
+
+
+def kernel_isa(kernel=None):
+    kernel = kernel or KERNEL
     src = os.path.join(ROOT, "vulkansift_amd", "csrc", "hip", "features.hip")
     out = "/tmp/_features_floor.s"
     import vulkansift_amd.build as b  # the flags the shipped kernels are compiled with
     cmd = [b.HIPCC] + [f for f in b.HIPFLAGS if f != "-fPIC"] + b._extra_flags("hip/features.hip") + b.INCLUDES + ["-S", "--cuda-device-only", "-o", out, src]
     subprocess.run(cmd, check=True, capture_output=True, cwd="/tmp")
     lines = open(out).read().split("\n")
-    s = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
+    s = next(i for i, l in enumerate(lines) if l.startswith(kernel + ":"))
     e = next(i for i in range(s, len(lines)) if lines[i].strip().startswith("s_endpgm"))
     return lines[s + 1:e + 1]
 
@@ -339,6 +373,9 @@ def report(args):
             res["hardware_counters_per_dispatch"] = {k: sq[k] / d for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_BUSY_CU_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT") if k in sq}
             res["predicted_over_counted"] = {"valu": total["valu"] / (sq["SQ_INSTS_VALU"] / d), "salu": total["salu"] / (sq["SQ_INSTS_SALU"] / d),
                                              "lds": total["lds"] / (sq["SQ_INSTS_LDS"] / d), "vmem": total["vmem"] / (sq["SQ_INSTS_VMEM"] / d)}
+    ori = orientation_report(inp, costs, args.sq)
+    if ori:
+        res["orientation"] = ori
     json.dump(res, open(args.out + ".json", "w"), indent=1)
     with open(args.out + ".md", "w") as f:
         w = f.write
@@ -365,10 +402,94 @@ def report(args):
         w("Sample loop, VALU instructions per iteration (two samples per lane) by mnemonic, most expensive first:\n\n| mnemonic | per iteration | ps each | ns |\n|---|---|---|---|\n")
         for k, c, p in loop_table:
             w(f"| `{k}` | {c} | {p:.0f} | {c * p / 1e3:.2f} |\n")
+        if ori:
+            w("\n# k_orientation: the same reconciliation\n\n")
+            oi = ori["inputs"]
+            w(f"{oi['keypoints']:.0f} keypoints (one wave each), {oi['interior_steps'] / 1e6:.2f} M steps of the interior window loop, {oi['border_steps'] / 1e6:.2f} M of the border loop, "
+              f"{oi['weight_sum_iterations'] / max(oi['keypoints'], 1):.1f} iterations of the weight-sum loop per keypoint.\n\n")
+            w("| region | executions per call (waves) | VALU | SALU | LDS | VMEM | VALU issue time each (ns per SIMD) |\n|---|---|---|---|---|---|---|\n")
+            for r in ori["regions"]:
+                i = r["instructions"]
+                w(f"| {r['region']} | {r['executions_per_call']:.3g} | {i.get('valu', 0):.0f} | {i.get('salu', 0):.0f} | {i.get('lds', 0):.0f} | {i.get('vmem', 0):.0f} | {r['valu_ps_per_execution'] / 1e3:.1f} |\n")
+            t = ori["predicted_wave_instructions_per_call"]
+            w(f"\nPredicted wave-instructions per call: VALU {t.get('valu', 0) / 1e6:.1f} M, SALU {t.get('salu', 0) / 1e6:.1f} M")
+            if "predicted_over_counted" in ori:
+                w(f"; counted: VALU {ori['hardware_counters_per_dispatch']['SQ_INSTS_VALU'] / 1e6:.1f} M, SALU {ori['hardware_counters_per_dispatch']['SQ_INSTS_SALU'] / 1e6:.1f} M "
+                  f"-> predicted / counted VALU {ori['predicted_over_counted']['valu']:.3f}, SALU {ori['predicted_over_counted']['salu']:.3f}")
+            w(f".\n\n**VALU issue time {ori['predicted_valu_issue_ms']:.2f} ms** of the measured **{ori['measured_orientation_ms']:.2f} ms** = "
+              f"{100 * ori['predicted_valu_issue_ms'] / ori['measured_orientation_ms']:.0f} %.\n")
         if unknown:
             w(f"\nMnemonics without a measured cost (priced as half-rate): {dict(unknown)}\n")
     print(json.dumps({k: res[k] for k in ("predicted_valu_issue_ms", "measured_descriptor_ms", "valu_issue_share_of_measured", "predicted_wave_instructions_per_call", "unpriced_mnemonics") if k in res}
                      | ({"predicted_over_counted": res["predicted_over_counted"]} if "predicted_over_counted" in res else {})))
+
+
+def orientation_report(inp, costs, sq_path):
+    """the same reconciliation for k_orientation<true, false>: one wave per keypoint; regions = per keypoint (everything outside the two window
+    loops, the weight-sum loop's body times its iteration count) / interior window loop / border window loop; the general-form fallback
+    blocks of both loops (v_div_scale inside) are left out like the descriptor's"""
+    o = inp.get("orientation")
+    if not o:
+        return None
+    blocks = blocks_of(kernel_isa(ORI_KERNEL))
+    has = lambda b, m: any(x == m for x in b[2])  # noqa: E731
+    # the window loops: contiguous runs of blocks at depth >= 2 that hold the histogram atomic
+    runs, cur = [], []
+    for i, b in enumerate(blocks):
+        if b[1] >= 2:
+            cur.append(i)
+        elif cur:
+            runs.append(cur)
+            cur = []
+    if cur:
+        runs.append(cur)
+    loops = [r for r in runs if any(has(blocks[i], "ds_add_u32") for i in r)]
+    # a run may hold both loops back to back: split at the blocks that load the four taps
+    loop_blocks = []
+    for r in loops:
+        heads = [i for i in r if sum(1 for m in blocks[i][2] if m == "buffer_load_dword") >= 4]
+        if len(heads) <= 1:
+            loop_blocks.append(r)
+        else:
+            for a, bnd in zip(heads, heads[1:] + [r[-1] + 1]):
+                loop_blocks.append([i for i in r if a <= i < bnd])
+    def priced(idxs, mult=None):
+        cnt, ps = collections.Counter(), 0.0
+        for i in idxs:
+            b = blocks[i]
+            if any(m == "v_div_scale_f32" for m in b[2]) and b[1] >= 2:
+                continue  # general-form fallback of a window loop
+            k = (mult or {}).get(i, 1.0)
+            for m in b[2]:
+                c = klass(m)
+                cnt[c] += k
+                if c == "valu":
+                    ps += costs.get(cost_key(m), costs["v_cvt_u32_f32_e32"]) * k
+        return cnt, ps
+    loop_blocks.sort(key=lambda r: sum(len(blocks[i][2]) for i in r))
+    in_loops = {i for r in loop_blocks for i in r}
+    interior, border = loop_blocks[0], loop_blocks[-1]
+    # the weight-sum loop: the depth-3 block with the lane broadcast; its iterations per keypoint come from the records
+    per_kp = [i for i in range(1, len(blocks)) if i not in in_loops]
+    mult = {i: o["weight_sum_iterations"] / max(o["keypoints"], 1) for i in per_kp if blocks[i][1] >= 3}
+    rows, total, total_ps = [], collections.Counter(), 0.0
+    for name, idxs, n, m in (("per keypoint: weight sum, window set-up, smoothing, peaks", per_kp, o["keypoints"], mult),
+                             ("interior window loop, one texel per lane per step", interior, o["interior_steps"], None),
+                             ("border window loop", border, o["border_steps"], None)):
+        cnt, ps = priced(idxs, m)
+        rows.append({"region": name, "executions_per_call": n, "instructions": {k: round(v, 1) for k, v in cnt.items()}, "valu_ps_per_execution": ps})
+        for k, v in cnt.items():
+            total[k] += v * n
+        total_ps += ps * n
+    res = {"kernel": "k_orientation<true, false> (one wave per keypoint)", "inputs": o, "regions": rows,
+           "predicted_wave_instructions_per_call": dict(total), "predicted_valu_issue_ms": total_ps / 1024 * 1e-9,
+           "measured_orientation_ms": inp["stage_ms_per_call"]["orientation_ms"]}
+    if sq_path and os.path.exists(sq_path):
+        sq = json.load(open(sq_path)).get("k_orientation<")
+        if sq:
+            res["hardware_counters_per_dispatch"] = {k: sq[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM") if k in sq}
+            res["predicted_over_counted"] = {"valu": total["valu"] / sq["SQ_INSTS_VALU"], "salu": total["salu"] / sq["SQ_INSTS_SALU"]}
+    return res
 
 
 def main():
