@@ -115,6 +115,8 @@ def lib():
         L.orc_dm_atan2f.restype = C.c_float
         L.orc_dm_div_2pi.argtypes = [C.c_float]
         L.orc_dm_div_2pi.restype = C.c_float
+        L.orc_check_div_3.argtypes = []
+        L.orc_check_div_3.restype = C.c_uint32
         L.orc_dm_expf_nb.argtypes = [C.c_float]
         L.orc_dm_expf_nb.restype = C.c_float
         L.orc_dm_expf_nb_nonpos.argtypes = [C.c_float]

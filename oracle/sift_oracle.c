@@ -977,6 +977,22 @@ float orc_dm_expf(float x) { return dm_expf(x); }
 float orc_dm_exp2f(float x) { return dm_exp2f(x); }
 float orc_dm_atan2f(float y, float x) { return dm_atan2f(y, x); }
 float orc_dm_div_2pi(float x) { return dm_div_2pi(x); }
+/* dm_div_3 against x / 3.f over every integer-valued float in [0, 2^32]: the number of results that differ in any bit (0 expected) */
+uint32_t orc_check_div_3(void)
+{
+  uint32_t bad = 0;
+  for (uint32_t i = 0; i < (1u << 23); i++)
+  {
+    const float x = (float)i, a = dm_div_3(x), b = x / 3.f;
+    bad += memcmp(&a, &b, 4) != 0;
+  }
+  for (uint32_t u = dm_f2u(0x1p23f); u <= dm_f2u(0x1p32f); u++) /* from 2^23 on every float is an integer */
+  {
+    const float x = dm_u2f(u), a = dm_div_3(x), b = x / 3.f;
+    bad += memcmp(&a, &b, 4) != 0;
+  }
+  return bad;
+}
 float orc_dm_expf_nb(float x) { return dm_expf_nb(x); }
 float orc_dm_expf_nb_nonpos(float x) { return dm_expf_nb_nonpos(x); } /* kernel-side helper, exported for tests/test_detmath.py only */ /* kernel-side helper, exported for tests/test_detmath.py only */
 float orc_dm_sinf(float t)

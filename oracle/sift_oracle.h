@@ -126,6 +126,7 @@ extern "C"
   float orc_dm_exp2f(float x);
   float orc_dm_atan2f(float y, float x);
   float orc_dm_div_2pi(float x);
+  uint32_t orc_check_div_3(void);
   float orc_dm_expf_nb(float x);
   float orc_dm_expf_nb_nonpos(float x);
   float orc_dm_sinf(float t);

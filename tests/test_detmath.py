@@ -154,3 +154,8 @@ def test_kernel_argument_ranges_against_float64(oracle):
     # exp2
     e = np.concatenate([np.linspace(-0.5, 2.5, 60001), rng.uniform(-0.5, 2.5, 20000)]).astype(np.float32)
     assert _ulp(_vec(L.orc_dm_exp2f, e), np.exp2(e.astype(np.float64))).max() <= 2.0
+
+
+def test_three_operation_division_by_3_over_every_integer_valued_float(oracle):
+    """dm_div_3 (detmath.h; the orientation kernel's histogram smoothing) against x / 3.f for every integer-valued float in [0, 2^32]"""
+    assert oracle.lib().orc_check_div_3() == 0

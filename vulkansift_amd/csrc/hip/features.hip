@@ -193,6 +193,8 @@ __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
       float lambda = 1.5f * (sigma * dm_pow2i(-octave_idx));
       int r = (int)floorf(3 * lambda);
       float es = -1.f / (2.f * lambda * lambda);
+      // the window's largest squared distance is 2 (r + 1)^2 (offsets of at most r + 0.5 + 0.5 per axis): can es * d2 pass the clamp of dm_expf?
+      const bool may_clamp = (2.f * (float)(r + 1) * (float)(r + 1)) * es < -87.f;
 
       // fixed-point scale: M = (sum_i e^{es i^2})^2 * sqrt(2)  (separable form of :75-79, same order as the oracle's det mode)
       float gsum = 1.f;
@@ -225,7 +227,12 @@ __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
       auto accumulate = [&](float sdx2, float tr, float tl, float td, float tu) {
         const float gradX = 0.5f * (tr - tl);
         const float gradY = 0.5f * (td - tu);
-        const float e = dm_expf_nb_nonpos(sdx2 * es); /* d2 >= 0 > es */
+        // dm_expf_nb_nonpos(sdx2 * es): its clamp as one v_max, its zero result only for keypoints whose window can reach the clamp at all
+        // (exponents below -87.3: never with lambda >= 0.08, i.e. for any sigma a SIFT configuration produces)
+        const float xe = sdx2 * es; /* d2 >= 0 > es */
+        float e = dm_expf_core_nonpos(fmaxf(xe, -87.3f));
+        if (may_clamp)
+          e = xe < -87.3f ? 0.f : e;
         float ori, len, fbin;
         bool odd;
         grad_polar<true>(gradX, gradY, &ori, &len, &odd);
@@ -239,11 +246,10 @@ __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
           fbin = dm_div_2pi(x36);
         }
         const float mag = e * len;
+        // ComputeOrientation.comp:107-112 wraps bin < 0 and bin >= 36; the angle is in [0, 2 pi] here (wrap_2pi), its quotient by 2 pi is
+        // the correctly rounded one of a non-negative number: only 36 itself can occur
         int bin = (int)fbin;
-        if (bin < 0)
-          bin += 36;
-        else if (bin >= 36)
-          bin -= 36;
+        bin = bin >= 36 ? bin - 36 : bin;
         atomicAdd(&hist[bin], (uint32_t)(mag * fp));
       };
       const int cxi = (int)rsx, cyi = (int)rsy;
@@ -301,7 +307,7 @@ __global__ void __launch_bounds__(256) k_orientation(Multi<FeatArgs> m)
       for (int it = 0; it < 6; it++)
       {
         uint32_t hm = __shfl(hv, lm, 64), hp = __shfl(hv, lp, 64);
-        hv = (uint32_t)((float)(hm + hv + hp) / 3.f);
+        hv = (uint32_t)dm_div_3((float)(hm + hv + hp)); // == / 3.f for every integer-valued float up to 2^32 (detmath.h)
       }
       uint32_t hm = __shfl(hv, lm, 64), hp = __shfl(hv, lp, 64);
       uint32_t mx = lane < 36 ? hv : 0u;
