@@ -789,7 +789,7 @@ def main():
                                   ("upload_ms", "pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")},
             "last_match_ms": match_ms,
             # where the scale-space buffers were put: rates (GB/s, 8 B per texel) of one whole-batch blur launch on every candidate
-            # memory range the instance timed when it allocated them (allocation order), and the two it kept
+            # memory range the instance timed when it allocated them (allocation order), and the one(s) it kept: one per scale-space buffer
             "scale_space_placement": placement,
             # K5 / K6 carry no roofline claim (latency / LDS-atomic / VALU bound, sparse reads): time per 1000 output
             # features, the unit of the reference's own figure (0.38 ms per 1000 features for K5 + K6 on an RTX 2060)

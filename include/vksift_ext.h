@@ -92,7 +92,7 @@ extern "C"
 #endif
   /* Where the scale-space was put: batch instances time a whole-batch blur launch on candidate memory ranges
    * when they allocate their scale-space buffers and keep the fastest. gbps[0 .. n): the rate of that launch (8 B per texel) on every
-   * candidate in allocation order, chosen[0 .. 1]: the indices in use (chosen[1] only with two buffers). Returns n — 0 when the
+   * candidate in allocation order, chosen[0 .. 1]: the indices in use (chosen[1] = chosen[0] unless the instance holds two buffers: VKSIFT_PYR_PINGPONG=2). Returns n — 0 when the
    * buffers were allocated plainly (single-image instances, VKSIFT_PYR_PLACEMENT=0). */
   VKSIFT_EXPORT uint32_t vksift_ext_getScaleSpacePlacement(vksift_Instance instance, float gbps[8], uint32_t chosen[2]);
 

@@ -445,11 +445,11 @@ class Instance:
         return d
 
     def getScaleSpacePlacement(self):
-        """candidate memory ranges timed at allocation: {"gbps": [...], "chosen": [...]} (empty lists: plain allocation)"""
+        """candidate memory ranges timed at allocation: {"gbps": [...], "chosen": [...]} (empty lists: plain allocation; one chosen range per scale-space buffer of the instance: one, or two with VKSIFT_PYR_PINGPONG=2)"""
         g = (C.c_float * 8)()
         ch = (C.c_uint32 * 2)()
         n = lib().vksift_ext_getScaleSpacePlacement(self._h, g, ch)
-        return {"gbps": [round(float(g[i]), 1) for i in range(n)], "chosen": [int(ch[0]), int(ch[1])] if n else []}
+        return {"gbps": [round(float(g[i]), 1) for i in range(n)], "chosen": list(dict.fromkeys([int(ch[0]), int(ch[1])])) if n else []}
 
     def getMatchTime(self):
         return lib().vksift_ext_getMatchTime(self._h)

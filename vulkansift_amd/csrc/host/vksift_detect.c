@@ -735,7 +735,8 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     vksift_hip_event_record(PS->ev_t[0], st);
   if (c.overlap)
   {
-    inst->pyr_cur ^= 1;
+    if (inst->pyr_nbuf == 2u)
+      inst->pyr_cur ^= 1;
     inst->d_pyr = inst->d_pyr_buf[inst->pyr_cur];
     if (inst->pyr_free_valid[inst->pyr_cur])
       HIP_CHECK(vksift_hip_stream_wait_event(inst->pyr_stream, inst->ev_pyr_free[inst->pyr_cur]), "pyramid buffer recycle");

@@ -137,13 +137,17 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
 #define ALLOC_D(ptr, bytes) ok = ok && ((ptr = vksift_hip_malloc(bytes)) != NULL)
 #define ALLOC_H(ptr, bytes) ok = ok && ((ptr = vksift_hip_host_malloc(bytes)) != NULL)
   {
-    /* Two pyramid buffers, so that the (bandwidth-bound) scale-space construction of detection N+1 runs under the
-     * (VALU-bound) descriptor and matching work of detection N: +6.5 % frames/s on batches of 128 frames (each blur
-     * launch gets ~6 % longer, the step 6.5 % shorter). Default: instances created for batches of 8 images and more
-     * (vksift_ext_createBatchInstance) — a single-image instance keeps one buffer (half the memory) and the hipGraph
-     * replay of small detections, which excludes overlapped calls. VKSIFT_PYR_PINGPONG=0 / 1 forces it off / on. */
+    /* Overlap mode: the (bandwidth-bound) scale-space construction of detection N+1 runs on its own stream, beside the matching
+     * queued behind detection N's descriptors (rounds 2-3 also ran it under the descriptors themselves, out of a second scale-space
+     * buffer: within 1 % in frames/s, and every stage interval measured the contention instead of the kernel — vksift_detect.c:
+     * ev_desc_start). With that gate the next scale-space starts only when every reader of the previous one is done, so ONE buffer
+     * serves (half the memory; and the measured placement, place_pyramid_buffers, has to find one fast range, not two).
+     * Default: instances created for batches of 8 images and more (vksift_ext_createBatchInstance) — a single-image instance keeps
+     * the hipGraph replay of small detections, which excludes overlapped calls. VKSIFT_PYR_PINGPONG=0 / 1 forces the mode off / on,
+     * =2 is the mode with two buffers (rounds 2-5). */
     const char *e = getenv("VKSIFT_PYR_PINGPONG");
-    inst->pyr_pingpong = e ? (e[0] == '1') : (batch_cap >= 8u);
+    inst->pyr_pingpong = e ? (e[0] == '1' || e[0] == '2') : (batch_cap >= 8u);
+    inst->pyr_nbuf = (e && e[0] == '2') ? 2u : 1u;
   }
   /* (the scale-space buffers themselves: below, once the stream exists — they are placed by measurement, place_pyramid_buffers) */
   ALLOC_D(inst->d_input, (size_t)inst->max_image_size * batch_cap);
@@ -185,7 +189,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   if (ok)
   {
     /* first of the large blocks after the stream: candidates need room, and everything allocated before stays where it is */
-    ok = place_pyramid_buffers(inst, pyr_texel_bytes(inst) * inst->pyr_img_stride * batch_cap, inst->pyr_img_stride, &L, inst->pyr_pingpong ? 2u : 1u,
+    ok = place_pyramid_buffers(inst, pyr_texel_bytes(inst) * inst->pyr_img_stride * batch_cap, inst->pyr_img_stride, &L, inst->pyr_nbuf,
                                inst->d_pyr_buf);
     inst->d_pyr = inst->d_pyr_buf[0];
   }
@@ -507,7 +511,7 @@ static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t i
         near_best += ms[i] <= lo * VKSIFT_PLACE_SPREAD ? 1u : 0u;
       if (near_best >= need && hi > lo * 1.08f)
         break; /* the fast mode has been seen `need` times, and a slow one beside it */
-      if (n >= need + 2u && hi <= lo * VKSIFT_PLACE_SPREAD)
+      if (n >= need + 3u && hi <= lo * VKSIFT_PLACE_SPREAD)
         break; /* this memory is all alike */
     }
     void *p = vksift_hip_malloc(bytes);
@@ -535,6 +539,8 @@ static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t i
       inst->place_chosen[k] = b;
       cand[b] = NULL;
     }
+    if (need == 1u)
+      inst->place_chosen[1] = inst->place_chosen[0];
     for (uint32_t i = 0; i < n; i++)
     {
       const double px = (double)(L->w[0] >= 512u ? (L->w[0] & ~255u) : (L->w[0] & ~3u)) * L->h[0] * inst->batch_cap * 2.0 * (double)pyr_texel_bytes(inst);
@@ -586,14 +592,14 @@ int grow_image_scratch(vksift_Instance inst, const PyrLayout *L)
   vksift_hip_free(inst->d_cand_xy);
   vksift_hip_free(inst->d_cand_flag);
   inst->d_pyr_buf[0] = inst->d_pyr_buf[1] = NULL;
-  (void)place_pyramid_buffers(inst, pyr_texel_bytes(inst) * new_pyr * n, new_pyr, L, inst->pyr_pingpong ? 2u : 1u, inst->d_pyr_buf);
+  (void)place_pyramid_buffers(inst, pyr_texel_bytes(inst) * new_pyr * n, new_pyr, L, inst->pyr_nbuf, inst->d_pyr_buf);
   inst->d_seg_mask = vksift_hip_malloc(sizeof(uint64_t) * new_seg * n);
   inst->d_seg_off = vksift_hip_malloc(sizeof(uint32_t) * new_seg * n);
   inst->d_cand_xy = vksift_hip_malloc(sizeof(uint32_t) * new_cand * n);
   inst->d_cand_flag = vksift_hip_malloc(sizeof(uint32_t) * new_cand * n);
   inst->pyr_free_valid[0] = inst->pyr_free_valid[1] = false;
   inst->cur_w = inst->cur_h = 0; /* no scale-space to download until the next detection */
-  const bool ok = inst->d_pyr_buf[0] && (!inst->pyr_pingpong || inst->d_pyr_buf[1]) && inst->d_seg_mask && inst->d_seg_off && inst->d_cand_xy && inst->d_cand_flag;
+  const bool ok = inst->d_pyr_buf[0] && (inst->pyr_nbuf < 2u || inst->d_pyr_buf[1]) && inst->d_seg_mask && inst->d_seg_off && inst->d_cand_xy && inst->d_cand_flag;
   if (!ok)
   {
     /* out of device memory: leave NO scratch behind (capacities 0), so that the next detection retries the allocation or
@@ -610,7 +616,7 @@ int grow_image_scratch(vksift_Instance inst, const PyrLayout *L)
     return -1;
   }
   inst->pyr_img_stride = new_pyr, inst->seg_cap = new_seg, inst->cand_cap = new_cand;
-  inst->d_pyr = inst->d_pyr_buf[inst->pyr_pingpong ? inst->pyr_cur : 0];
+  inst->d_pyr = inst->d_pyr_buf[inst->pyr_nbuf == 2u ? inst->pyr_cur : 0];
   return 0;
 }
 

@@ -121,7 +121,8 @@ struct vksift_Instance_T
   uint32_t place_chosen[2];
   float *d_pyr_buf[2];     /* ping-pong: detection N+1 builds its pyramid while detection N still reads its own */
   int pyr_cur;
-  bool pyr_pingpong;
+  bool pyr_pingpong;       /* overlap mode: the scale-space of a detection is built on its own stream, beside what is queued behind the previous detection's descriptors */
+  uint32_t pyr_nbuf;       /* scale-space buffers of the instance: 1, or 2 with VKSIFT_PYR_PINGPONG=2 (the next scale-space may then start before the previous detection's readers are done) */
   bool pyr_free_valid[2];
   uint64_t pyr_img_stride; /* floats reserved per image */
   uint8_t *d_input, *h_input;
