@@ -511,7 +511,7 @@ static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t i
         near_best += ms[i] <= lo * VKSIFT_PLACE_SPREAD ? 1u : 0u;
       if (near_best >= need && hi > lo * 1.08f)
         break; /* the fast mode has been seen `need` times, and a slow one beside it */
-      if (n >= need + 3u && hi <= lo * VKSIFT_PLACE_SPREAD)
+      if (n >= need + 5u && hi <= lo * VKSIFT_PLACE_SPREAD)
         break; /* this memory is all alike */
     }
     void *p = vksift_hip_malloc(bytes);
