@@ -395,6 +395,8 @@ def protocol_client(api):
             for f in (L.proto_serial, L.proto_pipelined):
                 f.restype = C.c_double
                 f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+            L.proto_plain.restype = C.c_double
+            L.proto_plain.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
             L.proto_single.restype = C.c_double
             L.proto_single.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
             _PROTO = L
@@ -482,6 +484,50 @@ def pipelined_protocol(api, dev_index, frames, W, H, B, do_match, steps):
         run(steps)
         dt = time.perf_counter() - t0
     return B * steps / dt
+
+
+def plain_api_protocol(api, dev_index, frames, W, H, do_match, budget_s=6.0):
+    """The reference's 20 entry points and nothing else (tests/native/protocol_client.c: proto_plain; an instance from
+    vksift_createInstance): one host image per vksift_detectFeatures call (vulkansift.c:315-344), count + features read per buffer.
+    What the library does with such a caller is its own business — runs of detect calls are staged and launched as one batched
+    detection (deferred submission, include/vksift_ext.h) — so this is the rate an application written against the reference gets
+    without touching an extension. frames/s per calling pattern:
+      detect_n_then_read[N]   a run of N detect calls into N buffers, then the N buffers are read
+      two_sets[N]             the same with 2 N buffers: the next run is issued before the current set is read (vulkansift.h:43-47)
+      ping_pong               two buffers, detect(frame k + 1) then read(frame k)
+    with_match: the two_sets[64] pattern with every frame also self-matched by vksift_matchFeatures / vksift_downloadMatches (one
+    pair per call: the reference's matching interface has a single result slot, so there is nothing to batch)."""
+    pc = protocol_client(api)
+    if pc is None:
+        return {"available": False, "reason": "gcc unavailable: tests/native/protocol_client.c could not be built"}
+    out = {"caller": "C (tests/native/protocol_client.c: proto_plain), reference entry points only, instance from vksift_createInstance",
+           "detect_n_then_read": {}, "two_sets": {}}
+    per_leg = budget_s / 8.0
+
+    def leg(nbuf, n, mode, match):
+        cfg = api.default_config(sift_buffer_count=nbuf, gpu_device_index=dev_index, input_image_max_size=max(W * H, 1024))
+        feat_buf = np.zeros(cfg.max_nb_sift_per_buffer, api.FEATURE_DTYPE)
+        match_buf = np.zeros(cfg.max_nb_sift_per_buffer, api.MATCH_DTYPE)
+        with api.Instance(cfg) as inst:
+            ptrs = inst.imagePointerArray(frames)
+            # a first short call sizes the timed one for the leg's share of the budget
+            frames_per_iter = 1 if mode == 2 else n
+            probe = 12 if mode == 2 else 3
+            dt = pc.proto_plain(inst._h, ptrs, len(frames), n, W, H, mode, int(match), probe, feat_buf.ctypes.data, match_buf.ctypes.data)
+            steps = int(max(probe, min(2000 if mode == 2 else 400, per_leg / max(dt / probe, 1e-6))))
+            dt = pc.proto_plain(inst._h, ptrs, len(frames), n, W, H, mode, int(match), steps, feat_buf.ctypes.data, match_buf.ctypes.data)
+            stats = inst.getDeferredStats()
+        return steps * frames_per_iter / dt, stats
+
+    for n in (2, 8, 64):
+        out["detect_n_then_read"][str(n)], _ = leg(n, n, 0, False)
+        out["two_sets"][str(n)], st = leg(2 * n, n, 1, False)
+    out["mean_images_per_launch_two_sets_64"] = round(st[1] / max(st[0], 1), 1)
+    out["ping_pong"], st = leg(2, 1, 2, False)
+    out["ping_pong_deferred_images"] = st[1]
+    if do_match:
+        out["two_sets_64_with_match"], _ = leg(128, 64, 1, True)
+    return out
 
 
 def single_image_latency(api, dev_index, img, runs=100, warm=10, detect_only=False):
@@ -828,6 +874,11 @@ def main():
             extras["value_host_input_pipelined"] = pipelined_protocol(api, dev.index, frames, W, H, B, do_match, 12)
         except Exception as e:  # noqa: BLE001
             extras["value_host_input_pipelined"] = {"error": repr(e)[:300]}
+    if not args.no_extras and world == 1:
+        try:
+            extras["plain_api"] = plain_api_protocol(api, dev.index, frames[:128], W, H, do_match)
+        except Exception as e:  # noqa: BLE001
+            extras["plain_api"] = {"error": repr(e)[:300]}
     if not args.no_extras and world == 1:
         # in a fresh process: how HIP maps an instance's dozen streams onto the four hardware queues depends on the streams the
         # process created before (the 640x480 instance above), and with it the attribution of an overlapped detection's time to

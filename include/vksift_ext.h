@@ -54,6 +54,14 @@ extern "C"
   VKSIFT_EXPORT uint32_t vksift_ext_getFilteredMatchesNumber(vksift_Instance instance, uint32_t pair);
   VKSIFT_EXPORT void vksift_ext_downloadFilteredMatches(vksift_Instance instance, uint32_t pair, vksift_ext_FilteredMatch *matches);
 
+  /* Deferred submission of vksift_detectFeatures (no counterpart in the reference, no change of its contract): consecutive plain
+   * detect calls into consecutive SIFT buffers, with nothing asked in between, are staged and launched as ONE batched detection by
+   * the first call that needs a result — any other entry point — or when 128 images (VKSIFT_DEFER_MAX) are staged. The first detect
+   * call after another entry point is launched at once unless the caller's previous run of detect calls held two or more, so
+   * detect + read and the two-buffer ping-pong keep their latency. VKSIFT_DEFER=0 launches every call at once. Results are
+   * identical either way. These counters say what the instance did: batches launched from staged images, and images in them. */
+  VKSIFT_EXPORT void vksift_ext_getDeferredStats(vksift_Instance instance, uint64_t *nb_batches, uint64_t *nb_images);
+
   /* Stage timings (milliseconds, HIP events on the instance stream) of the last detect call.
    * Enabled with vksift_ext_setProfiling(instance, true); disabled by default. Blocking. */
   typedef struct

@@ -8,7 +8,10 @@
  *                  records. Strictly serial: nothing is queued while the host waits or copies.
  * proto_single     one image per call, everything downloaded (BASELINE config 2 read literally)
  * proto_pipelined  the same inputs and outputs with two sets of n SIFT buffers: the detection of the next batch is queued before the
- *                  results of the current one are fetched (vulkansift.h:43-47: detection and matching calls are asynchronous). */
+ *                  results of the current one are fetched (vulkansift.h:43-47: detection and matching calls are asynchronous).
+ * proto_plain      the 20 entry points of the reference ONLY (vulkansift.h; an instance from vksift_createInstance): one host image
+ *                  per vksift_detectFeatures call, vksift_getFeaturesNumber + vksift_downloadFeatures per buffer — what an application
+ *                  written against the reference does when it has more than one image at hand. */
 #include <stdint.h>
 #include <stdlib.h>
 #include <time.h>
@@ -170,4 +173,76 @@ double proto_pipelined(vksift_Instance inst, const uint8_t *const *images, uint3
   free(ids0);
   free(ids1);
   return dt;
+}
+
+/* The reference's API and nothing else. `inst` comes from vksift_createInstance with sift_buffer_count >= n (mode 0), 2 n (mode 1) or 2
+ * (mode 2); images[k % n_images] is frame k.
+ *   mode 0  a run of n detect calls into buffers 0 .. n-1, then count + features of each (the detection cannot overlap the reads)
+ *   mode 1  two sets of n buffers: the run of detect calls for the next set is issued BEFORE the current set is read, so the GPU works
+ *           on one set while the host copies the other out (vulkansift.h:43-47)
+ *   mode 2  the two-buffer ping-pong of a video loop: detect(frame k + 1) into the other buffer, then read frame k
+ * do_match: every frame is also self-matched through vksift_matchFeatures + vksift_getMatchesNumber + vksift_downloadMatches (one
+ * pair per call is all the reference's matching interface offers: it has one result slot).
+ * Returns seconds for steps * n frames (mode 2: steps frames), after an untimed warm-up pass of min(steps, 10) iterations (16 in mode 2). */
+static void plain_read(vksift_Instance inst, uint32_t first, uint32_t n, int do_match, vksift_Feature *feat_buf, vksift_Match_2NN *match_buf)
+{
+  for (uint32_t i = 0; i < n; i++)
+  {
+    if (vksift_getFeaturesNumber(inst, first + i))
+      vksift_downloadFeatures(inst, feat_buf, first + i);
+    if (do_match)
+    {
+      vksift_matchFeatures(inst, first + i, first + i);
+      if (vksift_getMatchesNumber(inst))
+        vksift_downloadMatches(inst, match_buf);
+    }
+  }
+}
+
+static void plain_run(vksift_Instance inst, const uint8_t *const *images, uint32_t n_images, uint32_t n, uint32_t w, uint32_t h, int mode, int do_match,
+                      uint32_t iters, vksift_Feature *feat_buf, vksift_Match_2NN *match_buf)
+{
+  uint32_t k = 0;
+  if (mode == 0)
+  {
+    for (uint32_t it = 0; it < iters; it++)
+    {
+      for (uint32_t i = 0; i < n; i++)
+        vksift_detectFeatures(inst, images[k++ % n_images], w, h, i);
+      plain_read(inst, 0u, n, do_match, feat_buf, match_buf);
+    }
+    return;
+  }
+  if (mode == 1)
+  {
+    for (uint32_t i = 0; i < n; i++)
+      vksift_detectFeatures(inst, images[k++ % n_images], w, h, i);
+    for (uint32_t it = 0; it < iters; it++)
+    {
+      const uint32_t cur = it & 1u, nxt = cur ^ 1u;
+      if (it + 1 < iters)
+        for (uint32_t i = 0; i < n; i++)
+          vksift_detectFeatures(inst, images[k++ % n_images], w, h, nxt * n + i);
+      plain_read(inst, cur * n, n, do_match, feat_buf, match_buf);
+    }
+    return;
+  }
+  vksift_detectFeatures(inst, images[k++ % n_images], w, h, 0u);
+  for (uint32_t it = 0; it < iters; it++)
+  {
+    if (it + 1 < iters)
+      vksift_detectFeatures(inst, images[k++ % n_images], w, h, (it + 1u) & 1u);
+    plain_read(inst, it & 1u, 1u, do_match, feat_buf, match_buf);
+  }
+}
+
+double proto_plain(vksift_Instance inst, const uint8_t *const *images, uint32_t n_images, uint32_t n, uint32_t w, uint32_t h, int mode, int do_match,
+                   uint32_t steps, vksift_Feature *feat_buf, vksift_Match_2NN *match_buf)
+{
+  /* warm-up: long enough for the instance to have seen the calling pattern (its staging capacity doubles batch by batch) */
+  uint32_t warm = mode == 2 ? 16u : 10u;
+  plain_run(inst, images, n_images, n, w, h, mode, do_match, warm < steps ? warm : steps, feat_buf, match_buf);
+  const double t0 = now_s();
+  plain_run(inst, images, n_images, n, w, h, mode, do_match, steps, feat_buf, match_buf);
+  return now_s() - t0;
 }

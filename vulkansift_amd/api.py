@@ -134,6 +134,8 @@ def lib():
     L.vksift_ext_getScaleSpacePlacement.argtypes = [inst, C.POINTER(C.c_float), C.POINTER(u32)]
     L.vksift_ext_getScaleSpacePlacement.restype = u32
     L.vksift_ext_getAccumulatedDetectTimingsSized.argtypes = [inst, C.POINTER(vksift_ext_DetectTimings), C.c_size_t, C.POINTER(u32), C.c_bool]
+    L.vksift_ext_getDeferredStats.argtypes = [inst, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.vksift_ext_getDeferredStats.restype = None
     L.vksift_ext_getMatchTime.argtypes = [inst]
     L.vksift_ext_getMatchTime.restype = C.c_float
     L.vksift_ext_exportDescriptorsDevice.argtypes = [inst, u32, C.c_void_p]
@@ -453,6 +455,12 @@ class Instance:
 
     def getMatchTime(self):
         return lib().vksift_ext_getMatchTime(self._h)
+
+    def getDeferredStats(self):
+        """(batches launched from staged vksift_detectFeatures calls, images in them) — include/vksift_ext.h"""
+        b, n = C.c_uint64(0), C.c_uint64(0)
+        lib().vksift_ext_getDeferredStats(self._h, C.byref(b), C.byref(n))
+        return int(b.value), int(n.value)
 
     def exportDescriptorsDevice(self, gpu_buffer_id, dev_ptr):
         n = lib().vksift_ext_exportDescriptorsDevice(self._h, gpu_buffer_id, dev_ptr)

@@ -49,6 +49,7 @@ uint32_t buffer_counts(vksift_Instance inst, uint32_t buf, uint32_t *cnt, bool l
 
 uint32_t vksift_getFeaturesNumber(vksift_Instance instance, const uint32_t gpu_buffer_id)
 {
+  defer_sync(instance);
   if (!buffer_idx_valid(instance, gpu_buffer_id))
   {
     logError(LOG_TAG, "vksift_getFeaturesNumber(): bad argument.");
@@ -265,6 +266,7 @@ static bool download_one_packed(vksift_Instance inst, vksift_Feature *feats_ptr,
 
 void vksift_downloadFeatures(vksift_Instance instance, vksift_Feature *feats_ptr, uint32_t gpu_buffer_id)
 {
+  defer_sync(instance);
   if (!buffer_idx_valid(instance, gpu_buffer_id))
   {
     logError(LOG_TAG, "vksift_downloadFeatures(): bad argument.");
@@ -305,6 +307,7 @@ gpu_error:
 
 void vksift_uploadFeatures(vksift_Instance instance, const vksift_Feature *feats_ptr, const uint32_t nb_feats, const uint32_t gpu_buffer_id)
 {
+  defer_sync(instance);
   if (!buffer_idx_valid(instance, gpu_buffer_id) || nb_feats > instance->cfg.max_nb_sift_per_buffer)
   {
     if (nb_feats > instance->cfg.max_nb_sift_per_buffer)
@@ -335,10 +338,15 @@ gpu_error:
 /* ------------------------------------------------------------------------------------------------ */
 /* scale-space inspection (vulkansift.c:464-518, sift_memory.c:1303-1383)                           */
 /* ------------------------------------------------------------------------------------------------ */
-uint8_t vksift_getScaleSpaceNbOctaves(vksift_Instance instance) { return (uint8_t)instance->lay.n_oct; }
+uint8_t vksift_getScaleSpaceNbOctaves(vksift_Instance instance)
+{
+  defer_sync(instance);
+  return (uint8_t)instance->lay.n_oct;
+}
 
 void vksift_getScaleSpaceOctaveResolution(vksift_Instance instance, const uint8_t octave, uint32_t *octave_images_width, uint32_t *octave_images_height)
 {
+  defer_sync(instance);
   if (octave >= instance->lay.n_oct)
   {
     logError(LOG_TAG, "vksift_getScaleSpaceOctaveResolution(): octave %d requested, the current scale-space has %d",
@@ -353,6 +361,7 @@ void vksift_getScaleSpaceOctaveResolution(vksift_Instance instance, const uint8_
 static void download_plane(vksift_Instance inst, uint8_t octave, uint8_t scale, bool is_dog, float *dst, const char *fn)
 {
   float *tmp = NULL;
+  defer_sync(inst);
   uint32_t nscales = inst->S + (is_dog ? 2 : 3);
   if (octave >= inst->lay.n_oct || scale >= nscales)
   {

@@ -179,6 +179,7 @@ typedef struct
   bool prof;      /* HIP-event stage timings requested */
   bool overlap;   /* scale-space on its own stream and buffer (ping-pong), see detect_impl */
   bool upload;    /* host images were staged in h_input and have to be copied to d_input */
+  bool prestaged; /* ... they are in h_input already (deferred vksift_detectFeatures calls): nothing to stage */
   bool capturing; /* the sequence is being captured into a hipGraph: no host-visible events inside */
   bool gpu_busy;  /* an earlier detection was still running when this one was queued */
   bool post;      /* feature posting at the end of the sequence (vksift_internal.h: h_post) */
@@ -222,7 +223,7 @@ static void build_jobs(DetectCtx *c)
     j->seg_img_stride = nsegs_o;
     j->cand_xy = inst->d_cand_xy + L->cand_off[o];
     j->cand_flag = inst->d_cand_flag + L->cand_off[o];
-    j->cand_n = inst->d_cand_n + (size_t)o * inst->batch_cap;
+    j->cand_n = inst->d_cand_n + (size_t)o * inst->det_cap;
     j->cand_img_stride = inst->cand_cap;
     j->cand_cap = (uint32_t)L->cand_cap[o];
     j->ori_ang = inst->d_ori_ang + (size_t)b0->sec_off[o] * VKSIFT_HIP_MAX_ORI;
@@ -415,7 +416,8 @@ static int enqueue_detection(DetectCtx *c)
       uint32_t i1 = i0 + per;
       if (i1 >= c->count || c->count - i1 < per / 2u)
         i1 = c->count; /* a tail shorter than half a group joins the last one */
-      stage_images(inst->h_input, c->images, i0, i1, c->img_bytes);
+      if (!c->prestaged)
+        stage_images(inst->h_input, c->images, i0, i1, c->img_bytes);
       TRY(vksift_hip_memcpy_h2d(inst->d_input + (size_t)i0 * c->img_bytes, inst->h_input + (size_t)i0 * c->img_bytes, c->img_bytes * (i1 - i0), su), "image upload");
       if (grouped)
       {
@@ -611,14 +613,14 @@ static DetectGraph *graph_lookup(vksift_Instance inst, const DetectCtx *c)
   return victim;
 }
 
-static void detect_impl(vksift_Instance inst, const uint8_t *const *images, const uint8_t *d_images, uint32_t count, uint32_t w, uint32_t h,
+static void detect_impl(vksift_Instance inst, const uint8_t *const *images, const uint8_t *d_images, bool prestaged, uint32_t count, uint32_t w, uint32_t h,
                         uint32_t first_buf, const char *fn)
 {
   vksift_hip_stream st = inst->stream;
   bool capturing = false;
   bool seq_assigned = false; /* the target buffers already carry the sequence number of this (not yet queued) detection */
 
-  bool valid = count >= 1 && count <= inst->batch_cap && buffer_idx_valid(inst, first_buf) && buffer_idx_valid(inst, first_buf + count - 1) &&
+  bool valid = count >= 1 && count <= inst->det_cap && buffer_idx_valid(inst, first_buf) && buffer_idx_valid(inst, first_buf + count - 1) &&
                resolution_valid(inst, w, h);
   if (valid)
   {
@@ -640,7 +642,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
    * command buffers and staging memory are single-instanced. Here the instance's HIP stream is in-order, so GPU
    * work is already serialised; the host only has to wait for the resources it is about to overwrite: the pinned
    * image staging buffer, and (when profiling) the event set of the detection before the previous one. */
-  if (inst->staging_pending && images)
+  if (inst->staging_pending && images) /* (prestaged images: the deferring call waited before it wrote the first one) */
   {
     HIP_CHECK(vksift_hip_event_sync(inst->ev_staging), "staging synchronisation");
     inst->staging_pending = false;
@@ -690,8 +692,9 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
    * does not depend on anything the previous call (or a matching still in flight) reads or writes, so it runs on its own
    * stream, ordered only behind the last reader of the pyramid buffer it recycles; everything that touches the SIFT
    * buffers and the extraction scratch stays in instance-stream order. */
-  c.overlap = inst->pyr_pingpong && c.L->n_oct > 0;
-  c.upload = images != NULL;
+  c.overlap = inst->pyr_pingpong && c.L->n_oct > 0 && count >= inst->overlap_min_count;
+  c.upload = images != NULL || prestaged;
+  c.prestaged = prestaged;
   c.w = w, c.h = h, c.count = count, c.first_buf = first_buf;
   c.img_bytes = (size_t)w * h;
   c.nblur = 0;
@@ -748,12 +751,13 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   /* host images are staged into pinned memory while the sequence is enqueued (enqueue_detection): the caller may reuse its
    * memory as soon as we return (sift_memory.c:943) */
   c.images = images;
-  c.d_src = images ? inst->d_input : d_images;
+  c.d_src = c.upload ? inst->d_input : d_images;
   build_jobs(&c);
 
   /* host-visible events (staging, completion, profiling) stay outside a captured region; a captured graph holds the address
-   * of ONE pyramid buffer, so instances with two (ping-pong) never replay */
-  const bool replay = inst->use_graphs && !c.prof && !inst->pyr_pingpong && (uint64_t)count * w * h <= inst->graph_max_pixels;
+   * of ONE pyramid buffer, so instances with two (ping-pong) never replay, nor does a detection whose scale-space overlaps */
+  const bool replay = inst->use_graphs && !c.prof && !c.overlap && !(inst->pyr_pingpong && inst->pyr_nbuf == 2u) &&
+                      (uint64_t)count * w * h <= inst->graph_max_pixels;
   DetectGraph *dg = replay ? graph_lookup(inst, &c) : NULL;
   if (dg && dg->exec)
   {
@@ -791,13 +795,20 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   }
   if (dg)
     dg->stamp = ++inst->graph_stamp;
-  if (images && dg)
+  if (dg && inst->pyr_pingpong)
+  {
+    /* (recorded by enqueue_detection for every sequence that is not captured) a later overlapped detection recycles the buffer
+     * behind this one's readers */
+    HIP_CHECK(vksift_hip_event_record(inst->ev_pyr_free[inst->pyr_cur], st), "event record");
+    inst->pyr_free_valid[inst->pyr_cur] = true;
+  }
+  if (c.upload && dg)
   {
     /* graph replay: the upload is a node of the graph, the staging buffer is busy until the graph has run */
     HIP_CHECK(vksift_hip_event_record(inst->ev_staging, st), "event record");
     inst->staging_pending = true;
   }
-  inst->device_input_last = images == NULL;
+  inst->device_input_last = !c.upload;
   if (c.prof)
   {
     vksift_hip_event_record(PS->ev_t[6], st);
@@ -846,31 +857,127 @@ gpu_error:
   inst->error_cb(VKSIFT_VULKAN_ERROR);
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* deferred submission (vksift_internal.h: defer_enabled)                                           */
+/* ------------------------------------------------------------------------------------------------ */
+/* the staged images as ONE batched detection. Failures are reported through the error callback of whichever call got here. */
+void flush_deferred(vksift_Instance inst)
+{
+  const uint32_t n = inst->pend_n;
+  if (n == 0)
+    return;
+  inst->pend_n = 0;
+  inst->defer_batches++;
+  inst->defer_images += n;
+  vksift_hip_set_device(inst->device);
+  detect_impl(inst, NULL, NULL, true, n, inst->pend_w, inst->pend_h, inst->pend_first, "vksift_detectFeatures()");
+}
+
+/* true: the image was staged (and the batch launched if that filled it); false: the caller launches it the direct way */
+static bool defer_detect(vksift_Instance inst, const uint8_t *image, uint32_t w, uint32_t h, uint32_t buf)
+{
+  if (inst->pend_n)
+  {
+    /* a batch is one resolution into consecutive buffers; a buffer named twice keeps the order of its two detections */
+    if (buf != inst->pend_first + inst->pend_n || w != inst->pend_w || h != inst->pend_h)
+      flush_deferred(inst);
+  }
+  else if (inst->defer_grow && inst->det_cap < inst->defer_max)
+  {
+    /* the previous batch filled the capacity: twice as much for this one (the blocks follow what the caller does: an instance
+     * with 1000 SIFT buffers whose caller detects two images at a time holds the scratch of two) */
+    uint32_t cap = inst->det_cap * 2u;
+    cap = cap > inst->defer_max ? inst->defer_max : cap;
+    /* ... within a third of what the device has left */
+    const uint64_t per_image = pyr_texel_bytes(inst) * inst->pyr_img_stride * inst->pyr_nbuf + 12u * inst->seg_cap + 8u * inst->cand_cap +
+                               2u * (uint64_t)inst->max_image_size + (4u * VKSIFT_HIP_MAX_ORI + 4u) * inst->ori_cap;
+    const uint64_t room = vksift_hip_device_free_mem() / 3u;
+    inst->defer_grow = false;
+    if ((uint64_t)(cap - inst->det_cap) * per_image > room || resize_detect_scratch(inst, NULL, cap) != 0)
+      inst->defer_max = inst->det_cap; /* this is as far as it goes */
+  }
+  if (inst->det_cap < 2u || inst->h_input == NULL)
+  {
+    /* a single-image instance: room for two first (then doubling, see above). The second call of a run pays for it, once. */
+    if (inst->h_input == NULL || resize_detect_scratch(inst, NULL, 2u) != 0)
+    {
+      inst->defer_enabled = false;
+      return false;
+    }
+  }
+  if (inst->pend_n == 0)
+  {
+    if (inst->staging_pending)
+    {
+      if (vksift_hip_event_sync(inst->ev_staging) != 0)
+        return false;
+      inst->staging_pending = false;
+    }
+    inst->pend_first = buf, inst->pend_w = w, inst->pend_h = h;
+  }
+  memcpy(inst->h_input + (size_t)inst->pend_n * w * h, image, (size_t)w * h);
+  inst->pend_n++;
+  const uint32_t full = inst->det_cap < inst->defer_max ? inst->det_cap : inst->defer_max;
+  if (inst->pend_n >= full)
+  {
+    inst->defer_grow = inst->det_cap < inst->defer_max;
+    flush_deferred(inst);
+  }
+  return true;
+}
+
 void vksift_detectFeatures(vksift_Instance instance, const uint8_t *image_data, const uint32_t image_width, const uint32_t image_height,
                            const uint32_t gpu_buffer_id)
 {
+  vksift_Instance inst = instance;
   const uint8_t *imgs[1] = {image_data};
-  vksift_hip_set_device(instance->device);
-  detect_impl(instance, imgs, NULL, 1, image_width, image_height, gpu_buffer_id, "vksift_detectFeatures()");
+  vksift_hip_set_device(inst->device);
+  /* The first detection after any other call is launched at once — detect + read, the reference's own loop
+   * (src/perf/wrappers/vulkansift_wrapper.cpp:30-33), and the two-buffer ping-pong keep their path and their latency — unless the
+   * caller's last run of detect calls held several. From the second call of a run on the images are staged and go as one batch. */
+  const bool run = inst->epoch_detects > 0 || inst->batch_mode;
+  inst->epoch_detects++;
+  if (inst->defer_enabled && (run || inst->pend_n) && !inst->profiling && image_data != NULL && buffer_idx_valid(inst, gpu_buffer_id) &&
+      resolution_valid(inst, image_width, image_height) && (image_width < image_height ? image_width : image_height) >= 16u)
+  {
+    if (defer_detect(inst, image_data, image_width, image_height, gpu_buffer_id))
+      return;
+  }
+  /* invalid arguments take the direct path too: it reports them */
+  if (inst->pend_n)
+    flush_deferred(inst);
+  detect_impl(inst, imgs, NULL, false, 1, image_width, image_height, gpu_buffer_id, "vksift_detectFeatures()");
+}
+
+static bool ext_batch_count_valid(vksift_Instance inst, uint32_t count, const char *fn)
+{
+  if (count <= inst->batch_cap)
+    return true;
+  logError(LOG_TAG, "%s error: invalid input.", fn);
+  inst->error_cb(VKSIFT_INVALID_INPUT_ERROR);
+  return false;
 }
 
 void vksift_ext_detectFeaturesBatch(vksift_Instance instance, const uint8_t *const *images, uint32_t count, uint32_t image_width, uint32_t image_height,
                                     uint32_t first_gpu_buffer_id)
 {
   vksift_hip_set_device(instance->device);
-  detect_impl(instance, images, NULL, count, image_width, image_height, first_gpu_buffer_id, "vksift_ext_detectFeaturesBatch()");
+  defer_sync(instance);
+  if (ext_batch_count_valid(instance, count, "vksift_ext_detectFeaturesBatch()"))
+    detect_impl(instance, images, NULL, false, count, image_width, image_height, first_gpu_buffer_id, "vksift_ext_detectFeaturesBatch()");
 }
 
 void vksift_ext_detectFeaturesBatchDevice(vksift_Instance instance, const uint8_t *d_images, uint32_t count, uint32_t image_width, uint32_t image_height,
                                           uint32_t first_gpu_buffer_id)
 {
   vksift_hip_set_device(instance->device);
+  defer_sync(instance);
   if (d_images == NULL)
   {
     logError(LOG_TAG, "vksift_ext_detectFeaturesBatchDevice() error: invalid input.");
     instance->error_cb(VKSIFT_INVALID_INPUT_ERROR);
     return;
   }
-  detect_impl(instance, NULL, d_images, count, image_width, image_height, first_gpu_buffer_id, "vksift_ext_detectFeaturesBatchDevice()");
+  if (ext_batch_count_valid(instance, count, "vksift_ext_detectFeaturesBatchDevice()"))
+    detect_impl(instance, NULL, d_images, false, count, image_width, image_height, first_gpu_buffer_id, "vksift_ext_detectFeaturesBatchDevice()");
 }
-

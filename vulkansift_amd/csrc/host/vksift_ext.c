@@ -9,6 +9,7 @@
 /* ------------------------------------------------------------------------------------------------ */
 void vksift_ext_setProfiling(vksift_Instance instance, bool enabled)
 {
+  defer_sync(instance);
   instance->profiling = enabled;
   instance->prof[0].valid = instance->prof[1].valid = false;
   instance->prof[0].accounted = instance->prof[1].accounted = false;
@@ -31,6 +32,7 @@ static void accumulated_timings(vksift_Instance instance, vksift_ext_DetectTimin
 {
   memset(sum, 0, sizeof(*sum));
   *nb_calls = 0;
+  defer_sync(instance);
   if (!instance->profiling)
     return;
   vksift_hip_set_device(instance->device);
@@ -69,6 +71,15 @@ void vksift_ext_getAccumulatedDetectTimings(vksift_Instance instance, vksift_ext
   vksift_ext_getAccumulatedDetectTimingsSized(instance, sum, VKSIFT_EXT_DETECT_TIMINGS_V1_BYTES, nb_calls, reset);
 }
 
+void vksift_ext_getDeferredStats(vksift_Instance instance, uint64_t *nb_batches, uint64_t *nb_images)
+{
+  /* (no defer_sync: reading the statistics launches nothing) */
+  if (nb_batches)
+    *nb_batches = instance->defer_batches;
+  if (nb_images)
+    *nb_images = instance->defer_images;
+}
+
 vksift_Result vksift_ext_pinHostMemory(void *ptr, size_t bytes)
 {
   if (!ptr || !bytes || !vksift_g_loaded)
@@ -85,6 +96,13 @@ vksift_Result vksift_ext_unpinHostMemory(void *ptr)
 
 uint32_t vksift_ext_getScaleSpacePlacement(vksift_Instance instance, float gbps[8], uint32_t chosen[2])
 {
+  if (instance == NULL)
+  {
+    for (uint32_t i = 0; i < 8u; i++)
+      gbps[i] = 0.f;
+    chosen[0] = chosen[1] = 0;
+    return 0;
+  }
   for (uint32_t i = 0; i < 8u; i++)
     gbps[i] = i < instance->place_n ? instance->place_gbps[i] : 0.f;
   chosen[0] = instance->place_chosen[0], chosen[1] = instance->place_chosen[1];
@@ -94,6 +112,7 @@ uint32_t vksift_ext_getScaleSpacePlacement(vksift_Instance instance, float gbps[
 static void last_timings(vksift_Instance instance, vksift_ext_DetectTimings *out)
 {
   memset(out, 0, sizeof(*out));
+  defer_sync(instance);
   const ProfSet *ps = &instance->prof[instance->prof_cur];
   if (!instance->profiling || !ps->valid)
     return;
@@ -126,6 +145,7 @@ void vksift_ext_getDetectTimings(vksift_Instance instance, vksift_ext_DetectTimi
 
 float vksift_ext_getMatchTime(vksift_Instance instance)
 {
+  defer_sync(instance);
   if (!instance->profiling || !instance->match_timing_valid)
     return -1.f;
   vksift_hip_set_device(instance->device);
@@ -143,6 +163,7 @@ uint32_t vksift_ext_exportDescriptorsDevice(vksift_Instance instance, uint32_t g
   }
   vksift_Instance inst = instance;
   vksift_hip_set_device(inst->device);
+  defer_sync(inst);
   uint32_t n = 0;
   HIP_CHECK(wait_all(inst), "stream synchronisation");
   {

@@ -36,7 +36,7 @@ void compute_layout(vksift_Instance inst, uint32_t w, uint32_t h, PyrLayout *L)
   L->cand_total = co;
 }
 
-static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t img_stride, const PyrLayout *L, uint32_t need, float **out);
+static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t img_stride, const PyrLayout *L, uint32_t need, float **out, bool may_search);
 
 void set_buffer_sections(vksift_Instance inst, uint32_t buf, uint32_t n_oct, uint32_t w, uint32_t h)
 {
@@ -91,6 +91,18 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   inst->error_cb = config->on_error_callback_function;
   inst->S = config->nb_scales_per_octave;
   inst->batch_cap = batch_cap;
+  inst->det_cap = batch_cap;
+  {
+    /* deferred submission of plain detect calls (vksift_internal.h): needs a second SIFT buffer to have anything to batch */
+    const char *e = getenv("VKSIFT_DEFER");
+    inst->defer_enabled = !(e && e[0] == '0') && config->sift_buffer_count >= 2u;
+    e = getenv("VKSIFT_DEFER_MAX");
+    inst->defer_max = e ? (uint32_t)strtoul(e, NULL, 10) : 128u;
+    if (inst->defer_max > config->sift_buffer_count)
+      inst->defer_max = config->sift_buffer_count;
+    if (inst->defer_max < 2u)
+      inst->defer_enabled = false;
+  }
 
   int ndev = vksift_hip_device_count();
   int dev = config->gpu_device_index;
@@ -148,20 +160,24 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     const char *e = getenv("VKSIFT_PYR_PINGPONG");
     inst->pyr_pingpong = e ? (e[0] == '1' || e[0] == '2') : (batch_cap >= 8u);
     inst->pyr_nbuf = (e && e[0] == '2') ? 2u : 1u;
+    /* an instance whose detection capacity grew later (deferred submission) overlaps its batches of 8 and more only: its single
+     * detections keep the forked scale-space and the graph replay */
+    inst->overlap_min_count = 1u;
+    inst->overlap_forced = e != NULL;
   }
   /* (the scale-space buffers themselves: below, once the stream exists — they are placed by measurement, place_pyramid_buffers) */
-  ALLOC_D(inst->d_input, (size_t)inst->max_image_size * batch_cap);
-  ALLOC_H(inst->h_input, (size_t)inst->max_image_size * batch_cap);
+  ALLOC_D(inst->d_input, (size_t)inst->max_image_size * inst->det_cap);
+  ALLOC_H(inst->h_input, (size_t)inst->max_image_size * inst->det_cap);
   ALLOC_D(inst->d_feats, inst->buf_stride * config->sift_buffer_count);
   ALLOC_D(inst->d_found, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
   ALLOC_H(inst->h_found, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * config->sift_buffer_count);
-  ALLOC_D(inst->d_seg_mask, sizeof(uint64_t) * inst->seg_cap * batch_cap);
-  ALLOC_D(inst->d_seg_off, sizeof(uint32_t) * inst->seg_cap * batch_cap);
-  ALLOC_D(inst->d_cand_xy, sizeof(uint32_t) * inst->cand_cap * batch_cap);
-  ALLOC_D(inst->d_cand_flag, sizeof(uint32_t) * inst->cand_cap * batch_cap);
-  ALLOC_D(inst->d_cand_n, sizeof(uint32_t) * batch_cap * VKSIFT_MAX_OCTAVES);
-  ALLOC_D(inst->d_ori_ang, sizeof(float) * VKSIFT_HIP_MAX_ORI * inst->ori_cap * batch_cap);
-  ALLOC_D(inst->d_ori_cnt, sizeof(uint32_t) * inst->ori_cap * batch_cap);
+  ALLOC_D(inst->d_seg_mask, sizeof(uint64_t) * inst->seg_cap * inst->det_cap);
+  ALLOC_D(inst->d_seg_off, sizeof(uint32_t) * inst->seg_cap * inst->det_cap);
+  ALLOC_D(inst->d_cand_xy, sizeof(uint32_t) * inst->cand_cap * inst->det_cap);
+  ALLOC_D(inst->d_cand_flag, sizeof(uint32_t) * inst->cand_cap * inst->det_cap);
+  ALLOC_D(inst->d_cand_n, sizeof(uint32_t) * inst->det_cap * VKSIFT_MAX_OCTAVES);
+  ALLOC_D(inst->d_ori_ang, sizeof(float) * VKSIFT_HIP_MAX_ORI * inst->ori_cap * inst->det_cap);
+  ALLOC_D(inst->d_ori_cnt, sizeof(uint32_t) * inst->ori_cap * inst->det_cap);
   ALLOC_D(inst->d_desc_fp, sizeof(float) * DESC_FP_TAB_MAX);
   /* matching scratch: one slot per batch entry (slot 0 serves vksift_matchFeatures) */
   inst->desc_slot_stride = (((uint64_t)config->max_nb_sift_per_buffer * 128u + 256u) + 255u) & ~(uint64_t)255u;
@@ -189,8 +205,8 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
   if (ok)
   {
     /* first of the large blocks after the stream: candidates need room, and everything allocated before stays where it is */
-    ok = place_pyramid_buffers(inst, pyr_texel_bytes(inst) * inst->pyr_img_stride * batch_cap, inst->pyr_img_stride, &L, inst->pyr_nbuf,
-                               inst->d_pyr_buf);
+    ok = place_pyramid_buffers(inst, pyr_texel_bytes(inst) * inst->pyr_img_stride * inst->det_cap, inst->pyr_img_stride, &L, inst->pyr_nbuf,
+                               inst->d_pyr_buf, true);
     inst->d_pyr = inst->d_pyr_buf[0];
   }
   inst->pyr_stream = vksift_hip_stream_create();
@@ -296,6 +312,7 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
   assert(*instance_ptr != NULL);
   vksift_Instance inst = *instance_ptr;
   vksift_hip_set_device(inst->device);
+  inst->pend_n = 0; /* staged, never asked for: nobody can see the result of launching them */
   if (inst->pyr_stream)
     vksift_hip_stream_sync(inst->pyr_stream);
   if (inst->side_stream)
@@ -465,7 +482,7 @@ static float placement_probe_ms(vksift_Instance inst, void *buf, uint64_t img_st
   {
     dst.reverse = (uint32_t)(r & 1);
     if (vksift_hip_event_record(e0, inst->stream) != 0 ||
-        vksift_hip_blur(src, dst, &inst->taps[1 * VKSIFT_MAX_TAPS], inst->ntaps[1], inst->batch_cap, inst->stream) != 0 ||
+        vksift_hip_blur(src, dst, &inst->taps[1 * VKSIFT_MAX_TAPS], inst->ntaps[1], inst->det_cap, inst->stream) != 0 ||
         vksift_hip_event_record(e1, inst->stream) != 0 || vksift_hip_event_sync(e1) != 0)
       return -1.f;
     const float ms = vksift_hip_event_elapsed_ms(e0, e1);
@@ -476,8 +493,11 @@ static float placement_probe_ms(vksift_Instance inst, void *buf, uint64_t img_st
 }
 
 /* out[0 .. need): device blocks of `bytes` each for a scale-space of layout L (octave 0 is what gets timed); false: out of memory
- * (nothing is left allocated). */
-static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t img_stride, const PyrLayout *L, uint32_t need, float **out)
+ * (nothing is left allocated). may_search = false: plain allocation (re-allocations in the middle of a caller's detect call).
+ * The rejected candidates of a search stay allocated while it runs — freed, the allocator would hand the same range out again —
+ * so the search is bounded: the candidates together never hold more than VKSIFT_PLACE_MEM_FRACTION (40 %) of the memory that was
+ * free when it started, and 24 GB stay free for the rest of the instance and for whoever else uses the device. */
+static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t img_stride, const PyrLayout *L, uint32_t need, float **out, bool may_search)
 {
   int max_cand = 7;
   {
@@ -489,8 +509,9 @@ static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t i
   }
   inst->place_n = 0;
   vksift_hip_event e0 = NULL, e1 = NULL;
-  const bool search = max_cand > (int)need && inst->batch_cap >= 8u && bytes >= ((size_t)256 << 20) && L->n_oct > 0 && inst->stream != NULL &&
+  const bool search = may_search && max_cand > (int)need && inst->det_cap >= 8u && bytes >= ((size_t)256 << 20) && L->n_oct > 0 && inst->stream != NULL &&
                       (e0 = vksift_hip_event_create()) != NULL && (e1 = vksift_hip_event_create()) != NULL;
+  const size_t budget = search ? (size_t)((double)vksift_hip_device_free_mem() * 0.40) : 0;
   void *cand[VKSIFT_PLACE_MAX] = {NULL};
   float ms[VKSIFT_PLACE_MAX];
   uint32_t n = 0;
@@ -499,8 +520,8 @@ static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t i
   {
     if (n >= need)
     {
-      /* another candidate only while the device still has room for it and the rest of an instance */
-      if (vksift_hip_device_free_mem() < bytes + ((size_t)24 << 30))
+      /* another candidate only within the budget, and while the device still has room for it and the rest of an instance */
+      if ((size_t)(n + 1u) * bytes > budget || vksift_hip_device_free_mem() < bytes + ((size_t)24 << 30))
         break;
       /* stop rules (sorted view of what has been timed) */
       float lo = ms[0], hi = ms[0];
@@ -541,15 +562,18 @@ static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t i
     }
     if (need == 1u)
       inst->place_chosen[1] = inst->place_chosen[0];
+    float slowest = 0.f;
     for (uint32_t i = 0; i < n; i++)
     {
-      const double px = (double)(L->w[0] >= 512u ? (L->w[0] & ~255u) : (L->w[0] & ~3u)) * L->h[0] * inst->batch_cap * 2.0 * (double)pyr_texel_bytes(inst);
+      const double px = (double)(L->w[0] >= 512u ? (L->w[0] & ~255u) : (L->w[0] & ~3u)) * L->h[0] * inst->det_cap * 2.0 * (double)pyr_texel_bytes(inst);
       inst->place_gbps[i] = (search && ms[i] < 1e8f) ? (float)(px / (ms[i] * 1e-3) / 1e9) : 0.f;
+      if (inst->place_gbps[i] > 0.f && (slowest == 0.f || inst->place_gbps[i] < slowest))
+        slowest = inst->place_gbps[i];
     }
     inst->place_n = search ? n : 0;
     if (search)
-      logInfo(LOG_TAG, "scale-space placement: %u candidate range(s) of %.1f GB timed, fastest %.0f GB/s, slowest %.0f GB/s", n, bytes / 1e9,
-              inst->place_gbps[inst->place_chosen[0]], inst->place_gbps[0]);
+      logInfo(LOG_TAG, "scale-space placement: %u candidate range(s) of %.1f GB timed, chosen %.0f GB/s, slowest %.0f GB/s", n, bytes / 1e9,
+              inst->place_gbps[inst->place_chosen[0]], slowest);
   }
   else
     ok = false;
@@ -563,62 +587,127 @@ static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t i
   return ok;
 }
 
-/* The reservation made at creation covers a square image of input_image_max_size pixels plus 25 %. A narrow image of the
- * same area can need more (every row is padded to 64 floats on every octave: 139x356 needs 1.5x). The reference re-creates
- * its images for every new input resolution (sift_memory.c:362-452); here the per-image scratch grows, once, to what the
- * new layout needs. All work of the instance is drained first; captured launch graphs hold the old addresses and are dropped. */
-int grow_image_scratch(vksift_Instance inst, const PyrLayout *L)
+/* The reservation made at creation covers `det_cap` square images of input_image_max_size pixels plus 25 %. Two things outgrow it:
+ * a narrow image of the same area (every row is padded to 64 floats on every octave: 139x356 needs 1.5x; the reference re-creates its
+ * images for every new input resolution, sift_memory.c:362-452) — L != NULL, the per-image strides grow to what the layout needs —
+ * and a caller of the plain API who batches (deferred submission) — new_cap > det_cap, the blocks grow to new_cap images.
+ * All work of the instance is drained first; captured launch graphs hold the old addresses and are dropped.
+ * 0: done. 1: the larger capacity did not fit, the instance is as it was (capacity growth only). -1: out of device memory, the instance
+ * holds NO detection scratch (capacities 0): the next detection retries the allocation or fails cleanly with VKSIFT_VULKAN_ERROR. */
+static void free_detect_scratch(vksift_Instance inst, bool cap_blocks)
 {
-  if (wait_all(inst) != 0)
-    return -1;
-  if (inst->pyr_stream)
-    vksift_hip_stream_sync(inst->pyr_stream);
-  if (inst->side_stream)
-    vksift_hip_stream_sync(inst->side_stream);
-  for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
-  {
-    vksift_hip_graph_destroy(inst->graphs[i].exec);
-    memset(&inst->graphs[i], 0, sizeof(inst->graphs[i]));
-  }
-  const uint64_t pyr = L->img_floats + L->img_floats / 4 + 4096, seg = L->seg_total + L->seg_total / 4 + 1024, cand = L->cand_total + L->cand_total / 4 + 4096u;
-  const uint64_t new_pyr = pyr > inst->pyr_img_stride ? pyr : inst->pyr_img_stride;
-  const uint64_t new_seg = seg > inst->seg_cap ? seg : inst->seg_cap, new_cand = cand > inst->cand_cap ? cand : inst->cand_cap;
-  const uint64_t n = inst->batch_cap;
-  /* old blocks first: the pyramid is the largest allocation of the instance, two generations of it may not fit */
   vksift_hip_free(inst->d_pyr_buf[0]);
   vksift_hip_free(inst->d_pyr_buf[1]);
   vksift_hip_free(inst->d_seg_mask);
   vksift_hip_free(inst->d_seg_off);
   vksift_hip_free(inst->d_cand_xy);
   vksift_hip_free(inst->d_cand_flag);
-  inst->d_pyr_buf[0] = inst->d_pyr_buf[1] = NULL;
-  (void)place_pyramid_buffers(inst, pyr_texel_bytes(inst) * new_pyr * n, new_pyr, L, inst->pyr_nbuf, inst->d_pyr_buf);
-  inst->d_seg_mask = vksift_hip_malloc(sizeof(uint64_t) * new_seg * n);
-  inst->d_seg_off = vksift_hip_malloc(sizeof(uint32_t) * new_seg * n);
-  inst->d_cand_xy = vksift_hip_malloc(sizeof(uint32_t) * new_cand * n);
-  inst->d_cand_flag = vksift_hip_malloc(sizeof(uint32_t) * new_cand * n);
+  inst->d_pyr_buf[0] = inst->d_pyr_buf[1] = inst->d_pyr = NULL;
+  inst->d_seg_mask = NULL, inst->d_seg_off = NULL, inst->d_cand_xy = NULL, inst->d_cand_flag = NULL;
+  if (cap_blocks)
+  {
+    vksift_hip_free(inst->d_input);
+    vksift_hip_host_free(inst->h_input);
+    vksift_hip_free(inst->d_cand_n);
+    vksift_hip_free(inst->d_ori_ang);
+    vksift_hip_free(inst->d_ori_cnt);
+    inst->d_input = inst->h_input = NULL;
+    inst->d_cand_n = NULL, inst->d_ori_ang = NULL, inst->d_ori_cnt = NULL;
+  }
+}
+
+static bool alloc_detect_scratch(vksift_Instance inst, const PyrLayout *L, uint32_t cap, uint64_t pyr, uint64_t seg, uint64_t cand, bool cap_blocks, bool may_search)
+{
+  const uint64_t n = cap;
+  const uint32_t old_cap = inst->det_cap;
+  inst->det_cap = cap; /* the placement probe launches on `det_cap` images */
+  bool ok = place_pyramid_buffers(inst, pyr_texel_bytes(inst) * pyr * n, pyr, L, inst->pyr_nbuf, inst->d_pyr_buf, may_search);
+  inst->det_cap = old_cap;
+#define GROW_D(ptr, bytes) ok = ok && ((ptr = vksift_hip_malloc(bytes)) != NULL)
+  GROW_D(inst->d_seg_mask, sizeof(uint64_t) * seg * n);
+  GROW_D(inst->d_seg_off, sizeof(uint32_t) * seg * n);
+  GROW_D(inst->d_cand_xy, sizeof(uint32_t) * cand * n);
+  GROW_D(inst->d_cand_flag, sizeof(uint32_t) * cand * n);
+  if (cap_blocks)
+  {
+    GROW_D(inst->d_input, (size_t)inst->max_image_size * n);
+    ok = ok && (inst->h_input = vksift_hip_host_malloc((size_t)inst->max_image_size * n)) != NULL;
+    GROW_D(inst->d_cand_n, sizeof(uint32_t) * n * VKSIFT_MAX_OCTAVES);
+    GROW_D(inst->d_ori_ang, sizeof(float) * VKSIFT_HIP_MAX_ORI * inst->ori_cap * n);
+    GROW_D(inst->d_ori_cnt, sizeof(uint32_t) * inst->ori_cap * n);
+  }
+#undef GROW_D
+  return ok;
+}
+
+int resize_detect_scratch(vksift_Instance inst, const PyrLayout *L, uint32_t new_cap)
+{
+  assert(inst->pend_n == 0);
+  if (wait_all(inst) != 0)
+    return -1;
+  if (inst->pyr_stream)
+    vksift_hip_stream_sync(inst->pyr_stream);
+  if (inst->side_stream)
+    vksift_hip_stream_sync(inst->side_stream);
+  if (inst->up_stream)
+    vksift_hip_stream_sync(inst->up_stream);
+  inst->staging_pending = false;
+  inst->input_free_valid = false;
+  for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
+  {
+    vksift_hip_graph_destroy(inst->graphs[i].exec);
+    memset(&inst->graphs[i], 0, sizeof(inst->graphs[i]));
+  }
+  PyrLayout cur;
+  if (!L)
+  {
+    /* capacity growth alone: the layout the probe launch runs on is the reservation's */
+    compute_layout(inst, inst->cur_w ? inst->cur_w : (uint32_t)ceilf(sqrtf((float)inst->cfg.input_image_max_size)),
+                   inst->cur_h ? inst->cur_h : (uint32_t)ceilf(sqrtf((float)inst->cfg.input_image_max_size)), &cur);
+  }
+  const PyrLayout *PL = L ? L : &cur;
+  const uint64_t pyr = L ? L->img_floats + L->img_floats / 4 + 4096 : 0, seg = L ? L->seg_total + L->seg_total / 4 + 1024 : 0,
+                 cand = L ? L->cand_total + L->cand_total / 4 + 4096u : 0;
+  const uint64_t new_pyr = pyr > inst->pyr_img_stride ? pyr : inst->pyr_img_stride;
+  const uint64_t new_seg = seg > inst->seg_cap ? seg : inst->seg_cap, new_cand = cand > inst->cand_cap ? cand : inst->cand_cap;
+  const uint32_t old_cap = inst->det_cap;
+  const bool cap_blocks = new_cap != old_cap || inst->d_input == NULL; /* (NULL: lost by an earlier attempt that ran out of memory) */
+  /* old blocks first: the pyramid is the largest allocation of the instance, two generations of it may not fit */
+  free_detect_scratch(inst, cap_blocks);
   inst->pyr_free_valid[0] = inst->pyr_free_valid[1] = false;
   inst->cur_w = inst->cur_h = 0; /* no scale-space to download until the next detection */
-  const bool ok = inst->d_pyr_buf[0] && (inst->pyr_nbuf < 2u || inst->d_pyr_buf[1]) && inst->d_seg_mask && inst->d_seg_off && inst->d_cand_xy && inst->d_cand_flag;
+  int rc = 0;
+  /* (a capacity growth happens once per size, outside any detection that runs: it may search for fast memory; a stride growth sits in
+   * the middle of a detect call of whatever the caller is doing and takes plain allocations) */
+  bool ok = alloc_detect_scratch(inst, PL, new_cap, new_pyr, new_seg, new_cand, cap_blocks, cap_blocks);
+  uint32_t cap = new_cap;
+  if (!ok && cap_blocks)
+  {
+    /* the larger capacity does not fit: back to the one the instance had */
+    free_detect_scratch(inst, true);
+    ok = alloc_detect_scratch(inst, PL, old_cap, new_pyr, new_seg, new_cand, true, false);
+    cap = old_cap;
+    rc = 1;
+  }
   if (!ok)
   {
-    /* out of device memory: leave NO scratch behind (capacities 0), so that the next detection retries the allocation or
-     * fails cleanly with VKSIFT_VULKAN_ERROR instead of launching kernels on freed pointers */
-    vksift_hip_free(inst->d_pyr_buf[0]);
-    vksift_hip_free(inst->d_pyr_buf[1]);
-    vksift_hip_free(inst->d_seg_mask);
-    vksift_hip_free(inst->d_seg_off);
-    vksift_hip_free(inst->d_cand_xy);
-    vksift_hip_free(inst->d_cand_flag);
-    inst->d_pyr_buf[0] = inst->d_pyr_buf[1] = inst->d_pyr = NULL;
-    inst->d_seg_mask = NULL, inst->d_seg_off = NULL, inst->d_cand_xy = NULL, inst->d_cand_flag = NULL;
+    free_detect_scratch(inst, cap_blocks);
     inst->pyr_img_stride = 0, inst->seg_cap = 0, inst->cand_cap = 0;
     return -1;
   }
   inst->pyr_img_stride = new_pyr, inst->seg_cap = new_seg, inst->cand_cap = new_cand;
+  inst->det_cap = cap;
   inst->d_pyr = inst->d_pyr_buf[inst->pyr_nbuf == 2u ? inst->pyr_cur : 0];
-  return 0;
+  if (!inst->overlap_forced && inst->batch_cap < 8u && cap >= 8u && !inst->pyr_pingpong)
+  {
+    /* a plain instance that now takes batches: they overlap like a batch instance's, its small detections stay as they were */
+    inst->pyr_pingpong = true;
+    inst->overlap_min_count = 8u;
+  }
+  return rc;
 }
+
+int grow_image_scratch(vksift_Instance inst, const PyrLayout *L) { return resize_detect_scratch(inst, L, inst->det_cap) == 0 ? 0 : -1; }
 
 int wait_all(vksift_Instance inst)
 {
@@ -633,6 +722,7 @@ int wait_all(vksift_Instance inst)
 bool vksift_isBufferAvailable(vksift_Instance instance, const uint32_t gpu_buffer_id)
 {
   vksift_hip_set_device(instance->device);
+  defer_sync(instance);
   if (gpu_buffer_id >= instance->cfg.sift_buffer_count)
     return true;
   (void)detect_running(instance);

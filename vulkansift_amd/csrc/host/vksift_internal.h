@@ -104,7 +104,22 @@ struct vksift_Instance_T
   bool fp16;               /* VKSIFT_PYRAMID_PRECISION_FLOAT16: the scale-space holds IEEE binary16 texels (2 bytes), arithmetic stays fp32 */
   uint32_t max_image_size; /* rounded up to a square, sift_memory.c:644-647 */
   uint32_t max_octaves;
-  uint32_t batch_cap;
+  uint32_t batch_cap;      /* capacity the instance was created with: match slots, and the bound of the vksift_ext_*Batch entries */
+  uint32_t det_cap;        /* images one detection launch sequence can take (>= batch_cap): input staging, scale-space, extraction scratch.
+                            * Grows when a caller of the plain API turns out to batch (deferred submission, below) */
+
+  /* Deferred submission of vksift_detectFeatures (vksift_detect.c: defer_detect). The reference's caller hands over ONE image per call
+   * (vulkansift.c:315-344); a caller that issues several such calls in a row, into consecutive SIFT buffers, before it asks for
+   * anything gets them launched as ONE batched detection: the call stages its image in the pinned input block and returns, and the
+   * batch is launched by the first call that needs a result (every other entry point: defer_sync) or when it is full. The first
+   * detection after an accessor is launched at once unless the caller is known to batch (batch_mode), so detect + read keeps its path. */
+  bool defer_enabled;      /* VKSIFT_DEFER (default 1) and sift_buffer_count >= 2 */
+  uint32_t defer_max;      /* VKSIFT_DEFER_MAX (default 128): a deferred batch is launched when it holds this many images (or det_cap) */
+  uint32_t pend_n, pend_first, pend_w, pend_h; /* staged images: SIFT buffers [pend_first, pend_first + pend_n) */
+  uint32_t epoch_detects;  /* vksift_detectFeatures calls since the last call of any other entry point */
+  bool batch_mode;         /* the last such run held at least two: the next one is deferred from its first call on */
+  bool defer_grow;         /* the last deferred batch filled det_cap: double it before the next one is staged */
+  uint64_t defer_batches, defer_images; /* statistics (vksift_ext_getDeferredStats) */
 
   /* blur taps */
   float taps[(VKSIFT_MAX_SCALES + 3) * VKSIFT_MAX_TAPS];
@@ -119,9 +134,11 @@ struct vksift_Instance_T
   uint32_t place_n;        /* candidate ranges timed by place_pyramid_buffers (0: plain allocation), their rates, the chosen ones */
   float place_gbps[8];
   uint32_t place_chosen[2];
-  float *d_pyr_buf[2];     /* ping-pong: detection N+1 builds its pyramid while detection N still reads its own */
+  float *d_pyr_buf[2];     /* the scale-space buffer(s): ONE by default (the overlap gate makes a second unnecessary), two with VKSIFT_PYR_PINGPONG=2 */
   int pyr_cur;
   bool pyr_pingpong;       /* overlap mode: the scale-space of a detection is built on its own stream, beside what is queued behind the previous detection's descriptors */
+  uint32_t overlap_min_count; /* ... for detections of at least this many images (1; 8 on an instance whose capacity grew by deferred submission) */
+  bool overlap_forced;     /* VKSIFT_PYR_PINGPONG was given: the mode is the caller's */
   uint32_t pyr_nbuf;       /* scale-space buffers of the instance: 1, or 2 with VKSIFT_PYR_PINGPONG=2 (the next scale-space may then start before the previous detection's readers are done) */
   bool pyr_free_valid[2];
   uint64_t pyr_img_stride; /* floats reserved per image */
@@ -185,13 +202,13 @@ struct vksift_Instance_T
    * (otherwise idle) scale-space stream beside the octaves below — forked per octave, joined in front of the keypoint stages */
   vksift_hip_event ev_fork[VKSIFT_MAX_OCTAVES], ev_join[2];
   vksift_hip_stream side_stream; /* second branch stream (the first is pyr_stream) */
-  int fork_streams;              /* VKSIFT_FORK_STREAMS: 1 or 2 branch streams */
+  int fork_streams;              /* branch streams of a forked detection: 1 (two measured no faster in stream order, slower in a graph) */
   bool fork_scales; /* VKSIFT_FORK_SCALES (default 1) */
-  uint64_t fork_max_pixels; /* ... for detections of at most this many input pixels (VKSIFT_FORK_MAX_PIXELS) */
+  uint64_t fork_max_pixels; /* ... for detections of at most this many input pixels (16 Mpx) */
   uint32_t lds_chain_max; /* largest plane (texels) an octave of the chain may have: VKSIFT_LDS_CHAIN_MAX, at most 19200 (the LDS) */
   bool lds_chain_refuse; /* VKSIFT_LDS_CHAIN=refuse: test hook, the chain launch declines and the per-scale launches take over */
   bool lds_chain; /* VKSIFT_LDS_CHAIN (default 1): the trailing octaves that fit the LDS are built by one launch (vksift_hip_octave_chain) */
-  bool alt_order; /* VKSIFT_PYR_ALTERNATE (default 1): launches of a blur chain alternate their dispatch direction (vksift_hip_Plane::reverse) */
+  bool alt_order; /* always on: launches of a blur chain alternate their dispatch direction (vksift_hip_Plane::reverse) */
   vksift_hip_event ev_match;
   bool match_pending;
   DetectSlot det_ring[VKSIFT_DETECT_RING];
@@ -280,9 +297,22 @@ static inline bool counts_valid(const struct vksift_Instance_T *inst, uint32_t b
 VKSIFT_INTERNAL bool match_running(vksift_Instance inst);
 VKSIFT_INTERNAL int wait_all(vksift_Instance inst);
 VKSIFT_INTERNAL int grow_image_scratch(vksift_Instance inst, const PyrLayout *L);
+VKSIFT_INTERNAL int resize_detect_scratch(vksift_Instance inst, const PyrLayout *L, uint32_t new_cap);
 VKSIFT_INTERNAL vksift_hip_Plane plane_at(vksift_Instance inst, uint32_t o, uint64_t base_off, uint32_t layer);
 
 /* vksift_detect.c */
+VKSIFT_INTERNAL void flush_deferred(vksift_Instance inst);
+/* Every entry point but vksift_detectFeatures starts with this: what was deferred is launched, and the run of detect calls ends */
+static inline void defer_sync(vksift_Instance inst)
+{
+  if (inst->pend_n)
+    flush_deferred(inst);
+  if (inst->epoch_detects)
+  {
+    inst->batch_mode = inst->epoch_detects >= 2u;
+    inst->epoch_detects = 0;
+  }
+}
 VKSIFT_INTERNAL void account_set(vksift_Instance inst, ProfSet *ps);
 VKSIFT_INTERNAL void account_timings(vksift_Instance inst);
 

@@ -169,6 +169,8 @@ static void match_impl(vksift_Instance inst, const uint32_t *ids_a, const uint32
                        bool cross_check)
 {
   bool range_open = false;
+  vksift_hip_set_device(inst->device);
+  defer_sync(inst);
   bool valid = count >= 1 && count <= inst->batch_cap;
   for (uint32_t i = 0; valid && i < count; i++)
     valid = buffer_idx_valid(inst, ids_a[i]) && buffer_idx_valid(inst, ids_b[i]);
@@ -263,6 +265,7 @@ void vksift_ext_matchFeaturesFiltered(vksift_Instance instance, uint32_t count, 
 static void wait_match(vksift_Instance inst)
 {
   vksift_hip_set_device(inst->device);
+  defer_sync(inst);
   if (inst->match_pending)
   {
     vksift_hip_event_sync(inst->ev_match);
