@@ -80,6 +80,8 @@ def parse_args():
     ap.add_argument("--serialize-match", action="store_true",
                     help="the next detection's scale-space starts BEHIND the matching queued before it instead of beside it "
                          "(vksift_hip_tune VKSIFT_TUNE_PYR_GATE: stage times become kernel times; not the headline schedule)")
+    ap.add_argument("--tune", default="", help="development A/B: 'knob=value,...' passed to vksift_hip_tune (include/vksift_hip.h) before anything runs; "
+                                               "the line records it in config.tune — not the shipped configuration")
     ap.add_argument("--fp16", action="store_true", help="VKSIFT_PYRAMID_PRECISION_FLOAT16: binary16 scale-space storage (not the headline configuration)")
     ap.add_argument("--extras-timeout", type=float, default=300.0, help="seconds the legs after the timed region may take before the headline line is printed without them")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1: exercises every collective branch of the multi-GPU path on one GPU")
@@ -181,7 +183,39 @@ def pmc_traffic(w, h, batch, fp16=False):
     return None
 
 
-def roofline_from(acc, pmc, label):
+def own_pyramid_bytes(octs, src_px, texel=4):
+    """This build's algorithmic minimum for the scale-space of ONE image, all octaves (S = 3): octave 0 reads the u8 source once and
+    writes its 6 planes, every later octave's plane 0 is stored by the scale-S launch of the octave in front (4 B per texel of the
+    smaller octave) and it writes 5 planes; 4 plane reads per octave (the two-scale launch reads its source once for two scales)."""
+    b = float(src_px)
+    for o, (w, h) in enumerate(octs):
+        px = float(w) * h
+        b += texel * px * ((6 if o == 0 else 5) + 4)
+        if o > 0:
+            b += texel * px                       # its seed, stored by the previous octave's scale-S launch
+    return b
+
+
+def whole_pass(acc, pmc, octs, src_px, batch, texel=4):
+    """Every octave's scale-space launches (first launch of octave 0 to the last blur launch of the coarsest octave: pyramid_all_ms, HIP
+    events on the stream they run on) + the extrema scan. Counter bytes when the capture holds all launches, else algorithmic."""
+    calls = max(acc["nb_calls"], 1)
+    t = (acc.get("pyramid_all_ms", 0.0) + acc["scan_ms"]) * 1e-3
+    if t <= 0 or not octs:
+        return None
+    alg = calls * batch * (own_pyramid_bytes(octs, src_px, texel) + sum(float(w) * h for w, h in octs) * 6 * texel)
+    out = {"interval_ms_per_call": t / calls * 1e3, "pyramid_all_ms_per_call": acc.get("pyramid_all_ms", 0.0) / calls, "scan_ms_per_call": acc["scan_ms"] / calls,
+           "launches_per_call": acc.get("nb_blur_launches_all", 0) / calls + 1.0,
+           "algorithmic": {"bytes_per_call": alg / calls, "achieved": alg / t / 1e9, "frac": alg / t / 1e9 / HBM_PEAK_GBPS}}
+    allo = (pmc or {}).get("all_octaves")
+    if allo:
+        phys = allo["hbm_bytes_per_call"] * calls / t / 1e9
+        out.update({"traffic_per_call": allo["hbm_bytes_per_call"], "achieved": phys, "frac": phys / HBM_PEAK_GBPS,
+                    "traffic_over_algorithmic": allo["hbm_bytes_per_call"] * calls / alg, "launches": allo.get("launches")})
+    return out
+
+
+def roofline_from(acc, pmc, label, octs=None, src_px=0, batch=0, texel=4):
     """The scale-space + DoG pass of octave 0 (blur launches) and the extrema scan over all octaves (one launch), HIP-event durations
     from inside the timed region.
       frac / achieved  what the HARDWARE moved: HBM bytes of these launches from the rocprofv3 --pmc capture of the same kernel
@@ -234,6 +268,28 @@ def roofline_from(acc, pmc, label):
         out["traffic_over_algorithmic"] = per_call * calls / (own_pyr + own_scan)
         if pmc.get("per_launch"):
             out["per_launch"] = pmc["per_launch"]                       # bytes, us and fraction of each launch kind, from the capture itself
+    # Round 6: the HEADLINE fraction prices the WHOLE pass — every octave's blur launches inside the interval, not
+    # octave 0's alone. The octave-0 figures above move to `octave0_and_scan` (rounds 1-5's definition, kept for comparison).
+    wp = whole_pass(acc, pmc, octs, src_px, batch, texel) if octs else None
+    if wp is not None:
+        old = {k: out[k] for k in ("achieved", "frac", "basis", "traffic", "avg_launch_us", "launches_per_call", "algorithmic") if k in out}
+        if "traffic_over_algorithmic" in out:
+            old["traffic_over_algorithmic"] = out.pop("traffic_over_algorithmic")
+        out["octave0_and_scan"] = dict(old, kernel=label, note="rounds 1-5's `frac`: octave 0's blur launches + the scan; the coarse octaves' launches outside the interval")
+        out["kernel"] = "every scale-space launch of a detection call, all octaves (seed, two-scale launches, 9 / 11 / 13 taps per octave), + k_extrema_lean over all octaves"
+        n_l = max(wp["launches_per_call"], 1.0)
+        out["avg_launch_us"] = wp["interval_ms_per_call"] * 1e3 / n_l
+        out["launches_per_call"] = n_l
+        out["algorithmic"] = dict(wp["algorithmic"], bytes_per_launch=wp["algorithmic"]["bytes_per_call"] / n_l,
+                                  note="octave 0: 41.25 B/px, later octaves 37 B/px (36 for the last), + 24 B per pixel of every octave for the scan: what this build must move")
+        if "frac" in wp:
+            out.update({"achieved": wp["achieved"], "frac": wp["frac"], "traffic": wp["traffic_per_call"] / n_l, "traffic_over_algorithmic": wp["traffic_over_algorithmic"],
+                        "basis": "HBM bytes from rocprofv3 --pmc (FETCH_SIZE x 2 + WRITE_SIZE) of EVERY scale-space launch + the scan, same kernel sources / HIP-event durations in this run",
+                        "all_launches": wp.get("launches")})
+        else:
+            out.update({"achieved": wp["algorithmic"]["achieved"], "frac": wp["algorithmic"]["frac"], "traffic": None,
+                        "basis": "algorithmic minimum of this build over all octaves (no PMC capture of these kernel sources that holds every launch)"})
+        out["whole_pass_ms_per_call"] = {"pyramid_all_ms": wp["pyramid_all_ms_per_call"], "scan_ms": wp["scan_ms_per_call"]}
     return out
 
 
@@ -330,9 +386,10 @@ def _opencv_leg(frames, do_match):
         return dict(probe, error=repr(e)[:200])
 
 
-def cpu_baseline(frames, do_match, per_worker=2):
+def cpu_baseline(frames, do_match, per_worker=2, hd_frame=False):
     """The oracle rebuilt on this box with -O3 -march=native (its fp32 operation order stays pinned: -ffp-contract=off), one worker
-    PROCESS per usable host core, `per_worker` frames each."""
+    PROCESS per usable host core, `per_worker` frames each. hd_frame: also one 1920x1080 frame per core, detect only (BASELINE config
+    3's frames: north_star asks for both sizes beside a CPU figure)."""
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
     from oracle import oracle as O
@@ -358,6 +415,16 @@ def cpu_baseline(frames, do_match, per_worker=2):
         t0 = time.perf_counter()
         nfeat = list(ex.map(_cpu_worker, jobs))
         dt = time.perf_counter() - t0
+        hd = None
+        if hd_frame:
+            from vulkansift_amd import api
+            hd_imgs = [api.gen_synthetic_image(0x5EED0000 + i, 1920, 1080) for i in range(min(cores, 4))]
+            t0 = time.perf_counter()
+            nf_hd = list(ex.map(_cpu_worker, [(so, [hd_imgs[w % len(hd_imgs)]], False) for w in range(cores)]))
+            dt_hd = time.perf_counter() - t0
+            hd = {"value": cores / dt_hd, "unit": "frames/s", "cores": cores, "per_core_value": 1.0 / dt_hd,
+                  "sample": f"{cores} frames of 1920x1080 (BASELINE config 3's frames, 2x up-sampling, 7 octaves), one per worker process, detect only, "
+                            f"{int(sum(nf_hd) / cores)} features/frame, {dt_hd:.1f} s wall"}
     total = cores * per_worker
     return {
         "value": total / dt,
@@ -369,6 +436,7 @@ def cpu_baseline(frames, do_match, per_worker=2):
         "machine_logical_cpus": os.cpu_count(),
         "cpu_model": cpu_model(),
         "opencv": _opencv_leg(frames, do_match),
+        **({"frames_1920x1080": hd} if hd else {}),
         "build": build,
         "sample": f"{total} frames of the benchmark's {frames[0].shape[1]}x{frames[0].shape[0]} workload ({per_worker} per worker process, one process per usable core), detect"
                   + ("+self-match" if do_match else "") + f", {int(sum(nfeat) / total)} features/frame, {dt:.1f} s wall ({dt * cores:.0f} core-seconds); "
@@ -585,11 +653,13 @@ def c3_roofline(api, torch, dev, steps=5):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     acc = inst.getAccumulatedDetectTimings()
+    octs = [inst.getScaleSpaceOctaveResolution(o) for o in range(inst.getScaleSpaceNbOctaves())]
     inst.close()
-    r = roofline_from(acc, pmc_traffic(W, H, B), "the 5 blur launches of octave 0 (3840x2160 planes: seed, two-scale launch, 9 / 11 / 13 taps) + k_extrema_lean over all octaves, 64 x 1920x1080 frames")
+    r = roofline_from(acc, pmc_traffic(W, H, B), "the 5 blur launches of octave 0 (3840x2160 planes: seed, two-scale launch, 9 / 11 / 13 taps) + k_extrema_lean over all octaves, 64 x 1920x1080 frames",
+                      octs, W * H, B)
     r.update({"workload": "BASELINE config 3: 64 x 1920x1080 uint8 frames, detect only, default vksift_Config, inputs resident in HBM",
               "steps": steps, "frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "mean_features_per_frame": nfeat,
-              "stage_ms_per_step": {k: acc[k] / max(acc["nb_calls"], 1) for k in ("pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")}})
+              "stage_ms_per_step": {k: acc[k] / max(acc["nb_calls"], 1) for k in ("pyramid_ms", "pyramid_all_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")}})
     return r
 
 
@@ -727,6 +797,8 @@ def main():
     do_match = not args.no_match
     if args.serialize_match:
         api.lib().vksift_hip_tune(6, 1)   # VKSIFT_TUNE_PYR_GATE
+    for kv in filter(None, args.tune.split(",")):
+        api.lib().vksift_hip_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
 
     # synthetic frames (seeded per global frame index), uploaded once: inputs are HBM-resident when timing starts.
     # Up to 128 generated frames per rank (85 ms of host time each) and, for longer batches, their three mirror images: B distinct
@@ -822,6 +894,7 @@ def main():
                 "mean_features_per_frame": float(np.mean(nfeat)),
                 "parallelism": f"batch split x{world}, no collectives",
                 "input": "host images, upload inside the timed region" if args.host_input else "resident in HBM",
+                **({"tune": args.tune + " (development A/B, not the shipped configuration)"} if args.tune else {}),
                 "protocols": "value_host_input: the REFERENCE's own protocol and SURVEY.md 8(d)'s definition of the metric "
                              "(src/perf/wrappers/vulkansift_wrapper.cpp:30-33: host image in, count + features + matches downloaded, strictly "
                              "serial) — the figure to compare with the reference's published runtimes. value: batched detection on HBM-resident "
@@ -830,9 +903,10 @@ def main():
                              "in C: tests/native/protocol_client.c, public API only). "
                              "single_image_ms: BASELINE config 2 literally (one image per call)",
             },
-            "roofline": roofline_from(acc, pmc, "the 5 blur launches of octave 0 (1280x960 planes: k_blur_lean<5,1> seed, k_blur_pair_wide<5,7>, k_blur_wide<9/11/13>): scale-space construction, + k_extrema_lean over all octaves: the scan that forms the DoG values"),
+            "roofline": roofline_from(acc, pmc, "the 5 blur launches of octave 0 (1280x960 planes: k_blur_lean<5,1> seed, k_blur_pair_wide<5,7>, k_blur_wide<9/11/13>): scale-space construction, + k_extrema_lean over all octaves: the scan that forms the DoG values",
+                                      [inst.getScaleSpaceOctaveResolution(o) for o in range(inst.getScaleSpaceNbOctaves())], W * H, B, 2 if args.fp16 else 4),
             "stage_ms_per_call": {k: acc[k] / max(acc["nb_calls"], 1) for k in
-                                  ("upload_ms", "pyramid_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")},
+                                  ("upload_ms", "pyramid_ms", "pyramid_all_ms", "extrema_ms", "scan_ms", "orientation_ms", "descriptor_ms", "total_ms")},
             "last_match_ms": match_ms,
             # where the scale-space buffers were put: rates (GB/s, 8 B per texel) of one whole-batch blur launch on every candidate
             # memory range the instance timed when it allocated them (allocation order), and the one(s) it kept: one per scale-space buffer
@@ -949,8 +1023,15 @@ def main():
 
     if rank == 0:
         out.update(extras)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, do_match)
+        # the host-protocol figures beside `value` (SURVEY.md 8(d)'s own definition of the metric has host images in and results out)
+        for k in ("value_host_input", "value_host_input_pipelined"):
+            if isinstance(out.get(k), (int, float)) and out["value"] > 0:
+                out[k + "_over_value"] = out[k] / out["value"]
+        if not args.no_cpu_baseline:
+            # rank 0's host cores, after the timed region (the other ranks are idle by now). At N = 1 the full sample incl. a 1920x1080
+            # frame per core; at N > 1 (where the bench contract does not ask for it) one frame per core, so the line still carries it
+            out["cpu_baseline"] = cpu_baseline(frames, do_match, per_worker=2 if world == 1 else 1, hd_frame=(world == 1 and not args.no_extras))
+            out["cpu_baseline"]["measured_at_n_gpus"] = world
     watchdog.cancel()
     if rank == 0:
         emit(out)

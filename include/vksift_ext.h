@@ -76,8 +76,11 @@ extern "C"
     uint64_t pyramid_algorithmic_bytes; /* SURVEY.md §8(d) definition, whole batch */
     float scan_ms;                      /* the streaming extrema scan of octave 0 alone (mask clear + the kernel that reads the S+3 planes) */
     uint64_t scan_algorithmic_bytes;    /* 4*(S+2) B per octave-0 pixel, whole batch */
+    float pyramid_all_ms;               /* the scale-space construction of EVERY octave: first launch of octave 0 to the last blur launch of the
+                                         * coarsest octave, on the stream they run on (pyramid_ms: octave 0 alone) */
+    uint32_t nb_blur_launches_all;      /* launches inside that interval */
   } vksift_ext_DetectTimings;
-  /* The struct grew once (scan_ms, scan_algorithmic_bytes) and may grow again at its end. The two getters without a size
+  /* The struct grew twice (scan_ms, scan_algorithmic_bytes; pyramid_all_ms, nb_blur_launches_all) and may grow again at its end. The two getters without a size
    * argument therefore write only the first VKSIFT_EXT_DETECT_TIMINGS_V1_BYTES bytes — the struct of the first release, so a
    * client compiled against that header is never written past its storage; the ...Sized forms write min(out_bytes, sizeof)
    * bytes of the current struct (pass sizeof(vksift_ext_DetectTimings) of the header you compiled against). */

@@ -34,7 +34,7 @@ extern "C"
 /* u32 words of scratch vksift_hip_match_2nn_desc needs for na query rows against nb reference rows (norms of A and B, row flags /
  * row list, per-row partial lists of the decomposed kernels: 16 words per piece for the cell scan of large reference sets) */
 #define VKSIFT_HIP_MATCH_SCRATCH_U32(na, nb) (2u * (size_t)(na) + (size_t)(nb) + 72u + (size_t)(na) * 16u * VKSIFT_HIP_MATCH_CHUNKS)
-#define VKSIFT_HIP_ABI_VERSION 5u      /* bumped whenever a signature or a scratch contract of this header changes (vksift_hip_abi_version) */
+#define VKSIFT_HIP_ABI_VERSION 6u      /* bumped whenever a signature or a scratch contract of this header changes (vksift_hip_abi_version) */
 #define VKSIFT_HIP_GATHER_SLOTS 512u   /* SIFT buffers one vksift_hip_gather_sections launch serves */
 #define VKSIFT_HIP_MATCH_SLOTS 256u    /* pairs one vksift_hip_match_2nn_async launch sequence serves */
 #define VKSIFT_HIP_MATCH_PK_NB 32768u  /* reference sets of at most this many rows take the branch-free packed-key kernel (k_match_pk) */
@@ -98,6 +98,8 @@ extern "C"
     VKSIFT_TUNE_SCAN_FORM = 4,  /* development: launch form of the cell-scan matcher (0 = built-in) */
     VKSIFT_TUNE_PAIR_FORM = 5,  /* two-scale blur launch: 0 built-in, 1 two texels per lane, 2 four texels per lane */
     VKSIFT_TUNE_PYR_GATE = 6,   /* 1: the next detection's scale-space starts behind the matching queued before it (default: beside it) */
+    VKSIFT_TUNE_DENSE_ROWS = 7, /* 1: the descriptor launch does not write the matcher's dense rows (the gather pass of the first matching does, as
+                                 * for uploaded buffers); A/B and the bit-identity matrix */
     VKSIFT_TUNE_COUNT = 8
   };
   int vksift_hip_tune(int knob, int value);
@@ -209,7 +211,26 @@ extern "C"
                                * blur launch of the octave ran forward, so that the scan starts on the planes written last */
     uint32_t masks_cleared;   /* the caller has cleared seg_mask for this launch itself (vksift_hip_clear_segment_masks, e.g. on another
                                * stream, off the critical path): vksift_hip_extract_keypoints_multi skips its own fill */
+    uint32_t sec_index;       /* sections of the SIFT buffer in front of this octave's (vksift_hip_DenseRows); found[-sec_index .. ] are the
+                               * counters of the buffer's sections in order */
   } vksift_hip_OctaveJob;
+
+  /* The matcher's view of a freshly detected SIFT buffer, written by the descriptor launch itself (pack_BufferMemory,
+   * sift_memory.c:957-1047, without a pass of its own): feature k of section o is row sum_{j<o} min(found[j], sec_cap[j]) + k of the
+   * buffer's dense 128-byte descriptor rows — download order —, its shifted norm beside it, the row total in n[]; rows below 2 of a
+   * buffer with fewer features are zero-filled (quirk Q6). Image b of the batch: desc + b*desc_img_stride bytes, norm + b*norm_img_stride
+   * words, n[b*n_img_stride]. Every job of the call names its section (sec_index) and all jobs share the section table. */
+  typedef struct
+  {
+    uint8_t *desc;
+    uint64_t desc_img_stride;
+    uint32_t *norm;
+    uint64_t norm_img_stride;
+    uint32_t *n;
+    uint32_t n_img_stride;
+    uint32_t nsec;
+    uint32_t sec_cap[16];
+  } vksift_hip_DenseRows;
 
   /* ExtractKeypoints.comp (sift_detector.c:1106-1189) as a deterministic, atomic-free pipeline: streaming
    * 26-neighbour test -> per-64-pixel-segment candidate ballots -> exclusive scan -> compact candidate list ->
@@ -235,6 +256,10 @@ extern "C"
   int vksift_hip_selftest_inrange(uint32_t n, uint32_t seed, uint32_t *d_mismatches, vksift_hip_stream s);
   int vksift_hip_orientations_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s);
   int vksift_hip_descriptors_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s);
+  /* ... and the dense matcher rows of every buffer with them (dense == NULL: as above). The counters of ALL sections must be final:
+   * queue it behind vksift_hip_orientations_multi of every octave of the detection. */
+  int vksift_hip_descriptors_multi_dense(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, const vksift_hip_DenseRows *dense,
+                                         vksift_hip_stream s);
 
   /* ------------------------------------------------------------------ matcher */
   /* vksift_Feature records (stride 164 B) -> dense 128-byte descriptor rows (16-byte aligned). Replaces the
@@ -276,7 +301,9 @@ extern "C"
    * match_2nn_async (nslots <= VKSIFT_HIP_MATCH_SLOTS): slot i matches cache entry ids_a[i] against ids_b[i]; it first writes {N_A, N_B} of every slot to
    * n_dev[i*n_slot_stride + 0..1] (read by the kernels, the filter and the host). Strides in bytes for desc/matches and in
    * u32 elements for norms/redo/n. partial_scratch (may be NULL): 5*max_na*VKSIFT_HIP_MATCH_CHUNKS u32 used by the
-   * stream-decomposed single-pair kernel (nslots == 1; without it a single pair takes the batch kernels). redo: max_na u32 per slot of row flags for the exact scalar replay. */
+   * stream-decomposed single-pair kernel (nslots == 1; without it a single pair takes the batch kernels). redo: max_na u32 per slot of row flags for the exact scalar replay.
+   * max_na / max_nb: host-side bounds on the row counts of any slot (the counts themselves stay on the device); a batch whose max_nb is within the
+   * packed-key kernel's range launches that kernel only — the pruning kernels' grids for larger reference sets are not queued at all. */
   /* Download packing for a batch of up to 64 SIFT buffers that share one section table (the buffers of one batched detection):
    * slot i copies the stored records of buffer buf_ids[i] — sections in order, min(found, capacity) each, the order
    * vksift_downloadFeatures returns (sift_memory.c:957-1047, 1160-1196) — as dense 164-byte records to out + out_rows[i] * 164.
@@ -290,7 +317,7 @@ extern "C"
                                  uint32_t found_buf_stride, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint64_t desc_stride,
                                  uint32_t *norms, uint64_t norm_stride, uint32_t *n_out_dev, uint32_t n_stride, vksift_hip_stream s);
   int vksift_hip_match_2nn_async(const uint8_t *cache_desc, const uint32_t *cache_norm, const uint32_t *cache_n, const uint32_t *ids_a, const uint32_t *ids_b,
-                                 uint32_t max_na, uint32_t *redo, uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t cache_desc_stride,
+                                 uint32_t max_na, uint32_t max_nb, uint32_t *redo, uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t cache_desc_stride,
                                  uint64_t cache_norm_stride, uint64_t redo_slot_stride, uint64_t match_slot_stride, uint32_t n_slot_stride,
                                  uint32_t *partial_scratch, vksift_hip_stream s);
 

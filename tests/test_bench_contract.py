@@ -51,3 +51,26 @@ def test_roofline_object_fields():
     assert abs(r2["traffic"] - 12.0e9 / 6.0) < 1.0 and abs(r2["frac"] - 12.0e9 * 8 / 20.0e-3 / 1e9 / 8000.0) < 1e-9
     assert abs(r2["frac"] - r2["achieved"] / r2["peak"]) < 1e-12 and r2["algorithmic"]["frac"] == r["frac"]
     assert abs(r2["traffic_over_algorithmic"] - 12.0e9 * 8 / own) < 1e-9 and r2["per_launch"] == pmc["per_launch"]
+
+
+def test_whole_pass_roofline_prices_every_octave():
+    """round 6: `frac` covers every octave's scale-space launches + the scan; rounds 1-5's octave-0 figure moves to octave0_and_scan"""
+    b = _bench()
+    octs = [(1280, 960), (640, 480), (320, 240), (160, 120), (80, 60)]
+    per_img = b.own_pyramid_bytes(octs, 640 * 480)
+    p = [w * h for w, h in octs]
+    assert abs(per_img - (41.25 * p[0] + 37 * (p[1] + p[2] + p[3]) + 36 * p[4])) < 1.0
+    acc = {"nb_calls": 2, "nb_blur_launches": 10, "nb_blur_launches_all": 44, "pyramid_ms": 10.0, "pyramid_all_ms": 14.0, "scan_ms": 8.0,
+           "pyramid_algorithmic_bytes": 2 * 512 * 72.25 * p[0], "scan_algorithmic_bytes": 2 * 512 * 20.0 * sum(p)}
+    alg = 2 * 512 * (per_img + 24.0 * sum(p))
+    r = b.roofline_from(acc, None, "label", octs, 640 * 480, 512)
+    assert abs(r["achieved"] - alg / 22.0e-3 / 1e9) < 1e-3 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12 and r["traffic"] is None
+    assert r["launches_per_call"] == 23.0 and "all octaves" in r["kernel"] and r["algorithmic"]["frac"] == r["frac"]
+    o0 = r["octave0_and_scan"]
+    assert abs(o0["achieved"] - 2 * 512 * (41.25 * p[0] + 24.0 * sum(p)) / 18.0e-3 / 1e9) < 1e-3 and o0["launches_per_call"] == 6.0
+    pmc = {"hbm_bytes_per_call": 50.0e9, "_path": "profiles/x.json",
+           "all_octaves": {"hbm_bytes_per_call": 58.0e9, "hbm_bytes_blur_per_call": 36.0e9, "launches": [{"kernel": "k", "hbm_bytes": 1.0}]}}
+    r2 = b.roofline_from(acc, pmc, "label", octs, 640 * 480, 512)
+    assert abs(r2["frac"] - 58.0e9 * 2 / 22.0e-3 / 1e9 / 8000.0) < 1e-9 and abs(r2["traffic_over_algorithmic"] - 58.0e9 * 2 / alg) < 1e-9
+    assert abs(r2["octave0_and_scan"]["frac"] - 50.0e9 * 2 / 18.0e-3 / 1e9 / 8000.0) < 1e-9 and r2["all_launches"] == pmc["all_octaves"]["launches"]
+    assert abs(r2["frac"] - r2["achieved"] / r2["peak"]) < 1e-12 and r2["algorithmic"]["frac"] == r["frac"]

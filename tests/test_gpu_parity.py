@@ -219,7 +219,7 @@ def test_match_device_pointer_api_refuses_an_undersized_scratch(vk):
     its fill pattern; the library's own figure is accepted"""
     import torch
     L = vk.lib()
-    assert L.vksift_hip_abi_version() >= 5
+    assert L.vksift_hip_abi_version() >= 6
     na = nb = 40000
     a = torch.from_numpy(vk.gen_synthetic_descriptors(71, na)).cuda()
     b = torch.from_numpy(vk.gen_synthetic_descriptors(72, nb)).cuda()

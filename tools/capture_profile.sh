@@ -18,6 +18,13 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/c3/pmc_fetch -- python $R/tools/c
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/c3/pmc_write -- python $R/tools/c3_leg.py 1 > $OUT/c3_write.log 2>&1
 cd $R
 python tools/make_profile_report.py gpurun_out/$TAG/c3 ${TAG}_c3 1920 1080 64 > $OUT/report_c3.log 2>&1
+# the binary16 scale-space mode: traffic of its launches, same two counters (bench.py --fp16 reads <tag>_fp16_pmc_traffic.json)
+cd /tmp
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/fp16/pmc_fetch -- python $R/bench.py --fp16 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/fp16_fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/fp16/pmc_write -- python $R/bench.py --fp16 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/fp16_write.log 2>&1
+cd $R
+python tools/make_profile_report.py gpurun_out/$TAG/fp16 ${TAG}_fp16 $W $H $B fp16 > $OUT/report_fp16.log 2>&1
+rm -rf $OUT/fp16/pmc_fetch $OUT/fp16/pmc_write
 # SQ counters of the VALU-bound kernels and of the seed / scan launches, detections one after the other (clean attribution)
 VKSIFT_PYR_PINGPONG=0 PMC_GROUPS="SQ_WAVES,SQ_BUSY_CU_CYCLES,SQ_WAVE_CYCLES,SQ_INSTS_VALU;SQ_ACTIVE_INST_VALU,SQ_WAIT_INST_ANY,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE;SQ_VMEM_TA_ADDR_FIFO_FULL,SQ_INSTS_VMEM,SQ_INSTS_LDS,SQ_INSTS_SALU" PMC_PASS_TIMEOUT=240 \
   python tools/pmc_kernel.py "k_descriptor,k_orientation<,k_extrema_lean,k_blur_lean<5, 1,k_blur_pair_wide,k_blur_wide<13>@$(( ((2 * W + 127) / 128) * 64 ))" -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras \
@@ -27,5 +34,5 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> 
 cp $OUT/bench.json profiles/${TAG}_bench.json
 mkdir -p $OUT/profiles; cp profiles/${TAG}_* $OUT/profiles/
 # the raw traces are large: only the report travels back
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/c3/pmc_fetch $OUT/c3/pmc_write
 tail -c 1500 $OUT/report.log; tail -1 $OUT/bench.json | cut -c 1-1500

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn a gpurun_out/<tag>/ capture (bench.json, trace/, pmc_fetch/, pmc_write/) into the committed files under
 profiles/: <tag>_bench.json, <tag>_kernel_stats.csv, <tag>_kernel_summary.txt, <tag>_pmc_traffic.json.
-usage: make_profile_report.py gpurun_out/r01 r01 <width> <height> <batch>"""
+usage: make_profile_report.py gpurun_out/r01 r01 <width> <height> <batch> [fp16]"""
 import glob
 import io
 import json
@@ -23,6 +23,29 @@ def pmc(dirpath, counter, gridx, kernel=KERNEL):
     return json.loads(out.stdout)
 
 
+BLUR_KERNELS = ("k_blur_", "k_input_blit", "k_downsample", "k_octave_chain")
+
+
+def pmc_by_shape(dirpath, counter):
+    """{(kernel name, grid_x, grid_y): (dispatches, KiB summed)} of every scale-space launch in a --pmc capture"""
+    import sqlite3
+    from collections import defaultdict
+    out = defaultdict(lambda: [0, 0.0])
+    for p in glob.glob(os.path.join(dirpath, "**", "*.db"), recursive=True):
+        cur = sqlite3.connect(p).cursor()
+        cols = [r[1] for r in cur.execute("pragma table_info('counters_collection')")]
+        name_col = "kernel_name" if "kernel_name" in cols else "name"
+        per = {}
+        for name, value, disp, gx, gy in cur.execute(f"select {name_col}, value, dispatch_id, grid_size_x, grid_size_y from counters_collection where counter_name = ?", (counter,)):
+            if any(k in name for k in BLUR_KERNELS):
+                key = (name, int(gx), int(gy))
+                per.setdefault(disp, [key, 0.0])[1] += float(value)
+        for key, v in per.values():
+            out[key][0] += 1
+            out[key][1] += v
+    return {k: (c, v) for k, (c, v) in out.items()}
+
+
 def kernel_source_sha():
     import hashlib
     h = hashlib.sha256()
@@ -34,6 +57,7 @@ def kernel_source_sha():
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     w, h, batch = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    fp16 = len(sys.argv) > 6 and sys.argv[6] == "fp16"   # a capture of the binary16 scale-space mode (bench.py --fp16): stamped, bench.py refuses it for fp32
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     if os.path.exists(os.path.join(src, "bench.json")):
@@ -92,12 +116,13 @@ def main():
         blur_per_call = calls / scalls          # blur launches of octave 0 per detection call (= per scan launch)
         # per launch kind: HBM bytes (PMC) / average and minimum duration of the same launch shape in the kernel trace
         per_launch_rows = []
+        durs, durs3 = {}, {}
         if have_trace:
             import sqlite3
-            durs = {}
             for dbp in glob.glob(os.path.join(src, "trace", "**", "*.db"), recursive=True):
-                for name, st, en, gx in sqlite3.connect(dbp).execute("select name, start, end, grid_x from kernels"):
+                for name, st, en, gx, gy in sqlite3.connect(dbp).execute("select name, start, end, grid_x, grid_y from kernels"):
                     durs.setdefault((name, int(gx)), []).append(en - st)
+                    durs3.setdefault((name, int(gx), int(gy)), []).append(en - st)
             for name in list(f.keys()) + list(sf.keys()):
                 is_scan = name in sf
                 fk = (sf if is_scan else f)[name]
@@ -110,7 +135,24 @@ def main():
                 avg_us, min_us = sum(dd) / len(dd) / 1e3, min(dd) / 1e3
                 per_launch_rows.append({"kernel": name.replace("void (anonymous namespace)::", "").split("(")[0], "hbm_bytes": hbm, "avg_us": avg_us, "min_us": min_us,
                                         "frac_of_8TBps": hbm / (avg_us * 1e-6) / 8e12, "frac_at_min_duration": hbm / (min_us * 1e-6) / 8e12, "launches_in_trace": len(dd)})
-        rec = {"per_launch": per_launch_rows, "width": w, "height": h, "batch": batch, "kernel": KERNEL + " / k_blur_wide / k_blur_pair (octave-0 launches) + " + SCAN + " (one launch over all octaves)", "kernel_source_sha": kernel_source_sha(),
+        # every scale-space launch of a detection call, all octaves (round 6: the whole pass is what bench.py prices): FETCH_SIZE x 2 + WRITE_SIZE
+        # of every dispatch of the blur / blit / down-sampling kernels, grouped by launch shape
+        allf, allw = pmc_by_shape(os.path.join(src, "pmc_fetch"), "FETCH_SIZE"), pmc_by_shape(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+        all_rows, all_bytes_per_call = [], 0.0
+        for key in sorted(allf, key=lambda k: -allf[k][1]):
+            name, gx, gy = key
+            fc, fs = allf[key]
+            wc, ws = allw.get(key, (0, 0.0))
+            hbm = (2.0 * fs / max(fc, 1) + ws / max(wc, 1)) * 1024.0
+            per_call = fc / scalls
+            all_bytes_per_call += hbm * per_call
+            dd = durs3.get(key, [])
+            row = {"kernel": name.replace("void (anonymous namespace)::", "").split("(")[0], "grid_x": gx, "grid_y": gy, "launches_per_call": per_call, "hbm_bytes": hbm}
+            if dd and per_call > 0:
+                row.update({"avg_us": sum(dd) / len(dd) / 1e3, "min_us": min(dd) / 1e3, "frac_of_8TBps": hbm / (sum(dd) / len(dd) * 1e-9) / 8e12})
+            all_rows.append(row)
+        rec = {"fp16": fp16, "per_launch": per_launch_rows, "all_octaves": {"hbm_bytes_blur_per_call": all_bytes_per_call, "hbm_bytes_per_call": all_bytes_per_call + scan_launch,
+                                                              "launches": all_rows}, "width": w, "height": h, "batch": batch, "kernel": KERNEL + " / k_blur_wide / k_blur_pair (octave-0 launches) + " + SCAN + " (one launch over all octaves)", "kernel_source_sha": kernel_source_sha(),
                "launches_fetch_pass": calls, "launches_write_pass": wcalls, "scan_launches": scalls,
                "FETCH_SIZE_KiB_sum": fetch_kb, "WRITE_SIZE_KiB_sum": write_kb, "fetch_correction": 2.0,
                "hbm_bytes_per_blur_launch": per_launch, "hbm_bytes_per_scan_launch": scan_launch,

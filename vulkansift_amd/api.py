@@ -58,6 +58,7 @@ class vksift_ext_DetectTimings(C.Structure):
         ("upload_ms", C.c_float), ("pyramid_ms", C.c_float), ("extrema_ms", C.c_float), ("orientation_ms", C.c_float),
         ("descriptor_ms", C.c_float), ("total_ms", C.c_float), ("nb_blur_launches", C.c_uint32), ("pyramid_algorithmic_bytes", C.c_uint64),
         ("scan_ms", C.c_float), ("scan_algorithmic_bytes", C.c_uint64),
+        ("pyramid_all_ms", C.c_float), ("nb_blur_launches_all", C.c_uint32),
     ]
 
 

@@ -75,6 +75,7 @@ struct FeatArgs
   uint32_t use_vlfeat;
   const float *desc_fp_tab;
   uint32_t desc_fp_tab_len;
+  uint32_t sec; // section of the SIFT buffer this octave fills (k_descriptor's dense rows)
 };
 
 // ComputeDescriptors.comp:160-171 / ComputeOrientation.comp:100-104 wrap an angle with "if (t < 0) t += 2 pi; else if
@@ -143,8 +144,9 @@ __device__ __forceinline__ void grad_polar(float gradX, float gradY, float *ori,
     const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
     *ori = dm_atan2f_ratio(div_inrange(mn, mx == 0.f ? 1.f : mx), ax, ay, gradX, gradY);
     *len = sqrt_inrange(g2);
-    // g2 >= 2^-96 (then mx >= 2^-49) or 0; mn >= 2^-64 or 0
-    *odd = below_range<127 - 96>(g2) || below_range<127 - 64>(mn);
+    // mx >= 2^-48 (then g2 >= 2^-96 and no square underflowed) or 0; mn >= 2^-64 or 0. (Tested on mx, not on g2: a denormal mx beside
+    // mn = 0 squares to an exact 0, which a test of g2 lets through to rcp(denormal) = inf.)
+    *odd = below_range<127 - 48>(mx) || below_range<127 - 64>(mn);
   }
   else
   {
@@ -559,7 +561,8 @@ __device__ __forceinline__ void desc_scatter(const DescCtx &c, const DescSample 
 constexpr int DESC_MAX_ROWS = 256; // window rows handled per pass (R <= 127: every stock configuration); taller windows take several passes
 
 template <int NWV, bool IMG_FAST, bool F16>
-__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu((NWV == 2 && !F16) ? 8 : 6, 8))) k_descriptor(Multi<FeatArgs> m)
+__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu((NWV == 2 && !F16) ? 8 : 6, 8)))
+k_descriptor(Multi<FeatArgs> m, vksift_hip_DenseRows dr)
 {
   const VBlock vb = vblock(m); // virtual grid (images, blocks) when IMG_FAST, (blocks, images) otherwise
   const FeatArgs &a = m.oct[vb.o];
@@ -574,6 +577,37 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu((
   const uint32_t n1 = found < a.cap ? found : a.cap;
   GaussView g{a.gauss + (size_t)b * a.img_stride, a.w, a.h, a.pitch, (size_t)a.plane_stride};
   uint8_t *feats = a.feats + (size_t)b * a.feat_img_stride;
+  // Dense rows for the matcher (vksift_hip_DenseRows): this section's features follow the stored features of the sections in front of
+  // it. All counters are final here (the orientation launches of every octave precede this one); uniform scalar loads.
+  // (the row offset waits in LDS for the epilogue: nothing of this stays in registers across the sample loop)
+  __shared__ uint32_t s_row0;
+  if (dr.desc)
+  {
+    const uint32_t *fsec = a.found + (size_t)b * a.found_img_stride - a.sec; // counter of section 0 of this image's buffer
+    uint32_t row0 = 0, total = 0;
+    for (uint32_t j = 0; j < dr.nsec; j++)
+    {
+      const uint32_t f = fsec[j], n = f < dr.sec_cap[j] ? f : dr.sec_cap[j];
+      row0 += j < a.sec ? n : 0u;
+      total += n;
+    }
+    if (tid == 0)
+      s_row0 = row0; // read behind the barriers of the keypoint loop
+    // the buffer's row count and the zero rows of quirk Q6: first workgroup of section 0's share of this image
+    if (a.sec == 0 && (IMG_FAST ? vb.y : vb.x) == 0)
+    {
+      if (tid == 0)
+        dr.n[(size_t)b * dr.n_img_stride] = total;
+      if (total < 2u && tid < 64)
+      {
+        uint32_t *z = (uint32_t *)(dr.desc + (size_t)b * dr.desc_img_stride);
+        if (tid >= (int)total * 32)
+          z[tid] = 0u;
+        if (tid < 2 && tid >= (int)total)
+          dr.norm[(size_t)b * dr.norm_img_stride + tid] = 128u * 128u * 128u;
+      }
+    }
+  }
 
   for (uint32_t k = IMG_FAST ? vb.y : vb.x; k < n1; k += IMG_FAST ? vb.gy : vb.gx)
   {
@@ -797,6 +831,30 @@ __global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu((
         desc[lane >> 2] = p0;
         desc[16 + (lane >> 2)] = p1;
       }
+      if (dr.desc)
+      {
+        const uint32_t row0 = s_row0;
+        uint32_t *dense = (uint32_t *)(dr.desc + (size_t)b * dr.desc_img_stride) + (size_t)row0 * 32;
+        uint32_t *dense_norm = dr.norm + (size_t)b * dr.norm_img_stride + row0;
+        // the same 128 bytes as a dense row + |d - 128|^2 = sum d^2 - 256 sum d + 128 * 128^2 (k_shifted_norms): every lane of a
+        // group of four holds the group's two dwords, the sums run over the 16 groups
+        uint32_t s2 = __builtin_amdgcn_udot4(p0, p0, 0u, false), s1 = __builtin_amdgcn_udot4(p0, 0x01010101u, 0u, false);
+        s2 = __builtin_amdgcn_udot4(p1, p1, s2, false), s1 = __builtin_amdgcn_udot4(p1, 0x01010101u, s1, false);
+#pragma unroll
+        for (int dlt = 32; dlt >= 4; dlt >>= 1)
+        {
+          s2 += __shfl_xor(s2, dlt, 64);
+          s1 += __shfl_xor(s1, dlt, 64);
+        }
+        if ((lane & 3) == 0)
+        {
+          uint32_t *row = dense + (size_t)k * 32;
+          row[lane >> 2] = p0;
+          row[16 + (lane >> 2)] = p1;
+        }
+        if (lane == 0)
+          dense_norm[k] = s2 - 256u * s1 + 128u * 128u * 128u;
+      }
     }
   }
 }
@@ -815,6 +873,7 @@ FeatArgs make_args(const vksift_hip_OctaveJob *job)
   a.max_keep = mk > VKSIFT_HIP_MAX_ORI ? VKSIFT_HIP_MAX_ORI : mk;
   a.use_vlfeat = job->use_vlfeat;
   a.desc_fp_tab = job->desc_fp_tab, a.desc_fp_tab_len = job->desc_fp_tab_len;
+  a.sec = job->sec_index;
   return a;
 }
 
@@ -897,7 +956,7 @@ static int orientation_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_
   return (int)hipGetLastError();
 }
 
-static int descriptor_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t batch, hipStream_t hs)
+static int descriptor_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t batch, const vksift_hip_DenseRows &dr, hipStream_t hs)
 {
   Multi<FeatArgs> md;
   md.n = 0;
@@ -926,16 +985,16 @@ static int descriptor_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t
     if (f)                                                                              \
     {                                                                                   \
       if (f16)                                                                          \
-        hipLaunchKernelGGL((k_descriptor<N, true, true>), grid, dim3(64 * N), 0, hs, md);  \
+        hipLaunchKernelGGL((k_descriptor<N, true, true>), grid, dim3(64 * N), 0, hs, md, dr);  \
       else                                                                              \
-        hipLaunchKernelGGL((k_descriptor<N, true, false>), grid, dim3(64 * N), 0, hs, md); \
+        hipLaunchKernelGGL((k_descriptor<N, true, false>), grid, dim3(64 * N), 0, hs, md, dr); \
     }                                                                                   \
     else                                                                                \
     {                                                                                   \
       if (f16)                                                                          \
-        hipLaunchKernelGGL((k_descriptor<N, false, true>), grid, dim3(64 * N), 0, hs, md); \
+        hipLaunchKernelGGL((k_descriptor<N, false, true>), grid, dim3(64 * N), 0, hs, md, dr); \
       else                                                                              \
-        hipLaunchKernelGGL((k_descriptor<N, false, false>), grid, dim3(64 * N), 0, hs, md); \
+        hipLaunchKernelGGL((k_descriptor<N, false, false>), grid, dim3(64 * N), 0, hs, md, dr); \
     }                                                                                   \
   } while (0)
   if (nwv == 2)
@@ -998,6 +1057,26 @@ __global__ void __launch_bounds__(256) k_inrange_selftest(uint32_t n, uint32_t s
   y = (h2 & 1u) ? -y : y;
   asm volatile("" : "+v"(y));
   miss += __float_as_uint(div_2pi_inrange(y)) != __float_as_uint(y / (2.f * PI_F));
+  // grad_polar's own guard: wherever it does not ask for the general forms, the short forms must give their bits — components from
+  // denormals to 4 and exact zeros, incl. (0, denormal), whose squares underflow to 0
+  {
+    auto comp = [](uint32_t h, uint32_t i) {
+      const uint32_t kind = (h >> 27) & 7u;
+      float v = kind == 0u ? 0.f : (kind == 1u ? __uint_as_float(h & 0x7FFFFFu) /* denormal */ : __uint_as_float((((h >> 23) & 0xFFu) % 129u) << 23 | (h & 0x7FFFFFu)));
+      if (i == 4u)
+        v = __uint_as_float(1u);
+      return (h & 0x80000000u) ? -v : v;
+    };
+    float gx = comp(st_hash(h0 ^ 0x9E3779B9u), 0u), gy = comp(st_hash(h1 ^ 0x85EBCA6Bu), i);
+    if (i == 4u || i == 5u)
+      gx = 0.f;
+    asm volatile("" : "+v"(gx), "+v"(gy));
+    float o1, l1, o2, l2;
+    bool odd;
+    grad_polar<true>(gx, gy, &o1, &l1, &odd);
+    grad_polar<false>(gx, gy, &o2, &l2, nullptr);
+    miss += !odd && (__float_as_uint(o1) != __float_as_uint(o2) || __float_as_uint(l1) != __float_as_uint(l2));
+  }
   if (miss)
     atomicAdd(bad, miss);
 }
@@ -1021,11 +1100,27 @@ extern "C"
     return for_runs(jobs, n_jobs, [&](const vksift_hip_OctaveJob *j, uint32_t n) { return orientation_run(j, n, batch, (hipStream_t)s); });
   }
 
-  int vksift_hip_descriptors_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s)
+  int vksift_hip_descriptors_multi_dense(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, const vksift_hip_DenseRows *dense,
+                                         vksift_hip_stream s)
   {
     if (batch == 0)
       return 0;
-    return for_runs(jobs, n_jobs, [&](const vksift_hip_OctaveJob *j, uint32_t n) { return descriptor_run(j, n, batch, (hipStream_t)s); });
+    vksift_hip_DenseRows dr = {};
+    if (dense)
+    {
+      if (!dense->desc || !dense->norm || !dense->n || dense->nsec == 0 || dense->nsec > 16u)
+        return (int)hipErrorInvalidValue;
+      for (uint32_t i = 0; i < n_jobs; i++)
+        if (jobs[i].sec_index >= dense->nsec)
+          return (int)hipErrorInvalidValue;
+      dr = *dense;
+    }
+    return for_runs(jobs, n_jobs, [&](const vksift_hip_OctaveJob *j, uint32_t n) { return descriptor_run(j, n, batch, dr, (hipStream_t)s); });
+  }
+
+  int vksift_hip_descriptors_multi(const vksift_hip_OctaveJob *jobs, uint32_t n_jobs, uint32_t batch, vksift_hip_stream s)
+  {
+    return vksift_hip_descriptors_multi_dense(jobs, n_jobs, batch, nullptr, s);
   }
 
   int vksift_hip_orientations(const vksift_hip_OctaveJob *job, uint32_t batch, vksift_hip_stream s) { return vksift_hip_orientations_multi(job, 1, batch, s); }

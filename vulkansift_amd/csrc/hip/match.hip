@@ -254,19 +254,22 @@ __device__ __forceinline__ uint32_t stream_span(uint32_t nblocks, uint32_t tiles
 // compute units of the current device (workgroup slots of the stream decomposition)
 uint32_t device_cus()
 {
-  static int cached_dev = -1;
-  static uint32_t cached = 0;
+  // one slot per device, written once with the same value by whichever thread comes first: instances on different GPUs may be driven
+  // from different host threads of one process (tests/test_gpu_two_instances.py)
+  static uint32_t cached[64] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess)
     return 256u;
-  if (dev != cached_dev)
+  if (dev < 0 || dev >= 64 || cached[dev] == 0)
   {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       n = 256;
-    cached = (uint32_t)n, cached_dev = dev;
+    if (dev < 0 || dev >= 64)
+      return (uint32_t)n;
+    cached[dev] = (uint32_t)n;
   }
-  return cached;
+  return cached[dev];
 }
 
 // VKSIFT_MATCH_SCAN=0: single pairs with large reference sets take the stream-decomposed pruning kernel instead of the cell scan
@@ -1940,7 +1943,7 @@ extern "C"
   }
 
   int vksift_hip_match_2nn_async(const uint8_t *cache_desc, const uint32_t *cache_norm, const uint32_t *cache_n, const uint32_t *ids_a, const uint32_t *ids_b,
-                                 uint32_t max_na, uint32_t *redo, uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t cache_desc_stride,
+                                 uint32_t max_na, uint32_t max_nb, uint32_t *redo, uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t cache_desc_stride,
                                  uint64_t cache_norm_stride, uint64_t redo_slot_stride, uint64_t match_slot_stride, uint32_t n_slot_stride,
                                  uint32_t *partial_scratch, vksift_hip_stream s)
   {
@@ -2032,14 +2035,17 @@ extern "C"
       uint32_t gs = nslots;
       if (pk && nslots > 16u)
         gs = 16u, s2.nslots_loop = nslots;
-      if (max_na > S1)
+      /* no slot can have a reference set beyond the packed-key kernel's range: nothing is left for the pruning kernels (a batch of
+       * frames; their two mostly idle grids cost it 0.34 ms per 512 pairs) */
+      const bool prune = !pk || max_nb > VKSIFT_HIP_MATCH_PK_NB;
+      if (prune && max_na > S1)
       {
         const uint32_t n2 = max_na < S2 ? max_na : S2;
         const uint32_t gb = bounded((n2 + 63u) / 64u);
         hipLaunchKernelGGL(k_match_mfma<1>, s2.slot_fast ? dim3(gs, gb) : dim3(gb, gs), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,
                            (uint32_t *)matches, redo, n_dev, S1, S2, s2, (uint32_t *)nullptr, ids, 0u);
       }
-      if (max_na > S2)
+      if (prune && max_na > S2)
       {
         const uint32_t gb = bounded((max_na + 127u) / 128u);
         hipLaunchKernelGGL(k_match_mfma<2>, s2.slot_fast ? dim3(gs, gb) : dim3(gb, gs), dim3(256), 0, hs, da, norm_a, 0u, 0u, db, norm_b, 0u,

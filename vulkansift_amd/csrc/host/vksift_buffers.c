@@ -135,7 +135,9 @@ static bool download_from_batch(vksift_Instance inst, vksift_Feature *feats_ptr,
     /* A page-locked destination (vksift_ext_pinHostMemory, hipHostMalloc) takes its records by DMA straight out of the packed device
      * copy: no transfer into the pinned staging block for this detection at all. (A later pageable destination of the same detection
      * falls back to a plain copy out of the device block.) */
-    inst->dl_direct = vksift_hip_is_pinned(feats_ptr) == 1;
+    /* Only on an otherwise idle GPU: behind a queued detection each such transfer takes ~77 us against the staged path's ~7.5 us per
+     * buffer, so a pipelined caller with pinned destinations keeps the staged path. */
+    inst->dl_direct = !detect_running(inst) && vksift_hip_is_pinned(feats_ptr) == 1;
     if (inst->dl_direct)
     {
       if (!inst->dl_ev[0])

@@ -143,6 +143,8 @@ void account_set(vksift_Instance inst, ProfSet *ps)
   inst->acc_ms[4] += vksift_hip_event_elapsed_ms(e[4], e[5]);
   inst->acc_ms[5] += vksift_hip_event_elapsed_ms(e[0], e[6]);
   inst->acc_ms[6] += vksift_hip_event_elapsed_ms(e[2], ps->ev_scan);
+  inst->acc_ms[7] += vksift_hip_event_elapsed_ms(ps->ev_pt[0], ps->ev_pt[2]);
+  inst->acc_blur_launches_all += ps->blur_launches_all;
   inst->acc_calls++;
   inst->acc_blur_launches += ps->blur_launches;
   inst->acc_alg_bytes += ps->alg_bytes;
@@ -184,11 +186,13 @@ typedef struct
   bool gpu_busy;  /* an earlier detection was still running when this one was queued */
   bool post;      /* feature posting at the end of the sequence (vksift_internal.h: h_post) */
   bool fork;      /* scales S+1.. of every octave on the side stream (vksift_internal.h: ev_fork) */
+  bool dense;     /* the descriptor launch also writes the buffers' matcher cache entries (vksift_hip_DenseRows) */
   const uint8_t *const *images; /* upload: the caller's images, staged chunk by chunk while the sequence is enqueued */
   const uint8_t *d_src;
   uint32_t w, h, count, first_buf;
   size_t img_bytes;
   uint32_t nblur; /* blur launches of octave 0 (the profiled scale-space interval) */
+  uint32_t nblur_all; /* ... of every octave */
   vksift_hip_OctaveJob jobs[VKSIFT_MAX_OCTAVES];
 } DetectCtx;
 
@@ -234,6 +238,7 @@ static void build_jobs(DetectCtx *c)
     j->desc_fp_tab = inst->d_desc_fp;
     j->desc_fp_tab_len = inst->desc_fp_len;
     j->masks_cleared = 0;
+    j->sec_index = o;
     j->scan_reverse = 0; /* set by enqueue_pyramid: the direction opposite to the octave's last blur launch */
   }
 }
@@ -356,6 +361,7 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint3
   c->jobs[o].scan_reverse = inst->alt_order ? ((li & 1u) ^ 1u) : 0u;
 #undef PL
   vksift_hip_range_pop();
+  c->nblur_all += nb_o;
   if (o == 0)
   {
     c->nblur += nb_o;
@@ -518,6 +524,8 @@ static int enqueue_detection(DetectCtx *c)
         TRY(vksift_hip_stream_wait_event(sp, inst->ev_join[k]), "scale join");
       }
   }
+  if (c->prof)
+    vksift_hip_event_record(c->PS->ev_pt[2], sp); /* every octave's scale-space is queued (forked branches have joined) */
   if (c->overlap)
   {
     TRY(vksift_hip_event_record(inst->ev_pyr_done, sp), "event record");
@@ -538,7 +546,22 @@ static int enqueue_detection(DetectCtx *c)
     if (c->prof)
       vksift_hip_event_record(c->PS->ev_t[4], st);
     vksift_hip_range_push("ComputeDescriptors");
-    TRY(vksift_hip_descriptors_multi(c->jobs, L->n_oct, c->count, st), "descriptor");
+    if (c->dense)
+    {
+      /* the matcher's view of the buffers comes out of the same launch (pack_BufferMemory, sift_memory.c:957-1047): no gather pass */
+      const BufferInfo *b0 = &inst->bufs[c->first_buf];
+      vksift_hip_DenseRows dr;
+      memset(&dr, 0, sizeof(dr));
+      dr.desc = inst->d_cache_desc + (uint64_t)c->first_buf * inst->desc_slot_stride, dr.desc_img_stride = inst->desc_slot_stride;
+      dr.norm = inst->d_cache_norm + (uint64_t)c->first_buf * inst->cache_norm_stride, dr.norm_img_stride = inst->cache_norm_stride;
+      dr.n = inst->d_cache_n + c->first_buf, dr.n_img_stride = 1;
+      dr.nsec = b0->nb_sections;
+      for (uint32_t o = 0; o < b0->nb_sections; o++)
+        dr.sec_cap[o] = b0->sec_cap[o];
+      TRY(vksift_hip_descriptors_multi_dense(c->jobs, L->n_oct, c->count, &dr, st), "descriptor");
+    }
+    else
+      TRY(vksift_hip_descriptors_multi(c->jobs, L->n_oct, c->count, st), "descriptor");
     vksift_hip_range_pop();
     if (c->overlap)
     {
@@ -560,6 +583,7 @@ static int enqueue_detection(DetectCtx *c)
     vksift_hip_event_record(c->PS->ev_scan, st);
     vksift_hip_event_record(c->PS->ev_pt[0], st);
     vksift_hip_event_record(c->PS->ev_pt[1], st);
+    vksift_hip_event_record(c->PS->ev_pt[2], st);
   }
   if (inst->pyr_pingpong && !c->capturing)
   {
@@ -568,7 +592,7 @@ static int enqueue_detection(DetectCtx *c)
     TRY(vksift_hip_event_record(inst->ev_pyr_free[inst->pyr_cur], st), "event record");
     inst->pyr_free_valid[inst->pyr_cur] = true;
   }
-  inst->last_blur_launches = c->nblur;
+  inst->last_blur_launches = c->nblur, inst->last_blur_launches_all = c->nblur_all;
   /* profiling: the scale-space interval is octave 0's (77 % of the bytes), the scan interval covers the scan launch of all octaves */
   inst->last_alg_bytes = algorithmic_pyramid_bytes(inst, c->w, c->h, 1u) * c->count;
   /* "the extrema scan adds 20 B/px.octave" = one read of the S+2 DoG layers */
@@ -603,7 +627,8 @@ static DetectGraph *graph_lookup(vksift_Instance inst, const DetectCtx *c)
   for (int i = 0; i < VKSIFT_GRAPH_CACHE; i++)
   {
     DetectGraph *g = &inst->graphs[i];
-    if (g->exec && g->w == c->w && g->h == c->h && g->count == c->count && g->first_buf == c->first_buf && g->d_src == c->d_src && g->post == c->post)
+    if (g->exec && g->w == c->w && g->h == c->h && g->count == c->count && g->first_buf == c->first_buf && g->d_src == c->d_src && g->post == c->post &&
+        g->dense == c->dense)
       return g;
     if (g->stamp < victim->stamp)
       victim = g;
@@ -697,13 +722,16 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   c.prestaged = prestaged;
   c.w = w, c.h = h, c.count = count, c.first_buf = first_buf;
   c.img_bytes = (size_t)w * h;
-  c.nblur = 0;
+  c.nblur = 0, c.nblur_all = 0;
   c.capturing = false;
   c.gpu_busy = detect_running(inst);
   /* forked scale-space + LDS chain are latency measures for ONE image (or a handful): a batch on a single-buffer instance
    * (batch_cap < 8 or VKSIFT_PYR_PINGPONG=0) fills the chip with its per-scale launches and takes those */
   c.fork = inst->fork_scales && !c.overlap && !c.prof && count <= VKSIFT_FORK_MAX_COUNT && (uint64_t)count * w * h <= inst->fork_max_pixels;
   /* feature posting for single-image detections whose records fit the slot (every section is capacity-bounded) */
+  /* once the instance has matched (its cache blocks exist) a detection leaves the matcher's rows of its buffers behind itself */
+  c.dense = inst->d_cache_desc != NULL && inst->d_cache_norm != NULL && c.L->n_oct > 0 && c.L->n_oct == inst->bufs[first_buf].nb_sections &&
+            c.L->n_oct <= 16u && vksift_hip_tune_get(VKSIFT_TUNE_DENSE_ROWS) == 0;
   c.post = false;
   if (count == 1 && inst->post_enabled && inst->post_on && c.L->n_oct > 0 && inst->bufs[first_buf].nb_sections > 0 && inst->bufs[first_buf].nb_sections <= 16)
   {
@@ -789,7 +817,7 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
       vksift_hip_graph exec = NULL;
       HIP_CHECK(vksift_hip_capture_end(st, &exec), "detection graph capture");
       dg->exec = exec;
-      dg->w = w, dg->h = h, dg->count = count, dg->first_buf = first_buf, dg->d_src = c.d_src, dg->post = c.post;
+      dg->w = w, dg->h = h, dg->count = count, dg->first_buf = first_buf, dg->d_src = c.d_src, dg->post = c.post, dg->dense = c.dense;
       HIP_CHECK(vksift_hip_graph_launch(dg->exec, st), "detection graph launch");
     }
   }
@@ -809,12 +837,15 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
     inst->staging_pending = true;
   }
   inst->device_input_last = !c.upload;
+  if (c.dense)
+    for (uint32_t i = 0; i < count; i++)
+      inst->cache_valid[first_buf + i] = true; /* in stream order in front of every matching queued from here on */
   if (c.prof)
   {
     vksift_hip_event_record(PS->ev_t[6], st);
     PS->valid = true;
     PS->accounted = false;
-    PS->blur_launches = inst->last_blur_launches;
+    PS->blur_launches = inst->last_blur_launches, PS->blur_launches_all = inst->last_blur_launches_all;
     PS->alg_bytes = inst->last_alg_bytes;
     PS->scan_bytes = inst->last_scan_bytes;
   }

@@ -17,6 +17,7 @@ void vksift_ext_setProfiling(vksift_Instance instance, bool enabled)
   memset(instance->acc_ms, 0, sizeof(instance->acc_ms));
   instance->acc_calls = 0;
   instance->acc_blur_launches = 0;
+  instance->acc_blur_launches_all = 0;
   instance->acc_alg_bytes = 0;
   instance->acc_scan_bytes = 0;
 }
@@ -45,6 +46,8 @@ static void accumulated_timings(vksift_Instance instance, vksift_ext_DetectTimin
   sum->descriptor_ms = (float)instance->acc_ms[4];
   sum->total_ms = (float)instance->acc_ms[5];
   sum->scan_ms = (float)instance->acc_ms[6];
+  sum->pyramid_all_ms = (float)instance->acc_ms[7];
+  sum->nb_blur_launches_all = (uint32_t)instance->acc_blur_launches_all;
   sum->scan_algorithmic_bytes = instance->acc_scan_bytes;
   sum->nb_blur_launches = (uint32_t)instance->acc_blur_launches;
   sum->pyramid_algorithmic_bytes = instance->acc_alg_bytes;
@@ -54,6 +57,7 @@ static void accumulated_timings(vksift_Instance instance, vksift_ext_DetectTimin
     memset(instance->acc_ms, 0, sizeof(instance->acc_ms));
     instance->acc_calls = 0;
     instance->acc_blur_launches = 0;
+    instance->acc_blur_launches_all = 0;
     instance->acc_alg_bytes = 0;
     instance->acc_scan_bytes = 0;
   }
@@ -126,6 +130,8 @@ static void last_timings(vksift_Instance instance, vksift_ext_DetectTimings *out
   out->descriptor_ms = vksift_hip_event_elapsed_ms(e[4], e[5]);
   out->total_ms = vksift_hip_event_elapsed_ms(e[0], e[6]);
   out->scan_ms = vksift_hip_event_elapsed_ms(e[2], ps->ev_scan);
+  out->pyramid_all_ms = vksift_hip_event_elapsed_ms(ps->ev_pt[0], ps->ev_pt[2]);
+  out->nb_blur_launches_all = ps->blur_launches_all;
   out->scan_algorithmic_bytes = instance->last_scan_bytes;
   out->nb_blur_launches = instance->last_blur_launches;
   out->pyramid_algorithmic_bytes = instance->last_alg_bytes;

@@ -261,7 +261,7 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     inst->prof[0].ev_t[i] = vksift_hip_event_create();
     inst->prof[1].ev_t[i] = vksift_hip_event_create();
   }
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 3; i++)
   {
     inst->prof[0].ev_pt[i] = vksift_hip_event_create();
     inst->prof[1].ev_pt[i] = vksift_hip_event_create();
@@ -402,6 +402,8 @@ void vksift_destroyInstance(vksift_Instance *instance_ptr)
     vksift_hip_event_destroy(inst->prof[0].ev_pt[i]);
     vksift_hip_event_destroy(inst->prof[1].ev_pt[i]);
   }
+  vksift_hip_event_destroy(inst->prof[0].ev_pt[2]);
+  vksift_hip_event_destroy(inst->prof[1].ev_pt[2]);
   vksift_hip_stream_destroy(inst->stream);
   free(inst);
   *instance_ptr = NULL;

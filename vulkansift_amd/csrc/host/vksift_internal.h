@@ -74,7 +74,8 @@ typedef struct
   vksift_hip_graph exec;
   uint32_t w, h, count, first_buf;
   const uint8_t *d_src;
-  bool post; /* the sequence ends with the feature posting (see h_post) */
+  bool post;  /* the sequence ends with the feature posting (see h_post) */
+  bool dense; /* its descriptor launch writes the buffer's matcher cache entry (captured before the first matching: it does not) */
   uint64_t stamp;
 } DetectGraph;
 
@@ -88,10 +89,10 @@ typedef struct
 typedef struct
 {
   vksift_hip_event ev_t[8];  /* instance stream: start, upload end, pyramid end, extrema end, orientation end, descriptor end, call end */
-  vksift_hip_event ev_pt[2]; /* start / end of octave 0's scale-space construction on its own stream (overlapping detections) */
+  vksift_hip_event ev_pt[3]; /* start / end of octave 0's scale-space construction on its own stream (overlapping detections); [2]: end of the last octave's */
   vksift_hip_event ev_scan;  /* octave 0's streaming extrema scan (the kernel that forms the DoG values) has run */
   bool valid, accounted, overlap;
-  uint32_t blur_launches;
+  uint32_t blur_launches, blur_launches_all;
   uint64_t alg_bytes, scan_bytes;
 } ProfSet;
 
@@ -254,10 +255,10 @@ struct vksift_Instance_T
   int prof_cur;
   vksift_hip_event ev_m[2];
   bool match_timing_valid;
-  double acc_ms[7]; /* upload, pyramid, extrema stage, orientation, descriptor, total, extrema scan kernel alone */
+  double acc_ms[8]; /* upload, pyramid (octave 0), extrema stage, orientation, descriptor, total, extrema scan kernel alone, pyramid (all octaves) */
   uint32_t acc_calls;
-  uint64_t acc_blur_launches, acc_alg_bytes, acc_scan_bytes;
-  uint32_t last_blur_launches;
+  uint64_t acc_blur_launches, acc_blur_launches_all, acc_alg_bytes, acc_scan_bytes;
+  uint32_t last_blur_launches, last_blur_launches_all;
   uint64_t last_alg_bytes, last_scan_bytes;
   bool device_input_last;
 };

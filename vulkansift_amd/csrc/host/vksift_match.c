@@ -135,13 +135,14 @@ static int match_slots(vksift_Instance inst, const MatchScratch *ms, const uint3
     e = refresh_match_cache(inst, ids_b, count);
   if (e)
     return e;
-  uint32_t max_na = 0;
+  uint32_t max_na = 0, max_nb = 0;
   for (uint32_t i = 0; i < count; i++)
   {
-    const uint32_t r = rows_bound(inst, ids_a[i]);
+    const uint32_t r = rows_bound(inst, ids_a[i]), rb = rows_bound(inst, ids_b[i]);
     max_na = r > max_na ? r : max_na;
+    max_nb = rb > max_nb ? rb : max_nb;
   }
-  return vksift_hip_match_2nn_async(inst->d_cache_desc, inst->d_cache_norm, inst->d_cache_n, ids_a, ids_b, max_na,
+  return vksift_hip_match_2nn_async(inst->d_cache_desc, inst->d_cache_norm, inst->d_cache_n, ids_a, ids_b, max_na, max_nb,
                                     ms->redo + (uint64_t)first_slot * inst->redo_slot_stride, ms->match_n + (size_t)first_slot * 4,
                                     ms->matches + (uint64_t)first_slot * inst->match_slot_stride, count, inst->desc_slot_stride, inst->cache_norm_stride,
                                     inst->redo_slot_stride, inst->match_slot_stride, 4, inst->d_match_partial, inst->stream);
@@ -338,7 +339,7 @@ static void download_matches(vksift_Instance inst, uint32_t pair, vksift_Match_2
      * second download after a matching: a caller that samples one pair must not pay for all of them. */
     /* (a page-locked destination takes the records by DMA straight from the slot: vksift_ext_pinHostMemory) */
     if (inst->match_slots_used >= VKSIFT_DL_BATCH_MIN && !inst->md_asked)
-      inst->md_direct = vksift_hip_is_pinned(matches) == 1, inst->md_asked = true; /* once per matching: the query costs a microsecond */
+      inst->md_direct = !detect_running(inst) && vksift_hip_is_pinned(matches) == 1, inst->md_asked = true; /* once per matching: the query costs a microsecond; not behind a queued detection (vksift_buffers.c) */
     if (inst->match_slots_used >= VKSIFT_DL_BATCH_MIN && !inst->md_direct && (inst->md_valid || inst->md_hits++ > 0) &&
         packed_match_download(inst, pair, matches, n))
       return;
