@@ -100,7 +100,7 @@ extern "C"
     VKSIFT_TUNE_PYR_GATE = 6,   /* 1: the next detection's scale-space starts behind the matching queued before it (default: beside it) */
     VKSIFT_TUNE_DENSE_ROWS = 7, /* 1: the descriptor launch does not write the matcher's dense rows (the gather pass of the first matching does, as
                                  * for uploaded buffers); A/B and the bit-identity matrix */
-    VKSIFT_TUNE_COUNT = 8
+    VKSIFT_TUNE_COUNT = 12
   };
   int vksift_hip_tune(int knob, int value);
   int vksift_hip_tune_get(int knob);

@@ -1836,7 +1836,10 @@ extern "C"
         break;
       }
     }
-    const dim3 grid = stream_grid(src.w, src.h, batch, 10240u, &a.seg);
+    /* (11 taps and more: fewer, longer marches — the 2R-row warm-up of a 13-tap segment is 12 rows, and these launches are the VALU
+     * co-limited ones. 512 x 640x480 planes, tools/blur_ab.py: 11 taps 267 -> 256 us, 13 taps 301 -> 287 us with 240-row instead of 120-row
+     * segments; 320x240: 13 taps 95 -> 87 us; 9 taps and fewer: no difference) */
+    const dim3 grid = stream_grid(src.w, src.h, batch, ntaps >= 11u ? 3072u : 10240u, &a.seg);
     switch (ntaps)
     {
 #define VKSIFT_CASE(N)                                                        \
@@ -1878,7 +1881,9 @@ extern "C"
       /* four texels per lane on 256-column strips (k_blur_pair_wide) for launches that fill the chip */
       const uint32_t hcw = (r2 + 3u) & ~3u, oww = 256u - 2u * hcw, wstrips = (W + oww - 1u) / oww;
       const int pw = vksift_hip_tune_get(VKSIFT_TUNE_PAIR_FORM); /* 0: built-in, 1: two texels per lane, 2: four */
-      const bool fills = (uint64_t)wstrips * batch * ((H + 63u) / 64u) >= 2048u;
+      /* ... of planes at least 1024 texels wide: on 512 x 640x480 planes the two-texel form is the faster one (377 against 387 us), on 320x240
+       * by 9 % (109 / 119 us; tools/blur_ab.py) */
+      const bool fills = (uint64_t)wstrips * batch * ((H + 63u) / 64u) >= 2048u && W >= 1024u;
       if (pw != 1 && (fills || pw == 2) && hcw + ra1 <= W && (wstrips - 1u) * oww + 256u + ra1 <= 2u * W + hcw && ((src.pitch | dst1.pitch | dst2.pitch) & 3u) == 0)
       {
         PairArgs aw;

@@ -489,6 +489,7 @@ static int enqueue_detection(DetectCtx *c)
     }
     TRY(enqueue_pyramid(c, o, sp, 0, c->count, PYR_FIRST_GROUP | PYR_LAST_GROUP | (c->fork ? PYR_TRUNK : 0), &g0_done), "scale space construction");
   }
+
   if (c->fork)
   {
     /* Branches: octave o on side stream o & 1 (two, so that a branch does not queue behind the previous octave's). The first one
