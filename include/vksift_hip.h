@@ -100,6 +100,8 @@ extern "C"
     VKSIFT_TUNE_PYR_GATE = 6,   /* 1: the next detection's scale-space starts behind the matching queued before it (default: beside it) */
     VKSIFT_TUNE_DENSE_ROWS = 7, /* 1: the descriptor launch does not write the matcher's dense rows (the gather pass of the first matching does, as
                                  * for uploaded buffers); A/B and the bit-identity matrix */
+    VKSIFT_TUNE_SEED_WG = 8,    /* waves aimed at by the fused up-sampling + seed launch (0 = built-in) */
+    VKSIFT_TUNE_SCAN_BAND = 9,  /* rows per wave of the streaming extrema scan (0 = built-in: 32 on large octaves, 16 on small ones) */
     VKSIFT_TUNE_COUNT = 12
   };
   int vksift_hip_tune(int knob, int value);

@@ -16,9 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(w, h, warm=10, runs=100):
+def run(w, h, warm=int(os.environ.get("WARM", 10)), runs=int(os.environ.get("RUNS", 100))):
     from vulkansift_amd import api
     api.lib().vksift_setLogLevel(api.VKSIFT_LOG_ERROR)
+    for kv in filter(None, os.environ.get("TUNE", "").split(",")):   # development: "knob=value,..." for vksift_hip_tune
+        api.lib().vksift_hip_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
     img = api.gen_synthetic_image(0xABC0 + w, w, h)
     cfg = api.default_config(input_image_max_size=w * h)
     with api.Instance(cfg) as inst:

@@ -14,10 +14,15 @@ print(build.OBJ_DIR)
 PY
 )
 mkdir -p vulkansift_amd/lib/variants
-extra=""
-[ "$file" = match ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
+# the per-file flags of the regular build (vulkansift_amd/build.py: HIP_EXTRA — e.g. -fno-slp-vectorize for pyramid / features): a variant
+# built without them measures the flag, not the source change
+extra=$(python - <<PY
+from vulkansift_amd import build
+print(" ".join(build.HIP_EXTRA.get("hip/$file.hip", [])))
+PY
+)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-gpu-rdc $extra \
-  -Iinclude -Ivulkansift_amd/csrc/host -Ivulkansift_amd/csrc "$@" -c ${SRC:-vulkansift_amd/csrc/hip/$file.hip} -o /tmp/variant_${name}_$file.o
+  -Iinclude -Ivulkansift_amd/csrc/host -Ivulkansift_amd/csrc -Ivulkansift_amd/csrc/hip "$@" -c ${SRC:-vulkansift_amd/csrc/hip/$file.hip} -o /tmp/variant_${name}_$file.o
 objs=$(ls $OBJ/*.o | grep -v "/$file.hip.o" | grep -v "\.asan\.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o vulkansift_amd/lib/variants/lib_$name.so $objs /tmp/variant_${name}_$file.o \
   -L/opt/rocm/lib -lroctx64 -lm -ldl -Wl,-rpath,/opt/rocm/lib

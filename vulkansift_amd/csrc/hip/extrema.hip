@@ -11,7 +11,7 @@
 //   k_segment_scan   : exclusive prefix sum of popcount(mask) over segments in (scale, y, x) order
 //   k_cand_list      : one thread per segment writes its candidates' packed (x, y, s) at offset + rank
 //   k_refine_flags   : one thread per CANDIDATE (dense waves: no lane idles while a neighbour refines) -> accept flag
-//   k_chunk_offsets / k_cand_emit : two-level scan of the accept flags, accepted candidates recompute their record and store it
+//   k_cand_emit      : second level of the scan of the accept counts (block_sum_256), accepted candidates recompute their record and store it
 //                      at their rank (clamped to the section capacity); the un-clamped count goes to found[]
 // The arithmetic of refine_texel() is kept operation-for-operation identical to
 // oracle/sift_oracle.c:extract_one (fp32, no contraction) so results are bit-exact.
@@ -550,8 +550,8 @@ __global__ void __launch_bounds__(256, 4) k_extrema_lean(Multi<ExtremaArgs> m, i
 
 // Exclusive scan of popcount(mask) over the n segments of an image, in two parallel levels (a single workgroup per image
 // made this the longest kernel of a 1080p detection): every 1024-thread workgroup scans one chunk of SEG_CHUNK segments
-// locally and publishes the chunk total; k_chunk_offsets turns the totals of an image into chunk base offsets; the
-// consumer (k_cand_list) adds base + local offset.
+// locally and publishes the chunk total; the consumer (k_cand_list) adds up the totals in front of its chunk (block_sum_256)
+// and adds base + local offset.
 constexpr uint32_t SEG_CHUNK = 4096;
 
 __global__ void __launch_bounds__(1024) k_segment_scan(Multi<ExtremaArgs> m)
@@ -602,77 +602,55 @@ __global__ void __launch_bounds__(1024) k_segment_scan(Multi<ExtremaArgs> m)
     chunk_tot[(size_t)b * chunk_img_stride + vb.x] = total;
 }
 
-// In-place exclusive scan of the per-chunk totals of one image (one workgroup per image, the list is short: n / chunk
-// entries); the grand total goes to total_out[b * total_stride]. count_in != NULL: the number of valid entries is
-// ceil(min(count_in[b], count_cap) / per_chunk) (device-side candidate count), else n_entries.
-// ACCEPTED = false: the candidate-chunk totals of k_segment_scan (in the flag array) -> chunk bases, grand total -> cand_n[b];
-// ACCEPTED = true: the per-256-candidate accept counts of k_refine_flags (in the segment-offset array) -> bases, total -> found[b].
-template <bool ACCEPTED>
-__global__ void __launch_bounds__(1024) k_chunk_offsets(Multi<ExtremaArgs> m)
+// Sum of v[0 .. n) by a 256-thread workgroup (every thread calls it; two barriers). The second level of the two-level scans lives in
+// the consumers since round 6: the lists are short (an image has nsegs / 4096 segment chunks and candidates / 256 refinement chunks), and
+// a workgroup that adds up the entries in front of its own chunk costs less than the launch of a scan kernel did (k_chunk_offsets:
+// two launches of ~5 us each on the critical path of a single-image detection).
+__device__ __forceinline__ uint32_t block_sum_256(const uint32_t *__restrict__ v, uint32_t n, uint32_t *s_red)
 {
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t carry_s;
-  const VBlock vb = vblock(m); // virtual grid (images)
-  const ExtremaArgs &a = m.oct[vb.o];
-  const int b = (int)vb.x;
-  uint32_t *__restrict__ tot = ACCEPTED ? a.seg_off + (size_t)b * a.seg_img_stride : a.cand_flag + (size_t)b * a.cand_img_stride;
-  uint32_t *__restrict__ total_out = ACCEPTED ? a.found : a.cand_n;
-  const uint32_t total_stride = ACCEPTED ? a.found_img_stride : 1u;
-  uint32_t n = a.nchunks;
-  if (ACCEPTED)
-  {
-    uint32_t c = a.cand_n[b];
-    c = c < a.cand_cap ? c : a.cand_cap;
-    n = (c + 255u) / 256u;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0)
-    carry_s = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < n; base += 1024)
-  {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < n ? tot[i] : 0u;
-    uint32_t incl = v;
+  uint32_t acc = 0;
+  for (uint32_t c = threadIdx.x; c < n; c += 256u)
+    acc += v[c];
 #pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1)
-    {
-      uint32_t t = __shfl_up(incl, dlt, 64);
-      if (lane >= dlt)
-        incl += t;
-    }
-    if (lane == 63)
-      wave_tot[wave] = incl;
-    __syncthreads();
-    uint32_t wave_base = 0;
-    for (int wv = 0; wv < wave; wv++)
-      wave_base += wave_tot[wv];
-    const uint32_t carry = carry_s;
-    if (i < n)
-      tot[i] = carry + wave_base + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023)
-      carry_s = carry + wave_base + incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0)
-    total_out[(size_t)b * total_stride] = carry_s;
+  for (int dlt = 32; dlt >= 1; dlt >>= 1)
+    acc += __shfl_xor(acc, dlt, 64);
+  if ((threadIdx.x & 63) == 0)
+    s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  const uint32_t total = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  __syncthreads();
+  return total;
 }
 
 // One thread per 64-pixel segment: expand its candidate ballot into packed coordinates at offset + rank.
 __global__ void __launch_bounds__(256) k_cand_list(Multi<ExtremaArgs> mu)
 {
+  __shared__ uint32_t s_red[4];
   const VBlock vb = vblock(mu); // virtual grid (segment blocks, images)
   const ExtremaArgs &a = mu.oct[vb.o];
   const uint32_t seg = vb.x * 256 + threadIdx.x;
   const int b = (int)vb.y;
+  // base of this workgroup's chunk = the totals of the chunks in front of it (k_segment_scan left them at the start of the still unused
+  // flag array; a workgroup's 256 segments lie in one chunk of SEG_CHUNK); the first workgroup of an image also posts the candidate count
+  const uint32_t *chunk_tot = a.cand_flag + (size_t)b * a.cand_img_stride;
+  const uint32_t chunk_base = block_sum_256(chunk_tot, (vb.x * 256u) / SEG_CHUNK, s_red);
+  if (vb.x == 0)
+  {
+    const uint32_t total = block_sum_256(chunk_tot, a.nchunks, s_red);
+    if (threadIdx.x == 0)
+    {
+      a.cand_n[b] = total;
+      if (total == 0)
+        a.found[(size_t)b * a.found_img_stride] = 0; // no candidate: k_cand_emit visits no chunk of this image
+    }
+  }
   if (seg >= a.nsegs)
     return;
   unsigned long long m = a.seg_mask[seg + (size_t)b * a.seg_img_stride];
   if (m == 0ull)
     return;
-  // offset inside the chunk + base of the chunk (k_segment_scan / k_chunk_offsets; the bases sit in the still unused flag array)
-  uint32_t pos = a.seg_off[seg + (size_t)b * a.seg_img_stride] + a.cand_flag[(size_t)b * a.cand_img_stride + seg / SEG_CHUNK];
+  // offset inside the chunk (k_segment_scan) + base of the chunk
+  uint32_t pos = a.seg_off[seg + (size_t)b * a.seg_img_stride] + chunk_base;
   const uint32_t segx = seg % (uint32_t)a.nseg;
   const uint32_t yy = (seg / (uint32_t)a.nseg) % (uint32_t)a.h;
   const uint32_t sz = seg / ((uint32_t)a.nseg * (uint32_t)a.h);
@@ -689,7 +667,7 @@ __global__ void __launch_bounds__(256) k_cand_list(Multi<ExtremaArgs> mu)
 
 // Dense refinement: thread t of a 256-candidate chunk refines candidate chunk*256 + t (count read from HBM, workgroups
 // stride over the chunks). Besides the accept flags every chunk publishes its number of accepted candidates (into the
-// segment-offset array, free again after k_cand_list) for the two-level scan of k_chunk_offsets / k_cand_emit.
+// segment-offset array, free again after k_cand_list) for the second scan level inside k_cand_emit.
 template <bool F16, bool BUF>
 __global__ void __launch_bounds__(256) k_refine_flags(Multi<ExtremaArgs> m)
 {
@@ -737,6 +715,7 @@ template <bool F16, bool BUF>
 __global__ void __launch_bounds__(256) k_cand_emit(Multi<ExtremaArgs> m)
 {
   __shared__ uint32_t s_cnt[4];
+  __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_list[256];
   const VBlock vb = vblock(m); // virtual grid (images, chunks)
   const ExtremaArgs &a = m.oct[vb.o];
@@ -751,9 +730,11 @@ __global__ void __launch_bounds__(256) k_cand_emit(Multi<ExtremaArgs> m)
       __builtin_amdgcn_make_buffer_rsrc((void *)d.base, 0, (int)((unsigned)(a.S + 3) * (unsigned)a.plane_stride * (F16 ? 2u : 4u)), 0x00020000);
   const uint32_t *xy = a.cand_xy + (size_t)b * a.cand_img_stride;
   const uint32_t *flag = a.cand_flag + (size_t)b * a.cand_img_stride;
-  const uint32_t *chunk_base = a.seg_off + (size_t)b * a.seg_img_stride;
+  const uint32_t *chunk_sum = a.seg_off + (size_t)b * a.seg_img_stride; // accepted candidates per chunk (k_refine_flags)
   for (uint32_t chunk = vb.y; chunk < nch; chunk += vb.gy)
   {
+    // records of the chunks in front of this one (raster order is preserved); the image's last chunk posts the keypoint count
+    const uint32_t cbase = block_sum_256(chunk_sum, chunk, s_red);
     const uint32_t i = chunk * 256u + threadIdx.x;
     const bool v = i < n && flag[i] != 0u;
     const unsigned long long bal = __ballot(v);
@@ -767,7 +748,9 @@ __global__ void __launch_bounds__(256) k_cand_emit(Multi<ExtremaArgs> m)
     if (v)
       s_list[rank] = xy[i];
     __syncthreads();
-    const uint32_t idx = chunk_base[chunk] + threadIdx.x;
+    const uint32_t idx = cbase + threadIdx.x;
+    if (chunk + 1u == nch && threadIdx.x == 0)
+      a.found[(size_t)b * a.found_img_stride] = cbase + total; // un-clamped, like nb_elem (0 candidates: the counter reset's 0 stays)
     if (threadIdx.x < total && idx < a.cap)
     {
       const uint32_t c = s_list[threadIdx.x];
@@ -815,6 +798,8 @@ static int make_extrema_args(const vksift_hip_OctaveJob *job, ExtremaArgs *out)
   /* 32 rows per wave on the large octaves (3 % halo rows); 16 on the small ones, whose share of a launch is latency bound and
    * gains more from twice the waves */
   a.band = job->h > 256u ? 32 : 16;
+  if (vksift_hip_tune_get(VKSIFT_TUNE_SCAN_BAND) > 0)
+    a.band = vksift_hip_tune_get(VKSIFT_TUNE_SCAN_BAND);
   a.nsegs = job->S * job->h * (uint32_t)a.nseg;
   a.nchunks = (a.nsegs + SEG_CHUNK - 1u) / SEG_CHUNK;
   /* the per-image mask regions are contiguous (the clear below is one fill per octave), the chunk bases fit the flag array */
@@ -853,6 +838,16 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
   }
   const bool f16 = args[0].fp16 != 0;
   const int S = args[0].S;
+  {
+    /* A launch that cannot fill the chip (one image, a handful) is bound by the length of a wave's march, not by bandwidth: 16-row bands
+     * everywhere give it twice the waves at half the length (one 640x480 image: the scan 35 -> ~20 us, detection 0.367 -> 0.347 ms) */
+    uint64_t waves = 0;
+    for (uint32_t i = 0; i < n; i++)
+      waves += (uint64_t)batch * ((args[i].w + 127) / 128) * ((args[i].h + args[i].band - 1) / args[i].band);
+    if (waves < 2048u && vksift_hip_tune_get(VKSIFT_TUNE_SCAN_BAND) <= 0)
+      for (uint32_t i = 0; i < n; i++)
+        args[i].band = 16;
+  }
 
   /* 1. candidate ballots: only non-empty 64-pixel segments are stored (scattered 8-byte stores were the bottleneck of this
    * pass), so the mask arrays are cleared first: one fill when the octaves' regions follow each other (the instance's layout) */
@@ -911,8 +906,6 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
     VKSIFT_MULTI(m2, a.nchunks, batch, 1u)
     hipLaunchKernelGGL(k_segment_scan, dim3(m2.start[m2.n]), dim3(1024), 0, hs, m2);
   }
-  VKSIFT_MULTI(mi, batch, 1u, 1u) /* one workgroup per image */
-  hipLaunchKernelGGL(k_chunk_offsets<false>, dim3(mi.start[mi.n]), dim3(1024), 0, hs, mi);
   /* 3. compact list, 4. dense refinement (+ per-chunk accept counts), 5. scan of those counts, 6. accepted -> records */
   {
     VKSIFT_MULTI(m3, (a.nsegs + 255u) / 256u, batch, 1u)
@@ -940,7 +933,6 @@ static int extract_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t ba
     hipLaunchKernelGGL((k_refine_flags<false, true>), rgrid, dim3(256), 0, hs, mr);
   else
     hipLaunchKernelGGL((k_refine_flags<false, false>), rgrid, dim3(256), 0, hs, mr);
-  hipLaunchKernelGGL(k_chunk_offsets<true>, dim3(mi.start[mi.n]), dim3(1024), 0, hs, mi);
   if (f16 && buf)
     hipLaunchKernelGGL((k_cand_emit<true, true>), rgrid, dim3(256), 0, hs, mr);
   else if (f16)

@@ -1823,7 +1823,8 @@ extern "C"
     if (fills && !src.fp16 && !dst.fp16 && ((wide_mask >> ntaps) & 1) && (src.w % 4u) == 0 && ra <= src.w && wstrips * 256u + ra <= 2u * src.w &&
         wstrips * 256u - src.w <= 64u && ((src.pitch | dst.pitch) & 3u) == 0)
     {
-      const dim3 wgrid = stream_grid(src.w, src.h, batch, 10240u, &a.seg, 256u);
+      /* (from 11 taps on half as many, twice as long marches: 512 x 1280x960, tools/blur_ab.py: 11 taps 928 -> 905 us, 13 taps 988 -> 939 us) */
+      const dim3 wgrid = stream_grid(src.w, src.h, batch, ntaps >= 11u ? 5120u : 10240u, &a.seg, 256u);
       switch (ntaps)
       {
 #define VKSIFT_CASE(N)                                              \
@@ -1962,7 +1963,8 @@ extern "C"
     a.rev = (int)dst.reverse;
     for (uint32_t i = 0; i < VKSIFT_HIP_MAX_TAPS; i++)
       a.taps.k[i] = i < ntaps ? taps[i] : 0.f;
-    uint32_t nseg = (10240u + strips * batch - 1u) / (strips * batch); /* as the other launches (stream_grid): 2560 long-lived waves left the tail to a few CUs */
+    const uint32_t seed_wg = vksift_hip_tune_get(VKSIFT_TUNE_SEED_WG) > 0 ? (uint32_t)vksift_hip_tune_get(VKSIFT_TUNE_SEED_WG) : 10240u;
+    uint32_t nseg = (seed_wg + strips * batch - 1u) / (strips * batch); /* as the other launches (stream_grid): 2560 long-lived waves left the tail to a few CUs */
     const uint32_t waves64 = strips * batch * ((H + 63u) / 64u);
     const uint32_t seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u); /* latency-bound launches: shorter marches (stream_grid) */
     uint32_t max_seg = (H + seg_rows - 1u) / seg_rows;

@@ -497,7 +497,7 @@ static float placement_probe_ms(vksift_Instance inst, void *buf, uint64_t img_st
 /* out[0 .. need): device blocks of `bytes` each for a scale-space of layout L (octave 0 is what gets timed); false: out of memory
  * (nothing is left allocated). may_search = false: plain allocation (re-allocations in the middle of a caller's detect call).
  * The rejected candidates of a search stay allocated while it runs — freed, the allocator would hand the same range out again —
- * so the search is bounded: the candidates together never hold more than VKSIFT_PLACE_MEM_FRACTION (40 %) of the memory that was
+ * so the search is bounded: the candidates together never hold more than VKSIFT_PLACE_MEM_FRACTION (55 %) of the memory that was
  * free when it started, and 24 GB stay free for the rest of the instance and for whoever else uses the device. */
 static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t img_stride, const PyrLayout *L, uint32_t need, float **out, bool may_search)
 {
@@ -513,7 +513,7 @@ static bool place_pyramid_buffers(vksift_Instance inst, size_t bytes, uint64_t i
   vksift_hip_event e0 = NULL, e1 = NULL;
   const bool search = may_search && max_cand > (int)need && inst->det_cap >= 8u && bytes >= ((size_t)256 << 20) && L->n_oct > 0 && inst->stream != NULL &&
                       (e0 = vksift_hip_event_create()) != NULL && (e1 = vksift_hip_event_create()) != NULL;
-  const size_t budget = search ? (size_t)((double)vksift_hip_device_free_mem() * 0.40) : 0;
+  const size_t budget = search ? (size_t)((double)vksift_hip_device_free_mem() * 0.55) : 0;
   void *cand[VKSIFT_PLACE_MAX] = {NULL};
   float ms[VKSIFT_PLACE_MAX];
   uint32_t n = 0;
