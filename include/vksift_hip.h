@@ -102,6 +102,8 @@ extern "C"
                                  * for uploaded buffers); A/B and the bit-identity matrix */
     VKSIFT_TUNE_SEED_WG = 8,    /* waves aimed at by the fused up-sampling + seed launch (0 = built-in) */
     VKSIFT_TUNE_SCAN_BAND = 9,  /* rows per wave of the streaming extrema scan (0 = built-in: 32 on large octaves, 16 on small ones) */
+    VKSIFT_TUNE_TAIL_MULTI = 10, /* 1: no multi-octave launches for scales S+1, S+2 (batches queue every octave in full; forked detections one launch per
+                                  * octave and scale) */
     VKSIFT_TUNE_COUNT = 12
   };
   int vksift_hip_tune(int knob, int value);
@@ -144,6 +146,14 @@ extern "C"
    * sift_detector.c:1003-1034 for exactly halved sizes, stored from the registers that hold the blurred rows (the separate
    * pass re-reads the whole plane). Bit-identical to vksift_hip_blur + vksift_hip_downsample. Returns -1 without launching
    * anything when the shape or the selected kernel does not cover it: the caller then issues the two separate calls. */
+  /* One scale of n <= 8 octaves in ONE launch: dst[i] = blur(src[i]) for every i with the same taps (scales S+1 and S+2 of a detection's octaves
+   * feed nothing but the extrema scan, so they can be queued per scale instead of per octave). Returns -1 without launching anything when a
+   * plane is outside the strip-march kernel's domain, the texel types differ or the tap count has no multi-octave instantiation (9, 11, 13,
+   * 15 taps exist): the caller then takes vksift_hip_blur per plane. Same kernel body: bit-identical to those launches. */
+  /* the kernel vksift_hip_blur takes for this shape: 0 generic tiles, 1 two texels per lane (what vksift_hip_blur_multi launches), 2 four texels per lane */
+  int vksift_hip_blur_form(vksift_hip_Plane src, vksift_hip_Plane dst, uint32_t ntaps, uint32_t batch);
+  int vksift_hip_blur_multi(const vksift_hip_Plane *src, const vksift_hip_Plane *dst, uint32_t n, const float *taps, uint32_t ntaps, uint32_t batch,
+                            vksift_hip_stream s);
   int vksift_hip_blur_downsample(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane next, const float *taps, uint32_t ntaps, uint32_t batch,
                                  vksift_hip_stream s);
 

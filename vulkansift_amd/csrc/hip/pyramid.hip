@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#include "multi.h"
 #include "vksift_hip.h"
 
 namespace
@@ -320,8 +321,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base, 
 // SRC: 0 = a plane of the pyramid; 1 = the u8 input at half the resolution (UPS above); 2 = the u8 input at the plane's own
 // resolution (use_input_upsampling = false: vkCmdCopyBufferToImage + the 1:1 blit + the seed blur in one pass, value / 255
 // through the same table). a.src then points at the u8 images (a.src_img_stride in bytes), a.spitch is the source width.
+// (the body is shared by k_blur_lean — one plane set per launch, the launch grid is the work grid — and k_blur_lean_multi — several
+// octaves' planes in one flat launch, csrc/hip/multi.h: gx/gy/gz and bx/by/bz are then the octave's virtual grid)
 template <int NT, int SRC, bool F16>
-__global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
+__device__ __forceinline__ void blur_lean_body(const StreamArgs &a, const uint32_t bx_, const uint32_t by_, const uint32_t bz_, const uint32_t gx_,
+                                               const uint32_t gy_, const uint32_t gz_)
 {
   constexpr bool UPS = SRC == 1, U8 = SRC == 2;
   constexpr int NR = 8;
@@ -342,10 +346,10 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
   // XCD-aware work mapping: workgroup b is observed to run on XCD b % 8 (each XCD has its own L2). Give every XCD a
   // contiguous range of the (image, segment, strip) space, strips fastest, so that the workgroups that share halo
   // columns and warm-up rows run on the same XCD at about the same time and find them in its L2.
-  uint32_t bs = blockIdx.x, bseg = blockIdx.y, bimg = blockIdx.z;
+  uint32_t bs = bx_, bseg = by_, bimg = bz_;
   {
-    const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
-    const uint32_t b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const uint32_t total = gx_ * gy_ * gz_;
+    const uint32_t b = bx_ + gx_ * (by_ + gy_ * bz_);
     uint32_t wi = b;
     if ((total & 7u) == 0)
     {
@@ -356,10 +360,10 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
       wi = total - 1u - b;
     if ((total & 7u) == 0 || a.rev)
     {
-      bs = wi % gridDim.x;
-      const uint32_t r = wi / gridDim.x;
-      bseg = r % gridDim.y;
-      bimg = r / gridDim.y;
+      bs = wi % gx_;
+      const uint32_t r = wi / gx_;
+      bseg = r % gy_;
+      bimg = r / gy_;
     }
   }
   const int x0 = bs * TW;
@@ -714,6 +718,23 @@ __global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
     for (int k = 0; k < 2 * R; k++)
       wv[k] = wv[k + NR];
   }
+}
+
+template <int NT, int SRC, bool F16>
+__global__ void __launch_bounds__(64) k_blur_lean(StreamArgs a)
+{
+  blur_lean_body<NT, SRC, F16>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
+}
+
+// The same scale of SEVERAL octaves in one launch (round 6): scales S+1 and S+2 of an octave feed nothing but the extrema scan, so they can
+// wait until the chain seed -> ... -> scale S has run through every octave and then go as ONE launch per scale over all octaves instead of
+// one per octave and scale — for one image 8 dependent launches of 11 us become 4, for a batch the coarse octaves' launches (too small to fill the
+// chip) ride in the tail of the larger ones'. Flat grid, every workgroup looks up its octave and its place in that octave's own grid.
+template <int NT, bool F16>
+__global__ void __launch_bounds__(64) k_blur_lean_multi(Multi<StreamArgs> m)
+{
+  const VBlock vb = vblock(m);
+  blur_lean_body<NT, 0, F16>(m.oct[vb.o], vb.x, vb.y, vb.z, vb.gx, vb.gy, vb.gz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1786,6 +1807,27 @@ extern "C"
   }
 
   constexpr int WIDE_DEFAULT_MASK = (1 << 9) | (1 << 11) | (1 << 13);
+  /* which kernel a blur of this shape takes: 0 the generic tile kernel, 1 the two-texel strip march (k_blur_lean), 2 the four-texel one (k_blur_wide) */
+  static int blur_form(const vksift_hip_Plane &src, const vksift_hip_Plane &dst, uint32_t ntaps, uint32_t batch)
+  {
+    const uint32_t ra = ((ntaps - 1u) + 3u) & ~3u;
+    const uint32_t nstrips = (src.w + 127u) / 128u;
+    const bool lean = ntaps >= 2 && (src.w % 4u) == 0 && ra <= src.w && nstrips * 128u + ra <= 2u * src.w;
+    if (!lean)
+      return 0;
+    /* four texels per lane on 256-column strips (k_blur_wide): fp32 planes whose width wastes little of the last strip */
+    const int wide_mask = vksift_hip_tune_get(VKSIFT_TUNE_WIDE_MASK) >= 0 ? vksift_hip_tune_get(VKSIFT_TUNE_WIDE_MASK) : WIDE_DEFAULT_MASK;
+    const uint32_t wstrips = (src.w + 255u) / 256u;
+    /* (launches that cannot fill the chip — a single image, the coarse octaves of a small batch — are latency bound and want the larger
+     * number of shorter-lived waves the 128-column strips give them: one 640x480 image 0.355 -> 0.378 ms with wide strips everywhere) */
+    const bool fills = (uint64_t)wstrips * batch * ((src.h + 63u) / 64u) >= 2048u || vksift_hip_tune_get(VKSIFT_TUNE_WIDE_MASK) >= 0;
+    if (fills && !src.fp16 && !dst.fp16 && ((wide_mask >> ntaps) & 1) && (src.w % 4u) == 0 && ra <= src.w && wstrips * 256u + ra <= 2u * src.w &&
+        wstrips * 256u - src.w <= 64u && ((src.pitch | dst.pitch) & 3u) == 0)
+      return 2;
+    return 1;
+  }
+  int vksift_hip_blur_form(vksift_hip_Plane src, vksift_hip_Plane dst, uint32_t ntaps, uint32_t batch) { return blur_form(src, dst, ntaps, batch); }
+
   static int blur_impl(vksift_hip_Plane src, vksift_hip_Plane dst, vksift_hip_Plane ds, const float *taps, uint32_t ntaps, uint32_t batch, vksift_hip_stream s)
   {
     if (ntaps < 1 || ntaps > VKSIFT_HIP_MAX_TAPS || src.base == dst.base || dst.base == NULL)
@@ -1800,9 +1842,8 @@ extern "C"
       force_tile = (e && e[0] == 't') ? 1 : 0;
     }
     const uint32_t ra = ((ntaps - 1u) + 3u) & ~3u;
-    const uint32_t nstrips = (src.w + 127u) / 128u;
-    const bool lean = !force_tile && ntaps >= 2 && (src.w % 4u) == 0 && ra <= src.w && nstrips * 128u + ra <= 2u * src.w;
-    if (!lean)
+    const int form = force_tile ? 0 : blur_form(src, dst, ntaps, batch);
+    if (form == 0)
       return ds.base ? -1 : blur_tile_launch(src, dst, t, ntaps, batch, s);
 
     StreamArgs a;
@@ -1814,14 +1855,8 @@ extern "C"
     a.rev = (int)dst.reverse;
     a.taps = t;
     hipStream_t hs = (hipStream_t)s;
-    /* four texels per lane on 256-column strips (k_blur_wide): fp32 planes whose width wastes little of the last strip */
-    const int wide_mask = vksift_hip_tune_get(VKSIFT_TUNE_WIDE_MASK) >= 0 ? vksift_hip_tune_get(VKSIFT_TUNE_WIDE_MASK) : WIDE_DEFAULT_MASK;
-    const uint32_t wstrips = (src.w + 255u) / 256u;
-    /* (launches that cannot fill the chip — a single image, the coarse octaves of a small batch — are latency bound and want the larger
-     * number of shorter-lived waves the 128-column strips give them: one 640x480 image 0.355 -> 0.378 ms with wide strips everywhere) */
-    const bool fills = (uint64_t)wstrips * batch * ((src.h + 63u) / 64u) >= 2048u || vksift_hip_tune_get(VKSIFT_TUNE_WIDE_MASK) >= 0;
-    if (fills && !src.fp16 && !dst.fp16 && ((wide_mask >> ntaps) & 1) && (src.w % 4u) == 0 && ra <= src.w && wstrips * 256u + ra <= 2u * src.w &&
-        wstrips * 256u - src.w <= 64u && ((src.pitch | dst.pitch) & 3u) == 0)
+    (void)ra;
+    if (form == 2)
     {
       /* (from 11 taps on half as many, twice as long marches: 512 x 1280x960, tools/blur_ab.py: 11 taps 928 -> 905 us, 13 taps 988 -> 939 us) */
       const dim3 wgrid = stream_grid(src.w, src.h, batch, ntaps >= 11u ? 5120u : 10240u, &a.seg, 256u);
@@ -1856,6 +1891,60 @@ extern "C"
 #undef VKSIFT_CASE
     default:
       return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
+  }
+
+  /* One scale of n octaves (src[i] -> dst[i], same taps) in ONE launch of the two-texel strip march; -1 (nothing launched) when a plane is
+   * not covered by that kernel, the texel types differ or the tap count has no multi-octave instantiation: the caller then takes
+   * vksift_hip_blur per plane. Bit-identical to those launches (the same kernel body). */
+  int vksift_hip_blur_multi(const vksift_hip_Plane *src, const vksift_hip_Plane *dst, uint32_t n, const float *taps, uint32_t ntaps, uint32_t batch,
+                            vksift_hip_stream s)
+  {
+    if (n == 0 || batch == 0)
+      return 0;
+    if (n > (uint32_t)MULTI_MAX || ntaps < 2 || ntaps > VKSIFT_HIP_MAX_TAPS || getenv("VKSIFT_BLUR_KERNEL"))
+      return -1;
+    if (ntaps != 9 && ntaps != 11 && ntaps != 13 && ntaps != 15)
+      return -1;
+    Multi<StreamArgs> m;
+    m.n = 0;
+    const uint32_t ra = ((ntaps - 1u) + 3u) & ~3u;
+    for (uint32_t i = 0; i < n; i++)
+    {
+      const vksift_hip_Plane &p = src[i], &d = dst[i];
+      const uint32_t nstrips = (p.w + 127u) / 128u;
+      if (p.base == NULL || d.base == NULL || p.base == d.base || p.fp16 != src[0].fp16 || d.fp16 != src[0].fp16 || d.w != p.w || d.h != p.h || (p.w % 4u) != 0 ||
+          ra > p.w || nstrips * 128u + ra > 2u * p.w)
+        return -1;
+      StreamArgs a;
+      a.ds = NULL, a.ds_img_stride = 0, a.ds_pitch = 0;
+      a.src = p.base, a.dst = d.base;
+      a.src_img_stride = p.img_stride, a.dst_img_stride = d.img_stride;
+      a.spitch = (int)p.pitch, a.dpitch = (int)d.pitch;
+      a.w = (int)p.w, a.h = (int)p.h;
+      a.rev = (int)d.reverse;
+      for (uint32_t k = 0; k < VKSIFT_HIP_MAX_TAPS; k++)
+        a.taps.k[k] = k < ntaps ? taps[k] : 0.f;
+      const dim3 g = stream_grid(p.w, p.h, batch, ntaps >= 11u ? 3072u : 10240u, &a.seg);
+      if (!multi_add(m, a, g.x, g.y, g.z))
+        return -1;
+    }
+    const dim3 grid(m.start[m.n]);
+    const bool f16 = src[0].fp16 != 0;
+    switch (ntaps)
+    {
+#define VKSIFT_CASE(N)                                                                      \
+  case N:                                                                                   \
+    if (f16)                                                                                \
+      hipLaunchKernelGGL((k_blur_lean_multi<N, true>), grid, dim3(64), 0, (hipStream_t)s, m);  \
+    else                                                                                    \
+      hipLaunchKernelGGL((k_blur_lean_multi<N, false>), grid, dim3(64), 0, (hipStream_t)s, m); \
+    break;
+      VKSIFT_CASE(9) VKSIFT_CASE(11) VKSIFT_CASE(13) VKSIFT_CASE(15)
+#undef VKSIFT_CASE
+    default:
+      return -1;
     }
     return (int)hipGetLastError();
   }

@@ -193,6 +193,8 @@ typedef struct
   size_t img_bytes;
   uint32_t nblur; /* blur launches of octave 0 (the profiled scale-space interval) */
   uint32_t nblur_all; /* ... of every octave */
+  bool tail_batch;    /* a batch queues scales S+1, S+2 of its coarser octaves per SCALE (enqueue_tail), like a forked detection does */
+  bool tail[VKSIFT_MAX_OCTAVES]; /* octave o was queued up to scale S only: its last two scales go with enqueue_tail */
   vksift_hip_OctaveJob jobs[VKSIFT_MAX_OCTAVES];
 } DetectCtx;
 
@@ -318,7 +320,8 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint3
     }
     if ((group_flags & PYR_TRUNK) && s == inst->S + 1u)
     {
-      TRY(vksift_hip_event_record(inst->ev_fork[o], sp), "event record");
+      if (c->fork)
+        TRY(vksift_hip_event_record(inst->ev_fork[o], sp), "event record");
       break;
     }
     if ((group_flags & PYR_BRANCH) && s == inst->S + 1u)
@@ -368,6 +371,52 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint3
     if (c->prof && (group_flags & PYR_LAST_GROUP))
       vksift_hip_event_record(c->PS->ev_pt[1], sp);
   }
+  return 0;
+}
+
+/* Scales S+1 and S+2 of the octaves marked in c->tail[] among [o0, o1): they feed nothing but the extrema scan (scale S seeds the next octave,
+ * they do not), so they wait until the chain seed -> ... -> scale S has been queued for every octave and go as ONE launch per SCALE over all
+ * those octaves (vksift_hip_blur_multi: a flat multi-octave grid, csrc/hip/multi.h) — 2 launches instead of 2 per octave; shapes that kernel
+ * does not serve take one launch per octave and scale as before. Same kernel body either way: bit-identical planes. */
+static int enqueue_tail(DetectCtx *c, uint32_t o0, uint32_t o1, vksift_hip_stream sp)
+{
+  vksift_Instance inst = c->inst;
+  const PyrLayout *L = c->L;
+  for (uint32_t s = inst->S + 1u; s < inst->S + 3u; s++)
+  {
+    vksift_hip_Plane src[VKSIFT_MAX_OCTAVES], dst[VKSIFT_MAX_OCTAVES];
+    uint32_t n = 0;
+    for (uint32_t o = o0; o < o1 && o < L->n_oct; o++)
+      if (c->tail[o])
+      {
+        src[n] = plane_at(inst, o, L->gauss_off[o], s - 1u);
+        dst[n] = plane_at(inst, o, L->gauss_off[o], s);
+        dst[n].reverse = inst->alt_order ? (s & 1u) : 0u;
+        n++;
+      }
+    for (uint32_t i0 = 0; i0 < n; i0 += 8u)
+    {
+      const uint32_t k = n - i0 < 8u ? n - i0 : 8u;
+      const int me = vksift_hip_tune_get(VKSIFT_TUNE_TAIL_MULTI) == 1
+                         ? -1
+                         : vksift_hip_blur_multi(src + i0, dst + i0, k, &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], c->count, sp);
+      if (me > 0)
+        TRY(me, "multi-octave blur");
+      if (me == 0)
+      {
+        c->nblur_all++;
+        continue;
+      }
+      for (uint32_t i = i0; i < i0 + k; i++)
+      {
+        TRY(vksift_hip_blur(src[i], dst[i], &inst->taps[s * VKSIFT_MAX_TAPS], inst->ntaps[s], c->count, sp), "blur");
+        c->nblur_all++;
+      }
+    }
+  }
+  for (uint32_t o = o0; o < o1 && o < L->n_oct; o++)
+    if (c->tail[o])
+      c->jobs[o].scan_reverse = inst->alt_order ? (((inst->S + 2u) & 1u) ^ 1u) : 0u; /* opposite to the last launch */
   return 0;
 }
 
@@ -487,43 +536,41 @@ static int enqueue_detection(DetectCtx *c)
       g0_done = true;
       chain_from = L->n_oct;
     }
-    TRY(enqueue_pyramid(c, o, sp, 0, c->count, PYR_FIRST_GROUP | PYR_LAST_GROUP | (c->fork ? PYR_TRUNK : 0), &g0_done), "scale space construction");
+    /* a batch: octave 0 (and every octave whose last two scales take the four-texel kernel) in full, the coarser ones up to scale S */
+    bool tail_o = c->fork;
+    if (c->tail_batch && o >= 1u)
+    {
+      const vksift_hip_Plane p = plane_at(inst, o, L->gauss_off[o], 0);
+      tail_o = vksift_hip_blur_form(p, p, inst->ntaps[inst->S + 1u], c->count) == 1 && vksift_hip_blur_form(p, p, inst->ntaps[inst->S + 2u], c->count) == 1;
+    }
+    c->tail[o] = tail_o;
+    TRY(enqueue_pyramid(c, o, sp, 0, c->count, PYR_FIRST_GROUP | PYR_LAST_GROUP | (tail_o ? PYR_TRUNK : 0), &g0_done), "scale space construction");
   }
+  if (c->tail_batch)
+    TRY(enqueue_tail(c, 1u, L->n_oct, sp), "scale space construction");
 
   if (c->fork)
   {
-    /* Branches: octave o on side stream o & 1 (two, so that a branch does not queue behind the previous octave's). The first one
-     * also takes the two clears: its stream is ordered behind everything queued on the trunk stream up to scale S of the first
-     * octave — in particular behind the previous detection's readers of the counters and masks. */
-    vksift_hip_stream side[2] = {inst->pyr_stream, inst->fork_streams > 1 ? inst->side_stream : inst->pyr_stream};
-    bool used[2] = {false, false};
-    const uint32_t o0 = oct0_done ? 1u : 0u;
-    const bool has_branch = o0 < chain_from && o0 < L->n_oct;
-    if (has_branch)
+    /* Branch: the scales behind S of every forked octave on a side stream. It also takes the two clears: ordered behind everything queued on
+     * the trunk stream up to scale S of the first octave — in particular behind the previous detection's readers of the counters and masks. */
+    vksift_hip_stream side = inst->pyr_stream;
+    const uint32_t o0 = oct0_done ? 1u : 0u, o_end = chain_from < L->n_oct ? chain_from : L->n_oct;
+    if (o0 < o_end)
     {
-      TRY(vksift_hip_stream_wait_event(side[o0 & 1u], inst->ev_fork[o0]), "scale fork");
-      TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, side[o0 & 1u]),
-          "counter reset");
-      if (vksift_hip_clear_segment_masks(c->jobs, L->n_oct, c->count, side[o0 & 1u]) == 0)
+      TRY(vksift_hip_stream_wait_event(side, inst->ev_fork[o0]), "scale fork");
+      TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, side), "counter reset");
+      if (vksift_hip_clear_segment_masks(c->jobs, L->n_oct, c->count, side) == 0)
         for (uint32_t o = 0; o < L->n_oct; o++)
           c->jobs[o].masks_cleared = 1u;
-      used[o0 & 1u] = true;
+      /* ONE launch per scale over all forked octaves (round 6; one per octave and scale before: eight dependent launches on this stream
+       * were the end of a 640x480 detection's scale-space, 173 us after its start — with two the LDS chain of the coarsest octave is) */
+      TRY(vksift_hip_stream_wait_event(side, inst->ev_fork[o_end - 1u]), "scale fork");
+      TRY(enqueue_tail(c, o0, o_end, side), "scale space construction");
+      TRY(vksift_hip_event_record(inst->ev_join[0], side), "event record");
+      TRY(vksift_hip_stream_wait_event(sp, inst->ev_join[0]), "scale join");
     }
     else
       TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, sp), "counter reset");
-    for (uint32_t o = o0; o < chain_from && o < L->n_oct; o++)
-    {
-      TRY(enqueue_pyramid(c, o, side[o & 1u], 0, c->count, PYR_BRANCH, &g0_done), "scale space construction");
-      used[o & 1u] = true;
-    }
-    if (side[1] == side[0])
-      used[0] = used[0] || used[1], used[1] = false;
-    for (int k = 0; k < 2; k++)
-      if (used[k])
-      {
-        TRY(vksift_hip_event_record(inst->ev_join[k], side[k]), "event record");
-        TRY(vksift_hip_stream_wait_event(sp, inst->ev_join[k]), "scale join");
-      }
   }
   if (c->prof)
     vksift_hip_event_record(c->PS->ev_pt[2], sp); /* every octave's scale-space is queued (forked branches have joined) */
@@ -724,6 +771,9 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   c.w = w, c.h = h, c.count = count, c.first_buf = first_buf;
   c.img_bytes = (size_t)w * h;
   c.nblur = 0, c.nblur_all = 0;
+  memset(c.tail, 0, sizeof(c.tail));
+  /* (VKSIFT_TUNE_TAIL_MULTI = 1: every octave in full, one launch per octave and scale — A/B and the bit-identity matrix) */
+  c.tail_batch = !c.fork && count >= 8u && c.L->n_oct > 1u && vksift_hip_tune_get(VKSIFT_TUNE_TAIL_MULTI) == 0;
   c.capturing = false;
   c.gpu_busy = detect_running(inst);
   /* forked scale-space + LDS chain are latency measures for ONE image (or a handful): a batch on a single-buffer instance
