@@ -242,6 +242,13 @@ extern "C"
     uint32_t n_img_stride;
     uint32_t nsec;
     uint32_t sec_cap[16];
+    /* feature posting (single-image detections): the same rows as dense 164-byte RECORDS into host-mapped memory — what
+     * vksift_hip_pack_features would store there — and the buffer's found_post_n section counters beside them (image b: post +
+     * b*post_img_stride bytes, found_post + b*found_post_n words). NULL: off. desc / norm / n may then be NULL as well (rows not wanted). */
+    uint8_t *post;
+    uint64_t post_img_stride;
+    uint32_t *found_post;
+    uint32_t found_post_n;
   } vksift_hip_DenseRows;
 
   /* ExtractKeypoints.comp (sift_detector.c:1106-1189) as a deterministic, atomic-free pipeline: streaming

@@ -581,7 +581,10 @@ k_descriptor(Multi<FeatArgs> m, vksift_hip_DenseRows dr)
   // it. All counters are final here (the orientation launches of every octave precede this one); uniform scalar loads.
   // (the row offset waits in LDS for the epilogue: nothing of this stays in registers across the sample loop)
   __shared__ uint32_t s_row0;
-  if (dr.desc)
+  // (posting belongs to single-image detections, which take the four-wave form: the two-wave instantiation of batches — the kernel that
+  // sits on its instruction floor with 64 VGPRs — does not carry that code)
+  constexpr bool CAN_POST = NWV == 4;
+  if (dr.desc || (CAN_POST && dr.post))
   {
     const uint32_t *fsec = a.found + (size_t)b * a.found_img_stride - a.sec; // counter of section 0 of this image's buffer
     uint32_t row0 = 0, total = 0;
@@ -596,9 +599,11 @@ k_descriptor(Multi<FeatArgs> m, vksift_hip_DenseRows dr)
     // the buffer's row count and the zero rows of quirk Q6: first workgroup of section 0's share of this image
     if (a.sec == 0 && (IMG_FAST ? vb.y : vb.x) == 0)
     {
-      if (tid == 0)
+      if (CAN_POST && dr.post && (uint32_t)tid < dr.found_post_n)
+        dr.found_post[(size_t)b * dr.found_post_n + tid] = fsec[tid]; // the counters travel with the posted records
+      if (dr.desc && tid == 0)
         dr.n[(size_t)b * dr.n_img_stride] = total;
-      if (total < 2u && tid < 64)
+      if (dr.desc && total < 2u && tid < 64)
       {
         uint32_t *z = (uint32_t *)(dr.desc + (size_t)b * dr.desc_img_stride);
         if (tid >= (int)total * 32)
@@ -831,6 +836,18 @@ k_descriptor(Multi<FeatArgs> m, vksift_hip_DenseRows dr)
         desc[lane >> 2] = p0;
         desc[16 + (lane >> 2)] = p1;
       }
+      if (CAN_POST && dr.post)
+      {
+        // the posted record: 9 header words from the section record (written by the extraction and orientation launches), the
+        // descriptor's 32 words from the registers of the lanes that hold them
+        const uint32_t j = (uint32_t)lane & 15u;
+        const uint32_t d0 = __shfl(p0, (int)(4u * j), 64), d1 = __shfl(p1, (int)(4u * j), 64);
+        uint32_t *out = (uint32_t *)(dr.post + (size_t)b * dr.post_img_stride) + (size_t)(s_row0 + k) * 41u;
+        if (lane < 32)
+          out[9 + lane] = lane < 16 ? d0 : d1;
+        else if (lane < 41)
+          out[lane - 32] = ((const uint32_t *)rec)[lane - 32];
+      }
       if (dr.desc)
       {
         const uint32_t row0 = s_row0;
@@ -977,6 +994,8 @@ static int descriptor_run(const vksift_hip_OctaveJob *jobs, uint32_t n, uint32_t
    * 3-4 % faster with 2 (less redundant per-keypoint work, measured under the overlapped batch schedule) */
   /* waves per keypoint: 4 for single images (latency), 2 for batches (1 wave: 55 % slower, 8: no faster than 4; measured round 2) */
   const int nwv = batch >= 8u ? 2 : 4;
+  if (dr.post && nwv != 4)
+    return (int)hipErrorInvalidValue; /* posting is compiled into the four-wave form only */
   const bool f16 = md.oct[0].fp16 != 0;
   const dim3 grid(md.start[md.n]);
 #define VKSIFT_DESC(N)                                                                  \
@@ -1108,7 +1127,9 @@ extern "C"
     vksift_hip_DenseRows dr = {};
     if (dense)
     {
-      if (!dense->desc || !dense->norm || !dense->n || dense->nsec == 0 || dense->nsec > 16u)
+      const bool rows = dense->desc != NULL, post = dense->post != NULL;
+      if ((!rows && !post) || (rows && (!dense->norm || !dense->n)) || (post && (!dense->found_post || dense->found_post_n > 64u)) || dense->nsec == 0 ||
+          dense->nsec > 16u)
         return (int)hipErrorInvalidValue;
       for (uint32_t i = 0; i < n_jobs; i++)
         if (jobs[i].sec_index >= dense->nsec)

@@ -256,7 +256,7 @@ static vksift_hip_Plane plane_sub(vksift_Instance inst, vksift_hip_Plane p, uint
   return p;
 }
 
-enum { PYR_FIRST_GROUP = 1, PYR_LAST_GROUP = 2, PYR_TRUNK = 4, PYR_BRANCH = 8 };
+enum { PYR_FIRST_GROUP = 1, PYR_LAST_GROUP = 2, PYR_TRUNK = 4 };
 static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint32_t first, uint32_t count, int group_flags, bool *g0_done)
 {
   vksift_Instance inst = c->inst;
@@ -264,9 +264,7 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint3
   uint32_t nb_o = 0;
 #define PL(oct, layer) plane_sub(inst, plane_at(inst, (oct), L->gauss_off[(oct)], (layer)), first)
   vksift_hip_range_push("Scale space construction");
-  if (group_flags & PYR_BRANCH)
-    ; /* the octave's seed and its scales up to S were queued by the trunk pass */
-  else if (o == 0)
+  if (o == 0)
   {
     if (c->prof && (group_flags & PYR_FIRST_GROUP))
       vksift_hip_event_record(c->PS->ev_pt[0], sp);
@@ -302,30 +300,17 @@ static int enqueue_pyramid(DetectCtx *c, uint32_t o, vksift_hip_stream sp, uint3
   }
   else if (!*g0_done)
     TRY(vksift_hip_downsample(PL(o - 1, inst->S), PL(o, 0), count, sp), "downsample");
-  if (!(group_flags & PYR_BRANCH))
-    *g0_done = false;
+  *g0_done = false;
   /* consecutive launches of the chain walk the batch in opposite directions: a launch starts on the planes its predecessor wrote
    * last, which are still in the Infinity Cache (a whole-batch plane is 2.5x the cache: in the same direction every read misses);
    * the extrema scan continues the alternation */
   uint32_t li = 0;
   for (uint32_t s = 1; s < inst->S + 3; s++)
   {
-    /* forked detections (DetectCtx::fork): the launches up to scale S — the path to the next octave — are queued for ALL octaves
-     * first (PYR_TRUNK), the ones behind scale S afterwards on the side stream (PYR_BRANCH, sp is that stream then): the host
-     * queues a launch every ~5 us, and a branch launch queued in between would delay the trunk by as much */
-    if ((group_flags & PYR_BRANCH) && s <= inst->S)
-    {
-      li++;
-      continue;
-    }
+    /* PYR_TRUNK (forked detections, the coarser octaves of a batch): the launches up to scale S — the path to the next octave — only;
+     * scales S+1 and S+2 are queued per SCALE afterwards (enqueue_tail) */
     if ((group_flags & PYR_TRUNK) && s == inst->S + 1u)
-    {
-      if (c->fork)
-        TRY(vksift_hip_event_record(inst->ev_fork[o], sp), "event record");
       break;
-    }
-    if ((group_flags & PYR_BRANCH) && s == inst->S + 1u)
-      TRY(vksift_hip_stream_wait_event(sp, inst->ev_fork[o]), "scale fork");
     const vksift_hip_Plane srcp = PL(o, s - 1);
     vksift_hip_Plane dstp = PL(o, s);
     li++;
@@ -495,9 +480,20 @@ static int enqueue_detection(DetectCtx *c)
   if (c->prof)
     vksift_hip_event_record(c->PS->ev_t[1], st);
 
-  /* recClearBufferDataCmds (sift_detector.c:1081-1104); a forked detection clears on a side stream, off the path of the trunk */
+  /* recClearBufferDataCmds (sift_detector.c:1081-1104); a forked detection clears on the side stream, beside the seed launch: the side
+   * stream is ordered behind everything queued on the trunk stream so far — the previous detection's readers of the counters and masks —
+   * and the trunk never waits for it (a fork in the middle of the trunk costs its next launch ~5 us) */
   if (!c->fork)
     TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, st), "counter reset");
+  else
+  {
+    TRY(vksift_hip_event_record(inst->ev_join[1], sp), "event record");
+    TRY(vksift_hip_stream_wait_event(inst->pyr_stream, inst->ev_join[1]), "scale fork");
+    TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, inst->pyr_stream), "counter reset");
+    if (L->n_oct > 0 && vksift_hip_clear_segment_masks(c->jobs, L->n_oct, c->count, inst->pyr_stream) == 0)
+      for (uint32_t o = 0; o < L->n_oct; o++)
+        c->jobs[o].masks_cleared = 1u;
+  }
 
   /* The trailing octaves whose planes fit the LDS are built by ONE launch (vksift_hip_octave_chain: a workgroup per image walks all
    * their scales): from the first octave >= 1 behind which every octave qualifies. */
@@ -545,32 +541,27 @@ static int enqueue_detection(DetectCtx *c)
     }
     c->tail[o] = tail_o;
     TRY(enqueue_pyramid(c, o, sp, 0, c->count, PYR_FIRST_GROUP | PYR_LAST_GROUP | (tail_o ? PYR_TRUNK : 0), &g0_done), "scale space construction");
+    if (c->fork && (o + 1u == chain_from || o + 1u == L->n_oct))
+      TRY(vksift_hip_event_record(inst->ev_fork[0], sp), "event record"); /* scale S of the last per-scale octave is queued: the tail may follow */
   }
   if (c->tail_batch)
     TRY(enqueue_tail(c, 1u, L->n_oct, sp), "scale space construction");
 
   if (c->fork)
   {
-    /* Branch: the scales behind S of every forked octave on a side stream. It also takes the two clears: ordered behind everything queued on
-     * the trunk stream up to scale S of the first octave — in particular behind the previous detection's readers of the counters and masks. */
+    /* Branch: the scales behind S of every forked octave on the side stream (which already holds the two clears) */
     vksift_hip_stream side = inst->pyr_stream;
     const uint32_t o0 = oct0_done ? 1u : 0u, o_end = chain_from < L->n_oct ? chain_from : L->n_oct;
     if (o0 < o_end)
     {
-      TRY(vksift_hip_stream_wait_event(side, inst->ev_fork[o0]), "scale fork");
-      TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, side), "counter reset");
-      if (vksift_hip_clear_segment_masks(c->jobs, L->n_oct, c->count, side) == 0)
-        for (uint32_t o = 0; o < L->n_oct; o++)
-          c->jobs[o].masks_cleared = 1u;
       /* ONE launch per scale over all forked octaves (round 6; one per octave and scale before: eight dependent launches on this stream
        * were the end of a 640x480 detection's scale-space, 173 us after its start — with two the LDS chain of the coarsest octave is) */
-      TRY(vksift_hip_stream_wait_event(side, inst->ev_fork[o_end - 1u]), "scale fork");
+      TRY(vksift_hip_stream_wait_event(side, inst->ev_fork[0]), "scale fork");
       TRY(enqueue_tail(c, o0, o_end, side), "scale space construction");
-      TRY(vksift_hip_event_record(inst->ev_join[0], side), "event record");
-      TRY(vksift_hip_stream_wait_event(sp, inst->ev_join[0]), "scale join");
     }
-    else
-      TRY(vksift_hip_memset(inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, 0, sizeof(uint32_t) * VKSIFT_MAX_OCTAVES * c->count, sp), "counter reset");
+    /* the side stream rejoins (the clears at least are on it) */
+    TRY(vksift_hip_event_record(inst->ev_join[0], side), "event record");
+    TRY(vksift_hip_stream_wait_event(sp, inst->ev_join[0]), "scale join");
   }
   if (c->prof)
     vksift_hip_event_record(c->PS->ev_pt[2], sp); /* every octave's scale-space is queued (forked branches have joined) */
@@ -594,15 +585,24 @@ static int enqueue_detection(DetectCtx *c)
     if (c->prof)
       vksift_hip_event_record(c->PS->ev_t[4], st);
     vksift_hip_range_push("ComputeDescriptors");
-    if (c->dense)
+    if (c->dense || c->post)
     {
-      /* the matcher's view of the buffers comes out of the same launch (pack_BufferMemory, sift_memory.c:957-1047): no gather pass */
+      /* the matcher's view of the buffers comes out of the same launch (pack_BufferMemory, sift_memory.c:957-1047): no gather pass;
+       * so do the posted records of a single-image detection (vksift_internal.h: h_post): no pack launch behind the descriptors */
       const BufferInfo *b0 = &inst->bufs[c->first_buf];
       vksift_hip_DenseRows dr;
       memset(&dr, 0, sizeof(dr));
-      dr.desc = inst->d_cache_desc + (uint64_t)c->first_buf * inst->desc_slot_stride, dr.desc_img_stride = inst->desc_slot_stride;
-      dr.norm = inst->d_cache_norm + (uint64_t)c->first_buf * inst->cache_norm_stride, dr.norm_img_stride = inst->cache_norm_stride;
-      dr.n = inst->d_cache_n + c->first_buf, dr.n_img_stride = 1;
+      if (c->dense)
+      {
+        dr.desc = inst->d_cache_desc + (uint64_t)c->first_buf * inst->desc_slot_stride, dr.desc_img_stride = inst->desc_slot_stride;
+        dr.norm = inst->d_cache_norm + (uint64_t)c->first_buf * inst->cache_norm_stride, dr.norm_img_stride = inst->cache_norm_stride;
+        dr.n = inst->d_cache_n + c->first_buf, dr.n_img_stride = 1;
+      }
+      if (c->post)
+      {
+        dr.post = inst->h_post[c->first_buf & 1u], dr.post_img_stride = 0;
+        dr.found_post = inst->h_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, dr.found_post_n = VKSIFT_MAX_OCTAVES;
+      }
       dr.nsec = b0->nb_sections;
       for (uint32_t o = 0; o < b0->nb_sections; o++)
         dr.sec_cap[o] = b0->sec_cap[o];
@@ -649,16 +649,7 @@ static int enqueue_detection(DetectCtx *c)
     inst->last_scan_bytes += (uint64_t)L->w[o] * L->h[o] * pyr_texel_bytes(inst) * (inst->S + 2) * c->count;
 
   if (c->post)
-  {
-    /* the grid is sized for one keypoint per 128 pixels; the kernel strides over the device-side count */
-    const BufferInfo *b = &inst->bufs[c->first_buf];
-    const uint32_t zero = 0, id = c->first_buf;
-    const uint64_t est = (uint64_t)c->w * c->h / 128u + 64u;
-    TRY(vksift_hip_pack_features(inst->d_feats, inst->buf_stride, &id, &zero, 1, b->nb_sections, b->sec_off, b->sec_cap, inst->d_found, VKSIFT_MAX_OCTAVES,
-                                 inst->h_post[c->first_buf & 1u], est > 0xFFFFFFu ? 0xFFFFFFu : (uint32_t)est, inst->h_found, st),
-        "feature posting");
-    return 0; /* the counters went with the records */
-  }
+    return 0; /* records and counters were posted by the descriptor launch */
   /* recCopySIFTCountCmds (sift_detector.c:1261-1291) */
   TRY(vksift_hip_post_words(inst->h_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES, inst->d_found + (size_t)c->first_buf * VKSIFT_MAX_OCTAVES,
                             (size_t)VKSIFT_MAX_OCTAVES * c->count, st),
