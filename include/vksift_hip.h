@@ -104,6 +104,8 @@ extern "C"
     VKSIFT_TUNE_SCAN_BAND = 9,  /* rows per wave of the streaming extrema scan (0 = built-in: 32 on large octaves, 16 on small ones) */
     VKSIFT_TUNE_TAIL_MULTI = 10, /* 1: no multi-octave launches for scales S+1, S+2 (batches queue every octave in full; forked detections one launch per
                                   * octave and scale) */
+    VKSIFT_TUNE_ZERO_COPY = 11,  /* 1: a single host image is copied into device memory in front of the seed launch (default: the launch reads the pinned
+                                  * staging buffer itself) */
     VKSIFT_TUNE_COUNT = 12
   };
   int vksift_hip_tune(int knob, int value);

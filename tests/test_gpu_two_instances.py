@@ -1,5 +1,5 @@
 """SURVEY.md 8(b)'s in-process form of the drop-in: several vksift instances in ONE process, each driven by its own host thread
-(the reference: one GPU per instance, /root/reference/include/vulkansift/vulkansift.h:32-34 — an application with 8 GPUs creates 8
+(the reference: one GPU per instance, include/vulkansift/vulkansift.h:32-34 of the reference — an application with 8 GPUs creates 8
 instances). One GPU is all a test box has, so both instances sit on device 0; what is under test is the host side — per-instance
 streams, events, staging, the shared staging-thread pool, the lazily initialised process-wide state of the launch shims — under real
 concurrency (ctypes releases the GIL for the duration of every call). Every result must equal the serial run byte for byte."""

@@ -177,7 +177,8 @@ def kernel_isa(kernel=None):
     cmd = [b.HIPCC] + [f for f in b.HIPFLAGS if f != "-fPIC"] + b._extra_flags("hip/features.hip") + b.INCLUDES + ["-S", "--cuda-device-only", "-o", out, src]
     subprocess.run(cmd, check=True, capture_output=True, cwd="/tmp")
     lines = open(out).read().split("\n")
-    s = next(i for i, l in enumerate(lines) if l.startswith(kernel + ":"))
+    # (the name is matched as a prefix: further kernel parameters — the dense-row / posting struct of round 6 — extend the mangled name)
+    s = next(i for i, l in enumerate(lines) if re.match(re.escape(kernel) + r"\w*:", l))
     e = next(i for i in range(s, len(lines)) if lines[i].strip().startswith("s_endpgm"))
     return lines[s + 1:e + 1]
 

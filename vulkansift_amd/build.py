@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(OUT_DIR, "libvulkansift.so")
 
 HOST_SRCS = ["host/vksift_api.c", "host/vksift_instance.c", "host/vksift_detect.c", "host/vksift_buffers.c", "host/vksift_match.c", "host/vksift_ext.c", "host/vksift_sharded.c",
              "host/vksift_hostmath.c", "host/vksift_log.c", "host/vksift_synth.c"]
-HIP_SRCS = ["hip/runtime.hip", "hip/pyramid.hip", "hip/extrema.hip", "hip/features.hip", "hip/match.hip"]
+HIP_SRCS = ["hip/runtime.hip", "hip/pyramid.hip", "hip/extrema.hip", "hip/features.hip", "hip/match.hip", "hip/records.hip"]
 
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")

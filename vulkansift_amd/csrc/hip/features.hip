@@ -588,12 +588,16 @@ k_descriptor(Multi<FeatArgs> m, vksift_hip_DenseRows dr)
   {
     const uint32_t *fsec = a.found + (size_t)b * a.found_img_stride - a.sec; // counter of section 0 of this image's buffer
     uint32_t row0 = 0, total = 0;
-    for (uint32_t j = 0; j < dr.nsec; j++)
-    {
-      const uint32_t f = fsec[j], n = f < dr.sec_cap[j] ? f : dr.sec_cap[j];
-      row0 += j < a.sec ? n : 0u;
-      total += n;
-    }
+    // (constant indices into the by-value argument: a run-time index would send the struct through scratch memory — 8 bytes of scratch
+    // cost this kernel 4 %, tests/test_kernel_resources.py)
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; j++)
+      if (j < dr.nsec)
+      {
+        const uint32_t f = fsec[j], n = f < dr.sec_cap[j] ? f : dr.sec_cap[j];
+        row0 += j < a.sec ? n : 0u;
+        total += n;
+      }
     if (tid == 0)
       s_row0 = row0; // read behind the barriers of the keypoint loop
     // the buffer's row count and the zero rows of quirk Q6: first workgroup of section 0's share of this image
@@ -804,8 +808,13 @@ k_descriptor(Multi<FeatArgs> m, vksift_hip_DenseRows dr)
     __syncthreads();
     if (wave == 0)
     {
+      // (an opaque copy of the lane index for the whole epilogue: addresses and masks derived from it are recomputed per keypoint instead
+      // of being hoisted out of the keypoint loop into registers the sample loop cannot spare — hoisted, one of them was spilled, and any
+      // scratch costs this kernel per wave launched: tests/test_kernel_resources.py)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
       // normalise -> clamp at 0.2*norm -> renormalise -> x512 -> u8 (:200-265)
-      uint32_t w0 = desc_hist_read(s_work, lane), w1 = desc_hist_read(s_work, lane + 64);
+      uint32_t w0 = desc_hist_read(s_work, ln), w1 = desc_hist_read(s_work, ln + 64);
       uint32_t acc = w0 * w0 + w1 * w1;
 #pragma unroll
       for (int dlt = 32; dlt >= 1; dlt >>= 1)
@@ -824,29 +833,29 @@ k_descriptor(Multi<FeatArgs> m, vksift_hip_DenseRows dr)
       uint32_t b0 = (v0 != v0) ? 0u : (v0 < 0.f ? 0u : (v0 > 255.f ? 255u : (uint32_t)v0));
       uint32_t b1 = (v1 != v1) ? 0u : (v1 < 0.f ? 0u : (v1 > 255.f ? 255u : (uint32_t)v1));
       // pack 4 consecutive bytes per dword: lanes 4q..4q+3 hold bytes of dword q (first half) / q+16 (second half)
-      uint32_t sh = (uint32_t)(lane & 3) * 8u;
+      uint32_t sh = (uint32_t)(ln & 3) * 8u;
       uint32_t p0 = b0 << sh, p1 = b1 << sh;
       p0 |= __shfl_xor(p0, 1, 64);
       p0 |= __shfl_xor(p0, 2, 64);
       p1 |= __shfl_xor(p1, 1, 64);
       p1 |= __shfl_xor(p1, 2, 64);
-      if ((lane & 3) == 0)
+      if ((ln & 3) == 0)
       {
         uint32_t *desc = (uint32_t *)(feats + (size_t)k * 164 + 36);
-        desc[lane >> 2] = p0;
-        desc[16 + (lane >> 2)] = p1;
+        desc[ln >> 2] = p0;
+        desc[16 + (ln >> 2)] = p1;
       }
       if (CAN_POST && dr.post)
       {
         // the posted record: 9 header words from the section record (written by the extraction and orientation launches), the
         // descriptor's 32 words from the registers of the lanes that hold them
-        const uint32_t j = (uint32_t)lane & 15u;
+        const uint32_t j = (uint32_t)ln & 15u;
         const uint32_t d0 = __shfl(p0, (int)(4u * j), 64), d1 = __shfl(p1, (int)(4u * j), 64);
         uint32_t *out = (uint32_t *)(dr.post + (size_t)b * dr.post_img_stride) + (size_t)(s_row0 + k) * 41u;
-        if (lane < 32)
-          out[9 + lane] = lane < 16 ? d0 : d1;
-        else if (lane < 41)
-          out[lane - 32] = ((const uint32_t *)rec)[lane - 32];
+        if (ln < 32)
+          out[9 + ln] = ln < 16 ? d0 : d1;
+        else if (ln < 41)
+          out[ln - 32] = ((const uint32_t *)rec)[ln - 32];
       }
       if (dr.desc)
       {
@@ -863,13 +872,13 @@ k_descriptor(Multi<FeatArgs> m, vksift_hip_DenseRows dr)
           s2 += __shfl_xor(s2, dlt, 64);
           s1 += __shfl_xor(s1, dlt, 64);
         }
-        if ((lane & 3) == 0)
+        if ((ln & 3) == 0)
         {
           uint32_t *row = dense + (size_t)k * 32;
-          row[lane >> 2] = p0;
-          row[16 + (lane >> 2)] = p1;
+          row[ln >> 2] = p0;
+          row[16 + (ln >> 2)] = p1;
         }
-        if (lane == 0)
+        if (ln == 0)
           dense_norm[k] = s2 - 256u * s1 + 128u * 128u * 128u;
       }
     }

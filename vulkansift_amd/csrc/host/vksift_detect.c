@@ -193,6 +193,7 @@ typedef struct
   size_t img_bytes;
   uint32_t nblur; /* blur launches of octave 0 (the profiled scale-space interval) */
   uint32_t nblur_all; /* ... of every octave */
+  bool zero_copy;     /* one host image: the seed launch reads it straight out of the pinned staging buffer (no copy to d_input in front of it) */
   bool tail_batch;    /* a batch queues scales S+1, S+2 of its coarser octaves per SCALE (enqueue_tail), like a forked detection does */
   bool tail[VKSIFT_MAX_OCTAVES]; /* octave o was queued up to scale S only: its last two scales go with enqueue_tail */
   vksift_hip_OctaveJob jobs[VKSIFT_MAX_OCTAVES];
@@ -458,7 +459,8 @@ static int enqueue_detection(DetectCtx *c)
         i1 = c->count; /* a tail shorter than half a group joins the last one */
       if (!c->prestaged)
         stage_images(inst->h_input, c->images, i0, i1, c->img_bytes);
-      TRY(vksift_hip_memcpy_h2d(inst->d_input + (size_t)i0 * c->img_bytes, inst->h_input + (size_t)i0 * c->img_bytes, c->img_bytes * (i1 - i0), su), "image upload");
+      if (!c->zero_copy)
+        TRY(vksift_hip_memcpy_h2d(inst->d_input + (size_t)i0 * c->img_bytes, inst->h_input + (size_t)i0 * c->img_bytes, c->img_bytes * (i1 - i0), su), "image upload");
       if (grouped)
       {
         TRY(vksift_hip_event_record(inst->ev_up[g], su), "event record");
@@ -468,7 +470,7 @@ static int enqueue_detection(DetectCtx *c)
       }
       i0 = i1;
     }
-    if (!c->capturing)
+    if (!c->capturing && !c->zero_copy)
     {
       /* the pinned staging buffer is free again as soon as these copies have run; the seed pass waits for them */
       TRY(vksift_hip_event_record(inst->ev_staging, su), "event record");
@@ -546,6 +548,12 @@ static int enqueue_detection(DetectCtx *c)
   }
   if (c->tail_batch)
     TRY(enqueue_tail(c, 1u, L->n_oct, sp), "scale space construction");
+  if (c->zero_copy && !c->capturing)
+  {
+    /* the staging buffer was the seed launch's source: free again once that has run (octave 0's launches are on sp) */
+    TRY(vksift_hip_event_record(inst->ev_staging, sp), "event record");
+    inst->staging_pending = true;
+  }
 
   if (c->fork)
   {
@@ -821,7 +829,10 @@ static void detect_impl(vksift_Instance inst, const uint8_t *const *images, cons
   /* host images are staged into pinned memory while the sequence is enqueued (enqueue_detection): the caller may reuse its
    * memory as soon as we return (sift_memory.c:943) */
   c.images = images;
-  c.d_src = c.upload ? inst->d_input : d_images;
+  /* One host image (at most 1 MB): no copy into device memory first — the fused up-sampling + seed launch reads every source byte once, and
+   * reads them out of the pinned staging buffer over the bus (300 KB: ~6 us of bus time inside a 9 us launch) instead of behind a 9 us copy */
+  c.zero_copy = c.upload && count == 1u && c.img_bytes <= ((size_t)1 << 20) && vksift_hip_tune_get(VKSIFT_TUNE_ZERO_COPY) == 0;
+  c.d_src = c.upload ? (c.zero_copy ? inst->h_input : inst->d_input) : d_images;
   build_jobs(&c);
 
   /* host-visible events (staging, completion, profiling) stay outside a captured region; a captured graph holds the address
