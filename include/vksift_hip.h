@@ -324,7 +324,10 @@ extern "C"
    * u32 elements for norms/redo/n. partial_scratch (may be NULL): 5*max_na*VKSIFT_HIP_MATCH_CHUNKS u32 used by the
    * stream-decomposed single-pair kernel (nslots == 1; without it a single pair takes the batch kernels). redo: max_na u32 per slot of row flags for the exact scalar replay.
    * max_na / max_nb: host-side bounds on the row counts of any slot (the counts themselves stay on the device); a batch whose max_nb is within the
-   * packed-key kernel's range launches that kernel only — the pruning kernels' grids for larger reference sets are not queued at all. */
+   * packed-key kernel's range launches that kernel only — the pruning kernels' grids for larger reference sets are not queued at all. nb_exact: max_nb
+   * is the largest N_B itself (every count has reached the host), not a capacity bound: only then are the pruning kernels queued for the slots
+   * beyond the packed-key range; with a mere bound the packed-key kernel serves every slot of the batch whatever its N_B (exact for any size: it
+   * walks B in super-chunks of 4096 columns; beyond 32 768 rows the pruning kernel is the faster one, which is all the regime was for). */
   /* Download packing for a batch of up to 64 SIFT buffers that share one section table (the buffers of one batched detection):
    * slot i copies the stored records of buffer buf_ids[i] — sections in order, min(found, capacity) each, the order
    * vksift_downloadFeatures returns (sift_memory.c:957-1047, 1160-1196) — as dense 164-byte records to out + out_rows[i] * 164.
@@ -338,7 +341,7 @@ extern "C"
                                  uint32_t found_buf_stride, uint32_t max_rows, uint32_t pad_rows_to, uint8_t *desc, uint64_t desc_stride,
                                  uint32_t *norms, uint64_t norm_stride, uint32_t *n_out_dev, uint32_t n_stride, vksift_hip_stream s);
   int vksift_hip_match_2nn_async(const uint8_t *cache_desc, const uint32_t *cache_norm, const uint32_t *cache_n, const uint32_t *ids_a, const uint32_t *ids_b,
-                                 uint32_t max_na, uint32_t max_nb, uint32_t *redo, uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t cache_desc_stride,
+                                 uint32_t max_na, uint32_t max_nb, uint32_t nb_exact, uint32_t *redo, uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t cache_desc_stride,
                                  uint64_t cache_norm_stride, uint64_t redo_slot_stride, uint64_t match_slot_stride, uint32_t n_slot_stride,
                                  uint32_t *partial_scratch, vksift_hip_stream s);
 

@@ -104,3 +104,26 @@ def test_packed_kernel_equals_the_pruning_kernels(vk, monkeypatch):
         assert r.returncode == 0, r.stderr[-1500:]
         crcs.append([ln for ln in r.stdout.splitlines() if ln.startswith("CRC")][-1])
     assert crcs[0] == crcs[1]
+
+
+def test_batch_with_reference_sets_beyond_32k_rows_and_counts_still_on_the_device(vk):
+    """A batched matching queued right behind its detection: the counts are on the device, so the host cannot know whether a slot lies beyond
+    the packed-key kernel's usual range (32 768 reference rows) and queues no pruning-kernel grid for it — the packed-key kernel serves
+    every slot, walking B in super-chunks of 4096 columns. The same matching again, once the counts have reached the host (then the pruning
+    kernels take the slots beyond the range), and the single-pair path must give the same records."""
+    w, h = 3456, 2304
+    imgs = [vk.gen_synthetic_image(31 + i, w, h) for i in range(2)]
+    with vk.Instance(vk.default_config(input_image_max_size=w * h, sift_buffer_count=2, max_nb_sift_per_buffer=100000), batch_capacity=2) as inst:
+        inst.detectFeaturesBatch(imgs, 0)
+        inst.matchFeaturesBatch([0, 1], [1, 0])                   # counts unknown: packed-key kernel for both slots
+        first = [inst.downloadMatchesBatch(k) for k in range(2)]
+        n = [inst.getFeaturesNumber(i) for i in range(2)]
+        assert min(n) > 32768, n                                  # the case under test
+        inst.matchFeaturesBatch([0, 1], [1, 0])                   # counts known and beyond the range: pruning kernels
+        second = [inst.downloadMatchesBatch(k) for k in range(2)]
+        inst.matchFeatures(0, 1)                                  # single pair: stream decomposition
+        single = inst.downloadMatches()
+    assert [len(m) for m in first] == n
+    for a, b in zip(first, second):
+        assert a.tobytes() == b.tobytes()
+    assert first[0].tobytes() == single.tobytes()

@@ -6,6 +6,7 @@ import glob
 import io
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -36,8 +37,14 @@ def pmc_by_shape(dirpath, counter):
         cols = [r[1] for r in cur.execute("pragma table_info('counters_collection')")]
         name_col = "kernel_name" if "kernel_name" in cols else "name"
         per = {}
-        for name, value, disp, gx, gy in cur.execute(f"select {name_col}, value, dispatch_id, grid_size_x, grid_size_y from counters_collection where counter_name = ?", (counter,)):
-            if any(k in name for k in BLUR_KERNELS):
+        rows = list(cur.execute(f"select {name_col}, value, dispatch_id, grid_size_x, grid_size_y from counters_collection where counter_name = ?", (counter,)))
+        # an instance TIMES a whole-batch blur launch on every candidate memory range before its first detection (vksift_instance.c:
+        # place_pyramid_buffers): those dispatches are not part of any detection call — everything in front of the first seed launch
+        # (k_blur_lean<N, 1 | 2, ...>: the fused copy-in + seed blur, or the input blit) is left out
+        seeds = [disp for name, _, disp, _, _ in rows if re.search(r"k_blur_lean<\d+, [12],", name) or "k_input_blit" in name]
+        first = min(seeds) if seeds else 0
+        for name, value, disp, gx, gy in rows:
+            if disp >= first and any(k in name for k in BLUR_KERNELS):
                 key = (name, int(gx), int(gy))
                 per.setdefault(disp, [key, 0.0])[1] += float(value)
         for key, v in per.values():

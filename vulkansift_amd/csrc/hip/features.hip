@@ -661,6 +661,9 @@ k_descriptor(Multi<FeatArgs> m, vksift_hip_DenseRows dr)
     // 1-2 cells and serialise: measured 8 % slower). Integer adds commute: the result does not depend on the order.
     const float offx = c.rsx - c.scale_x, offy = c.rsy - c.scale_y;
     const float T = 2.5f + 0.01f;
+    // (reciprocals by v_rcp_f32, 1 ulp: the spans are conservative by 0.01 in T and 0.01 px at both ends, six orders of magnitude more than
+    // that error on coordinates below 2^14 — the four IEEE divisions per row cost every wave 44 instructions per keypoint, round 6)
+    const float ia0 = __builtin_amdgcn_rcpf(c.kcos), ia1 = __builtin_amdgcn_rcpf(-c.ksin);
     for (int rb = 0; rb < bh; rb += DESC_MAX_ROWS)
     {
       const int nrows = min(DESC_MAX_ROWS, bh - rb);
@@ -673,11 +676,11 @@ k_descriptor(Multi<FeatArgs> m, vksift_hip_DenseRows dr)
 #pragma unroll
         for (int e = 0; e < 2; e++)
         {
-          const float aa = e == 0 ? c.kcos : -c.ksin;
+          const float aa = e == 0 ? c.kcos : -c.ksin, ia = e == 0 ? ia0 : ia1;
           const float bb = e == 0 ? c.ksin * fy : c.kcos * fy;
           if (fabsf(aa) > 1e-12f)
           {
-            const float ctr = -bb / aa - offx, half = T / fabsf(aa);
+            const float ctr = -bb * ia - offx, half = T * fabsf(ia);
             lo = fmaxf(lo, ctr - half);
             hi = fminf(hi, ctr + half);
           }

@@ -1683,7 +1683,7 @@ extern "C"
   }
 
   int vksift_hip_match_2nn_async(const uint8_t *cache_desc, const uint32_t *cache_norm, const uint32_t *cache_n, const uint32_t *ids_a, const uint32_t *ids_b,
-                                 uint32_t max_na, uint32_t max_nb, uint32_t *redo, uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t cache_desc_stride,
+                                 uint32_t max_na, uint32_t max_nb, uint32_t nb_exact, uint32_t *redo, uint32_t *n_dev, uint8_t *matches, uint32_t nslots, uint64_t cache_desc_stride,
                                  uint64_t cache_norm_stride, uint64_t redo_slot_stride, uint64_t match_slot_stride, uint32_t n_slot_stride,
                                  uint32_t *partial_scratch, vksift_hip_stream s)
   {
@@ -1742,9 +1742,13 @@ extern "C"
        * B-split kernel is not launched) on a grid of 16 row blocks per slot — every launch of a mostly idle grid costs the batch
        * 4-5 us (4096 workgroups that only read their slot's counts) */
       const bool pk = match_use_pk();
+      /* what is left for the pruning kernels: the slots beyond the packed-key range — if the host KNOWS there is one (nb_exact). A batch whose
+       * counts are still on the device (the usual case: the matching is queued behind its detection) is served by the packed-key kernel alone,
+       * whatever the N_B of a slot turns out to be: no grid is queued for slots that "could" exist (vksift_hip.h) */
+      const bool prune = !pk || (max_nb > VKSIFT_HIP_MATCH_PK_NB && nb_exact != 0u);
       if (pk)
       {
-        ss.pk_nb_max = VKSIFT_HIP_MATCH_PK_NB;
+        ss.pk_nb_max = prune ? VKSIFT_HIP_MATCH_PK_NB : 0xFFFFFFFFu;
         SlotStrides sp = ss;
         sp.slot_fast = nslots > 1 ? 1u : 0u;
         /* (8 waves x 128-column tiles: swept against <4,128>, <4,64>, <8,64>, <16,128>, <2,64> on 512 self-matches of 1.9 k x 1.9 k:
@@ -1771,9 +1775,6 @@ extern "C"
       uint32_t gs = nslots;
       if (pk && nslots > 16u)
         gs = 16u, s2.nslots_loop = nslots;
-      /* no slot can have a reference set beyond the packed-key kernel's range: nothing is left for the pruning kernels (a batch of
-       * frames; their two mostly idle grids cost it 0.34 ms per 512 pairs) */
-      const bool prune = !pk || max_nb > VKSIFT_HIP_MATCH_PK_NB;
       if (prune && max_na > S1)
       {
         const uint32_t n2 = max_na < S2 ? max_na : S2;

@@ -136,13 +136,15 @@ static int match_slots(vksift_Instance inst, const MatchScratch *ms, const uint3
   if (e)
     return e;
   uint32_t max_na = 0, max_nb = 0;
+  bool nb_exact = true; /* every reference buffer's count is known on the host (uploaded, or its detection has completed) */
   for (uint32_t i = 0; i < count; i++)
   {
     const uint32_t r = rows_bound(inst, ids_a[i]), rb = rows_bound(inst, ids_b[i]);
     max_na = r > max_na ? r : max_na;
     max_nb = rb > max_nb ? rb : max_nb;
+    nb_exact = nb_exact && (inst->bufs[ids_b[i]].nb_sections == 0 || counts_valid(inst, ids_b[i]));
   }
-  return vksift_hip_match_2nn_async(inst->d_cache_desc, inst->d_cache_norm, inst->d_cache_n, ids_a, ids_b, max_na, max_nb,
+  return vksift_hip_match_2nn_async(inst->d_cache_desc, inst->d_cache_norm, inst->d_cache_n, ids_a, ids_b, max_na, max_nb, nb_exact ? 1u : 0u,
                                     ms->redo + (uint64_t)first_slot * inst->redo_slot_stride, ms->match_n + (size_t)first_slot * 4,
                                     ms->matches + (uint64_t)first_slot * inst->match_slot_stride, count, inst->desc_slot_stride, inst->cache_norm_stride,
                                     inst->redo_slot_stride, inst->match_slot_stride, 4, inst->d_match_partial, inst->stream);
