@@ -86,7 +86,9 @@ extern "C"
   void vksift_hip_range_push(const char *name);       /* roctx marker == VK_EXT_debug_marker region */
   void vksift_hip_range_pop(void);
 
-  /* Development / test knobs of the launch shims (A/B tools, tests of fallback paths). Every setting produces identical results. */
+  /* Development / test knobs of the launch shims (A/B tools, tests of fallback paths). Every setting produces identical results.
+   * PROCESS-WIDE and not synchronised: they act on every instance of the process; set them before instances are created (tests, tools),
+   * never while another thread is inside a library call. */
   enum
   {
     VKSIFT_TUNE_WG_TARGET = 0,  /* waves per strip-march launch aimed at (0 = built-in) */

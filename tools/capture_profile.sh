@@ -30,6 +30,12 @@ VKSIFT_PYR_PINGPONG=0 PMC_GROUPS="SQ_WAVES,SQ_BUSY_CU_CYCLES,SQ_WAVE_CYCLES,SQ_I
   python tools/pmc_kernel.py "k_descriptor,k_orientation<,k_extrema_lean,k_blur_lean<5, 1,k_blur_pair_wide,k_blur_wide<13>@$(( ((2 * W + 127) / 128) * 64 ))" -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras \
   > profiles/${TAG}_sq_counters.json 2> $OUT/sq.log
 timeout 1200 python tools/capture_match_counters.py $TAG > $OUT/match_counters.log 2>&1
+# timeline of ONE single-image detection (launch count, durations, idle gaps): profiles/<tag>_latency_timeline.txt
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/lat -- python $R/tools/bench_latency.py 640x480 > $OUT/lat.log 2>&1
+cd $R
+python tools/latency_timeline.py gpurun_out/$TAG/lat > profiles/${TAG}_latency_timeline.txt 2>&1
+rm -rf $OUT/lat
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 cp $OUT/bench.json profiles/${TAG}_bench.json
 mkdir -p $OUT/profiles; cp profiles/${TAG}_* $OUT/profiles/
