@@ -11,7 +11,7 @@
 //   k_segment_scan   : exclusive prefix sum of popcount(mask) over segments in (scale, y, x) order
 //   k_cand_list      : one thread per segment writes its candidates' packed (x, y, s) at offset + rank
 //   k_refine_flags   : one thread per CANDIDATE (dense waves: no lane idles while a neighbour refines) -> accept flag
-//   k_cand_emit      : second level of the scan of the accept counts (block_sum_256), accepted candidates recompute their record and store it
+//   k_cand_emit      : second level of the scan of the accept counts, accepted candidates recompute their record and store it
 //                      at their rank (clamped to the section capacity); the un-clamped count goes to found[]
 // The arithmetic of refine_texel() is kept operation-for-operation identical to
 // oracle/sift_oracle.c:extract_one (fp32, no contraction) so results are bit-exact.
@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256, 4) k_extrema_lean(Multi<ExtremaArgs> m, i
 
 // Exclusive scan of popcount(mask) over the n segments of an image, in two parallel levels (a single workgroup per image
 // made this the longest kernel of a 1080p detection): every 1024-thread workgroup scans one chunk of SEG_CHUNK segments
-// locally and publishes the chunk total; the consumer (k_cand_list) adds up the totals in front of its chunk (block_sum_256)
+// locally and publishes the chunk total; the consumer (k_cand_list) adds up the totals in front of its chunk (in place)
 // and adds base + local offset.
 constexpr uint32_t SEG_CHUNK = 4096;
 
@@ -602,55 +602,44 @@ __global__ void __launch_bounds__(1024) k_segment_scan(Multi<ExtremaArgs> m)
     chunk_tot[(size_t)b * chunk_img_stride + vb.x] = total;
 }
 
-// Sum of v[0 .. n) by a 256-thread workgroup (every thread calls it; two barriers). The second level of the two-level scans lives in
-// the consumers since round 6: the lists are short (an image has nsegs / 4096 segment chunks and candidates / 256 refinement chunks), and
-// a workgroup that adds up the entries in front of its own chunk costs less than the launch of a scan kernel did (k_chunk_offsets:
-// two launches of ~5 us each on the critical path of a single-image detection).
-__device__ __forceinline__ uint32_t block_sum_256(const uint32_t *__restrict__ v, uint32_t n, uint32_t *s_red)
-{
-  uint32_t acc = 0;
-  for (uint32_t c = threadIdx.x; c < n; c += 256u)
-    acc += v[c];
-#pragma unroll
-  for (int dlt = 32; dlt >= 1; dlt >>= 1)
-    acc += __shfl_xor(acc, dlt, 64);
-  if ((threadIdx.x & 63) == 0)
-    s_red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  const uint32_t total = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-  __syncthreads();
-  return total;
-}
+// The second level of the two-level scans lives in the consumers since round 6: the lists are short (an image has nsegs / 4096 segment
+// chunks and candidates / 256 refinement chunks), and adding up the entries in front of one's own chunk costs less than the launch of a
+// scan kernel did (k_chunk_offsets: two launches of ~5 us each on the critical path of a single-image detection).
 
 // One thread per 64-pixel segment: expand its candidate ballot into packed coordinates at offset + rank.
 __global__ void __launch_bounds__(256) k_cand_list(Multi<ExtremaArgs> mu)
 {
-  __shared__ uint32_t s_red[4];
   const VBlock vb = vblock(mu); // virtual grid (segment blocks, images)
   const ExtremaArgs &a = mu.oct[vb.o];
   const uint32_t seg = vb.x * 256 + threadIdx.x;
   const int b = (int)vb.y;
-  // base of this workgroup's chunk = the totals of the chunks in front of it (k_segment_scan left them at the start of the still unused
-  // flag array; a workgroup's 256 segments lie in one chunk of SEG_CHUNK); the first workgroup of an image also posts the candidate count
+  // (k_segment_scan left the chunk totals at the start of the still unused flag array)
   const uint32_t *chunk_tot = a.cand_flag + (size_t)b * a.cand_img_stride;
-  const uint32_t chunk_base = block_sum_256(chunk_tot, (vb.x * 256u) / SEG_CHUNK, s_red);
-  if (vb.x == 0)
+  if (vb.x == 0 && threadIdx.x == 0)
   {
-    const uint32_t total = block_sum_256(chunk_tot, a.nchunks, s_red);
-    if (threadIdx.x == 0)
-    {
-      a.cand_n[b] = total;
-      if (total == 0)
-        a.found[(size_t)b * a.found_img_stride] = 0; // no candidate: k_cand_emit visits no chunk of this image
-    }
+    // the first workgroup of an image posts the candidate count: the totals of all its chunks (15 for a 1280x960 octave)
+    uint32_t total = 0;
+    for (uint32_t c = 0; c < a.nchunks; c++)
+      total += chunk_tot[c];
+    a.cand_n[b] = total;
+    if (total == 0)
+      a.found[(size_t)b * a.found_img_stride] = 0; // no candidate: k_cand_emit visits no chunk of this image
   }
-  if (seg >= a.nsegs)
-    return;
-  unsigned long long m = a.seg_mask[seg + (size_t)b * a.seg_img_stride];
+  unsigned long long m = seg < a.nsegs ? a.seg_mask[seg + (size_t)b * a.seg_img_stride] : 0ull;
+  if (__ballot(m != 0ull) == 0ull)
+    return; // (wave-uniform) no candidate in these 64 segments: most waves of the launch
+  // offset inside the chunk (k_segment_scan) + base of the chunk = the totals of the chunks in front of it: a wave's 64 segments lie in one
+  // chunk, so the wave adds the totals up together — lane c loads chunk c (one load for up to 64 chunks), a butterfly sums them. No barrier,
+  // no dependent chain of loads (a per-lane loop over the 15 totals of a 1280x960 octave was one).
+  uint32_t base = 0;
+  for (uint32_t c = threadIdx.x & 63u, nc = (vb.x * 256u) / SEG_CHUNK; c < nc; c += 64u)
+    base += chunk_tot[c];
+#pragma unroll
+  for (int dlt = 32; dlt >= 1; dlt >>= 1)
+    base += __shfl_xor(base, dlt, 64);
   if (m == 0ull)
     return;
-  // offset inside the chunk (k_segment_scan) + base of the chunk
-  uint32_t pos = a.seg_off[seg + (size_t)b * a.seg_img_stride] + chunk_base;
+  uint32_t pos = a.seg_off[seg + (size_t)b * a.seg_img_stride] + base;
   const uint32_t segx = seg % (uint32_t)a.nseg;
   const uint32_t yy = (seg / (uint32_t)a.nseg) % (uint32_t)a.h;
   const uint32_t sz = seg / ((uint32_t)a.nseg * (uint32_t)a.h);
@@ -733,14 +722,21 @@ __global__ void __launch_bounds__(256) k_cand_emit(Multi<ExtremaArgs> m)
   const uint32_t *chunk_sum = a.seg_off + (size_t)b * a.seg_img_stride; // accepted candidates per chunk (k_refine_flags)
   for (uint32_t chunk = vb.y; chunk < nch; chunk += vb.gy)
   {
-    // records of the chunks in front of this one (raster order is preserved); the image's last chunk posts the keypoint count
-    const uint32_t cbase = block_sum_256(chunk_sum, chunk, s_red);
+    // records of the chunks in front of this one (raster order is preserved): partial sums of their accept counts ride on the barrier
+    // the rank computation needs anyway; the image's last chunk posts the keypoint count
+    uint32_t part = 0;
+    for (uint32_t c = threadIdx.x; c < chunk; c += 256u)
+      part += chunk_sum[c];
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1)
+      part += __shfl_xor(part, dlt, 64);
     const uint32_t i = chunk * 256u + threadIdx.x;
     const bool v = i < n && flag[i] != 0u;
     const unsigned long long bal = __ballot(v);
     if (lane == 0)
-      s_cnt[wave] = (uint32_t)__popcll(bal);
+      s_cnt[wave] = (uint32_t)__popcll(bal), s_red[wave] = part;
     __syncthreads();
+    const uint32_t cbase = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
     for (int wv = 0; wv < wave; wv++)
       rank += s_cnt[wv];
