@@ -108,7 +108,8 @@ extern "C"
                                   * octave and scale) */
     VKSIFT_TUNE_ZERO_COPY = 11,  /* 1: a single host image is copied into device memory in front of the seed launch (default: the launch reads the pinned
                                   * staging buffer itself) */
-    VKSIFT_TUNE_COUNT = 12
+    VKSIFT_TUNE_MIN_MARCH = 12,  /* output rows per wave of the smallest strip-march launches (a single image's): 0 = built-in */
+    VKSIFT_TUNE_COUNT = 16
   };
   int vksift_hip_tune(int knob, int value);
   int vksift_hip_tune_get(int knob);

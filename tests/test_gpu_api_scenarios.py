@@ -416,11 +416,12 @@ def test_every_runtime_switch_is_bit_identical(vk):
     # PROBE_TUNE: knob 1 = wide-blur mask (0: two texels per lane everywhere), 2 = octaves per multi-octave launch, 3 = pointer form of the refinement,
     # 5 = lane width of the two-scale blur launch, 6 = the next scale-space behind (not beside) the matching queued before it,
     # 7 = the matcher's dense rows by the gather pass instead of the descriptor launch, 9 = rows per wave of the extrema scan,
-    # 10 = scales S+1, S+2 one launch per octave instead of one per scale, 11 = a single host image copied to device memory first
+    # 10 = scales S+1, S+2 one launch per octave instead of one per scale, 11 = a single host image copied to device memory first,
+    # 12 = output rows per wave of the smallest strip-march launches
     variants = [{}, {"VKSIFT_BLUR_KERNEL": "tile"}, {"VKSIFT_PYR_PINGPONG": "1"}, {"VKSIFT_PYR_PINGPONG": "0"}, {"VKSIFT_PYR_PINGPONG": "2"},
                 {"VKSIFT_GRAPH": "1"}, {"VKSIFT_GRAPH": "0"}, {"PROBE_TUNE": "2=2"}, {"PROBE_TUNE": "2=1"}, {"PROBE_TUNE": "3=1"}, {"PROBE_TUNE": "1=0"},
                 {"PROBE_TUNE": "1=1048575"}, {"VKSIFT_BLUR_PAIR": "0"}, {"VKSIFT_FORK_SCALES": "0"}, {"VKSIFT_LDS_CHAIN": "0"}, {"VKSIFT_POST_FEATURES": "0"},
-                {"VKSIFT_PYR_PLACEMENT": "0"}, {"VKSIFT_MATCH_PK": "0"}, {"PROBE_TUNE": "5=1"}, {"PROBE_TUNE": "5=2"}, {"PROBE_TUNE": "7=1"}, {"PROBE_TUNE": "9=32"}, {"PROBE_TUNE": "10=1"}, {"PROBE_TUNE": "11=1"}, {"VKSIFT_PYR_PINGPONG": "1", "PROBE_TUNE": "6=1"}, {"VKSIFT_PYR_PINGPONG": "1", "PROBE_TUNE": "2=2,3=1", "VKSIFT_BLUR_PAIR": "0"}]
+                {"VKSIFT_PYR_PLACEMENT": "0"}, {"VKSIFT_MATCH_PK": "0"}, {"PROBE_TUNE": "5=1"}, {"PROBE_TUNE": "5=2"}, {"PROBE_TUNE": "7=1"}, {"PROBE_TUNE": "9=32"}, {"PROBE_TUNE": "10=1"}, {"PROBE_TUNE": "11=1"}, {"PROBE_TUNE": "12=16"}, {"VKSIFT_PYR_PINGPONG": "1", "PROBE_TUNE": "6=1"}, {"VKSIFT_PYR_PINGPONG": "1", "PROBE_TUNE": "2=2,3=1", "VKSIFT_BLUR_PAIR": "0"}]
     digests = {}
     for v in variants:
         env = dict(os.environ)

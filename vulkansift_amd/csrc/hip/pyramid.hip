@@ -1787,6 +1787,16 @@ extern "C"
   /* Row segments of the streaming kernel: enough workgroups to give every CU ~40 waves over the launch (2560 long-lived waves
    * left the slowest CU to set the time), but segments long enough that the 2R-row warm-up stays a small fraction; launches
    * that cannot fill the GPU anyway (small octaves, small batches) are latency bound and take shorter marches. */
+  /* shortest march (output rows per wave) a launch of this size is cut into: launches that cannot fill the chip are bound by the length of
+   * one wave's march (2R warm-up rows + its own), not by bandwidth */
+  static uint32_t march_rows(uint32_t waves64)
+  {
+    const int t = vksift_hip_tune_get(VKSIFT_TUNE_MIN_MARCH);
+    /* (one 640x480 image: 8-row marches 0.302-0.313 ms against 0.314-0.326 with 16 rows, four alternations of 4 000 detections each) */
+    const uint32_t smallest = t > 0 ? (uint32_t)t : 8u;
+    return waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : (waves64 >= 192u ? 16u : smallest));
+  }
+
   static dim3 stream_grid(uint32_t w, uint32_t h, uint32_t batch, uint32_t wg_target, int *seg_out, uint32_t strip_w = 128u)
   {
     const uint32_t strips = (w + strip_w - 1u) / strip_w;
@@ -1794,7 +1804,7 @@ extern "C"
       wg_target = (uint32_t)vksift_hip_tune_get(VKSIFT_TUNE_WG_TARGET);
     uint32_t nseg = (wg_target + strips * batch - 1u) / (strips * batch);
     const uint32_t waves64 = strips * batch * ((h + 63u) / 64u);
-    const uint32_t seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u);
+    const uint32_t seg_rows = march_rows(waves64);
     const uint32_t max_seg = (h + seg_rows - 1u) / seg_rows;
     if (nseg > max_seg)
       nseg = max_seg;
@@ -2007,7 +2017,7 @@ extern "C"
     /* launches that cannot fill the GPU (a single image, the coarse octaves of a small batch) are latency bound: shorter marches,
      * as stream_grid() — one 640x480 image: 4 pair launches of 27 us each with 64-row segments */
     const uint32_t waves64 = strips * batch * ((H + 63u) / 64u);
-    const uint32_t seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u);
+    const uint32_t seg_rows = march_rows(waves64);
     const uint32_t max_seg = (H + seg_rows - 1u) / seg_rows;
     if (nseg > max_seg)
       nseg = max_seg;
@@ -2055,7 +2065,7 @@ extern "C"
     const uint32_t seed_wg = vksift_hip_tune_get(VKSIFT_TUNE_SEED_WG) > 0 ? (uint32_t)vksift_hip_tune_get(VKSIFT_TUNE_SEED_WG) : 10240u;
     uint32_t nseg = (seed_wg + strips * batch - 1u) / (strips * batch); /* as the other launches (stream_grid): 2560 long-lived waves left the tail to a few CUs */
     const uint32_t waves64 = strips * batch * ((H + 63u) / 64u);
-    const uint32_t seg_rows = waves64 >= 2048u ? 64u : (waves64 >= 512u ? 32u : 16u); /* latency-bound launches: shorter marches (stream_grid) */
+    const uint32_t seg_rows = march_rows(waves64); /* latency-bound launches: shorter marches (stream_grid) */
     uint32_t max_seg = (H + seg_rows - 1u) / seg_rows;
     if (nseg > max_seg)
       nseg = max_seg;

@@ -22,7 +22,7 @@ extern "C"
   uint32_t vksift_hip_abi_version(void) { return VKSIFT_HIP_ABI_VERSION; }
 
   /* development / test knobs of the launch shims (vksift_hip.h: VKSIFT_TUNE_*): 0 = the built-in choice, WIDE_MASK -1 */
-  static int g_tune[VKSIFT_TUNE_COUNT] = {0, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  static int g_tune[VKSIFT_TUNE_COUNT] = {0, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int vksift_hip_tune(int knob, int value)
   {
     if (knob < 0 || knob >= VKSIFT_TUNE_COUNT)
