@@ -27,7 +27,9 @@ def test_stale_pmc_capture_is_refused(monkeypatch):
     # ... and for the workload it was taken on
     assert b.pmc_traffic(newest["width"] + 2, newest["height"], newest["batch"]) is None
     # ... and in the pyramid precision mode it was taken in: binary16 planes move half the bytes, an fp32 capture must not price them
-    assert b.pmc_traffic(newest["width"], newest["height"], newest["batch"], fp16=not newest.get("fp16", False)) is None
+    # (round 6 commits a capture of the binary16 mode as well: the other mode's query gets THAT file or nothing, never this one)
+    other = b.pmc_traffic(newest["width"], newest["height"], newest["batch"], fp16=not newest.get("fp16", False))
+    assert other is None or (bool(other.get("fp16", False)) != bool(newest.get("fp16", False)) and other["hbm_bytes_per_call"] != newest["hbm_bytes_per_call"])
     # any other kernel source hash: no traffic figure rather than a stale one
     monkeypatch.setattr(b, "kernel_source_sha", lambda: "0" * 16)
     assert b.pmc_traffic(newest["width"], newest["height"], newest["batch"]) is None
