@@ -56,7 +56,8 @@ extern "C"
 
   /* Deferred submission of vksift_detectFeatures (no counterpart in the reference, no change of its contract): consecutive plain
    * detect calls into consecutive SIFT buffers, with nothing asked in between, are staged and launched as ONE batched detection by
-   * the first call that needs a result — any other entry point — or when 128 images (VKSIFT_DEFER_MAX) are staged. The first detect
+   * the first call that needs a result — any other entry point — or when 128 images (VKSIFT_DEFER_MAX) are staged, or 16 (VKSIFT_DEFER_CHUNK)
+   * while the GPU has no detection to work on. The first detect
    * call after another entry point is launched at once unless the caller's previous run of detect calls held two or more, so
    * detect + read and the two-buffer ping-pong keep their latency. VKSIFT_DEFER=0 launches every call at once. Results are
    * identical either way. These counters say what the instance did: batches launched from staged images, and images in them. */

@@ -12,11 +12,26 @@ TUNE_DENSE_ROWS = 7
 
 
 def _export(inst, buf, n):
-    import torch
+    """vksift_ext_exportDescriptorsDevice into device memory of the library's own allocator (no torch: the file also runs under the
+    sanitizer build, where torch does not load)"""
+    import ctypes as C
+    from vulkansift_amd import api
 
-    d = torch.zeros((max(n, 1), 128), dtype=torch.uint8, device="cuda")
-    assert inst.exportDescriptorsDevice(buf, d.data_ptr()) == n
-    return d.cpu().numpy()[:n]
+    L = api.lib()
+    L.vksift_hip_malloc.restype = C.c_void_p
+    L.vksift_hip_malloc.argtypes = [C.c_size_t]
+    L.vksift_hip_free.argtypes = [C.c_void_p]
+    L.vksift_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.vksift_hip_stream_sync.argtypes = [C.c_void_p]
+    d = L.vksift_hip_malloc(max(n, 1) * 128)
+    assert d
+    try:
+        assert inst.exportDescriptorsDevice(buf, d) == n
+        out = np.zeros((max(n, 1), 128), np.uint8)
+        assert L.vksift_hip_memcpy_d2h(out.ctypes.data, d, max(n, 1) * 128, None) == 0 and L.vksift_hip_stream_sync(None) == 0
+    finally:
+        L.vksift_hip_free(d)
+    return out[:n]
 
 
 def _blank(w, h):

@@ -1007,6 +1007,15 @@ static bool defer_detect(vksift_Instance inst, const uint8_t *image, uint32_t w,
     inst->defer_grow = inst->det_cap < inst->defer_max;
     flush_deferred(inst);
   }
+  else if (inst->defer_chunk && inst->pend_n >= inst->defer_chunk && !detect_running(inst))
+  {
+    /* an idle GPU and a worthwhile number of staged images: launch them now, beside the staging of the rest of the caller's run (the
+     * strictly serial pattern "detect into N buffers, then read them" otherwise leaves the GPU idle for the whole staging phase and the host
+     * idle for the whole detection). With a detection in flight — the pattern with two buffer sets — nothing is launched early: whole runs
+     * make the better batches. */
+    inst->defer_grow = inst->det_cap < inst->defer_max; /* the caller's runs are longer than this chunk */
+    flush_deferred(inst);
+  }
   return true;
 }
 

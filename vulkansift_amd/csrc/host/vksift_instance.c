@@ -98,6 +98,10 @@ static vksift_Result create_instance(vksift_Instance *instance_ptr, const vksift
     inst->defer_enabled = !(e && e[0] == '0') && config->sift_buffer_count >= 2u;
     e = getenv("VKSIFT_DEFER_MAX");
     inst->defer_max = e ? (uint32_t)strtoul(e, NULL, 10) : 128u;
+    {
+      const char *c = getenv("VKSIFT_DEFER_CHUNK");
+      inst->defer_chunk = c ? (uint32_t)strtoul(c, NULL, 10) : 16u;
+    }
     if (inst->defer_max > config->sift_buffer_count)
       inst->defer_max = config->sift_buffer_count;
     if (inst->defer_max < 2u)

@@ -116,6 +116,7 @@ struct vksift_Instance_T
    * detection after an accessor is launched at once unless the caller is known to batch (batch_mode), so detect + read keeps its path. */
   bool defer_enabled;      /* VKSIFT_DEFER (default 1) and sift_buffer_count >= 2 */
   uint32_t defer_max;      /* VKSIFT_DEFER_MAX (default 128): a deferred batch is launched when it holds this many images (or det_cap) */
+  uint32_t defer_chunk;    /* VKSIFT_DEFER_CHUNK (default 16; 0: off): ... or this many while the GPU has no detection to work on */
   uint32_t pend_n, pend_first, pend_w, pend_h; /* staged images: SIFT buffers [pend_first, pend_first + pend_n) */
   uint32_t epoch_detects;  /* vksift_detectFeatures calls since the last call of any other entry point */
   bool batch_mode;         /* the last such run held at least two: the next one is deferred from its first call on */
