@@ -77,3 +77,30 @@ def test_thresholds_at_defaults(oracle):
     thr = np.float32(cfg.intensity_threshold) / np.float32(3)
     assert abs(thr - 0.013333) < 1e-6
     assert abs((np.float32(11) ** 2) / np.float32(10) - 12.1) < 1e-5
+
+
+def test_byte_over_255_without_division_or_table(tmp_path):
+    """The seed launch converts its u8 source through unit_of_byte (pyramid.hip): q = x * fl(1/255); q + fma(-255, q, x) * fl(1/255). It has
+    to be the IEEE quotient x / 255.f for all 256 bytes (the plain product is not, for 126 of them). Checked in C with the build's own
+    contraction rules (gcc -ffp-contract=off, explicit fmaf)."""
+    import subprocess
+
+    src = tmp_path / "q.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <math.h>
+#include <string.h>
+int main(void) {
+  const float r = 0x1.010102p-8f; int plain = 0, corrected = 0;
+  float one = 1.0f / 255.0f; if (memcmp(&one, &r, 4)) return 2;
+  for (int i = 0; i < 256; i++) {
+    const float x = (float)i, ref = x / 255.0f, q = x * r, c = fmaf(fmaf(-255.0f, q, x), r, q);
+    plain += memcmp(&q, &ref, 4) != 0; corrected += memcmp(&c, &ref, 4) != 0;
+  }
+  printf("%d %d\n", plain, corrected); return 0;
+}
+""")
+    exe = tmp_path / "q"
+    subprocess.run(["gcc", "-O1", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["126", "0"], out

@@ -315,12 +315,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *base, 
 }
 
 // UPS: the source is the u8 input image at half the resolution; the staged rows are produced on the fly by the exact
-// 2:1 LINEAR blit of k_input_blit_2x (same expressions, value/255 through a 256-entry table of the same correctly
+// 2:1 LINEAR blit of k_input_blit_2x (same expressions, value/255 by unit_of_byte: the same correctly
 // rounded quotients), i.e. vkCmdCopyBufferToImage + vkCmdBlitImage + the seed blur in one pass: the up-sampled plane
 // never exists in HBM. a.src then points at the u8 images (a.src_img_stride in bytes), a.spitch is the source width.
 // SRC: 0 = a plane of the pyramid; 1 = the u8 input at half the resolution (UPS above); 2 = the u8 input at the plane's own
 // resolution (use_input_upsampling = false: vkCmdCopyBufferToImage + the 1:1 blit + the seed blur in one pass, value / 255
-// through the same table). a.src then points at the u8 images (a.src_img_stride in bytes), a.spitch is the source width.
+// through the same conversion). a.src then points at the u8 images (a.src_img_stride in bytes), a.spitch is the source width.
+// byte k of d as float(byte) / 255.f, correctly rounded, without a division and without a table: q = x * fl(1/255) is off by an ulp for 126
+// of the 256 values; one residual step — e = fma(-255, q, x), q + e * fl(1/255) — gives the IEEE quotient for all 256 (checked exhaustively:
+// tests/test_oracle_host_math.py). v_cvt_f32_ubyteK + 3 VALU per texel instead of 3 VALU + a dependent LDS table read.
+template <int K>
+__device__ __forceinline__ float unit_of_byte(unsigned d)
+{
+  const float x = (float)((d >> (8 * K)) & 0xffu), r = 0x1.010102p-8f; // fl(1 / 255)
+  const float q = x * r;
+  return fmaf(fmaf(-255.f, q, x), r, q);
+}
+__device__ __forceinline__ void unit_of_bytes(unsigned d, float t[4])
+{
+  t[0] = unit_of_byte<0>(d), t[1] = unit_of_byte<1>(d), t[2] = unit_of_byte<2>(d), t[3] = unit_of_byte<3>(d);
+}
+
 // (the body is shared by k_blur_lean — one plane set per launch, the launch grid is the work grid — and k_blur_lean_multi — several
 // octaves' planes in one flat launch, csrc/hip/multi.h: gx/gy/gz and bx/by/bz are then the octave's virtual grid)
 template <int NT, int SRC, bool F16>
@@ -394,13 +409,10 @@ __device__ __forceinline__ void blur_lean_body(const StreamArgs &a, const uint32
   // UPS: the 4 output columns X..X+3 (X = real column of the float4 after mirroring) come from the source bytes
   // X/2-1 .. X/2+2, clamped to the row: one (byte-aligned) dword load + a lane-constant byte permutation
   unsigned perm_sel = 0x03020100u;
-  __shared__ float s_lut[(UPS || U8) ? 256 : 1];
   if (U8 && lane < NV4)
     ld_off /= EB; // one byte per source texel: the (mirrored) column index itself, a multiple of 4
   if (UPS || U8)
   {
-    for (int i = lane; i < 256; i += 64)
-      s_lut[i] = (float)i / 255.f;
     if (UPS && lane < NV4)
     {
       const int X = (int)(ld_off / EB);
@@ -424,7 +436,7 @@ __device__ __forceinline__ void blur_lean_body(const StreamArgs &a, const uint32
   float vb[NR]; // UPS: vertical weight of the lower source row (wave-uniform)
   // UPS, group away from the top and bottom edges: output rows 2m+1 and 2m+2 interpolate between the SAME two source rows
   // (m, m+1) with weights 0.25 / 0.75, so the 8 rows of a group need 5 or 6 distinct source rows, not 16: each is loaded,
-  // sent through the table and interpolated horizontally once (the same expressions on the same values: bit-identical).
+  // converted and interpolated horizontally once (the same expressions on the same values: bit-identical).
   // Groups start on rows of the parity of R (segments start on multiples of 8).
   constexpr int UPS_PAR = R & 1, UPS_NSRC = UPS_PAR ? 5 : 6;
   auto ups_shared = [&](int r0) { return r0 >= 2 && r0 + NR + 2 <= H; };
@@ -507,9 +519,7 @@ __device__ __forceinline__ void blur_lean_body(const StreamArgs &a, const uint32
         auto hrow = [&](int s) {
           const unsigned d = __builtin_amdgcn_perm(pf[s].x, pf[s].x, perm_sel);
           float t[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            t[k] = s_lut[(d >> (8 * k)) & 0xffu];
+          unit_of_bytes(d, t);
 #pragma unroll
           for (int k = 0; k < 4; k++)
           {
@@ -570,12 +580,8 @@ __device__ __forceinline__ void blur_lean_body(const StreamArgs &a, const uint32
         {
           const unsigned d0 = __builtin_amdgcn_perm(v.x, v.x, perm_sel), d1 = __builtin_amdgcn_perm(v.y, v.y, perm_sel);
           float t0[4], t1[4], res[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-          {
-            t0[k] = s_lut[(d0 >> (8 * k)) & 0xffu];
-            t1[k] = s_lut[(d1 >> (8 * k)) & 0xffu];
-          }
+          unit_of_bytes(d0, t0);
+          unit_of_bytes(d1, t1);
           const float b = vb[j];
 #pragma unroll
           for (int k = 0; k < 4; k++)
@@ -593,10 +599,10 @@ __device__ __forceinline__ void blur_lean_body(const StreamArgs &a, const uint32
         else if (U8)
         {
           float res[4];
+          unit_of_bytes(v.x, res);
 #pragma unroll
           for (int k = 0; k < 4; k++)
           {
-            res[k] = s_lut[(v.x >> (8 * k)) & 0xffu];
             if (F16)
               res[k] = (float)to_h(res[k]); // the blit target is an image of the pyramid format
           }
