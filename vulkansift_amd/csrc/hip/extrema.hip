@@ -791,10 +791,10 @@ static int make_extrema_args(const vksift_hip_OctaveJob *job, ExtremaArgs *out)
   a.cand_xy = job->cand_xy, a.cand_flag = job->cand_flag, a.cand_n = job->cand_n;
   a.cand_img_stride = job->cand_img_stride, a.cand_cap = job->cand_cap;
   a.scan_rev = (int)job->scan_reverse;
-  /* 32 rows per wave on the large octaves (3 % halo rows); 16 on the small ones, whose share of a launch is latency bound and
-   * gains more from twice the waves */
-  a.band = job->h > 256u ? 32 : 16;
-  if (vksift_hip_tune_get(VKSIFT_TUNE_SCAN_BAND) > 0)
+  /* 48 rows per wave on the large octaves (2 halo rows per band: 4 %; swept in the pipeline, 512 frames: 32 rows 3.91 ms, 40 3.85, 48 3.83,
+   * 56 3.84, 64 3.89); 16 on the small ones, whose share of a launch is latency bound and gains more from twice the waves */
+  a.band = job->h > 256u ? 48 : 16;
+  if (vksift_hip_tune_get(VKSIFT_TUNE_SCAN_BAND) > 0 && job->h > 256u)
     a.band = vksift_hip_tune_get(VKSIFT_TUNE_SCAN_BAND);
   a.nsegs = job->S * job->h * (uint32_t)a.nseg;
   a.nchunks = (a.nsegs + SEG_CHUNK - 1u) / SEG_CHUNK;
