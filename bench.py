@@ -21,15 +21,20 @@ RCCL all-gather of the reference descriptors) and rank 0 prints the CRC-32 of th
 same number at N = 1, 2, 4, 8. PyTorch is used for torch.distributed (RCCL) and device buffers only.
 
 Objects on the JSON line besides the contract fields:
-  roofline          octave 0's scale-space construction (fused up-sampling + seed blur, the two-scale launch, three more scale blurs)
-                    plus the streaming extrema scan (k_extrema_lean, ONE launch over all octaves) — the launches that produce the
-                    Gaussian planes and form the DoG values; durations from HIP events recorded on the streams the kernels run on,
-                    inside the timed region. `frac` is what the hardware moved: HBM bytes from the rocprofv3 --pmc capture of the same
-                    kernel sources (profiles/*pmc_traffic*.json, refused for any other source hash) / those durations / 8 TB/s, with
-                    `per_launch` rows (bytes, us, fraction per launch kind) from that capture. `algorithmic` = this build's own minimum
-                    (41.25 B per octave-0 pixel + 24 B per scanned pixel; <= traffic by construction); `survey_8d` = SURVEY.md 8(d)'s
-                    pricing of the reference's schedule (72.25 + 20 B/px), kept for comparison with earlier rounds only.
+  roofline          the WHOLE scale-space + DoG pass (round 6): every scale-space launch of EVERY octave (fused up-sampling + seed blur, the
+                    two-scale launches, the 9 / 11 / 13-tap launches, the per-scale launches over the coarse octaves) — the interval
+                    pyramid_all_ms, first launch of octave 0 to the last blur launch of the coarsest octave — plus the streaming extrema
+                    scan (k_extrema_lean, ONE launch over all octaves: it forms the DoG values); durations from HIP events recorded on the
+                    streams the kernels run on, inside the timed region. `frac` is what the hardware moved: HBM bytes of those launches
+                    from the rocprofv3 --pmc capture of the same kernel sources (profiles/*pmc_traffic*.json: `all_octaves`; refused for any
+                    other source hash) / those durations / 8 TB/s, with `all_launches` rows (bytes, us, fraction per launch shape) from that
+                    capture. `algorithmic` = this build's own minimum (41.25 B per octave-0 pixel, 37 B per pixel of the coarser octaves,
+                    24 B per scanned pixel; <= traffic by construction). `octave0_and_scan` = rounds 1-5's definition (octave 0's five
+                    launches + the scan) with its own `frac`, `algorithmic` and `per_launch` rows; `survey_8d` = SURVEY.md 8(d)'s pricing of
+                    the reference's schedule (72.25 + 20 B/px), kept for comparison with rounds 1-3 only.
   roofline_c3       the same for BASELINE config 3 (64 x 1920x1080, detect only), 5 steps
+  plain_api         the 20 reference entry points ONLY (C caller, instance from vksift_createInstance): detect into N buffers then read them,
+                    the same with two buffer sets, the two-buffer ping-pong — what deferred submission gives a caller of the reference
   value_host_input  the reference's own measurement protocol on the same frames (src/perf/wrappers/vulkansift_wrapper.cpp:
                     30-33): host images in, vksift_getFeaturesNumber + vksift_downloadFeatures (+ matches) out, strictly serial
   value_host_input_pipelined  the same inputs and outputs with two buffer sets: the next batch's detection is queued before
